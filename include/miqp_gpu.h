@@ -1,0 +1,94 @@
+/*
+ * miqp_gpu.h - C ABI of libmiqp_gpu.so, the MI355X-native replacement of the reference's
+ * CPLEX/OPL solve path (L1+L2+L3 of SURVEY.md section 1).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the planner-miqp
+ * checkout).  The Eigen-typed class with the reference's own name and methods is the header-only
+ * adapter include/cplex_wrapper.hpp, which forwards to these functions.
+ *
+ * Threading: one caller thread per solver handle; handles are independent (src/cplex_wrapper.hpp:61-275
+ * has the same contract: one IloEnv per wrapper).  No GPU context is touched before the first solve.
+ */
+#ifndef MIQP_GPU_H
+#define MIQP_GPU_H
+
+#include "miqp_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct miqp_solver miqp_solver_t;
+
+typedef struct miqp_solver_opts {
+  int precision;            /* CplexWrapper ctor `precision` (cplex_wrapper.hpp:81-115); inputs are rounded to
+                               precision-2 decimals like ModelInputDataSource (hpp:88); <= 0 -> 12 */
+  int device;               /* HIP device ordinal, -1: current */
+  int nodes_per_round;      /* B&B nodes solved per instance and round (0: default 16) */
+  int max_open_nodes;       /* per-instance open-list capacity (0: default 4096) */
+  double gap_override;      /* < 0: use ModelParameters.relative_mip_gap_tolerance */
+  int verbose;
+} miqp_solver_opts;
+
+/* CplexWrapper::CplexWrapper(...) / ~CplexWrapper()            src/cplex_wrapper.hpp:81-158 */
+miqp_solver_t* miqp_solver_create(const miqp_solver_opts* opts);
+void miqp_solver_destroy(miqp_solver_t* s);
+
+/* CplexWrapper::resetParameters(shared_ptr<ModelParameters>)   src/cplex_wrapper.cpp:661-664
+ * + ModelInputDataSource::read (rounding, edge tuples)         src/model_input_data_source.cpp:180-275
+ * The arrays are copied; returns 0 on success, <0 on invalid sizes. */
+int miqp_solver_set_params(miqp_solver_t* s, const miqp_model_params_c* p);
+
+/* CplexWrapper::setParameterDatFileAbsolute + DATFILE source   src/cplex_wrapper.cpp:30-42
+ * Reads the OPL .dat subset of the fixtures (no rounding, as OPL would). */
+int miqp_solver_load_dat(miqp_solver_t* s, const char* path);
+
+/* CplexWrapper::overrideSolverSettingsDataSource               src/cplex_wrapper.cpp:893-896 */
+int miqp_solver_override_settings(miqp_solver_t* s, double max_solution_time, double relative_mip_gap_tolerance);
+
+/* CplexWrapper::addRecedingHorizonWarmstart / setLastSolutionWarmstart   src/cplex_wrapper.cpp:459-483
+ * The vector is tried as an initial incumbent (CPLEX MIPStartSolveMIP: binaries of the start are fixed,
+ * the continuous QP is solved on the device; an infeasible start is ignored). */
+int miqp_solver_set_warmstart(miqp_solver_t* s, const miqp_raw_results_c* start, int warmstart_type);
+
+/* CplexWrapper::callCplex(timestamp)                           src/cplex_wrapper.cpp:65-249
+ * Returns OptimizationStatus (MIQP_STATUS_*); never throws.  Fails with MIQP_STATUS_FAILED_SEG_FAULT when
+ * no HIP device / kernel image is available - there is no CPU fallback. */
+int miqp_solver_solve(miqp_solver_t* s, double timestamp);
+
+/* Batch of independent instances (receding-horizon steps / scenario seeds) solved concurrently on one
+ * device; statuses[k] receives the OptimizationStatus of solver k.  All instances must share
+ * NumCars, NumSteps, nr_obstacles and max_lines_obstacles.  Returns 0 on success. */
+int miqp_solver_solve_batch(miqp_solver_t* const* solvers, int n, int* statuses);
+
+/* CplexWrapper::getRawResults()                                src/cplex_wrapper.hpp:204, cpp:311-448
+ * Fills the caller-allocated record (sizes must match the instance). */
+int miqp_solver_get_results(const miqp_solver_t* s, miqp_raw_results_c* out);
+
+/* CplexWrapper::getSolutionProperties()                        src/cplex_wrapper.hpp:206-208, cpp:672-690 */
+int miqp_solver_get_properties(const miqp_solver_t* s, miqp_solution_properties_c* out);
+
+/* sizes of the loaded instance: out[0..5] = NumCars, NumSteps, nr_regions, nr_environments,
+ * nr_obstacles, max_lines_obstacles                            (collectRawResults, cpp:314-327) */
+int miqp_solver_get_dims(const miqp_solver_t* s, int* out6);
+
+/* cplex.exportModel(".lp") debug output                        src/cplex_wrapper.cpp:150-154 */
+int miqp_solver_export_lp(const miqp_solver_t* s, const char* path);
+
+/* continuous QP with the binaries of `fixed` asserted, solved by the device interior-point kernel
+ * (used by the parity tests to compare the QP machinery with the CPU oracle and with K3);
+ * returns 0 when feasible */
+int miqp_solver_solve_fixed(miqp_solver_t* s, const miqp_raw_results_c* fixed, miqp_raw_results_c* out,
+                            double* objective, int* iterations);
+
+/* timing of the last solve / batch in seconds, measured with HIP events on the solver stream:
+ * out[0] = whole solve, out[1] = interior-point kernel total, out[2] = number of IPM kernel launches,
+ * out[3] = node relaxations solved, out[4] = IPM iterations (summed over nodes), out[5] = rows x iterations */
+int miqp_solver_last_timing(const miqp_solver_t* s, double* out6);
+
+const char* miqp_gpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIQP_GPU_H */

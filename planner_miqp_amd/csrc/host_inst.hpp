@@ -1,0 +1,375 @@
+// host_inst.hpp - host-side instance of the MIQP solve path and its compilation into device tables.
+//
+// Product code (no dependency on oracle/).  Restates, for the device solver:
+//   ModelInputDataSource::read / addLineSet       src/model_input_data_source.cpp:167-275 (rounding, edges)
+//   cplexmodel/parameters.mod:24-32               big-M constants
+//   cplexmodel/initial_conditions.mod:30-48       step-1 jerk box
+//   cplexmodel/model_region_constraints.mod:43-114 region block (sector, front polynomials, boxes, curvature)
+//   cplexmodel/minimum_speed_constraints.mod:9-49 low-speed freeze -> non-slow half-planes per sector
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/miqp_types.h"
+
+namespace miqp {
+
+constexpr int MAXC = 2;          // cars supported by the device kernels in this round
+constexpr int REGSZ = 32;        // doubles per (car, possible region) table entry
+constexpr double BIGM_JERK = 10.0, BIGM_ACC = 10.0;
+
+struct HostInst {
+  int N = 0, C = 0, R = 0, E = 0, O = 0, L = 0;
+  double ts = 0, vmin = 0, vmax = 0, amin = 0, amax = 0, jmin = 0, jmax = 0, max_slack = 0, w_slack = 0,
+         w_slack_obs = 0, vm = 0, gap = 0.1, tilim = 10;
+  std::vector<double> safety, safety_slack, W /*C*8*/, wb, rad, x0 /*C*6*/, ref /*C*N*6*/, acc_lim, jerk_lim /*C*R*4*/,
+      frac /*R*4*/, poly[6] /*R*3: SINT_UB SINT_LB COSS_UB COSS_LB KMAX KMIN*/, env_edges /*4 per edge*/, obs_edges;
+  std::vector<int> init_region, possible, env_off, obs_soft;
+  int NP() const { return C * (C - 1) / 2; }
+};
+
+inline double round_dec(double v, int dec) {
+  if (dec < 0) return v;
+  double s = std::pow(10.0, dec);
+  return std::round(v * s) / s;
+}
+
+inline bool inst_from_params(const miqp_model_params_c* p, int dec, HostInst& I, std::string& err) {
+  I = HostInst();
+  I.N = p->NumSteps; I.C = p->NumCars; I.R = p->nr_regions; I.E = p->nr_environments; I.O = p->nr_obstacles;
+  I.L = p->max_lines_obstacles;
+  if (I.C < 1 || I.N < 2 || I.R < 1) { err = "invalid sizes"; return false; }
+  auto r = [&](double v) { return round_dec(v, dec); };
+  I.ts = r(p->ts); I.vmin = r(p->min_vel_x_y); I.vmax = r(p->max_vel_x_y); I.amin = r(p->total_min_acc);
+  I.amax = r(p->total_max_acc); I.jmin = r(p->total_min_jerk); I.jmax = r(p->total_max_jerk);
+  I.max_slack = r(p->maximum_slack); I.w_slack = r(p->WEIGHTS_SLACK); I.w_slack_obs = r(p->WEIGHTS_SLACK_OBSTACLE);
+  I.vm = r(p->minimum_region_change_speed); I.gap = r(p->relative_mip_gap_tolerance); I.tilim = r(p->max_solution_time);
+  int N = I.N, C = I.C, R = I.R;
+  I.safety.resize(N); I.safety_slack.resize(N);
+  for (int i = 0; i < N; ++i) { I.safety[i] = r(p->agent_safety_distance[i]); I.safety_slack[i] = r(p->agent_safety_distance_slack[i]); }
+  const double* Ws[8] = {p->WEIGHTS_POS_X, p->WEIGHTS_VEL_X, p->WEIGHTS_ACC_X, p->WEIGHTS_POS_Y,
+                         p->WEIGHTS_VEL_Y, p->WEIGHTS_ACC_Y, p->WEIGHTS_JERK_X, p->WEIGHTS_JERK_Y};
+  I.W.assign(C * 8, 0); I.wb.resize(C); I.rad.resize(C); I.x0.resize(C * 6); I.ref.assign((size_t)C * N * 6, 0);
+  I.acc_lim.resize((size_t)C * R * 4); I.jerk_lim.resize((size_t)C * R * 4); I.init_region.resize(C); I.possible.resize(C * R);
+  for (int c = 0; c < C; ++c) {
+    for (int k = 0; k < 8; ++k) I.W[c * 8 + k] = r(Ws[k][c]);
+    I.wb[c] = r(p->WheelBase[c]); I.rad[c] = r(p->CollisionRadius[c]);
+    for (int k = 0; k < 6; ++k) I.x0[c * 6 + k] = r(p->IntitialState[c * 6 + k]);
+    for (int i = 0; i < N; ++i) {
+      double* f = &I.ref[((size_t)c * N + i) * 6];
+      f[0] = r(p->x_ref[c * N + i]); f[1] = r(p->vx_ref[c * N + i]); f[3] = r(p->y_ref[c * N + i]); f[4] = r(p->vy_ref[c * N + i]);
+    }
+    for (int j = 0; j < R; ++j) {
+      double* a = &I.acc_lim[((size_t)c * R + j) * 4]; double* jl = &I.jerk_lim[((size_t)c * R + j) * 4];
+      a[0] = r(p->min_acc_x[c * R + j]); a[1] = r(p->max_acc_x[c * R + j]); a[2] = r(p->min_acc_y[c * R + j]); a[3] = r(p->max_acc_y[c * R + j]);
+      jl[0] = r(p->min_jerk_x[c * R + j]); jl[1] = r(p->max_jerk_x[c * R + j]); jl[2] = r(p->min_jerk_y[c * R + j]); jl[3] = r(p->max_jerk_y[c * R + j]);
+      I.possible[c * R + j] = p->possible_region[c * R + j];
+    }
+    I.init_region[c] = p->initial_region[c];
+  }
+  const double* Ps[6] = {p->POLY_SINT_UB, p->POLY_SINT_LB, p->POLY_COSS_UB, p->POLY_COSS_LB, p->POLY_KAPPA_AX_MAX, p->POLY_KAPPA_AX_MIN};
+  I.frac.resize(R * 4);
+  for (int k = 0; k < R * 4; ++k) I.frac[k] = r(p->fraction_parameters[k]);
+  for (int t = 0; t < 6; ++t) { I.poly[t].resize(R * 3); for (int k = 0; k < R * 3; ++k) I.poly[t][k] = r(Ps[t][k]); }
+  I.env_off.assign(I.E + 1, 0);
+  for (int e = 0; e < I.E; ++e) {
+    int a = p->env_offsets[e], b = p->env_offsets[e + 1], n = b - a;
+    I.env_off[e] = a; I.env_off[e + 1] = b;
+    for (int k = 0; k < n; ++k) {  // addLineSet: consecutive vertices, last edge wraps around
+      int k2 = (k + 1) % n;
+      I.env_edges.push_back(r(p->env_vertices[2 * (a + k)])); I.env_edges.push_back(r(p->env_vertices[2 * (a + k) + 1]));
+      I.env_edges.push_back(r(p->env_vertices[2 * (a + k2)])); I.env_edges.push_back(r(p->env_vertices[2 * (a + k2) + 1]));
+    }
+  }
+  I.obs_soft.resize(I.O);
+  I.obs_edges.resize((size_t)I.O * N * I.L * 4);
+  for (int o = 0; o < I.O; ++o) {
+    I.obs_soft[o] = p->obstacle_is_soft[o];
+    for (int i = 0; i < N; ++i)
+      for (int k = 0; k < I.L; ++k) {
+        int k2 = (k + 1) % I.L;
+        const double* v = p->obstacle_vertices + ((size_t)(o * N + i) * I.L) * 2;
+        double* ed = &I.obs_edges[((size_t)(o * N + i) * I.L + k) * 4];
+        ed[0] = r(v[2 * k]); ed[1] = r(v[2 * k + 1]); ed[2] = r(v[2 * k2]); ed[3] = r(v[2 * k2 + 1]);
+      }
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------- OPL .dat subset
+struct DatValue {
+  bool is_num = false; double num = 0; char open = 0; std::vector<DatValue> items;
+  void flatten(std::vector<double>& out) const { if (is_num) out.push_back(num); else for (auto& v : items) v.flatten(out); }
+  int row_width() const { if (is_num) return 1; if (!items.empty() && !items[0].is_num) return items[0].row_width(); return (int)items.size(); }
+};
+
+class DatReader {
+ public:
+  explicit DatReader(const std::string& text) : s_(text) {}
+  bool parse(std::vector<std::pair<std::string, DatValue>>& out) {
+    for (;;) {
+      ws(); if (pos_ >= s_.size()) return true;
+      size_t st = pos_;
+      while (pos_ < s_.size() && (isalnum((unsigned char)s_[pos_]) || s_[pos_] == '_')) pos_++;
+      if (pos_ == st) return false;
+      std::string name = s_.substr(st, pos_ - st);
+      ws(); if (pos_ >= s_.size() || s_[pos_] != '=') return false; pos_++;
+      DatValue v; if (!value(v)) return false;
+      ws(); if (pos_ >= s_.size() || s_[pos_] != ';') return false; pos_++;
+      out.emplace_back(name, std::move(v));
+    }
+  }
+ private:
+  void ws() {
+    for (;;) {
+      while (pos_ < s_.size() && (isspace((unsigned char)s_[pos_]) || s_[pos_] == ',')) pos_++;
+      if (pos_ + 1 < s_.size() && s_[pos_] == '/' && s_[pos_ + 1] == '*') { size_t e = s_.find("*/", pos_ + 2); pos_ = e == std::string::npos ? s_.size() : e + 2; }
+      else if (pos_ + 1 < s_.size() && s_[pos_] == '/' && s_[pos_ + 1] == '/') { while (pos_ < s_.size() && s_[pos_] != '\n') pos_++; }
+      else return;
+    }
+  }
+  bool value(DatValue& v) {
+    ws(); if (pos_ >= s_.size()) return false;
+    char ch = s_[pos_];
+    if (ch == '[' || ch == '{' || ch == '<') {
+      char close = ch == '[' ? ']' : (ch == '{' ? '}' : '>');
+      v.open = ch; pos_++;
+      for (;;) {
+        ws(); if (pos_ >= s_.size()) return false;
+        if (s_[pos_] == close) { pos_++; return true; }
+        DatValue it; if (!value(it)) return false; v.items.push_back(std::move(it));
+      }
+    }
+    char* end = nullptr; v.is_num = true; v.num = std::strtod(s_.c_str() + pos_, &end);
+    if (end == s_.c_str() + pos_) return false;
+    pos_ = (size_t)(end - s_.c_str());
+    return true;
+  }
+  const std::string& s_; size_t pos_ = 0;
+};
+
+inline bool inst_from_dat(const char* path, HostInst& I, std::string& err) {
+  FILE* f = std::fopen(path, "rb");
+  if (!f) { err = std::string("cannot open ") + path; return false; }
+  std::string text; char buf[65536]; size_t n;
+  while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, n);
+  std::fclose(f);
+  std::vector<std::pair<std::string, DatValue>> ents;
+  DatReader rd(text);
+  if (!rd.parse(ents)) { err = "syntax error in .dat"; return false; }
+  auto find = [&](const char* nm) -> const DatValue* { for (auto& e : ents) if (e.first == nm) return &e.second; return nullptr; };
+  bool miss = false;
+  auto num = [&](const char* nm) { auto* v = find(nm); if (!v || !v->is_num) { miss = true; err = std::string("missing ") + nm; return 0.0; } return v->num; };
+  // table narrower than the header says is zero filled (cplexmodel.dat: 16-wide tables under nr_regions = 32)
+  auto table = [&](const char* nm, int rows, int width) {
+    std::vector<double> out((size_t)rows * width, 0.0);
+    auto* v = find(nm); if (!v) { miss = true; err = std::string("missing ") + nm; return out; }
+    std::vector<double> flat; v->flatten(flat);
+    int w = v->row_width(); if (w <= 0) w = 1;
+    int rs = (int)flat.size() / w;
+    for (int r = 0; r < rows && r < rs; ++r) for (int k = 0; k < width && k < w; ++k) out[(size_t)r * width + k] = flat[(size_t)r * w + k];
+    return out;
+  };
+  I = HostInst();
+  I.N = (int)num("NumSteps"); I.C = (int)num("NumCars"); I.R = (int)num("nr_regions"); I.E = (int)num("nr_environments");
+  I.O = (int)num("nr_obstacles"); I.L = (int)num("max_lines_obstacles");
+  if (miss || I.C < 1 || I.N < 2) { if (err.empty()) err = "invalid sizes"; return false; }
+  int N = I.N, C = I.C, R = I.R;
+  I.ts = num("ts"); I.vmin = num("min_vel_x_y"); I.vmax = num("max_vel_x_y"); I.amin = num("total_min_acc"); I.amax = num("total_max_acc");
+  I.jmin = num("total_min_jerk"); I.jmax = num("total_max_jerk"); I.max_slack = num("maximum_slack"); I.w_slack = num("WEIGHTS_SLACK");
+  I.w_slack_obs = num("WEIGHTS_SLACK_OBSTACLE"); I.vm = num("minimum_region_change_speed"); I.gap = num("relative_mip_gap_tolerance");
+  I.tilim = num("max_solution_time");
+  I.safety = table("agent_safety_distance", 1, N); I.safety_slack = table("agent_safety_distance_slack", 1, N);
+  const char* wn[8] = {"WEIGHTS_POS_X", "WEIGHTS_VEL_X", "WEIGHTS_ACC_X", "WEIGHTS_POS_Y", "WEIGHTS_VEL_Y", "WEIGHTS_ACC_Y", "WEIGHTS_JERK_X", "WEIGHTS_JERK_Y"};
+  I.W.assign(C * 8, 0);
+  for (int k = 0; k < 8; ++k) { auto t = table(wn[k], 1, C); for (int c = 0; c < C; ++c) I.W[c * 8 + k] = t[c]; }
+  I.wb = table("WheelBase", 1, C); I.rad = table("CollisionRadius", 1, C); I.x0 = table("IntitialState", C, 6);
+  I.ref.assign((size_t)C * N * 6, 0);
+  const char* rn[4] = {"x_ref", "vx_ref", "y_ref", "vy_ref"}; const int ri[4] = {0, 1, 3, 4};
+  for (int k = 0; k < 4; ++k) { auto t = table(rn[k], C, N); for (int c = 0; c < C; ++c) for (int i = 0; i < N; ++i) I.ref[((size_t)c * N + i) * 6 + ri[k]] = t[(size_t)c * N + i]; }
+  const char* an[4] = {"min_acc_x", "max_acc_x", "min_acc_y", "max_acc_y"}; const char* jn[4] = {"min_jerk_x", "max_jerk_x", "min_jerk_y", "max_jerk_y"};
+  I.acc_lim.assign((size_t)C * R * 4, 0); I.jerk_lim.assign((size_t)C * R * 4, 0);
+  for (int k = 0; k < 4; ++k) {
+    auto ta = table(an[k], C, R); auto tj = table(jn[k], C, R);
+    for (int q = 0; q < C * R; ++q) { I.acc_lim[(size_t)q * 4 + k] = ta[q]; I.jerk_lim[(size_t)q * 4 + k] = tj[q]; }
+  }
+  { auto t = table("initial_region", 1, C); I.init_region.resize(C); for (int c = 0; c < C; ++c) I.init_region[c] = (int)t[c]; }
+  { auto t = table("possible_region", C, R); I.possible.resize(C * R); for (int q = 0; q < C * R; ++q) I.possible[q] = (int)t[q]; }
+  I.frac = table("fraction_parameters", R, 4);
+  const char* pn[6] = {"POLY_SINT_UB", "POLY_SINT_LB", "POLY_COSS_UB", "POLY_COSS_LB", "POLY_KAPPA_AX_MAX", "POLY_KAPPA_AX_MIN"};
+  for (int t = 0; t < 6; ++t) I.poly[t] = table(pn[t], R, 3);
+  const DatValue* env = find("MultiEnvironmentConvexPolygon"); const DatValue* obs = find("ObstacleConvexPolygon");
+  I.env_off.assign(I.E + 1, 0);
+  if (I.E > 0 && (!env || (int)env->items.size() < I.E)) { err = "MultiEnvironmentConvexPolygon too short"; return false; }
+  for (int e = 0; e < I.E; ++e) {
+    I.env_off[e] = (int)I.env_edges.size() / 4;
+    for (auto& t : env->items[e].items) for (int q = 1; q <= 4; ++q) I.env_edges.push_back(q < (int)t.items.size() ? t.items[q].num : 0.0);
+  }
+  I.env_off[I.E] = (int)I.env_edges.size() / 4;
+  I.obs_edges.assign((size_t)I.O * N * I.L * 4, 0.0); I.obs_soft.assign(I.O, 0);
+  if (I.O > 0) {
+    if (!obs || (int)obs->items.size() < I.O) { err = "ObstacleConvexPolygon too short"; return false; }
+    for (int o = 0; o < I.O; ++o)
+      for (int i = 0; i < N && i < (int)obs->items[o].items.size(); ++i) {
+        auto& set = obs->items[o].items[i];
+        for (int k = 0; k < I.L && k < (int)set.items.size(); ++k)
+          for (int q = 1; q <= 4 && q < (int)set.items[k].items.size(); ++q)
+            I.obs_edges[((size_t)(o * N + i) * I.L + k) * 4 + q - 1] = set.items[k].items[q].num;
+      }
+    auto t = table("obstacle_is_soft", 1, I.O); for (int o = 0; o < I.O; ++o) I.obs_soft[o] = (int)t[o];
+  }
+  if (miss) return false;
+  return true;
+}
+
+// ---------------------------------------------------------------- device table layout (shared by a batch)
+struct Layout {
+  int C, N, R, P, E, EL, O, L, NP;   // P = max possible regions per car, EL = max edges per environment piece
+  int nx, nu, nz, SC, NSLOT, ROWCAP;
+  // double offsets
+  int d_x0, d_wd, d_ref, d_glob, d_u0box, d_misc, d_dsep, d_ssl, d_smax, d_reg, d_env, d_obs, d_theta, dstride;
+  // int offsets
+  int i_nposs, i_regj, i_nhs, i_hs, i_envn, i_obssoft, i_initj, istride;
+  // fix record (bytes)
+  int f_reg, f_env, f_obs, f_c2c, fixlen;
+};
+
+inline Layout make_layout(int C, int N, int R, int P, int E, int EL, int O, int L) {
+  Layout Y; std::memset(&Y, 0, sizeof(Y));
+  Y.C = C; Y.N = N; Y.R = R; Y.P = P; Y.E = E; Y.EL = EL; Y.O = O; Y.L = L; Y.NP = C * (C - 1) / 2;
+  Y.nx = 6 * C; Y.nu = 2 * C; Y.nz = 8 * C;
+  Y.SC = 16 + 5 * EL + 5 * O; Y.NSLOT = C * Y.SC + Y.NP * 8; Y.ROWCAP = N * Y.NSLOT;
+  int o = 0;
+  Y.d_x0 = o; o += C * 6; Y.d_wd = o; o += Y.nz; Y.d_ref = o; o += N * Y.nz; Y.d_glob = o; o += 8; Y.d_u0box = o; o += C * 4;
+  Y.d_misc = o; o += 4; Y.d_dsep = o; o += Y.NP * N; Y.d_ssl = o; o += N; Y.d_smax = o; o += N; Y.d_reg = o; o += C * P * REGSZ;
+  Y.d_env = o; o += E * EL * 3; Y.d_obs = o; o += O * N * L * 3; Y.d_theta = o; o += C * 4; Y.dstride = (o + 7) & ~7;
+  o = 0;
+  Y.i_nposs = o; o += C; Y.i_regj = o; o += C * P; Y.i_nhs = o; o += C * P; Y.i_hs = o; o += C * P * 4; Y.i_envn = o; o += E;
+  Y.i_obssoft = o; o += O; Y.i_initj = o; o += C; Y.istride = (o + 3) & ~3;
+  Y.f_reg = 0; Y.f_env = Y.f_reg + C * N; Y.f_obs = Y.f_env + C * N * 5; Y.f_c2c = Y.f_obs + C * O * N * 5;
+  Y.fixlen = (Y.f_c2c + Y.NP * N * 4 + 15) & ~15;
+  return Y;
+}
+
+// non-slow half-planes of a sector: sector \ slow-square = U_h sector ^ {sign*v_axis >= vm}, dominated ones dropped
+inline int nonslow_halfplanes(const double* F, int hs[2][2]) {
+  double t1 = std::atan2(F[1], F[0]), t2 = std::atan2(F[3], F[2]);
+  if (t2 < t1) t2 += 2 * M_PI;
+  const int cand[4][2] = {{0, 1}, {0, -1}, {1, 1}, {1, -1}};
+  double vals[4][65]; bool ok[4];
+  for (int q = 0; q < 4; ++q) {
+    ok[q] = false;
+    for (int s = 0; s < 65; ++s) {
+      double th = t1 + (t2 - t1) * s / 64.0;
+      vals[q][s] = cand[q][0] == 0 ? cand[q][1] * std::cos(th) : cand[q][1] * std::sin(th);
+      if (vals[q][s] > 1e-12) ok[q] = true;
+    }
+  }
+  int n = 0;
+  for (int a = 0; a < 4; ++a) {
+    if (!ok[a]) continue;
+    bool dom = false;
+    for (int b = 0; b < 4 && !dom; ++b) {
+      if (a == b || !ok[b]) continue;
+      bool all_ge = true, any_gt = false;
+      for (int s = 0; s < 65; ++s) {
+        if (vals[a][s] <= 1e-12) continue;
+        if (vals[b][s] < vals[a][s] - 1e-12) all_ge = false;
+        if (vals[b][s] > vals[a][s] + 1e-12) any_gt = true;
+      }
+      if (all_ge && (any_gt || b < a)) dom = true;
+    }
+    if (!dom && n < 2) { hs[n][0] = cand[a][0]; hs[n][1] = cand[a][1]; n++; }
+  }
+  return n;
+}
+
+inline int max_possible(const HostInst& I) {
+  int P = 1;
+  for (int c = 0; c < I.C; ++c) { int n = 0; for (int j = 0; j < I.R; ++j) n += I.possible[c * I.R + j] == 1; P = std::max(P, n); }
+  return P;
+}
+inline int max_env_edges(const HostInst& I) {
+  int m = 0; for (int e = 0; e < I.E; ++e) m = std::max(m, I.env_off[e + 1] - I.env_off[e]); return m;
+}
+
+// fills one instance's block of the device tables
+inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int* T) {
+  std::fill(D, D + Y.dstride, 0.0); std::fill(T, T + Y.istride, 0);
+  int C = I.C, N = I.N, R = I.R;
+  for (int k = 0; k < C * 6; ++k) D[Y.d_x0 + k] = I.x0[k];
+  for (int c = 0; c < C; ++c) {
+    for (int k = 0; k < 6; ++k) D[Y.d_wd + 6 * c + k] = I.W[c * 8 + k];
+    D[Y.d_wd + 6 * C + 2 * c] = I.W[c * 8 + 6]; D[Y.d_wd + 6 * C + 2 * c + 1] = I.W[c * 8 + 7];
+    for (int i = 0; i < N; ++i) for (int k = 0; k < 6; ++k) D[Y.d_ref + i * Y.nz + 6 * c + k] = I.ref[((size_t)c * N + i) * 6 + k];
+    double th = std::atan2(I.x0[c * 6 + 4], I.x0[c * 6 + 1]);
+    D[Y.d_theta + c * 4 + 0] = I.x0[c * 6 + 0] + std::cos(th) * I.wb[c]; D[Y.d_theta + c * 4 + 1] = I.x0[c * 6 + 3] + std::sin(th) * I.wb[c];
+  }
+  double* G = D + Y.d_glob; G[0] = I.vmin; G[1] = I.vmax; G[2] = I.amin; G[3] = I.amax; G[4] = I.jmin; G[5] = I.jmax; G[6] = I.vm; G[7] = I.ts;
+  for (int c = 0; c < C; ++c) {  // initial_conditions.mod:30-48
+    int j0 = I.init_region[c] - 1;
+    for (int s = 0; s < 2; ++s) {
+      double hi = I.jmax, lo = I.jmin;
+      for (int j = 0; j < R; ++j) {
+        double M = j == j0 ? 0.0 : BIGM_JERK; const double* jl = &I.jerk_lim[((size_t)c * R + j) * 4];
+        hi = std::min(hi, jl[2 * s + 1] + M); lo = std::max(lo, jl[2 * s] - M);
+      }
+      D[Y.d_u0box + c * 4 + 2 * s] = lo; D[Y.d_u0box + c * 4 + 2 * s + 1] = hi;
+    }
+  }
+  D[Y.d_misc + 0] = I.w_slack; D[Y.d_misc + 1] = I.w_slack_obs;
+  { int p = 0;
+    for (int a = 0; a < C; ++a) for (int b = a + 1; b < C; ++b) { for (int i = 0; i < N; ++i) D[Y.d_dsep + p * N + i] = I.rad[a] + I.rad[b] + I.safety[i]; p++; } }
+  for (int i = 0; i < N; ++i) { D[Y.d_ssl + i] = I.safety_slack[i]; D[Y.d_smax + i] = std::max(0.0, std::min(I.safety_slack[i], I.max_slack)); }
+  for (int c = 0; c < C; ++c) {
+    std::vector<int> pl; for (int j = 0; j < R; ++j) if (I.possible[c * R + j] == 1) pl.push_back(j);
+    T[Y.i_nposs + c] = (int)pl.size(); T[Y.i_initj + c] = I.init_region[c] - 1;
+    for (int q = 0; q < (int)pl.size(); ++q) {
+      int j = pl[q]; T[Y.i_regj + c * Y.P + q] = j;
+      double* g = D + Y.d_reg + (c * Y.P + q) * REGSZ; const double* F = &I.frac[j * 4];
+      double n1 = std::hypot(F[0], F[1]), n3 = std::hypot(F[2], F[3]);
+      g[0] = F[1] / n1; g[1] = -F[0] / n1;   //  F2*vx - F1*vy <= 0
+      g[2] = -F[3] / n3; g[3] = F[2] / n3;   // -F4*vx + F3*vy <= 0
+      g[4] = (F[1] + F[3]) / (F[0] + F[2]);
+      for (int k = 0; k < 3; ++k) { g[5 + k] = I.poly[4][j * 3 + k]; g[8 + k] = I.poly[5][j * 3 + k]; }
+      for (int s = 0; s < 2; ++s) {
+        double hi = I.amax, lo = I.amin, jh = I.jmax, jlo = I.jmin;
+        for (int jj : pl) {
+          double Ma = jj == j ? 0.0 : BIGM_ACC, Mj = jj == j ? 0.0 : BIGM_JERK;
+          const double* al = &I.acc_lim[((size_t)c * R + jj) * 4]; const double* jl = &I.jerk_lim[((size_t)c * R + jj) * 4];
+          hi = std::min(hi, al[2 * s + 1] + Ma); lo = std::max(lo, al[2 * s] - Ma);
+          jh = std::min(jh, jl[2 * s + 1] + Mj); jlo = std::max(jlo, jl[2 * s] - Mj);
+        }
+        g[11 + 2 * s] = lo; g[12 + 2 * s] = hi; g[15 + 2 * s] = jlo; g[16 + 2 * s] = jh;
+      }
+      const int order[4] = {2, 3, 0, 1};  // COSS_UB, COSS_LB, SINT_UB, SINT_LB
+      for (int t = 0; t < 4; ++t) for (int k = 0; k < 3; ++k) g[19 + 3 * t + k] = I.wb[c] * I.poly[order[t]][j * 3 + k];
+      int hs[2][2] = {{0, 1}, {0, 1}}; int nh = nonslow_halfplanes(F, hs);
+      T[Y.i_nhs + c * Y.P + q] = nh;
+      for (int h = 0; h < 2; ++h) { T[Y.i_hs + ((c * Y.P + q) * 2 + h) * 2] = hs[h][0]; T[Y.i_hs + ((c * Y.P + q) * 2 + h) * 2 + 1] = hs[h][1]; }
+    }
+  }
+  for (int e = 0; e < I.E; ++e) {
+    int n = I.env_off[e + 1] - I.env_off[e]; T[Y.i_envn + e] = n;
+    for (int k = 0; k < n; ++k) {  // inside: cross >= 0  <=>  dy*X - dx*Y <= dy*x1 - dx*y1
+      const double* ed = &I.env_edges[(size_t)(I.env_off[e] + k) * 4];
+      double dx = ed[2] - ed[0], dy = ed[3] - ed[1], al = dy, be = -dx, nr = std::hypot(al, be);
+      double* g = D + Y.d_env + (e * Y.EL + k) * 3;
+      if (nr > 0) { g[0] = al / nr; g[1] = be / nr; g[2] = (al * ed[0] + be * ed[1]) / nr; }
+    }
+  }
+  for (int o = 0; o < I.O; ++o) {
+    T[Y.i_obssoft + o] = I.obs_soft[o];
+    for (int i = 0; i < N; ++i) for (int k = 0; k < I.L; ++k) {  // separated: cross <= 0
+      const double* ed = &I.obs_edges[((size_t)(o * N + i) * I.L + k) * 4];
+      double dx = ed[2] - ed[0], dy = ed[3] - ed[1], al = -dy, be = dx, nr = std::hypot(al, be);
+      double* g = D + Y.d_obs + ((o * N + i) * I.L + k) * 3;
+      if (nr > 0) { g[0] = al / nr; g[1] = be / nr; g[2] = (al * ed[0] + be * ed[1]) / nr; }
+    }
+  }
+}
+
+}  // namespace miqp

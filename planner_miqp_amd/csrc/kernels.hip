@@ -1,0 +1,924 @@
+// kernels.hip - CDNA4 (gfx950) device code of the MIQP solver.
+//
+//   ipm_kernel<C>     one 64-lane wavefront per B&B node: stage-banded primal-dual interior point on the node's
+//                     QP relaxation (rows decoded on the fly from compact per-instance tables, stage Hessians
+//                     assembled in LDS, Riccati recursion over the N stages).
+//   eval_kernel<C>    one wavefront per node: completion of undecided disjunctions, incumbent update
+//                     (64-bit atomicMin), choice of the branching disjunction (wave reduction), child emission.
+//   select_kernel     one workgroup per instance: prune, bitonic sort of the open list by bound in LDS, pick the
+//                     best nodes for the next round, instance termination test.
+//
+// The model being solved is the disjunctive form of cplexmodel/*.mod described in host_inst.hpp / DESIGN.md.
+#include <hip/hip_runtime.h>
+
+#include "host_inst.hpp"
+
+namespace miqp {
+
+constexpr double RHO_EL = 1.0e5;     // exact-penalty weight of the elastic rows
+constexpr double FEAS_TOL = 1.0e-6;
+constexpr double QP_TOL = 1.0e-10;
+constexpr double QP_SIGMA = 0.1;
+constexpr int QP_MAXIT = 80;
+constexpr int NFIELD = 6;            // per-row state: s, lambda, t, ds, dlambda, dt
+
+enum { PT_R = 0, PT_U = 1, PT_L = 2 };
+__device__ __constant__ int ENV_PT_D[5][2] = {{PT_R, PT_R}, {PT_U, PT_U}, {PT_L, PT_U}, {PT_U, PT_L}, {PT_L, PT_L}};
+__device__ __constant__ int OBS_PT_D[5][2] = {{PT_R, PT_R}, {PT_L, PT_L}, {PT_U, PT_L}, {PT_L, PT_U}, {PT_U, PT_U}};
+
+struct DevBuf {
+  Layout Y;
+  const double* inst_d; const int* inst_i;
+  // node pool
+  signed char* pool_fix;         // [pool_cap][fixlen]
+  int* pool_count; int pool_cap;
+  // open lists per instance
+  double* open_bound; int* open_node; int* open_count; int open_cap;
+  // per instance state
+  unsigned long long* inc_key;   // orderable(objective) with the batch slot in the low 20 bits
+  unsigned long long* inc_seen;  // key whose solution has been copied to inc_fix / inc_Z
+  double* inc_obj;               // objective of the stored incumbent
+  signed char* inc_fix; double* inc_Z;
+  double* lower_bound; int* inst_done; int* inst_flags; double* inst_gap; double* inst_const;
+  long long* inst_nodes; long long* inst_iters; int* inst_ninc;
+  // batch of the current round
+  int* batch_count; int* batch_node; int* batch_inst; int batch_cap;
+  double* batch_Z; double* batch_obj; double* batch_viol; int* batch_ok; int* batch_it; double* batch_bound;
+  signed char* batch_comp;       // completed fix record of feasible nodes
+  double* rowstate;              // [batch_cap][NFIELD][ROWCAP]
+  int* active_insts;             // number of instances not yet done
+  int nodes_per_round; int n_inst;
+  unsigned long long* stat_rowiters;
+};
+
+__device__ inline unsigned long long d2key(double v) {
+  unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ inline double key2d(unsigned long long k) {
+  unsigned long long u = (k & 0x8000000000000000ull) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  return __longlong_as_double((long long)u);
+}
+
+// objective stored in an incumbent key (low 20 bits = batch slot); 1e300 when no incumbent exists
+__device__ inline double inc_from_key(unsigned long long key) {
+  if (key >= 0xFFF0000000000000ull) return 1e300;
+  return key2d(key & ~0xFFFFFull);
+}
+
+__device__ inline double wave_min(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ inline double wave_max(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ inline double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// alpha*X + beta*Y of car c added to a dense row over the stage vector
+__device__ inline void add_point(double* g, double& rhs, int c, const double* rt, int tx, int ty, double al, double be) {
+  g[6 * c + 0] += al;
+  if (tx != PT_R) { const double* p = rt + 19 + (tx == PT_U ? 0 : 3); rhs -= al * p[0]; g[6 * c + 1] += al * p[1]; g[6 * c + 4] += al * p[2]; }
+  g[6 * c + 3] += be;
+  if (ty != PT_R) { const double* p = rt + 25 + (ty == PT_U ? 0 : 3); rhs -= be * p[0]; g[6 * c + 1] += be * p[1]; g[6 * c + 4] += be * p[2]; }
+}
+
+struct RowOut { double rhs; double aq; bool active; };
+
+// rows of the relaxation of a node (only alternatives that are fixed); g is this lane's LDS row
+template <int C>
+__device__ inline RowOut decode_row(const Layout& Y, const double* D, const int* T, const signed char* fix, int i, int slot, double* g) {
+  constexpr int NZ = 8 * C;
+  RowOut r; r.rhs = 0; r.aq = 0; r.active = false;
+#pragma unroll
+  for (int q = 0; q < NZ; ++q) g[q] = 0.0;
+  const int N = Y.N;
+  const double* G = D + Y.d_glob;
+  if (slot < C * Y.SC) {
+    int c = slot / Y.SC, rr = slot - c * Y.SC;
+    int code = i >= 1 ? (int)fix[Y.f_reg + c * N + i] : -1;
+    const double* rt = code >= 0 ? D + Y.d_reg + (c * Y.P + (code >> 2)) * REGSZ : nullptr;
+    if (rr < 7) {
+      if (i < 1) return r;
+      r.active = true;
+      switch (rr) {
+        case 0: g[6 * c + 1] = -1; r.rhs = -G[0]; break;
+        case 1: g[6 * c + 4] = -1; r.rhs = -G[0]; break;
+        case 2: g[6 * c + 1] = 1; r.rhs = G[1]; break;
+        case 3: g[6 * c + 2] = 1; r.rhs = rt ? rt[12] : G[3]; break;
+        case 4: g[6 * c + 2] = -1; r.rhs = -(rt ? rt[11] : G[2]); break;
+        case 5: g[6 * c + 5] = 1; r.rhs = rt ? rt[14] : G[3]; break;
+        default: g[6 * c + 5] = -1; r.rhs = -(rt ? rt[13] : G[2]); break;
+      }
+      return r;
+    }
+    if (rr < 11) {
+      if (i > N - 2) return r;
+      int s = (rr - 7) >> 1, up = ((rr - 7) & 1) == 0;
+      double lo, hi;
+      if (i == 0) { lo = D[Y.d_u0box + c * 4 + 2 * s]; hi = D[Y.d_u0box + c * 4 + 2 * s + 1]; }
+      else if (rt) { lo = rt[15 + 2 * s]; hi = rt[16 + 2 * s]; }
+      else { lo = G[4]; hi = G[5]; }
+      r.active = true;
+      g[6 * C + 2 * c + s] = up ? 1.0 : -1.0; r.rhs = up ? hi : -lo;
+      return r;
+    }
+    if (rr < 16) {
+      if (i < 1 || code < 0) return r;
+      int h = code & 3, k = rr - 11;
+      if (h == 3) {
+        if (k > 3) return r;
+        r.active = true; r.rhs = G[6];
+        g[6 * c + (k < 2 ? 1 : 4)] = (k & 1) ? -1.0 : 1.0;
+        return r;
+      }
+      r.active = true;
+      switch (k) {
+        case 0: g[6 * c + 1] = rt[0]; g[6 * c + 4] = rt[1]; break;
+        case 1: g[6 * c + 1] = rt[2]; g[6 * c + 4] = rt[3]; break;
+        case 2: {
+          const int* hs = T + Y.i_hs + ((c * Y.P + (code >> 2)) * 2 + h) * 2;
+          g[6 * c + (hs[0] == 0 ? 1 : 4)] = -(double)hs[1]; r.rhs = -G[6];
+        } break;
+        case 3: g[6 * c + 5] = 1; g[6 * c + 2] = -rt[4]; g[6 * c + 1] = -rt[6]; g[6 * c + 4] = -rt[7]; r.rhs = rt[5]; break;
+        default: g[6 * c + 5] = -1; g[6 * c + 2] = rt[4]; g[6 * c + 1] = rt[9]; g[6 * c + 4] = rt[10]; r.rhs = -rt[8]; break;
+      }
+      return r;
+    }
+    int q = rr - 16;
+    if (q < 5 * Y.EL) {
+      if (i < 1 || Y.E < 1) return r;
+      int pt = q / Y.EL, k = q - pt * Y.EL;
+      int e = Y.E == 1 ? 0 : (int)fix[Y.f_env + (c * N + i) * 5 + pt];
+      if (e < 0 || k >= T[Y.i_envn + e] || (pt > 0 && code < 0)) return r;
+      const double* ed = D + Y.d_env + (e * Y.EL + k) * 3;
+      r.active = true; r.rhs = ed[2];
+      add_point(g, r.rhs, c, rt, ENV_PT_D[pt][0], ENV_PT_D[pt][1], ed[0], ed[1]);
+      return r;
+    }
+    q -= 5 * Y.EL;
+    int o = q / 5, pt = q - o * 5;
+    if (i < 1) return r;
+    int kk = (int)fix[Y.f_obs + ((c * Y.O + o) * N + i) * 5 + pt];
+    if (kk < 0 || kk >= Y.L || (pt > 0 && code < 0)) return r;
+    const double* ed = D + Y.d_obs + ((o * N + i) * Y.L + kk) * 3;
+    r.active = true; r.rhs = ed[2];
+    add_point(g, r.rhs, c, rt, OBS_PT_D[pt][0], OBS_PT_D[pt][1], ed[0], ed[1]);
+    return r;
+  }
+  if (C < 2 || i < 1) return r;
+  int q = slot - C * Y.SC;
+  int p = q >> 3, grp = (q & 7) >> 1, which = q & 1;
+  int c1 = 0, c2 = 1;  // C == 2: the single pair
+  int alt = (int)fix[Y.f_c2c + (p * N + i) * 4 + grp];
+  if (alt < 0) return r;
+  int code1 = (int)fix[Y.f_reg + c1 * N + i], code2 = (int)fix[Y.f_reg + c2 * N + i];
+  bool need1 = grp >= 2, need2 = (grp == 1 || grp == 3);
+  if ((need1 && code1 < 0) || (need2 && code2 < 0)) return r;
+  const double* rt1 = code1 >= 0 ? D + Y.d_reg + (c1 * Y.P + (code1 >> 2)) * REGSZ : nullptr;
+  const double* rt2 = code2 >= 0 ? D + Y.d_reg + (c2 * Y.P + (code2 >> 2)) * REGSZ : nullptr;
+  double Dsep = D[Y.d_dsep + p * N + i], S = D[Y.d_ssl + i], smax = D[Y.d_smax + i], wsl = D[Y.d_misc + 0];
+  bool soft = (grp == 0 || grp == 3);
+  if (!soft && which == 1) return r;
+  if (soft && which == 1 && !(smax > 0 && wsl > 0)) return r;
+  bool isx = alt < 2, lo = (alt == 0 || alt == 2);
+  int ca, cb, ta, tb;
+  if (grp == 0) { ta = tb = PT_R; ca = lo ? c1 : c2; cb = lo ? c2 : c1; }
+  else if (grp == 1) { if (lo) { ca = c1; ta = PT_R; cb = c2; tb = PT_L; } else { ca = c2; ta = PT_U; cb = c1; tb = PT_R; } }
+  else if (grp == 2) { if (lo) { ca = c2; ta = PT_R; cb = c1; tb = PT_L; } else { ca = c1; ta = PT_U; cb = c2; tb = PT_R; } }
+  else { if (lo) { ca = c2; ta = PT_U; cb = c1; tb = PT_L; } else { ca = c1; ta = PT_U; cb = c2; tb = PT_L; } }
+  double al = isx ? 1.0 : 0.0, be = isx ? 0.0 : 1.0;
+  r.active = true;
+  r.rhs = soft ? (which == 0 ? -(Dsep + S) + smax : -(Dsep + S)) : -Dsep;
+  r.aq = (soft && which == 1) ? 2.0 * wsl : 0.0;
+  add_point(g, r.rhs, ca, ca == c1 ? rt1 : rt2, ta, ta, al, be);
+  add_point(g, r.rhs, cb, cb == c1 ? rt1 : rt2, tb, tb, -al, -be);
+  return r;
+}
+
+// entry (q, b) of [A B] of the triple integrator chains (model_region_constraints.mod:11-19)
+template <int C>
+__device__ inline double ab_entry(int q, int b, double ts) {
+  constexpr int NX = 6 * C;
+  int ch = q / 3, k = q - 3 * ch;
+  if (b < NX) {
+    int chb = b / 3, kb = b - 3 * chb;
+    if (chb != ch || kb < k) return 0.0;
+    int d = kb - k;
+    return d == 0 ? 1.0 : (d == 1 ? ts : 0.5 * ts * ts);
+  }
+  if (b - NX != ch) return 0.0;
+  return k == 0 ? ts * ts * ts / 6.0 : (k == 1 ? 0.5 * ts * ts : ts);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(64) ipm_kernel(DevBuf B) {
+  constexpr int NX = 6 * C, NU = 2 * C, NZ = 8 * C, GS = NZ + 1;
+  const Layout& Y = B.Y;
+  const int node = blockIdx.x, lane = threadIdx.x;
+  if (node >= *B.batch_count) return;
+  const int inst = B.batch_inst[node];
+  const double* D = B.inst_d + (size_t)inst * Y.dstride;
+  const int* T = B.inst_i + (size_t)inst * Y.istride;
+  const int N = Y.N, NSLOT = Y.NSLOT;
+  const double ts = D[Y.d_glob + 7];
+
+  extern __shared__ double lds[];
+  double* Z = lds;                       // [N][NZ]
+  double* dZ = Z + N * NZ;               // [N][NZ]
+  double* Kg = dZ + N * NZ;              // [N][NU*NX]
+  double* kg = Kg + N * NU * NX;         // [N][NU]
+  double* Gh = kg + N * NU;              // [slots rounded to 64][GS]
+  const int nsl64 = (NSLOT + 63) & ~63;
+  double* fs = Gh + nsl64 * GS;          // [nsl64]
+  double* Phi = fs + nsl64;              // [NZ*NZ]  (becomes S)
+  double* rr = Phi + NZ * NZ;            // [NZ]     (becomes sv)
+  double* Tm = rr + NZ;                  // [NX*NZ]
+  double* Pm = Tm + NX * NZ;             // [NX*NX]
+  double* pv = Pm + NX * NX;             // [NX]
+  double* Lc = pv + NX;                  // [NU*NU]
+  double* Wd = Lc + NU * NU;             // [NZ]
+  signed char* fix = (signed char*)(Wd + NZ);  // [fixlen]
+
+  {
+    const signed char* src = B.pool_fix + (size_t)B.batch_node[node] * Y.fixlen;
+    for (int k = lane; k < Y.fixlen; k += 64) fix[k] = src[k];
+    for (int k = lane; k < NZ; k += 64) Wd[k] = D[Y.d_wd + k];
+    for (int k = lane; k < N * NZ; k += 64) { Z[k] = 0.0; dZ[k] = 0.0; }
+  }
+  __syncthreads();
+  if (lane < NX) Z[lane] = D[Y.d_x0 + lane];
+  __syncthreads();
+  for (int i = 0; i + 1 < N; ++i) {  // free rollout (u = 0)
+    if (lane < NX) {
+      double acc = 0;
+      for (int q = 0; q < NX; ++q) acc += ab_entry<C>(lane, q, ts) * Z[i * NZ + q];
+      Z[(i + 1) * NZ + lane] = acc;
+    }
+    __syncthreads();
+  }
+  double* RS = B.rowstate + (size_t)node * NFIELD * Y.ROWCAP;
+  double* rs_s = RS, *rs_l = RS + Y.ROWCAP, *rs_t = RS + 2 * Y.ROWCAP, *rs_ds = RS + 3 * Y.ROWCAP,
+         *rs_dl = RS + 4 * Y.ROWCAP, *rs_dt = RS + 5 * Y.ROWCAP;
+  const double* Rf = D + Y.d_ref;
+
+  // ---- initial row state, complementarity
+  double csum = 0.0; int cnt = 0;
+  for (int i = 0; i < N; ++i)
+    for (int sb = 0; sb < NSLOT; sb += 64) {
+      int slot = sb + lane;
+      if (slot < NSLOT) {
+        double* g = Gh + lane * GS;
+        RowOut r = decode_row<C>(Y, D, T, fix, i, slot, g);
+        if (r.active) {
+          double c = r.rhs;
+          for (int q = 0; q < NZ; ++q) c -= g[q] * Z[i * NZ + q];
+          double s, lam, t = 0.0;
+          if (r.aq == 0.0) { lam = 1.0; s = fmax(c, 0.0) + 1.0; t = s - c; csum += s * lam + t * (RHO_EL - lam); cnt += 2; }
+          else { lam = fmax(1.0, -2.0 * c * r.aq + 1.0); s = c + lam / r.aq; csum += s * lam; cnt += 1; }
+          int idx = i * NSLOT + slot;
+          rs_s[idx] = s; rs_l[idx] = lam; rs_t[idx] = t;
+        }
+      }
+    }
+  double comp = wave_sum(csum);
+  int ncomp = (int)wave_sum((double)cnt);
+  if (ncomp < 1) ncomp = 1;
+  comp /= ncomp;
+
+  int it = 0, ok = 0;
+  double resid_fac = 1.0, R0 = 0.0, obj = 0.0;
+  unsigned long long rowiters = 0;
+  for (it = 1; it <= QP_MAXIT; ++it) {
+    {
+      double o = 0.0;
+      for (int k = lane; k < N * NZ; k += 64) { double d = Z[k] - Rf[k]; o += Wd[k % NZ] * d * d; }
+      obj = wave_sum(o);
+    }
+    if (comp < QP_TOL * fmax(1.0, fabs(obj)) && resid_fac * R0 < 1e-7) { ok = 1; break; }
+    const double tau = QP_SIGMA * comp;
+    // ================= backward sweep
+    for (int k = lane; k < NX * NX; k += 64) Pm[k] = 0.0;
+    if (lane < NX) pv[lane] = 0.0;
+    double rmax = 0.0;
+    for (int i = N - 1; i >= 0; --i) {
+      __syncthreads();
+      for (int sb = 0; sb < nsl64; sb += 64) {
+        int slot = sb + lane;
+        double* g = Gh + slot * GS;
+        double fsv = 0.0;
+        bool act = false;
+        if (slot < NSLOT) {
+          RowOut r = decode_row<C>(Y, D, T, fix, i, slot, g);
+          act = r.active;
+          if (act) {
+            int idx = i * NSLOT + slot;
+            double s = rs_s[idx], lam = rs_l[idx], zz, r2mu = 0.0;
+            if (r.aq == 0.0) { double t = rs_t[idx], mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
+            else zz = 1.0 / r.aq;
+            double Dd = s / lam + zz, w = 1.0 / Dd;
+            double kap = ((tau - s * lam) / lam - r2mu) / Dd;
+            double sw = sqrt(w);
+            fsv = (lam + kap) / sw;
+#pragma unroll
+            for (int q = 0; q < NZ; ++q) g[q] *= sw;
+          }
+        }
+        if (!act) {
+#pragma unroll
+          for (int q = 0; q < NZ; ++q) g[q] = 0.0;
+        }
+        fs[slot] = fsv;
+      }
+      __syncthreads();
+      // Phi = 2W + Gh' Gh ; rr = 2W(z - ref) + Gh' fs
+      for (int e = lane; e < NZ * NZ; e += 64) {
+        int a = e / NZ, b = e - a * NZ;
+        double acc = (a == b) ? 2.0 * Wd[a] : 0.0;
+        for (int sl = 0; sl < NSLOT; ++sl) acc += Gh[sl * GS + a] * Gh[sl * GS + b];
+        Phi[e] = acc;
+      }
+      if (lane < NZ) {
+        double acc = 2.0 * Wd[lane] * (Z[i * NZ + lane] - Rf[i * NZ + lane]);
+        for (int sl = 0; sl < NSLOT; ++sl) acc += Gh[sl * GS + lane] * fs[sl];
+        rr[lane] = acc;
+        if (it == 1) rmax = fmax(rmax, fabs(acc));
+      }
+      __syncthreads();
+      if (i == N - 1) {  // u_{N-1} = 0 (initial_conditions.mod:25-26)
+        for (int e = lane; e < NX * NX; e += 64) { int a = e / NX, b = e - a * NX; Pm[e] = Phi[a * NZ + b]; }
+        if (lane < NX) pv[lane] = rr[lane];
+        continue;
+      }
+      // T = P [A B]
+      for (int e = lane; e < NX * NZ; e += 64) {
+        int a = e / NZ, b = e - a * NZ;
+        double acc = 0.0;
+        int q0 = b < NX ? 3 * (b / 3) : 3 * (b - NX);
+        for (int q = q0; q < q0 + 3; ++q) acc += Pm[a * NX + q] * ab_entry<C>(q, b, ts);
+        Tm[e] = acc;
+      }
+      __syncthreads();
+      // S = Phi + [A B]' T ; sv = rr + [A B]' p
+      for (int e = lane; e < NZ * NZ; e += 64) {
+        int a = e / NZ, b = e - a * NZ;
+        double acc = Phi[e];
+        int q0 = a < NX ? 3 * (a / 3) : 3 * (a - NX);
+        for (int q = q0; q < q0 + 3; ++q) acc += ab_entry<C>(q, a, ts) * Tm[q * NZ + b];
+        Phi[e] = acc;
+      }
+      if (lane < NZ) {
+        int a = lane; double acc = rr[a];
+        int q0 = a < NX ? 3 * (a / 3) : 3 * (a - NX);
+        for (int q = q0; q < q0 + 3; ++q) acc += ab_entry<C>(q, a, ts) * pv[q];
+        rr[a] = acc;
+      }
+      __syncthreads();
+      // Cholesky of Suu (NU x NU), serial on lane 0 (tiny)
+      if (lane == 0) {
+        for (int a = 0; a < NU; ++a)
+          for (int b = 0; b <= a; ++b) {
+            double acc = Phi[(NX + a) * NZ + NX + b];
+            for (int q = 0; q < b; ++q) acc -= Lc[a * NU + q] * Lc[b * NU + q];
+            if (a == b) Lc[a * NU + a] = sqrt(fmax(acc, 1e-300)); else Lc[a * NU + b] = acc / Lc[b * NU + b];
+          }
+      }
+      __syncthreads();
+      // K = Suu^-1 Sux, k = Suu^-1 su : one lane per right-hand side column
+      double* Ki = Kg + i * NU * NX; double* ki = kg + i * NU;
+      if (lane <= NX) {
+        double y[NU];
+        for (int a = 0; a < NU; ++a) {
+          double acc = lane < NX ? Phi[(NX + a) * NZ + lane] : rr[NX + a];
+          for (int q = 0; q < a; ++q) acc -= Lc[a * NU + q] * y[q];
+          y[a] = acc / Lc[a * NU + a];
+        }
+        for (int a = NU - 1; a >= 0; --a) {
+          double acc = y[a];
+          for (int q = a + 1; q < NU; ++q) acc -= Lc[q * NU + a] * y[q];
+          y[a] = acc / Lc[a * NU + a];
+        }
+        for (int a = 0; a < NU; ++a) { if (lane < NX) Ki[a * NX + lane] = y[a]; else ki[a] = y[a]; }
+      }
+      __syncthreads();
+      // P = Sxx - Sxu K (symmetrised), p = sx - Sxu k
+      for (int e = lane; e < NX * NX; e += 64) {
+        int a = e / NX, b = e - a * NX;
+        double acc = Phi[a * NZ + b], acc2 = Phi[b * NZ + a];
+        for (int q = 0; q < NU; ++q) { acc -= Phi[a * NZ + NX + q] * Ki[q * NX + b]; acc2 -= Phi[b * NZ + NX + q] * Ki[q * NX + a]; }
+        Pm[e] = 0.5 * (acc + acc2);
+      }
+      if (lane < NX) {
+        double acc = rr[lane];
+        for (int q = 0; q < NU; ++q) acc -= Phi[lane * NZ + NX + q] * ki[q];
+        pv[lane] = acc;
+      }
+    }
+    if (it == 1) R0 = wave_max(rmax);
+    __syncthreads();
+    // ================= forward sweep
+    if (lane < NZ) dZ[lane] = 0.0;
+    __syncthreads();
+    for (int i = 0; i + 1 < N; ++i) {
+      const double* Ki = Kg + i * NU * NX; const double* ki = kg + i * NU;
+      if (lane < NU) {
+        double acc = -ki[lane];
+        for (int q = 0; q < NX; ++q) acc -= Ki[lane * NX + q] * dZ[i * NZ + q];
+        dZ[i * NZ + NX + lane] = acc;
+      }
+      __syncthreads();
+      if (lane < NX) {
+        double acc = 0.0;
+        int q0 = 3 * (lane / 3);
+        for (int q = q0; q < q0 + 3; ++q) acc += ab_entry<C>(lane, q, ts) * dZ[i * NZ + q];
+        acc += ab_entry<C>(lane, NX + lane / 3, ts) * dZ[i * NZ + NX + lane / 3];
+        dZ[(i + 1) * NZ + lane] = acc;
+      }
+      __syncthreads();
+    }
+    if (lane < NU) dZ[(N - 1) * NZ + NX + lane] = 0.0;
+    __syncthreads();
+    // ================= step length
+    double amax = 1e300, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int i = 0; i < N; ++i)
+      for (int sb = 0; sb < NSLOT; sb += 64) {
+        int slot = sb + lane;
+        if (slot < NSLOT) {
+          double* g = Gh + lane * GS;
+          RowOut r = decode_row<C>(Y, D, T, fix, i, slot, g);
+          if (r.active) {
+            int idx = i * NSLOT + slot;
+            double gd = 0.0;
+            for (int q = 0; q < NZ; ++q) gd += g[q] * dZ[i * NZ + q];
+            double s = rs_s[idx], lam = rs_l[idx], zz, r2mu = 0.0, t = 0.0, mu = 0.0;
+            if (r.aq == 0.0) { t = rs_t[idx]; mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
+            else zz = 1.0 / r.aq;
+            double Dd = s / lam + zz, w = 1.0 / Dd;
+            double kap = ((tau - s * lam) / lam - r2mu) / Dd;
+            double dl = w * gd + kap;
+            double ds = ((tau - s * lam) - s * dl) / lam;
+            double dt = 0.0;
+            if (ds < 0) amax = fmin(amax, -s / ds);
+            if (dl < 0) amax = fmin(amax, -lam / dl);
+            a0 += s * lam; a1 += s * dl + lam * ds; a2 += ds * dl;
+            if (r.aq == 0.0) {
+              double dmu = -dl;
+              dt = ((tau - t * mu) - t * dmu) / mu;
+              if (dt < 0) amax = fmin(amax, -t / dt);
+              if (dmu < 0) amax = fmin(amax, -mu / dmu);
+              a0 += t * mu; a1 += t * dmu + mu * dt; a2 += dt * dmu;
+            }
+            rs_ds[idx] = ds; rs_dl[idx] = dl; rs_dt[idx] = dt;
+            rowiters++;
+          }
+        }
+      }
+    amax = wave_min(amax);
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    double alpha = fmin(1.0, 0.995 * amax);
+    comp = (a0 + alpha * a1 + alpha * alpha * a2) / ncomp;
+    // ================= update
+    for (int k = lane; k < N * NZ; k += 64) Z[k] += alpha * dZ[k];
+    for (int idx = lane; idx < Y.ROWCAP; idx += 64) {
+      // inactive rows hold garbage that is never read; updating them is harmless
+      rs_s[idx] += alpha * rs_ds[idx]; rs_l[idx] += alpha * rs_dl[idx]; rs_t[idx] += alpha * rs_dt[idx];
+    }
+    resid_fac *= (1.0 - alpha);
+    __syncthreads();
+    if (alpha < 1e-12) break;
+  }
+  // ---- final measures: worst elastic violation, slack cost
+  double viol = 0.0, scost = 0.0;
+  for (int i = 0; i < N; ++i)
+    for (int sb = 0; sb < NSLOT; sb += 64) {
+      int slot = sb + lane;
+      if (slot < NSLOT) {
+        double* g = Gh + lane * GS;
+        RowOut r = decode_row<C>(Y, D, T, fix, i, slot, g);
+        if (r.active) {
+          double c = r.rhs;
+          for (int q = 0; q < NZ; ++q) c -= g[q] * Z[i * NZ + q];
+          if (r.aq == 0.0) viol = fmax(viol, -c);
+          else { double t = rs_l[i * NSLOT + slot] / r.aq; scost += 0.5 * r.aq * t * t; }
+        }
+      }
+    }
+  viol = wave_max(viol); scost = wave_sum(scost);
+  {
+    double o = 0.0;
+    for (int k = lane; k < N * NZ; k += 64) { double d = Z[k] - Rf[k]; o += Wd[k % NZ] * d * d; }
+    obj = wave_sum(o) + scost;
+  }
+  double* Zo = B.batch_Z + (size_t)node * N * NZ;
+  for (int k = lane; k < N * NZ; k += 64) Zo[k] = Z[k];
+  if (lane == 0) {
+    B.batch_obj[node] = obj; B.batch_viol[node] = viol; B.batch_ok[node] = ok; B.batch_it[node] = it > QP_MAXIT ? QP_MAXIT : it;
+    atomicAdd((unsigned long long*)&B.inst_iters[inst], (unsigned long long)(it > QP_MAXIT ? QP_MAXIT : it));
+    atomicAdd((unsigned long long*)&B.inst_nodes[inst], 1ull);
+  }
+  rowiters = (unsigned long long)wave_sum((double)rowiters);
+  if (lane == 0) atomicAdd(B.stat_rowiters, rowiters);
+}
+
+// ------------------------------------------------------------------------------------------------
+//  eval kernel helpers: violation of alternatives evaluated directly from the stage state
+struct CarState { double px, vx, ax, py, vy, ay, ux, uy; };
+
+__device__ inline void point_xy(const CarState& s, const double* rt, int tx, int ty, double& X, double& Y) {
+  X = s.px; Y = s.py;
+  if (tx != PT_R) { const double* p = rt + 19 + (tx == PT_U ? 0 : 3); X += p[0] + p[1] * s.vx + p[2] * s.vy; }
+  if (ty != PT_R) { const double* p = rt + 25 + (ty == PT_U ? 0 : 3); Y += p[0] + p[1] * s.vx + p[2] * s.vy; }
+}
+
+__device__ inline double box_viol(const CarState& s, const double* rt, bool with_jerk) {
+  double v = fmax(fmax(s.ax - rt[12], rt[11] - s.ax), fmax(s.ay - rt[14], rt[13] - s.ay));
+  if (with_jerk) v = fmax(v, fmax(fmax(s.ux - rt[16], rt[15] - s.ux), fmax(s.uy - rt[18], rt[17] - s.uy)));
+  return v;
+}
+
+__device__ inline double region_alt_viol(const Layout& Y, const double* D, const int* T, int c, int q, int h, const CarState& s,
+                                         bool with_jerk) {
+  const double* rt = D + Y.d_reg + (c * Y.P + q) * REGSZ;
+  double vm = D[Y.d_glob + 6];
+  double v = box_viol(s, rt, with_jerk);
+  if (h == 3) return fmax(v, fmax(fabs(s.vx) - vm, fabs(s.vy) - vm));
+  v = fmax(v, rt[0] * s.vx + rt[1] * s.vy);
+  v = fmax(v, rt[2] * s.vx + rt[3] * s.vy);
+  const int* hs = T + Y.i_hs + ((c * Y.P + q) * 2 + h) * 2;
+  v = fmax(v, vm - hs[1] * (hs[0] == 0 ? s.vx : s.vy));
+  v = fmax(v, s.ay - rt[4] * s.ax - rt[6] * s.vx - rt[7] * s.vy - rt[5]);
+  v = fmax(v, -s.ay + rt[4] * s.ax + rt[9] * s.vx + rt[10] * s.vy + rt[8]);
+  return v;
+}
+
+__device__ inline double env_alt_viol(const Layout& Y, const double* D, const int* T, int e, double X, double Yc) {
+  double v = -1e300; int n = T[Y.i_envn + e];
+  for (int k = 0; k < n; ++k) { const double* ed = D + Y.d_env + (e * Y.EL + k) * 3; v = fmax(v, ed[0] * X + ed[1] * Yc - ed[2]); }
+  return v;
+}
+
+// zero-slack violation of c2c alternative (C == 2)
+__device__ inline double c2c_alt_viol(const Layout& Y, const double* D, int p, int i, int grp, int alt, const CarState& s1, const double* rt1,
+                                      const CarState& s2, const double* rt2) {
+  double Dsep = D[Y.d_dsep + p * Y.N + i], S = D[Y.d_ssl + i];
+  bool isx = alt < 2, lo = (alt == 0 || alt == 2);
+  bool soft = (grp == 0 || grp == 3);
+  int a1, ta, tb;  // A is car a1 (1 or 2), B the other
+  if (grp == 0) { ta = tb = PT_R; a1 = lo ? 1 : 2; }
+  else if (grp == 1) { if (lo) { a1 = 1; ta = PT_R; tb = PT_L; } else { a1 = 2; ta = PT_U; tb = PT_R; } }
+  else if (grp == 2) { if (lo) { a1 = 2; ta = PT_R; tb = PT_L; } else { a1 = 1; ta = PT_U; tb = PT_R; } }
+  else { if (lo) { a1 = 2; ta = PT_U; tb = PT_L; } else { a1 = 1; ta = PT_U; tb = PT_L; } }
+  double XA, YA, XB, YB;
+  if (a1 == 1) { point_xy(s1, rt1, ta, ta, XA, YA); point_xy(s2, rt2, tb, tb, XB, YB); }
+  else { point_xy(s2, rt2, ta, ta, XA, YA); point_xy(s1, rt1, tb, tb, XB, YB); }
+  double lhs = isx ? XA - XB : YA - YB;
+  return lhs + (soft ? Dsep + S : Dsep);
+}
+
+struct BranchDesc { int prio; int kind; int c; int o; int i; int pt; };  // kind: 0 region 1 env 2 obs 3 c2c
+
+template <int C>
+__global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
+  constexpr int NZ = 8 * C;
+  const Layout& Y = B.Y;
+  const int node = blockIdx.x, lane = threadIdx.x;
+  if (node >= *B.batch_count) return;
+  const int inst = B.batch_inst[node];
+  const double* D = B.inst_d + (size_t)inst * Y.dstride;
+  const int* T = B.inst_i + (size_t)inst * Y.istride;
+  const int N = Y.N, P = Y.P;
+  extern __shared__ double lds[];
+  double* Z = lds;                                   // [N][NZ]
+  double* slowv = Z + N * NZ;                        // [C*N][P] slow-alternative violation per possible region
+  double* fastv = slowv + C * N * P;                 // [C*N] best fast alternative violation
+  int* fastc = (int*)(fastv + C * N);                // [C*N] its code
+  int* vflag = fastc + C * N;                        // [C*N] region violated
+  int* altbuf = vflag + C * N;                       // [64]
+  double* altval = (double*)(altbuf + 64);           // [64]
+  signed char* fix = (signed char*)(altval + 64);    // [fixlen]
+  signed char* comp = fix + Y.fixlen;                // [fixlen]
+  __shared__ BranchDesc chosen;
+  __shared__ int sh_base[3];
+
+  const double* Zi = B.batch_Z + (size_t)node * N * NZ;
+  const signed char* src = B.pool_fix + (size_t)B.batch_node[node] * Y.fixlen;
+  for (int k = lane; k < N * NZ; k += 64) Z[k] = Zi[k];
+  for (int k = lane; k < Y.fixlen; k += 64) { fix[k] = src[k]; comp[k] = src[k]; }
+  __syncthreads();
+  const double viol = B.batch_viol[node];
+  const int okq = B.batch_ok[node];
+  if (viol > FEAS_TOL || !okq) return;  // infeasible relaxation
+  // soft obstacles that this node ignores cost WEIGHTS_SLACK_OBSTACLE each (obstacle_environment_constraints.mod:85-91)
+  int nign = 0;
+  for (int k = lane; k < C * Y.O * N * 5; k += 64) nign += fix[Y.f_obs + k] >= Y.L ? 1 : 0;
+  nign = (int)wave_sum((double)nign);
+  const double obj = B.batch_obj[node] + B.inst_const[inst] + nign * D[Y.d_misc + 1];
+  const double inc_now = inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]);
+  if (inc_now < 1e300 && !(obj < inc_now - 1e-12 * fabs(inc_now))) return;  // bound not better than the incumbent
+  const double tol = FEAS_TOL;
+  const int NCI = C * (N - 1);
+  // ---------------- phase R: region alternatives per (c, i)
+  for (int L0 = 0; L0 < NCI; L0 += 64) {
+    int L = L0 + lane;
+    if (L < NCI) {
+      int c = L / (N - 1), i = 1 + L % (N - 1);
+      const double* z = Z + i * NZ;
+      CarState s = {z[6 * c], z[6 * c + 1], z[6 * c + 2], z[6 * c + 3], z[6 * c + 4], z[6 * c + 5], z[6 * C + 2 * c], z[6 * C + 2 * c + 1]};
+      bool wj = i <= N - 2;
+      int np = T[Y.i_nposs + c];
+      int nxt = (i + 1 < N) ? (int)fix[Y.f_reg + c * N + i + 1] : -1;
+      int nxtq = (nxt >= 0 && (nxt & 3) == 3) ? (nxt >> 2) : -1;  // next step frozen to this region
+      double bv = 1e300; int bc = -1;
+      for (int q = 0; q < np; ++q) {
+        slowv[(c * N + i) * P + q] = (nxtq >= 0 && nxtq != q) ? 1e300 : region_alt_viol(Y, D, T, c, q, 3, s, wj);
+        if (nxtq >= 0 && nxtq != q) continue;
+        int nh = T[Y.i_nhs + c * P + q];
+        for (int h = 0; h < nh; ++h) {
+          double v = region_alt_viol(Y, D, T, c, q, h, s, wj);
+          if (v < bv) { bv = v; bc = q * 4 + h; }
+        }
+      }
+      fastv[c * N + i] = bv; fastc[c * N + i] = bc; vflag[c * N + i] = 0;
+    }
+  }
+  __syncthreads();
+  if (lane < C) {  // sequential resolution of the freeze (slow => same region as the previous step)
+    int c = lane; int prevj = T[Y.i_initj + c];
+    int np = T[Y.i_nposs + c];
+    for (int i = 1; i < N; ++i) {
+      int code = (int)fix[Y.f_reg + c * N + i];
+      if (code < 0) {
+        double bv = fastv[c * N + i]; int bc = fastc[c * N + i];
+        for (int q = 0; q < np; ++q)
+          if (T[Y.i_regj + c * P + q] == prevj) { double v = slowv[(c * N + i) * P + q]; if (v < bv) { bv = v; bc = q * 4 + 3; } }
+        if (bc < 0 || bv > tol) { vflag[c * N + i] = 1; if (bc < 0) bc = 0; }
+        comp[Y.f_reg + c * N + i] = (signed char)bc;
+        code = bc;
+      }
+      prevj = T[Y.i_regj + c * P + (code >> 2)];
+    }
+  }
+  __syncthreads();
+  // ---------------- phase L: leaf disjunctions; every lane keeps its most urgent violated disjunction
+  BranchDesc mine; mine.prio = 0x7FFFFFFF; mine.kind = 0; mine.c = 0; mine.o = 0; mine.i = 0; mine.pt = 0;
+  auto consider = [&](int step, int kind, int c, int o, int pt) {
+    int prio = ((step * 4 + kind) << 12) | ((c & 7) << 9) | ((o & 31) << 4) | (pt & 15);
+    if (prio < mine.prio) { mine.prio = prio; mine.kind = kind; mine.c = c; mine.o = o; mine.i = step; mine.pt = pt; }
+  };
+  for (int L0 = 0; L0 < NCI; L0 += 64) {
+    int L = L0 + lane;
+    if (L < NCI) {
+      int c = L / (N - 1), i = 1 + L % (N - 1);
+      const double* z = Z + i * NZ;
+      CarState s = {z[6 * c], z[6 * c + 1], z[6 * c + 2], z[6 * c + 3], z[6 * c + 4], z[6 * c + 5], z[6 * C + 2 * c], z[6 * C + 2 * c + 1]};
+      if (vflag[c * N + i]) consider(i, 0, c, 0, 0);
+      int code = (int)comp[Y.f_reg + c * N + i];
+      const double* rt = D + Y.d_reg + (c * P + (code >> 2)) * REGSZ;
+      bool runfixed = fix[Y.f_reg + c * N + i] < 0;
+      if (Y.E >= 1)
+        for (int pt = 0; pt < 5; ++pt) {
+          double X, Yc; point_xy(s, rt, ENV_PT_D[pt][0], ENV_PT_D[pt][1], X, Yc);
+          if (Y.E == 1) {
+            if (pt > 0 && runfixed && env_alt_viol(Y, D, T, 0, X, Yc) > tol) consider(i, 0, c, 0, 0);
+            comp[Y.f_env + (c * N + i) * 5 + pt] = 0;
+            continue;
+          }
+          int fx = (int)fix[Y.f_env + (c * N + i) * 5 + pt];
+          if (fx >= 0 && !(pt > 0 && runfixed)) continue;
+          bool okk;
+          if (fx >= 0) okk = env_alt_viol(Y, D, T, fx, X, Yc) <= tol;
+          else {
+            double bv = 1e300; int be = 0;
+            for (int e = 0; e < Y.E; ++e) { double v = env_alt_viol(Y, D, T, e, X, Yc); if (v < bv) { bv = v; be = e; } }
+            okk = bv <= tol; comp[Y.f_env + (c * N + i) * 5 + pt] = (signed char)be;
+          }
+          if (!okk) { if (pt > 0 && runfixed) consider(i, 0, c, 0, 0); else consider(i, 1, c, 0, pt); }
+        }
+      for (int o = 0; o < Y.O; ++o)
+        for (int pt = 0; pt < 5; ++pt) {
+          int fx = (int)fix[Y.f_obs + ((c * Y.O + o) * N + i) * 5 + pt];
+          if (fx >= 0 && (fx >= Y.L || !(pt > 0 && runfixed))) continue;
+          double X, Yc; point_xy(s, rt, OBS_PT_D[pt][0], OBS_PT_D[pt][1], X, Yc);
+          bool okk;
+          if (fx >= 0) { const double* ed = D + Y.d_obs + ((o * N + i) * Y.L + fx) * 3; okk = ed[0] * X + ed[1] * Yc - ed[2] <= tol; }
+          else {
+            double bv = 1e300; int bk = 0;
+            for (int k = 0; k < Y.L; ++k) { const double* ed = D + Y.d_obs + ((o * N + i) * Y.L + k) * 3; double v = ed[0] * X + ed[1] * Yc - ed[2]; if (v < bv) { bv = v; bk = k; } }
+            okk = bv <= tol; comp[Y.f_obs + ((c * Y.O + o) * N + i) * 5 + pt] = (signed char)bk;
+          }
+          if (!okk) { if (pt > 0 && runfixed) consider(i, 0, c, 0, 0); else consider(i, 2, c, o, pt); }
+        }
+    }
+  }
+  if (C == 2) {
+    for (int L0 = 0; L0 < N - 1; L0 += 64) {
+      int L = L0 + lane;
+      if (L < N - 1) {
+        int i = 1 + L; const double* z = Z + i * NZ;
+        CarState s1 = {z[0], z[1], z[2], z[3], z[4], z[5], z[6 * C], z[6 * C + 1]};
+        CarState s2 = {z[6], z[7], z[8], z[9], z[10], z[11], z[6 * C + 2], z[6 * C + 3]};
+        int code1 = (int)comp[Y.f_reg + 0 * N + i], code2 = (int)comp[Y.f_reg + 1 * N + i];
+        const double* rt1 = D + Y.d_reg + (0 * P + (code1 >> 2)) * REGSZ; const double* rt2 = D + Y.d_reg + (1 * P + (code2 >> 2)) * REGSZ;
+        for (int g = 0; g < 4; ++g) {
+          bool need1 = g >= 2, need2 = (g == 1 || g == 3);
+          int unf = -1;
+          if (need1 && fix[Y.f_reg + 0 * N + i] < 0) unf = 0; else if (need2 && fix[Y.f_reg + 1 * N + i] < 0) unf = 1;
+          int fx = (int)fix[Y.f_c2c + (0 * N + i) * 4 + g];
+          if (fx >= 0 && unf < 0) continue;
+          bool okk;
+          if (fx >= 0) okk = c2c_alt_viol(Y, D, 0, i, g, fx, s1, rt1, s2, rt2) <= tol;
+          else {
+            double bv = 1e300; int ba = 0;
+            for (int a = 0; a < 4; ++a) { double v = c2c_alt_viol(Y, D, 0, i, g, a, s1, rt1, s2, rt2); if (v < bv) { bv = v; ba = a; } }
+            okk = bv <= tol; comp[Y.f_c2c + (0 * N + i) * 4 + g] = (signed char)ba;
+          }
+          if (!okk) { if (unf >= 0) consider(i, 0, unf, 0, 0); else consider(i, 3, 0, g, 0); }
+        }
+      }
+    }
+  }
+  // wave-wide most urgent disjunction
+  int best = mine.prio;
+  for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+  __syncthreads();
+  if (best == 0x7FFFFFFF) {
+    // integer feasible: candidate incumbent.  The winner of the 64-bit atomicMin owns the low 20 bits (batch slot).
+    signed char* dst = B.batch_comp + (size_t)node * Y.fixlen;
+    for (int k = lane; k < Y.fixlen; k += 64) dst[k] = comp[k];
+    if (lane == 0) {
+      unsigned long long key = (d2key(obj) & ~0xFFFFFull) | (unsigned long long)node;
+      atomicMin(&B.inc_key[inst], key);
+      B.batch_obj[node] = obj;
+      atomicAdd(&B.inst_ninc[inst], 1);
+    }
+    return;
+  }
+  unsigned long long bal = __ballot(mine.prio == best);
+  int winner = __ffsll((long long)bal) - 1;
+  if (lane == winner) chosen = mine;
+  __syncthreads();
+  // ---------------- alternatives of the chosen disjunction, most promising first
+  int nalt = 0;
+  if (lane == 0) {
+    BranchDesc d = chosen; int i = d.i;
+    const double* z = Z + i * NZ;
+    if (d.kind == 0) {
+      int c = d.c; int np = T[Y.i_nposs + c];
+      CarState s = {z[6 * c], z[6 * c + 1], z[6 * c + 2], z[6 * c + 3], z[6 * c + 4], z[6 * c + 5], z[6 * C + 2 * c], z[6 * C + 2 * c + 1]};
+      int prevj = -2;
+      if (i == 1) prevj = T[Y.i_initj + c]; else if (fix[Y.f_reg + c * N + i - 1] >= 0) prevj = T[Y.i_regj + c * P + (fix[Y.f_reg + c * N + i - 1] >> 2)];
+      int nxt = (i + 1 < N) ? (int)fix[Y.f_reg + c * N + i + 1] : -1;
+      int nxtq = (nxt >= 0 && (nxt & 3) == 3) ? (nxt >> 2) : -1;
+      for (int q = 0; q < np; ++q) {
+        if (nxtq >= 0 && nxtq != q) continue;
+        int nh = T[Y.i_nhs + c * P + q];
+        for (int h = 0; h < 4; ++h) {
+          if (h < 3 && h >= nh) continue;
+          if (h == 3 && prevj != -2 && prevj != T[Y.i_regj + c * P + q]) continue;
+          if (nalt < 63) { altbuf[nalt] = q * 4 + h; altval[nalt] = region_alt_viol(Y, D, T, c, q, h, s, i <= N - 2); nalt++; }
+        }
+      }
+    } else if (d.kind == 1) {
+      int c = d.c; CarState s = {z[6 * c], z[6 * c + 1], z[6 * c + 2], z[6 * c + 3], z[6 * c + 4], z[6 * c + 5], 0, 0};
+      int code = (int)comp[Y.f_reg + c * N + i]; const double* rt = D + Y.d_reg + (c * P + (code >> 2)) * REGSZ;
+      double X, Yc; point_xy(s, rt, ENV_PT_D[d.pt][0], ENV_PT_D[d.pt][1], X, Yc);
+      for (int e = 0; e < Y.E && nalt < 64; ++e) { altbuf[nalt] = e; altval[nalt] = env_alt_viol(Y, D, T, e, X, Yc); nalt++; }
+    } else if (d.kind == 2) {
+      int c = d.c; CarState s = {z[6 * c], z[6 * c + 1], z[6 * c + 2], z[6 * c + 3], z[6 * c + 4], z[6 * c + 5], 0, 0};
+      int code = (int)comp[Y.f_reg + c * N + i]; const double* rt = D + Y.d_reg + (c * P + (code >> 2)) * REGSZ;
+      double X, Yc; point_xy(s, rt, OBS_PT_D[d.pt][0], OBS_PT_D[d.pt][1], X, Yc);
+      for (int k = 0; k < Y.L; ++k) { const double* ed = D + Y.d_obs + ((d.o * N + i) * Y.L + k) * 3; altbuf[nalt] = k; altval[nalt] = ed[0] * X + ed[1] * Yc - ed[2]; nalt++; }
+      if (T[Y.i_obssoft + d.o]) { altbuf[nalt] = Y.L; altval[nalt] = 1e299; nalt++; }
+    } else {
+      CarState s1 = {z[0], z[1], z[2], z[3], z[4], z[5], 0, 0}, s2 = {z[6], z[7], z[8], z[9], z[10], z[11], 0, 0};
+      int code1 = (int)comp[Y.f_reg + 0 * N + i], code2 = (int)comp[Y.f_reg + 1 * N + i];
+      const double* rt1 = D + Y.d_reg + (0 * P + (code1 >> 2)) * REGSZ; const double* rt2 = D + Y.d_reg + (1 * P + (code2 >> 2)) * REGSZ;
+      for (int a = 0; a < 4; ++a) { altbuf[nalt] = a; altval[nalt] = c2c_alt_viol(Y, D, 0, i, d.o, a, s1, rt1, s2, rt2); nalt++; }
+    }
+    for (int a = 1; a < nalt; ++a) {  // insertion sort by violation
+      int ia = altbuf[a]; double va = altval[a]; int b = a - 1;
+      while (b >= 0 && altval[b] > va) { altbuf[b + 1] = altbuf[b]; altval[b + 1] = altval[b]; b--; }
+      altbuf[b + 1] = ia; altval[b + 1] = va;
+    }
+    int nb = atomicAdd(B.pool_count, nalt);
+    int ob = atomicAdd(&B.open_count[inst], nalt);
+    if (nb + nalt > B.pool_cap || ob + nalt > B.open_cap) { atomicOr(&B.inst_flags[inst], 1); nalt = 0; }
+    sh_base[0] = nb; sh_base[1] = ob; sh_base[2] = nalt;
+  }
+  __syncthreads();
+  nalt = sh_base[2];
+  if (nalt <= 0) return;
+  {
+    BranchDesc d = chosen;
+    int off;
+    if (d.kind == 0) off = Y.f_reg + d.c * N + d.i;
+    else if (d.kind == 1) off = Y.f_env + (d.c * N + d.i) * 5 + d.pt;
+    else if (d.kind == 2) off = Y.f_obs + ((d.c * Y.O + d.o) * N + d.i) * 5 + d.pt;
+    else off = Y.f_c2c + (0 * N + d.i) * 4 + d.o;
+    int nb = sh_base[0], ob = sh_base[1];
+    for (int a = 0; a < nalt; ++a) {
+      signed char* dst = B.pool_fix + (size_t)(nb + a) * Y.fixlen;
+      for (int k = lane; k < Y.fixlen; k += 64) dst[k] = (k == off) ? (signed char)altbuf[a] : fix[k];
+    }
+    if (lane < nalt) {
+      size_t oi = (size_t)inst * B.open_cap + ob + lane;
+      // a soft obstacle that is ignored costs WEIGHTS_SLACK_OBSTACLE (obstacle_environment_constraints.mod:85-91)
+      B.open_bound[oi] = obj - B.inst_const[inst]; B.open_node[oi] = nb + lane;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+//  select: per instance prune + sort + pick
+constexpr int SEL_THREADS = 256;
+
+__global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round) {
+  const Layout& Y = B.Y;
+  const int inst = blockIdx.x, tid = threadIdx.x;
+  extern __shared__ double lds[];
+  const int cap = B.open_cap;
+  int cap2 = 1; while (cap2 < cap) cap2 <<= 1;
+  double* kb = lds;                  // [cap2] bounds
+  int* kn = (int*)(kb + cap2);       // [cap2] node ids
+  __shared__ int sh_n, sh_take, sh_base;
+  __shared__ double sh_inc;
+  if (B.inst_done[inst]) return;
+  // ---- incumbent bookkeeping: copy the solution of the atomicMin winner of the last round
+  if (tid == 0) {
+    unsigned long long key = B.inc_key[inst];
+    sh_inc = inc_from_key(key);
+    sh_take = -1;
+    if (key != B.inc_seen[inst]) { sh_take = (int)(key & 0xFFFFFull); B.inc_seen[inst] = key; }
+  }
+  __syncthreads();
+  if (sh_take >= 0) {
+    int slot = sh_take;
+    const signed char* cf = B.batch_comp + (size_t)slot * Y.fixlen; signed char* df = B.inc_fix + (size_t)inst * Y.fixlen;
+    for (int k = tid; k < Y.fixlen; k += SEL_THREADS) df[k] = cf[k];
+    const double* zs = B.batch_Z + (size_t)slot * Y.N * Y.nz; double* zd = B.inc_Z + (size_t)inst * Y.N * Y.nz;
+    for (int k = tid; k < Y.N * Y.nz; k += SEL_THREADS) zd[k] = zs[k];
+    if (tid == 0) B.inc_obj[inst] = B.batch_obj[slot];
+  }
+  __syncthreads();
+  const double inc = sh_inc < 1e300 ? B.inc_obj[inst] : 1e300;
+  const double cst = B.inst_const[inst];
+  const double gap = B.inst_gap[inst];
+  int n = B.open_count[inst]; if (n > cap) n = cap;
+  // bounds in the open list exclude the instance constant
+  double lb = 1e300;
+  for (int k = tid; k < cap2; k += SEL_THREADS) {
+    double b = 1e300; int nd = -1;
+    if (k < n) { b = B.open_bound[(size_t)inst * cap + k]; nd = B.open_node[(size_t)inst * cap + k]; lb = fmin(lb, b); }
+    // prune: cannot improve the incumbent by more than the gap
+    if (k < n && inc < 1e300 && (inc - (b + cst)) <= gap * (1e-10 + fabs(inc))) { b = 1e300; nd = -1; }
+    kb[k] = b; kn[k] = nd;
+  }
+  __shared__ double red[SEL_THREADS];
+  red[tid] = lb; __syncthreads();
+  for (int s = SEL_THREADS / 2; s > 0; s >>= 1) { if (tid < s) red[tid] = fmin(red[tid], red[tid + s]); __syncthreads(); }
+  lb = red[0];
+  // bitonic sort ascending by bound
+  for (int k2 = 2; k2 <= cap2; k2 <<= 1)
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < cap2; t += SEL_THREADS) {
+        int ixj = t ^ j;
+        if (ixj > t) {
+          bool up = (t & k2) == 0;
+          double a = kb[t], b = kb[ixj];
+          if ((a > b) == up) { kb[t] = b; kb[ixj] = a; int x = kn[t]; kn[t] = kn[ixj]; kn[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  if (tid == 0) {
+    int m = 0; while (m < cap2 && kb[m] < 1e299) m++;
+    sh_n = m;
+    int take = m < B.nodes_per_round ? m : B.nodes_per_round;
+    sh_take = take;
+    sh_base = take > 0 ? atomicAdd(B.batch_count, take) : 0;
+    double lbt = (n > 0 ? lb + cst : inc);
+    if (inc < 1e300 && lbt > inc) lbt = inc;
+    B.lower_bound[inst] = lbt;
+    if (m == 0) {  // tree exhausted or everything within the gap
+      B.inst_done[inst] = 1; atomicSub(B.active_insts, 1);
+    }
+  }
+  __syncthreads();
+  int m = sh_n, take = sh_take, base = sh_base;
+  for (int k = tid; k < take; k += SEL_THREADS) {
+    if (base + k < B.batch_cap) { B.batch_node[base + k] = kn[k]; B.batch_inst[base + k] = inst; B.batch_bound[base + k] = kb[k]; }
+  }
+  for (int k = tid; k < m - take; k += SEL_THREADS) {
+    B.open_bound[(size_t)inst * cap + k] = kb[take + k]; B.open_node[(size_t)inst * cap + k] = kn[take + k];
+  }
+  __syncthreads();
+  if (tid == 0) B.open_count[inst] = m - take;
+  (void)round;
+}
+
+}  // namespace miqp

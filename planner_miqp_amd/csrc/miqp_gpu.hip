@@ -1,0 +1,669 @@
+// miqp_gpu.hip - host side of libmiqp_gpu.so: C ABI (include/miqp_gpu.h), device buffer management and the
+// round loop  select -> interior point -> evaluate/branch  of the on-device branch and bound.
+//
+// There is no CPU solve path in this library: without a HIP device the solve entry points return
+// MIQP_STATUS_FAILED_SEG_FAULT (the reference's code for "the solver could not run", cplex_wrapper.cpp:97-109).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/miqp_gpu.h"
+#include "kernels.hip"
+
+using namespace miqp;
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "[miqp_gpu] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return false; } } while (0)
+
+struct miqp_solver {
+  miqp_solver_opts opts{};
+  HostInst inst; bool has_inst = false;
+  // last solution
+  int status = MIQP_STATUS_FAILED_NO_SOLUT;
+  miqp_solution_properties_c props{};
+  std::vector<double> Z; std::vector<signed char> comp; bool has_sol = false;
+  Layout lay{};
+  double timing[6] = {0, 0, 0, 0, 0, 0};
+  // warm start (tried as first incumbent)
+  bool has_ws = false; std::vector<signed char> ws_fix;
+  std::string err;
+};
+
+// host copies of the corner tables (kernels.hip keeps them in constant memory)
+static const int ENV_PT_H[5][2] = {{PT_R, PT_R}, {PT_U, PT_U}, {PT_L, PT_U}, {PT_U, PT_L}, {PT_L, PT_L}};
+static const int OBS_PT_H[5][2] = {{PT_R, PT_R}, {PT_L, PT_L}, {PT_U, PT_L}, {PT_L, PT_U}, {PT_U, PT_U}};
+
+namespace {
+
+// ---------------------------------------------------------------- raw model sizes
+void raw_sizes(const HostInst& I, int& rows, int& bin, int& cont, int& nnz_unused) {
+  long C = I.C, N = I.N, R = I.R, E = I.E, O = I.O, L = I.L, K = I.C - 1;
+  bin = (int)(C * N * (5 * E + R + 5 + 5 * O * L) + K * K * N * 16);
+  cont = (int)(C * N * (12 + 5 * O) + K * K * N * 4);
+  long a4 = 0;
+  for (int c = 0; c < C; ++c) { long P = 0; for (int j = 0; j < R; ++j) P += I.possible[c * R + j] == 1; a4 += 20 * P + (R - P) + 1; }
+  long env_edges = E > 0 ? I.env_off[E] : 0;
+  long r = C * (17 + 5 * R) + 6 * (N - 1) * C + 12 * N * C + (N - 1) * a4 + 15 * R * (N - 1) * C;
+  if (E > 0) r += N * C * (5 * env_edges + 5);
+  if (O > 0) r += N * C * O * (5 * L + 5);
+  if (C > 1) { long tri = 0; for (long c1 = 2; c1 <= K; ++c1) tri += c1 - 1; r += N * 20 * tri + 24 * N * C * (C - 1) / 2; }
+  rows = (int)r; nnz_unused = 0;
+}
+
+// ---------------------------------------------------------------- host geometry helpers (results, step-1 presolve)
+struct HostGeo {
+  const HostInst& I; const Layout& Y; const double* D; const int* T;
+  void point(int c, int i, int q /*possible idx*/, const double* z, int tx, int ty, double& X, double& Yc) const {
+    if (i == 0) {
+      X = I.x0[c * 6 + 0]; Yc = I.x0[c * 6 + 3];
+      if (tx != PT_R) X = D[Y.d_theta + c * 4 + 0];
+      if (ty != PT_R) Yc = D[Y.d_theta + c * 4 + 1];
+      return;
+    }
+    const double* rt = D + Y.d_reg + (c * Y.P + q) * REGSZ;
+    double vx = z[6 * c + 1], vy = z[6 * c + 4];
+    X = z[6 * c + 0]; Yc = z[6 * c + 3];
+    if (tx != PT_R) { const double* p = rt + 19 + (tx == PT_U ? 0 : 3); X += p[0] + p[1] * vx + p[2] * vy; }
+    if (ty != PT_R) { const double* p = rt + 25 + (ty == PT_U ? 0 : 3); Yc += p[0] + p[1] * vx + p[2] * vy; }
+  }
+  double env_viol(int e, double X, double Yc) const {
+    double v = -1e300; for (int k = 0; k < T[Y.i_envn + e]; ++k) { const double* ed = D + Y.d_env + (e * Y.EL + k) * 3; v = std::max(v, ed[0] * X + ed[1] * Yc - ed[2]); }
+    return v;
+  }
+  double obs_viol(int o, int i, int k, double X, double Yc) const { const double* ed = D + Y.d_obs + ((o * Y.N + i) * Y.L + k) * 3; return ed[0] * X + ed[1] * Yc - ed[2]; }
+  // zero-slack violation of (pair, step, group, alt): lhs + sep
+  double c2c_viol(int p, int c1, int c2, int i, int grp, int alt, int q1, int q2, const double* z) const {
+    double Dsep = D[Y.d_dsep + p * Y.N + i], S = D[Y.d_ssl + i];
+    bool isx = alt < 2, lo = (alt == 0 || alt == 2), soft = (grp == 0 || grp == 3);
+    int ca, cb, ta, tb;
+    if (grp == 0) { ta = tb = PT_R; ca = lo ? c1 : c2; cb = lo ? c2 : c1; }
+    else if (grp == 1) { if (lo) { ca = c1; ta = PT_R; cb = c2; tb = PT_L; } else { ca = c2; ta = PT_U; cb = c1; tb = PT_R; } }
+    else if (grp == 2) { if (lo) { ca = c2; ta = PT_R; cb = c1; tb = PT_L; } else { ca = c1; ta = PT_U; cb = c2; tb = PT_R; } }
+    else { if (lo) { ca = c2; ta = PT_U; cb = c1; tb = PT_L; } else { ca = c1; ta = PT_U; cb = c2; tb = PT_L; } }
+    double XA, YA, XB, YB;
+    point(ca, i, ca == c1 ? q1 : q2, z, ta, ta, XA, YA); point(cb, i, cb == c1 ? q1 : q2, z, tb, tb, XB, YB);
+    return (isx ? XA - XB : YA - YB) + (soft ? Dsep + S : Dsep);
+  }
+};
+
+// step 1 of the horizon is fixed by initial_conditions.mod:11-24 -> every row of it is a constant
+bool step0_check(const HostGeo& G, double& cobj) {
+  const HostInst& I = G.I; const Layout& Y = G.Y; double tol = FEAS_TOL; cobj = 0;
+  for (int c = 0; c < I.C; ++c) {
+    if (I.E >= 1)
+      for (int pt = 0; pt < 5; ++pt) {
+        double X, Yc; G.point(c, 0, 0, nullptr, ENV_PT_H[pt][0], ENV_PT_H[pt][1], X, Yc);
+        bool any = false; for (int e = 0; e < I.E && !any; ++e) any = G.env_viol(e, X, Yc) <= tol;
+        if (!any) return false;
+      }
+    for (int o = 0; o < I.O; ++o)
+      for (int pt = 0; pt < 5; ++pt) {
+        double X, Yc; G.point(c, 0, 0, nullptr, OBS_PT_H[pt][0], OBS_PT_H[pt][1], X, Yc);
+        bool any = false; for (int k = 0; k < I.L && !any; ++k) any = G.obs_viol(o, 0, k, X, Yc) <= tol;
+        if (!any) { if (I.obs_soft[o]) cobj += I.w_slack_obs; else return false; }
+      }
+  }
+  int p = 0;
+  for (int c1 = 0; c1 < I.C; ++c1)
+    for (int c2 = c1 + 1; c2 < I.C; ++c2, ++p)
+      for (int g = 0; g < 4; ++g) {
+        double best = 1e300; double smax = G.D[Y.d_smax + 0];
+        for (int a = 0; a < 4; ++a) {
+          double v = G.c2c_viol(p, c1, c2, 0, g, a, 0, 0, nullptr);
+          bool soft = (g == 0 || g == 3);
+          if (v - (soft ? smax : 0.0) > tol) continue;
+          double need = soft ? std::max(0.0, v) : 0.0;
+          best = std::min(best, I.w_slack * need * need);
+        }
+        if (best > 1e299) return false;
+        cobj += best;
+      }
+  return true;
+}
+
+}  // namespace
+
+
+// ================================================================================================
+//  device context (buffers are cached between calls with the same shape)
+// ================================================================================================
+namespace {
+
+struct DevCtx {
+  bool ready = false; int device = -1;
+  hipStream_t stream = nullptr;
+  Layout Y{}; int n_inst = 0, open_cap = 0, batch_cap = 0, pool_cap = 0, npr = 0;
+  DevBuf B{};
+  std::vector<void*> allocs;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> ipm_ev;  // pairs
+  template <class Tp> bool alloc(Tp** p, size_t n) {
+    void* q = nullptr;
+    if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(Tp)) != hipSuccess) { std::fprintf(stderr, "[miqp_gpu] hipMalloc of %zu bytes failed\n", n * sizeof(Tp)); return false; }
+    allocs.push_back(q); *p = (Tp*)q; return true;
+  }
+  void release() {
+    for (void* q : allocs) (void)hipFree(q);
+    allocs.clear();
+    for (auto e : ipm_ev) (void)hipEventDestroy(e);
+    ipm_ev.clear();
+    ready = false;
+  }
+};
+
+DevCtx g_ctx;
+
+bool same_layout(const Layout& a, const Layout& b) { return std::memcmp(&a, &b, sizeof(Layout)) == 0; }
+
+bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, int device) {
+  int batch_cap = n_inst * npr;
+  if (X.ready && same_layout(X.Y, Y) && X.n_inst == n_inst && X.open_cap == open_cap && X.npr == npr) return true;
+  if (X.ready || !X.allocs.empty()) X.release();
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { std::fprintf(stderr, "[miqp_gpu] no HIP device: the solver has no CPU path\n"); return false; }
+  if (device >= 0) HIP_OK(hipSetDevice(device));
+  if (!X.stream) HIP_OK(hipStreamCreate(&X.stream));
+  if (!X.ev0) { HIP_OK(hipEventCreate(&X.ev0)); HIP_OK(hipEventCreate(&X.ev1)); }
+  X.Y = Y; X.n_inst = n_inst; X.open_cap = open_cap; X.npr = npr; X.batch_cap = batch_cap;
+  // node pool: every processed node emits at most a handful of children; records are not recycled inside one solve
+  size_t want = (size_t)n_inst * 16384; size_t maxrec = (size_t)3 << 30; maxrec /= (size_t)Y.fixlen;
+  X.pool_cap = (int)std::min(want, std::min(maxrec, (size_t)1 << 20) * 1);
+  if (X.pool_cap < n_inst * 64) X.pool_cap = n_inst * 64;
+  DevBuf& B = X.B; std::memset(&B, 0, sizeof(B));
+  B.Y = Y; B.pool_cap = X.pool_cap; B.open_cap = open_cap; B.batch_cap = batch_cap; B.nodes_per_round = npr; B.n_inst = n_inst;
+  double* dd; int* ii;
+  if (!X.alloc(&dd, (size_t)n_inst * Y.dstride)) return false; B.inst_d = dd;
+  if (!X.alloc(&ii, (size_t)n_inst * Y.istride)) return false; B.inst_i = ii;
+  if (!X.alloc(&B.pool_fix, (size_t)X.pool_cap * Y.fixlen)) return false;
+  if (!X.alloc(&B.pool_count, 1)) return false;
+  if (!X.alloc(&B.open_bound, (size_t)n_inst * open_cap)) return false;
+  if (!X.alloc(&B.open_node, (size_t)n_inst * open_cap)) return false;
+  if (!X.alloc(&B.open_count, n_inst)) return false;
+  if (!X.alloc(&B.inc_key, n_inst)) return false;
+  if (!X.alloc(&B.inc_seen, n_inst)) return false;
+  if (!X.alloc(&B.inc_obj, n_inst)) return false;
+  if (!X.alloc(&B.inc_fix, (size_t)n_inst * Y.fixlen)) return false;
+  if (!X.alloc(&B.inc_Z, (size_t)n_inst * Y.N * Y.nz)) return false;
+  if (!X.alloc(&B.lower_bound, n_inst)) return false;
+  if (!X.alloc(&B.inst_done, n_inst)) return false;
+  if (!X.alloc(&B.inst_flags, n_inst)) return false;
+  if (!X.alloc(&B.inst_gap, n_inst)) return false;
+  if (!X.alloc(&B.inst_const, n_inst)) return false;
+  if (!X.alloc(&B.inst_nodes, n_inst)) return false;
+  if (!X.alloc(&B.inst_iters, n_inst)) return false;
+  if (!X.alloc(&B.inst_ninc, n_inst)) return false;
+  if (!X.alloc(&B.batch_count, 1)) return false;
+  if (!X.alloc(&B.batch_node, batch_cap)) return false;
+  if (!X.alloc(&B.batch_inst, batch_cap)) return false;
+  if (!X.alloc(&B.batch_Z, (size_t)batch_cap * Y.N * Y.nz)) return false;
+  if (!X.alloc(&B.batch_obj, batch_cap)) return false;
+  if (!X.alloc(&B.batch_viol, batch_cap)) return false;
+  if (!X.alloc(&B.batch_ok, batch_cap)) return false;
+  if (!X.alloc(&B.batch_it, batch_cap)) return false;
+  if (!X.alloc(&B.batch_bound, batch_cap)) return false;
+  if (!X.alloc(&B.batch_comp, (size_t)batch_cap * Y.fixlen)) return false;
+  if (!X.alloc(&B.rowstate, (size_t)batch_cap * NFIELD * Y.ROWCAP)) return false;
+  if (!X.alloc(&B.active_insts, 1)) return false;
+  if (!X.alloc(&B.stat_rowiters, 1)) return false;
+  X.ready = true;
+  return true;
+}
+
+size_t ipm_lds_bytes(const Layout& Y) {
+  int NZ = Y.nz, NX = Y.nx, NU = Y.nu, N = Y.N, nsl64 = (Y.NSLOT + 63) & ~63;
+  size_t d = (size_t)2 * N * NZ + (size_t)N * NU * NX + (size_t)N * NU + (size_t)nsl64 * (NZ + 1) + nsl64 + NZ * NZ + NZ + NX * NZ + NX * NX + NX + NU * NU + NZ;
+  return d * 8 + (size_t)Y.fixlen + 16;
+}
+size_t eval_lds_bytes(const Layout& Y) {
+  size_t d = (size_t)Y.N * Y.nz + (size_t)Y.C * Y.N * Y.P + (size_t)Y.C * Y.N;
+  return d * 8 + (size_t)(2 * Y.C * Y.N + 64) * 4 + 64 * 8 + 2 * (size_t)Y.fixlen + 64;
+}
+size_t select_lds_bytes(int open_cap) { int c2 = 1; while (c2 < open_cap) c2 <<= 1; return (size_t)c2 * 12 + 16; }
+
+template <int C> void launch_ipm(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { hipLaunchKernelGGL(ipm_kernel<C>, dim3(nblocks), dim3(64), lds, st, B); }
+template <int C> void launch_eval(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { hipLaunchKernelGGL(eval_kernel<C>, dim3(nblocks), dim3(64), lds, st, B); }
+
+bool set_kernel_lds(const Layout& Y, size_t ipm_lds, size_t eval_lds, size_t sel_lds) {
+  if (Y.C == 1) {
+    HIP_OK(hipFuncSetAttribute((const void*)ipm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipm_lds));
+    HIP_OK(hipFuncSetAttribute((const void*)eval_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eval_lds));
+  } else {
+    HIP_OK(hipFuncSetAttribute((const void*)ipm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipm_lds));
+    HIP_OK(hipFuncSetAttribute((const void*)eval_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eval_lds));
+  }
+  HIP_OK(hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+  return true;
+}
+
+// ---------------------------------------------------------------- results (collectRawResults, cplex_wrapper.cpp:311-448)
+// canonical binaries: 0 wherever the asserted side holds for the returned continuous point
+void fill_results(const HostInst& I, const Layout& Y, const double* D, const int* T, const signed char* comp, const double* Z,
+                  miqp_raw_results_c* r) {
+  HostGeo G{I, Y, D, T};
+  const int C = I.C, N = I.N, R = I.R, E = I.E, O = I.O, L = I.L, K = I.C - 1, nz = Y.nz;
+  const double tol = 10 * FEAS_TOL;
+  r->N = N; r->NrEnvironments = E; r->NrRegions = R; r->NrObstacles = O; r->MaxLinesObstacles = L; r->NrCarToCarCollisions = K; r->NrCars = C;
+  for (int c = 0; c < C; ++c)
+    for (int i = 0; i < N; ++i) {
+      const double* z = Z + (size_t)i * nz; int qi = c * N + i;
+      r->pos_x[qi] = z[6 * c]; r->vel_x[qi] = z[6 * c + 1]; r->acc_x[qi] = z[6 * c + 2];
+      r->pos_y[qi] = z[6 * c + 3]; r->vel_y[qi] = z[6 * c + 4]; r->acc_y[qi] = z[6 * c + 5];
+      r->u_x[qi] = z[6 * C + 2 * c]; r->u_y[qi] = z[6 * C + 2 * c + 1];
+      int code = i >= 1 ? (int)comp[Y.f_reg + c * N + i] : -1;
+      int q = i >= 1 ? (code >> 2) : 0;
+      int j = i >= 1 ? T[Y.i_regj + c * Y.P + q] : I.init_region[c] - 1;
+      double X, Yc;
+      G.point(c, i, q, z, PT_U, PT_U, X, Yc); r->pos_x_front_UB[qi] = X; r->pos_y_front_UB[qi] = Yc;
+      G.point(c, i, q, z, PT_L, PT_L, X, Yc); r->pos_x_front_LB[qi] = X; r->pos_y_front_LB[qi] = Yc;
+      for (int jj = 0; jj < R; ++jj) r->active_region[(c * N + i) * R + jj] = jj == j ? 1 : 0;
+      int xp = 0, yp = 0, xn = 0, yn = 0, cb = 0;
+      if (i >= 1) {
+        double vx = z[6 * c + 1], vy = z[6 * c + 4];
+        xp = vx <= I.vm; xn = vx >= -I.vm; yp = vy <= I.vm; yn = vy >= -I.vm;
+        int h = code & 3;
+        if (h == 3) { xp = xn = yp = yn = cb = 1; }
+        else {
+          const int* hs = T + Y.i_hs + ((c * Y.P + q) * 2 + h) * 2;
+          if (hs[0] == 0 && hs[1] > 0) xp = 0;
+          if (hs[0] == 0 && hs[1] < 0) xn = 0;
+          if (hs[0] == 1 && hs[1] > 0) yp = 0;
+          if (hs[0] == 1 && hs[1] < 0) yn = 0;
+        }
+      }
+      r->region_change_not_allowed_x_positive[qi] = xp; r->region_change_not_allowed_y_positive[qi] = yp;
+      r->region_change_not_allowed_x_negative[qi] = xn; r->region_change_not_allowed_y_negative[qi] = yn;
+      r->region_change_not_allowed_combined[qi] = cb;
+      int* nw[5] = {r->notWithinEnvironmentRear, r->notWithinEnvironmentFrontUbUb, r->notWithinEnvironmentFrontLbUb,
+                    r->notWithinEnvironmentFrontUbLb, r->notWithinEnvironmentFrontLbLb};
+      for (int pt = 0; pt < 5; ++pt) {
+        G.point(c, i, q, z, ENV_PT_H[pt][0], ENV_PT_H[pt][1], X, Yc);
+        for (int e = 0; e < E; ++e) nw[pt][(c * E + e) * N + i] = G.env_viol(e, X, Yc) <= tol ? 0 : 1;
+      }
+      for (int o = 0; o < O; ++o)
+        for (int pt = 0; pt < 5; ++pt) {
+          bool ignored = i >= 1 && comp[Y.f_obs + ((c * O + o) * N + i) * 5 + pt] >= L;
+          G.point(c, i, q, z, OBS_PT_H[pt][0], OBS_PT_H[pt][1], X, Yc);
+          for (int k = 0; k < L; ++k) {
+            int d = (G.obs_viol(o, i, k, X, Yc) <= tol && !ignored) ? 0 : 1;
+            if (pt == 0) r->deltacc[((c * O + o) * N + i) * L + k] = d; else r->deltacc_front[(((c * O + o) * N + i) * L + k) * 4 + pt - 1] = d;
+          }
+          if (pt == 0) r->slackvarsObstacle[(c * O + o) * N + i] = ignored ? 1 : 0; else r->slackvarsObstacle_front[((c * O + o) * N + i) * 4 + pt - 1] = ignored ? 1 : 0;
+        }
+    }
+  for (int a = 0; a < K * K * N * 16; ++a) r->car2car_collision[a] = 0;
+  for (int a = 0; a < K * K * N * 4; ++a) { r->slackvars[a] = 0; if (r->slackvars_real) r->slackvars_real[a] = 0; }
+  int p = 0;
+  for (int c1 = 0; c1 < C; ++c1)
+    for (int c2 = c1 + 1; c2 < C; ++c2, ++p)
+      for (int i = 0; i < N; ++i) {
+        const double* z = Z + (size_t)i * nz;
+        int q1 = i >= 1 ? (comp[Y.f_reg + c1 * N + i] >> 2) : 0, q2 = i >= 1 ? (comp[Y.f_reg + c2 * N + i] >> 2) : 0;
+        for (int g = 0; g < 4; ++g) {
+          double vals[4]; for (int a = 0; a < 4; ++a) vals[a] = G.c2c_viol(p, c1, c2, i, g, a, q1, q2, z);
+          int chosen = i >= 1 ? (int)comp[Y.f_c2c + (p * N + i) * 4 + g] : -1;
+          if (chosen < 0) { chosen = 0; for (int a = 1; a < 4; ++a) if (vals[a] < vals[chosen]) chosen = a; }
+          double sl[2] = {0, 0};
+          if ((g == 0 || g == 3) && vals[chosen] > 0) sl[chosen < 2 ? 0 : 1] = vals[chosen];
+          for (int a = 0; a < 4; ++a) {
+            double need = vals[a] - ((g == 0 || g == 3) ? sl[a < 2 ? 0 : 1] : 0.0);
+            r->car2car_collision[((c1 * K + (c2 - 1)) * N + i) * 16 + 4 * g + a] = (a == chosen || need <= tol) ? 0 : 1;
+          }
+          if (g == 0 || g == 3)
+            for (int s = 0; s < 2; ++s) {
+              int idx = ((c1 * K + (c2 - 1)) * N + i) * 4 + (g == 0 ? 0 : 2) + s;
+              r->slackvars[idx] = (int)sl[s];  // truncation to int as in RawResults (miqp_planner_data.hpp:84-88)
+              if (r->slackvars_real) r->slackvars_real[idx] = sl[s];
+            }
+        }
+      }
+}
+
+// fix record from a complete assignment (warm start / solve_fixed): first asserted alternative of each disjunction
+bool fix_from_results(const HostInst& I, const Layout& Y, const int* T, const miqp_raw_results_c* f, std::vector<signed char>& fix) {
+  const int C = I.C, N = I.N, R = I.R, E = I.E, O = I.O, L = I.L, K = I.C - 1;
+  fix.assign(Y.fixlen, -1);
+  for (int c = 0; c < C; ++c)
+    for (int i = 1; i < N; ++i) {
+      int j = -1; for (int jj = 0; jj < R; ++jj) if (f->active_region[(c * N + i) * R + jj] == 1) j = jj;
+      int q = -1; for (int k = 0; k < T[Y.i_nposs + c]; ++k) if (T[Y.i_regj + c * Y.P + k] == j) q = k;
+      if (q < 0) return false;
+      int h = 3;
+      if (f->region_change_not_allowed_combined[c * N + i] != 1) {
+        h = 0;
+        for (int k = 0; k < T[Y.i_nhs + c * Y.P + q]; ++k) {
+          const int* hs = T + Y.i_hs + ((c * Y.P + q) * 2 + k) * 2;
+          int b = hs[0] == 0 ? (hs[1] > 0 ? f->region_change_not_allowed_x_positive[c * N + i] : f->region_change_not_allowed_x_negative[c * N + i])
+                             : (hs[1] > 0 ? f->region_change_not_allowed_y_positive[c * N + i] : f->region_change_not_allowed_y_negative[c * N + i]);
+          if (b == 0) { h = k; break; }
+        }
+      }
+      fix[Y.f_reg + c * N + i] = (signed char)(q * 4 + h);
+      const int* nw[5] = {f->notWithinEnvironmentRear, f->notWithinEnvironmentFrontUbUb, f->notWithinEnvironmentFrontLbUb,
+                          f->notWithinEnvironmentFrontUbLb, f->notWithinEnvironmentFrontLbLb};
+      for (int pt = 0; pt < 5; ++pt) {
+        for (int e = 0; e < E; ++e) if (nw[pt][(c * E + e) * N + i] == 0) { fix[Y.f_env + (c * N + i) * 5 + pt] = (signed char)e; break; }
+        for (int o = 0; o < O; ++o) {
+          int so = pt == 0 ? f->slackvarsObstacle[(c * O + o) * N + i] : f->slackvarsObstacle_front[((c * O + o) * N + i) * 4 + pt - 1];
+          if (so >= 1 && I.obs_soft[o]) { fix[Y.f_obs + ((c * O + o) * N + i) * 5 + pt] = (signed char)L; continue; }
+          for (int k = 0; k < L; ++k) {
+            int d = pt == 0 ? f->deltacc[((c * O + o) * N + i) * L + k] : f->deltacc_front[(((c * O + o) * N + i) * L + k) * 4 + pt - 1];
+            if (d == 0) { fix[Y.f_obs + ((c * O + o) * N + i) * 5 + pt] = (signed char)k; break; }
+          }
+        }
+      }
+    }
+  int p = 0;
+  for (int c1 = 0; c1 < C; ++c1)
+    for (int c2 = c1 + 1; c2 < C; ++c2, ++p)
+      for (int i = 1; i < N; ++i)
+        for (int g = 0; g < 4; ++g)
+          for (int a = 0; a < 4; ++a)
+            if (f->car2car_collision[((c1 * K + (c2 - 1)) * N + i) * 16 + 4 * g + a] == 0) { fix[Y.f_c2c + (p * N + i) * 4 + g] = (signed char)a; break; }
+  return true;
+}
+
+struct BatchShape { Layout Y; bool ok; std::string err; };
+
+BatchShape batch_layout(miqp_solver_t* const* S, int n) {
+  BatchShape bs; bs.ok = false;
+  const HostInst& I0 = S[0]->inst;
+  int P = 1, EL = 0;
+  for (int k = 0; k < n; ++k) {
+    if (!S[k] || !S[k]->has_inst) { bs.err = "solver without parameters"; return bs; }
+    const HostInst& I = S[k]->inst;
+    if (I.C != I0.C || I.N != I0.N || I.O != I0.O || I.L != I0.L || I.E != I0.E || I.R != I0.R) { bs.err = "instances of one batch must share NumCars, NumSteps, nr_regions, nr_environments, nr_obstacles, max_lines_obstacles"; return bs; }
+    P = std::max(P, max_possible(I)); EL = std::max(EL, max_env_edges(I));
+  }
+  if (I0.C > MAXC) { bs.err = "NumCars > 2 is not supported by this build of the device kernels"; return bs; }
+  if (P > 15) { bs.err = "more than 15 possible regions per car"; return bs; }
+  if (I0.E > 100 || I0.L > 100) { bs.err = "too many environment pieces / obstacle edges"; return bs; }
+  bs.Y = make_layout(I0.C, I0.N, I0.R, P, I0.E, EL, I0.O, I0.L); bs.ok = true;
+  return bs;
+}
+
+double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---------------------------------------------------------------- the batch solve
+bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
+  BatchShape bs = batch_layout(S, n);
+  if (!bs.ok) { for (int k = 0; k < n; ++k) { if (S[k]) S[k]->err = bs.err; statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; } std::fprintf(stderr, "[miqp_gpu] %s\n", bs.err.c_str()); return false; }
+  const Layout& Y = bs.Y;
+  const miqp_solver_opts& O0 = S[0]->opts;
+  int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(512, 4096 / n));
+  int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : 4096;
+  if (open_cap < 64) open_cap = 64;
+  if ((size_t)n * npr >= ((size_t)1 << 20)) npr = (int)((((size_t)1 << 20) - 1) / n);
+  DevCtx& X = g_ctx;
+  if (!ctx_prepare(X, Y, n, open_cap, npr, O0.device)) { for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
+  DevBuf& B = X.B;
+  size_t l_ipm = ipm_lds_bytes(Y), l_eval = eval_lds_bytes(Y), l_sel = select_lds_bytes(open_cap);
+  if (l_ipm > 160 * 1024 || l_sel > 160 * 1024) { std::fprintf(stderr, "[miqp_gpu] instance too large for LDS (%zu bytes)\n", l_ipm); for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
+  if (!set_kernel_lds(Y, l_ipm, l_eval, l_sel)) { for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
+  // ---- host tables, step-1 presolve
+  std::vector<double> hD((size_t)n * Y.dstride); std::vector<int> hT((size_t)n * Y.istride);
+  std::vector<double> h_const(n, 0.0), h_gap(n), h_tlim(n);
+  std::vector<int> h_done(n, 0);
+  std::vector<signed char> roots((size_t)n * Y.fixlen, (signed char)-1);
+  std::vector<double> ob((size_t)n * open_cap, 0.0); std::vector<int> on((size_t)n * open_cap, 0), oc(n, 1);
+  int active = 0;
+  for (int k = 0; k < n; ++k) {
+    miqp_solver* s = S[k]; s->lay = Y; s->has_sol = false;
+    compile_instance(s->inst, Y, &hD[(size_t)k * Y.dstride], &hT[(size_t)k * Y.istride]);
+    HostGeo G{s->inst, Y, &hD[(size_t)k * Y.dstride], &hT[(size_t)k * Y.istride]};
+    double cobj = 0; bool feas0 = step0_check(G, cobj);
+    h_const[k] = cobj; h_gap[k] = s->opts.gap_override >= 0 ? s->opts.gap_override : s->inst.gap; h_tlim[k] = s->inst.tilim;
+    if (!feas0) { h_done[k] = 1; oc[k] = 0; } else active++;
+    ob[(size_t)k * open_cap] = -1e300; on[(size_t)k * open_cap] = k;
+    if (s->has_ws && (int)s->ws_fix.size() == Y.fixlen && feas0) {  // MIP start: its binaries as a second root candidate
+      oc[k] = 2; ob[(size_t)k * open_cap + 1] = -1e300; on[(size_t)k * open_cap + 1] = n + k;
+    }
+    int rows, bin, cont, nnz; raw_sizes(s->inst, rows, bin, cont, nnz);
+    s->props = miqp_solution_properties_c{}; s->props.NrConstraints = rows; s->props.NrBinaryVariables = bin; s->props.NrFloatVariables = cont;
+    s->props.NonZeroCoefficients = 0;
+  }
+  hipStream_t st = X.stream;
+  HIP_OK(hipMemcpyAsync((void*)B.inst_d, hD.data(), hD.size() * 8, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync((void*)B.inst_i, hT.data(), hT.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(B.pool_fix, roots.data(), roots.size(), hipMemcpyHostToDevice, st));
+  for (int k = 0; k < n; ++k)
+    if (S[k]->has_ws && (int)S[k]->ws_fix.size() == Y.fixlen) HIP_OK(hipMemcpyAsync(B.pool_fix + (size_t)(n + k) * Y.fixlen, S[k]->ws_fix.data(), Y.fixlen, hipMemcpyHostToDevice, st));
+  int pool0 = 2 * n;
+  HIP_OK(hipMemcpyAsync(B.pool_count, &pool0, 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(B.open_bound, ob.data(), ob.size() * 8, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(B.open_node, on.data(), on.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(B.open_count, oc.data(), n * 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemsetAsync(B.inc_key, 0xFF, (size_t)n * 8, st));
+  HIP_OK(hipMemsetAsync(B.inc_seen, 0xFF, (size_t)n * 8, st));
+  { std::vector<double> big(n, 1e300); HIP_OK(hipMemcpyAsync(B.inc_obj, big.data(), n * 8, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(B.lower_bound, big.data(), n * 8, hipMemcpyHostToDevice, st)); HIP_OK(hipStreamSynchronize(st)); }
+  HIP_OK(hipMemcpyAsync(B.inst_done, h_done.data(), n * 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemsetAsync(B.inst_flags, 0, (size_t)n * 4, st));
+  HIP_OK(hipMemcpyAsync(B.inst_gap, h_gap.data(), n * 8, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(B.inst_const, h_const.data(), n * 8, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemsetAsync(B.inst_nodes, 0, (size_t)n * 8, st));
+  HIP_OK(hipMemsetAsync(B.inst_iters, 0, (size_t)n * 8, st));
+  HIP_OK(hipMemsetAsync(B.inst_ninc, 0, (size_t)n * 4, st));
+  HIP_OK(hipMemcpyAsync(B.active_insts, &active, 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemsetAsync(B.stat_rowiters, 0, 8, st));
+  HIP_OK(hipStreamSynchronize(st));
+
+  // ---- rounds
+  double t0 = wall_s();
+  double tlim = 0; for (int k = 0; k < n; ++k) tlim = std::max(tlim, h_tlim[k]);
+  HIP_OK(hipEventRecord(X.ev0, st));
+  size_t nev = 0; int rounds = 0; long long launched_nodes = 0; bool timed_out = false;
+  for (;;) {
+    HIP_OK(hipMemsetAsync(B.batch_count, 0, 4, st));
+    hipLaunchKernelGGL(select_kernel, dim3(n), dim3(SEL_THREADS), l_sel, st, B, rounds);
+    int bc = 0;
+    HIP_OK(hipMemcpyAsync(&bc, B.batch_count, 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (bc <= 0) break;
+    if (bc > X.batch_cap) bc = X.batch_cap;
+    if (wall_s() - t0 > tlim) { timed_out = true; break; }
+    if (X.ipm_ev.size() < nev + 2) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); X.ipm_ev.push_back(a); X.ipm_ev.push_back(b); }
+    HIP_OK(hipEventRecord(X.ipm_ev[nev], st));
+    if (Y.C == 1) launch_ipm<1>(B, bc, l_ipm, st); else launch_ipm<2>(B, bc, l_ipm, st);
+    HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
+    nev += 2;
+    if (Y.C == 1) launch_eval<1>(B, bc, l_eval, st); else launch_eval<2>(B, bc, l_eval, st);
+    launched_nodes += bc; rounds++;
+    if (O0.verbose > 1) std::fprintf(stderr, "[miqp_gpu] round %d: %d nodes\n", rounds, bc);
+  }
+  HIP_OK(hipEventRecord(X.ev1, st));
+  HIP_OK(hipStreamSynchronize(st));
+  HIP_OK(hipGetLastError());
+  float ms_all = 0; HIP_OK(hipEventElapsedTime(&ms_all, X.ev0, X.ev1));
+  double ms_ipm = 0;
+  for (size_t e = 0; e + 1 < nev; e += 2) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, X.ipm_ev[e], X.ipm_ev[e + 1])); ms_ipm += ms; }
+  double t_solve = wall_s() - t0;
+
+  // ---- results
+  std::vector<double> h_inc(n), h_lb(n); std::vector<int> h_flags(n), h_ninc(n), h_oc(n); std::vector<long long> h_nodes(n), h_iters(n);
+  std::vector<unsigned long long> h_key(n);
+  unsigned long long rowiters = 0;
+  HIP_OK(hipMemcpy(h_inc.data(), B.inc_obj, n * 8, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(h_key.data(), B.inc_key, n * 8, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(h_lb.data(), B.lower_bound, n * 8, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(h_flags.data(), B.inst_flags, n * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(h_ninc.data(), B.inst_ninc, n * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(h_oc.data(), B.open_count, n * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(h_nodes.data(), B.inst_nodes, n * 8, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(h_iters.data(), B.inst_iters, n * 8, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(&rowiters, B.stat_rowiters, 8, hipMemcpyDeviceToHost));
+  std::vector<signed char> h_fix((size_t)n * Y.fixlen); std::vector<double> h_Z((size_t)n * Y.N * Y.nz);
+  HIP_OK(hipMemcpy(h_fix.data(), B.inc_fix, h_fix.size(), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(h_Z.data(), B.inc_Z, h_Z.size() * 8, hipMemcpyDeviceToHost));
+  long long tot_iters = 0; for (int k = 0; k < n; ++k) tot_iters += h_iters[k];
+  for (int k = 0; k < n; ++k) {
+    miqp_solver* s = S[k];
+    bool have = h_inc[k] < 1e299;
+    bool unfinished = timed_out || (h_flags[k] & 1) || h_oc[k] > 0;
+    s->props.time = t_solve; s->props.NrIterations = (int)std::min<long long>(h_iters[k], 2147483647LL); s->props.nodes = h_nodes[k];
+    s->props.NrSolutionPool = h_ninc[k];
+    s->timing[0] = ms_all * 1e-3; s->timing[1] = ms_ipm * 1e-3; s->timing[2] = (double)(nev / 2); s->timing[3] = (double)launched_nodes;
+    s->timing[4] = (double)tot_iters; s->timing[5] = (double)rowiters;
+    if (have) {
+      s->status = MIQP_STATUS_SUCCESS; s->has_sol = true;
+      s->props.objective = h_inc[k];
+      double lb = std::min(h_lb[k], h_inc[k]);
+      if (!unfinished) lb = std::max(lb, std::min(h_inc[k], h_inc[k] - h_gap[k] * std::fabs(h_inc[k])));
+      s->props.best_bound = lb; s->props.gap = std::fabs(lb - h_inc[k]) / (1e-10 + std::fabs(h_inc[k]));
+      s->props.status = unfinished ? MIQP_CPX_STAT_TIME_LIM_FEAS : (s->props.gap <= 1e-9 ? MIQP_CPX_STAT_OPTIMAL : MIQP_CPX_STAT_OPTIMAL_TOL);
+      s->Z.assign(h_Z.begin() + (size_t)k * Y.N * Y.nz, h_Z.begin() + (size_t)(k + 1) * Y.N * Y.nz);
+      s->comp.assign(h_fix.begin() + (size_t)k * Y.fixlen, h_fix.begin() + (size_t)(k + 1) * Y.fixlen);
+    } else {
+      s->status = unfinished ? MIQP_STATUS_FAILED_TIMEOUT : MIQP_STATUS_FAILED_NO_SOLUT;
+      s->props.objective = NAN; s->props.gap = NAN; s->props.best_bound = h_lb[k];
+      s->props.status = unfinished ? MIQP_CPX_STAT_TIME_LIM_INFEAS : MIQP_CPX_STAT_INFEASIBLE;
+    }
+    statuses[k] = s->status;
+  }
+  return true;
+}
+
+}  // namespace
+
+// ================================================================================================
+//  C ABI
+// ================================================================================================
+extern "C" {
+
+const char* miqp_gpu_version(void) { return "miqp_gpu 0.1 (gfx950)"; }
+
+miqp_solver_t* miqp_solver_create(const miqp_solver_opts* opts) {
+  miqp_solver* s = new miqp_solver();
+  if (opts) s->opts = *opts; else { s->opts.precision = 12; s->opts.device = -1; s->opts.gap_override = -1; }
+  if (s->opts.precision <= 0) s->opts.precision = 12;
+  return s;
+}
+
+void miqp_solver_destroy(miqp_solver_t* s) { delete s; }
+
+int miqp_solver_set_params(miqp_solver_t* s, const miqp_model_params_c* p) {
+  if (!s || !p) return -1;
+  s->has_inst = inst_from_params(p, s->opts.precision - 2, s->inst, s->err);
+  s->has_sol = false; s->has_ws = false;
+  return s->has_inst ? 0 : -2;
+}
+
+int miqp_solver_load_dat(miqp_solver_t* s, const char* path) {
+  if (!s || !path) return -1;
+  s->has_inst = inst_from_dat(path, s->inst, s->err);
+  s->has_sol = false; s->has_ws = false;
+  if (!s->has_inst) std::fprintf(stderr, "[miqp_gpu] %s\n", s->err.c_str());
+  return s->has_inst ? 0 : -2;
+}
+
+int miqp_solver_override_settings(miqp_solver_t* s, double max_solution_time, double relative_mip_gap_tolerance) {
+  if (!s || !s->has_inst) return -1;
+  s->inst.tilim = max_solution_time; s->inst.gap = relative_mip_gap_tolerance;
+  return 0;
+}
+
+int miqp_solver_get_dims(const miqp_solver_t* s, int* o) {
+  if (!s || !s->has_inst) return -1;
+  o[0] = s->inst.C; o[1] = s->inst.N; o[2] = s->inst.R; o[3] = s->inst.E; o[4] = s->inst.O; o[5] = s->inst.L;
+  return 0;
+}
+
+int miqp_solver_set_warmstart(miqp_solver_t* s, const miqp_raw_results_c* start, int warmstart_type) {
+  if (!s || !s->has_inst) return -1;
+  if (warmstart_type == MIQP_WARMSTART_NONE || !start) { s->has_ws = false; return 0; }
+  miqp_solver_t* one[1] = {s};
+  BatchShape bs = batch_layout(one, 1);
+  if (!bs.ok) return -2;
+  std::vector<double> D(bs.Y.dstride); std::vector<int> T(bs.Y.istride);
+  compile_instance(s->inst, bs.Y, D.data(), T.data());
+  s->has_ws = fix_from_results(s->inst, bs.Y, T.data(), start, s->ws_fix);
+  return s->has_ws ? 0 : -3;
+}
+
+int miqp_solver_solve_batch(miqp_solver_t* const* solvers, int n, int* statuses) {
+  if (!solvers || n < 1 || !statuses) return -1;
+  return solve_batch_impl(solvers, n, statuses) ? 0 : -2;
+}
+
+int miqp_solver_solve(miqp_solver_t* s, double timestamp) {
+  (void)timestamp;
+  if (!s || !s->has_inst) return MIQP_STATUS_FAILED_SEG_FAULT;
+  miqp_solver_t* one[1] = {s}; int st = MIQP_STATUS_FAILED_SEG_FAULT;
+  if (!solve_batch_impl(one, 1, &st)) return MIQP_STATUS_FAILED_SEG_FAULT;
+  return st;
+}
+
+int miqp_solver_get_results(const miqp_solver_t* s, miqp_raw_results_c* out) {
+  if (!s || !out || !s->has_sol) return -1;
+  std::vector<double> D(s->lay.dstride); std::vector<int> T(s->lay.istride);
+  compile_instance(s->inst, s->lay, D.data(), T.data());
+  fill_results(s->inst, s->lay, D.data(), T.data(), s->comp.data(), s->Z.data(), out);
+  return 0;
+}
+
+int miqp_solver_get_properties(const miqp_solver_t* s, miqp_solution_properties_c* out) {
+  if (!s || !out) return -1;
+  *out = s->props;
+  return 0;
+}
+
+int miqp_solver_last_timing(const miqp_solver_t* s, double* out6) {
+  if (!s || !out6) return -1;
+  for (int k = 0; k < 6; ++k) out6[k] = s->timing[k];
+  return 0;
+}
+
+int miqp_solver_export_lp(const miqp_solver_t* s, const char* path) {
+  (void)s; (void)path;
+  return -1;  // LP export is a debug format of the reference; not built in this round
+}
+
+int miqp_solver_solve_fixed(miqp_solver_t* s, const miqp_raw_results_c* fixed, miqp_raw_results_c* out, double* objective, int* iterations) {
+  if (!s || !s->has_inst || !fixed) return -1;
+  miqp_solver_t* one[1] = {s};
+  BatchShape bs = batch_layout(one, 1);
+  if (!bs.ok) return -2;
+  const Layout& Y = bs.Y;
+  DevCtx& X = g_ctx;
+  if (!ctx_prepare(X, Y, 1, 64, 16, s->opts.device)) return -3;
+  if (!set_kernel_lds(Y, ipm_lds_bytes(Y), eval_lds_bytes(Y), select_lds_bytes(64))) return -3;
+  std::vector<double> D(Y.dstride); std::vector<int> T(Y.istride);
+  compile_instance(s->inst, Y, D.data(), T.data());
+  std::vector<signed char> fix;
+  if (!fix_from_results(s->inst, Y, T.data(), fixed, fix)) return -4;
+  DevBuf& B = X.B; hipStream_t st = X.stream;
+  int one_i = 1, zero = 0;
+  if (hipMemcpyAsync((void*)B.inst_d, D.data(), D.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess) return -3;
+  (void)hipMemcpyAsync((void*)B.inst_i, T.data(), T.size() * 4, hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(B.pool_fix, fix.data(), Y.fixlen, hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(B.batch_count, &one_i, 4, hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(B.batch_node, &zero, 4, hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(B.batch_inst, &zero, 4, hipMemcpyHostToDevice, st);
+  (void)hipMemsetAsync(B.inst_nodes, 0, 8, st); (void)hipMemsetAsync(B.inst_iters, 0, 8, st); (void)hipMemsetAsync(B.stat_rowiters, 0, 8, st);
+  if (Y.C == 1) launch_ipm<1>(B, 1, ipm_lds_bytes(Y), st); else launch_ipm<2>(B, 1, ipm_lds_bytes(Y), st);
+  std::vector<double> Z((size_t)Y.N * Y.nz); double obj = 0, viol = 0; int ok = 0, it = 0;
+  (void)hipMemcpyAsync(Z.data(), B.batch_Z, Z.size() * 8, hipMemcpyDeviceToHost, st);
+  (void)hipMemcpyAsync(&obj, B.batch_obj, 8, hipMemcpyDeviceToHost, st);
+  (void)hipMemcpyAsync(&viol, B.batch_viol, 8, hipMemcpyDeviceToHost, st);
+  (void)hipMemcpyAsync(&ok, B.batch_ok, 4, hipMemcpyDeviceToHost, st);
+  (void)hipMemcpyAsync(&it, B.batch_it, 4, hipMemcpyDeviceToHost, st);
+  if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return -3;
+  HostGeo G{s->inst, Y, D.data(), T.data()}; double cobj = 0; (void)step0_check(G, cobj);
+  if (objective) *objective = obj + cobj;
+  if (iterations) *iterations = it;
+  if (!ok || viol > FEAS_TOL) return 1;
+  if (out) {
+    // undecided leaf disjunctions: canonical completion is done by fill_results (it evaluates every side)
+    for (auto& b : fix) if (b < 0) b = 0;
+    fill_results(s->inst, Y, D.data(), T.data(), fix.data(), Z.data(), out);
+  }
+  return 0;
+}
+
+}  // extern "C"

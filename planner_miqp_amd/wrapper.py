@@ -1,0 +1,264 @@
+"""Python mirror of miqp::planner::cplex::CplexWrapper (src/cplex_wrapper.hpp:61-275) over libmiqp_gpu.so.
+
+Method names, argument meaning and error behaviour follow the reference class so that parity tests read
+like test/cplex_wrapper_test.cc.  All solving happens in the HIP library; this file only marshals."""
+import ctypes as C
+import enum
+import os
+import subprocess
+
+from .ctypes_types import (ModelParameters, ModelParamsC, RawResults, RawResultsC, SolutionPropertiesC, SolverOptsC)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def library_path():
+    return os.path.join(_HERE, "libmiqp_gpu.so")
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 build of the in-tree shared library (cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc", "miqp_gpu.hip")
+    out = library_path()
+    deps = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    deps += [os.path.join(_HERE, "..", "include", f) for f in ("miqp_gpu.h", "miqp_types.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-o", out, src]
+    subprocess.check_call(cmd)
+    return out
+
+
+def load_library():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError("libmiqp_gpu.so is not built (run __graft_entry__.build()); the solver has no CPU fallback")
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.miqp_solver_create.restype = vp; L.miqp_solver_create.argtypes = [C.POINTER(SolverOptsC)]
+    L.miqp_solver_destroy.restype = None; L.miqp_solver_destroy.argtypes = [vp]
+    L.miqp_solver_set_params.restype = C.c_int; L.miqp_solver_set_params.argtypes = [vp, C.POINTER(ModelParamsC)]
+    L.miqp_solver_load_dat.restype = C.c_int; L.miqp_solver_load_dat.argtypes = [vp, C.c_char_p]
+    L.miqp_solver_override_settings.restype = C.c_int; L.miqp_solver_override_settings.argtypes = [vp, C.c_double, C.c_double]
+    L.miqp_solver_set_warmstart.restype = C.c_int; L.miqp_solver_set_warmstart.argtypes = [vp, C.POINTER(RawResultsC), C.c_int]
+    L.miqp_solver_solve.restype = C.c_int; L.miqp_solver_solve.argtypes = [vp, C.c_double]
+    L.miqp_solver_solve_batch.restype = C.c_int; L.miqp_solver_solve_batch.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
+    L.miqp_solver_get_results.restype = C.c_int; L.miqp_solver_get_results.argtypes = [vp, C.POINTER(RawResultsC)]
+    L.miqp_solver_get_properties.restype = C.c_int; L.miqp_solver_get_properties.argtypes = [vp, C.POINTER(SolutionPropertiesC)]
+    L.miqp_solver_get_dims.restype = C.c_int; L.miqp_solver_get_dims.argtypes = [vp, C.POINTER(C.c_int)]
+    L.miqp_solver_export_lp.restype = C.c_int; L.miqp_solver_export_lp.argtypes = [vp, C.c_char_p]
+    L.miqp_solver_solve_fixed.restype = C.c_int
+    L.miqp_solver_solve_fixed.argtypes = [vp, C.POINTER(RawResultsC), C.POINTER(RawResultsC), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.miqp_solver_last_timing.restype = C.c_int; L.miqp_solver_last_timing.argtypes = [vp, C.POINTER(C.c_double)]
+    L.miqp_gpu_version.restype = C.c_char_p
+    _LIB = L
+    return L
+
+
+EXPORTED_SYMBOLS = ["miqp_solver_create", "miqp_solver_destroy", "miqp_solver_set_params", "miqp_solver_load_dat",
+                    "miqp_solver_override_settings", "miqp_solver_set_warmstart", "miqp_solver_solve",
+                    "miqp_solver_solve_batch", "miqp_solver_get_results", "miqp_solver_get_properties",
+                    "miqp_solver_get_dims", "miqp_solver_export_lp", "miqp_solver_solve_fixed",
+                    "miqp_solver_last_timing", "miqp_gpu_version"]
+
+
+class OptimizationStatus(enum.IntEnum):  # src/cplex_wrapper.hpp:54-59
+    SUCCESS = 0
+    FAILED_NO_SOLUT = 1
+    FAILED_SEG_FAULT = 2
+    FAILED_TIMEOUT = 3
+
+
+class WarmstartType(enum.IntEnum):  # src/miqp_planner_settings.h:13-18
+    NO_WARMSTART = 0
+    RECEDING_HORIZON_WARMSTART = 1
+    LAST_SOLUTION_WARMSTART = 2
+    BOTH_WARMSTART_STRATEGIES = 3
+
+
+class ParameterSource(enum.IntEnum):  # src/cplex_wrapper.hpp:63
+    DATFILE = 0
+    CPPINPUTS = 1
+    MIXED = 2
+
+
+class SolutionProperties:  # src/cplex_wrapper.hpp:41-52
+    def __init__(self, c=None):
+        for n, _ in SolutionPropertiesC._fields_:
+            setattr(self, n, getattr(c, n) if c is not None else 0)
+
+    def __repr__(self):
+        return "SolutionProperties(" + ", ".join("%s=%r" % (n, getattr(self, n)) for n, _ in SolutionPropertiesC._fields_) + ")"
+
+
+class CplexWrapper:
+    """Same public surface as the reference class; ``modfile`` is accepted and ignored (the OPL model is
+    built into the device solver)."""
+
+    def __init__(self, modfile="cplexmodel.mod", parameterSource=ParameterSource.CPPINPUTS, precision=12, modpath="cplexmodel/",
+                 nodes_per_round=0, max_open_nodes=0, gap_override=-1.0, verbose=0, device=-1):
+        self._L = load_library()
+        self._opts = SolverOptsC(int(precision), int(device), int(nodes_per_round), int(max_open_nodes), float(gap_override), int(verbose))
+        self._h = self._L.miqp_solver_create(C.byref(self._opts))
+        self.parameterSource_ = ParameterSource(parameterSource)
+        self.modfile_ = modpath + modfile
+        self.datfile_ = ""
+        self._params = None
+        self._keep = None
+        self._results = None
+        self._warm = None
+        self.useSpecialOrderedSets_ = False
+        self.useBranchingPriorities_ = False
+        self.doWarmstart_ = WarmstartType.NO_WARMSTART
+        self.debugOutputFilePath_ = ""
+        self.debugOutputFilePrefix_ = ""
+        self.print_debug_outputs_ = False
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.miqp_solver_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- parameters
+    def setParameterDatFileRelative(self, datfile):
+        self.datfile_ = "cplexmodel/" + datfile
+
+    def setParameterDatFileAbsolute(self, datfile):
+        self.datfile_ = datfile
+
+    def resetParameters(self, parameters: ModelParameters):
+        self._params = parameters  # shared with the caller, re-read on every callCplex (cplex_wrapper.cpp:661-664)
+
+    def overrideSolverSettingsDataSource(self, parameters: ModelParameters):
+        if self._params is not None:
+            for n in ["max_solution_time", "relative_mip_gap_tolerance", "mipdisplay", "mipemphasis", "relobjdif", "cutpass",
+                      "probe", "repairtries", "rinsheur", "varsel", "mircuts", "parallelmode"]:
+                setattr(self._params, n, getattr(parameters, n))
+
+    # ---- options that only steer CPLEX's search (accepted, no effect on the result: K7)
+    def setSpecialOrderedSets(self, v):
+        self.useSpecialOrderedSets_ = bool(v)
+
+    def setUseBranchingPriorities(self, v):
+        self.useBranchingPriorities_ = bool(v)
+
+    def setBranchingPriorityValueExtent(self, value, extent):
+        self.branchingPriority_ = (value, extent)
+
+    def setBufferCplexOutputsToStream(self, v):
+        pass
+
+    def setDebugOutputPrint(self, v):
+        self.print_debug_outputs_ = bool(v)
+
+    def setDebugOutputFilePath(self, p):
+        self.debugOutputFilePath_ = p
+
+    def setDebugOutputFilePrefix(self, p):
+        self.debugOutputFilePrefix_ = p
+
+    # ---- warm start
+    def addRecedingHorizonWarmstart(self, warmstart: RawResults, wt=WarmstartType.RECEDING_HORIZON_WARMSTART):
+        self.doWarmstart_ = wt if wt == WarmstartType.RECEDING_HORIZON_WARMSTART else WarmstartType.BOTH_WARMSTART_STRATEGIES
+        self._warm = warmstart
+
+    def setLastSolutionWarmstart(self, wt=WarmstartType.LAST_SOLUTION_WARMSTART):
+        self.doWarmstart_ = wt if wt == WarmstartType.LAST_SOLUTION_WARMSTART else WarmstartType.BOTH_WARMSTART_STRATEGIES
+
+    def deleteLastSolutionWarmstartFile(self):
+        self._last = None
+
+    # ---- solve
+    def _push_inputs(self):
+        if self.parameterSource_ == ParameterSource.DATFILE:
+            rc = self._L.miqp_solver_load_dat(self._h, self.datfile_.encode())
+        else:
+            if self._params is None:
+                return -1
+            s, self._keep = self._params.to_c()
+            rc = self._L.miqp_solver_set_params(self._h, C.byref(s))
+        if rc != 0:
+            return rc
+        ws = None
+        if self.doWarmstart_ in (WarmstartType.RECEDING_HORIZON_WARMSTART, WarmstartType.BOTH_WARMSTART_STRATEGIES):
+            ws = self._warm
+        if ws is None and self.doWarmstart_ in (WarmstartType.LAST_SOLUTION_WARMSTART, WarmstartType.BOTH_WARMSTART_STRATEGIES):
+            ws = getattr(self, "_last", None)
+        if ws is not None:
+            wc = ws.to_c()
+            self._L.miqp_solver_set_warmstart(self._h, C.byref(wc), int(self.doWarmstart_))
+        return 0
+
+    def _collect(self, status):
+        if status == OptimizationStatus.SUCCESS:
+            d = (C.c_int * 6)()
+            self._L.miqp_solver_get_dims(self._h, d)
+            res = RawResults(*list(d))
+            rc = res.to_c()
+            self._L.miqp_solver_get_results(self._h, C.byref(rc))
+            self._results = res
+            self._last = res
+        return OptimizationStatus(status)
+
+    def callCplex(self, timestamp=0.0):
+        if self._push_inputs() != 0:
+            return OptimizationStatus.FAILED_SEG_FAULT
+        st = self._L.miqp_solver_solve(self._h, float(timestamp))
+        return self._collect(st)
+
+    def getRawResults(self):
+        return self._results
+
+    def getSolutionProperties(self):
+        p = SolutionPropertiesC()
+        self._L.miqp_solver_get_properties(self._h, C.byref(p))
+        return SolutionProperties(p)
+
+    def getTmpWarmstartFile(self):
+        return "/tmp/warmstart_debug_res.mst"
+
+    def getDebugOutputParameterFilePath(self):
+        return ""
+
+    # ---- extras of this implementation
+    def solveFixed(self, fixed: RawResults):
+        """continuous QP with the binaries of ``fixed`` asserted (device interior point kernel)"""
+        if self._push_inputs() != 0:
+            return None
+        d = (C.c_int * 6)()
+        self._L.miqp_solver_get_dims(self._h, d)
+        out = RawResults(*list(d))
+        oc = out.to_c()
+        fc = fixed.to_c()
+        obj = C.c_double(0)
+        it = C.c_int(0)
+        rc = self._L.miqp_solver_solve_fixed(self._h, C.byref(fc), C.byref(oc), C.byref(obj), C.byref(it))
+        return rc, out, obj.value, it.value
+
+    def lastTiming(self):
+        t = (C.c_double * 6)()
+        self._L.miqp_solver_last_timing(self._h, t)
+        return dict(solve_s=t[0], ipm_s=t[1], ipm_launches=int(t[2]), nodes=int(t[3]), ipm_iters=int(t[4]), row_iters=int(t[5]))
+
+
+def solve_batch(wrappers):
+    """Solves independent instances concurrently on one device (miqp_solver_solve_batch)."""
+    L = load_library()
+    for w in wrappers:
+        if w._push_inputs() != 0:
+            raise RuntimeError("invalid parameters")
+    n = len(wrappers)
+    hs = (C.c_void_p * n)(*[w._h for w in wrappers])
+    st = (C.c_int * n)()
+    rc = L.miqp_solver_solve_batch(hs, n, st)
+    if rc != 0:
+        return [OptimizationStatus.FAILED_SEG_FAULT] * n
+    return [w._collect(st[k]) for k, w in enumerate(wrappers)]
