@@ -1,0 +1,140 @@
+"""bench.py - MIQP solves/sec to 1% gap on 2-agent x 20-step x 32-region instances (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic instances: every rank solves its own shard of
+independent planning instances (weak scaling: fixed batch per GPU, instance b -> rank b mod G, no data-path
+collective); `value` = instances solved to the gap by all ranks / wall time of the K timed steps (max over ranks).
+Inputs are generated and packed before the timed region; the solve call uploads ~12 KB per instance.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK = 78.6e12  # MI355X FP64 matrix == FP64 vector peak (AMD public spec; half the f32 rate of MI355X_MICROARCH.md)
+
+
+def f_iter(C, N):
+    """algorithmic flops of one interior-point iteration on the stage-banded KKT of one node:
+    N stages of size n_s = 8C coupled through n_c = 6C states"""
+    ns, nc = 8 * C, 6 * C
+    return N * (ns ** 3 / 3.0 + 2 * ns * ns * nc + ns * nc * nc + 4 * ns * ns)
+
+
+F_ROW = 2 * 6 * (6 + 2)  # sparse assembly per active row and iteration (<= 6 non-zeros per row)
+
+
+def cpu_baseline(params_list, gap, budget_s=20.0):
+    """the CPU oracle (same algorithm class, one host core) on a bounded sample of the same workload"""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    lib = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    O = oracle_lib.Oracle(lib)
+    t0 = time.time(); solved = 0; tried = 0
+    per = max(2.0, budget_s / 4)
+    for p in params_list:
+        if time.time() - t0 > budget_s:
+            break
+        h = O.from_params(p, 10)
+        st, res, pr = O.solve(h, O.dims(p), gap=gap, time_limit=per)
+        O.free(h)
+        tried += 1
+        solved += int(st == 0 and pr.status in (101, 102))
+    dt = time.time() - t0
+    return dict(value=solved / dt if dt > 0 else 0.0, unit="MIQP solves/s", cores=1, kind="port",
+                sample="first %d instances of rank 0's batch, %.1f s time limit each, %d reached the gap in %.1f s" % (tried, per, solved, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="instances per GPU and step")
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--gap", type=float, default=0.01)
+    ap.add_argument("--time-limit", type=float, default=10.0, help="max_solution_time per instance (reference default 10 s)")
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    import planner_miqp_amd as P
+    from planner_miqp_amd import synthetic
+
+    def sync():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+
+    B = a.batch
+    # weak scaling: seeds rank*B .. rank*B+B-1 of step s are offset by s*world*B
+    def make_batch(step):
+        ps = [synthetic.generate(a.config, (step * world + rank) * B + k, gap=a.gap, max_time=a.time_limit) for k in range(B)]
+        ws = []
+        for p in ps:
+            w = P.CplexWrapper(device=local); w.resetParameters(p); ws.append(w)
+        return ps, ws
+
+    batches = [make_batch(s) for s in range(a.warmup + a.steps)]
+    for s in range(a.warmup):
+        P.solve_batch(batches[s][1])
+    sync()
+    t0 = time.time()
+    solved = 0; attempted = 0; ipm_s = 0.0; launches = 0; iters = 0; rowit = 0; nodes = 0
+    for s in range(a.warmup, a.warmup + a.steps):
+        ps, ws = batches[s]
+        sts = P.solve_batch(ws)
+        attempted += len(ws)
+        for w, st in zip(ws, sts):
+            pr = w.getSolutionProperties()
+            solved += int(st == P.OptimizationStatus.SUCCESS and pr.status in (101, 102))
+        tm = ws[0].lastTiming()
+        ipm_s += tm["ipm_s"]; launches += tm["ipm_launches"]; iters += tm["ipm_iters"]; rowit += tm["row_iters"]; nodes += tm["nodes"]
+    sync()
+    dt = time.time() - t0
+    from planner_miqp_amd.sharding import gather_counts
+    dev = torch.device("cuda", local) if (world > 1 and torch.cuda.is_available()) else None
+    g = gather_counts([dt, solved, attempted, ipm_s, launches, iters, rowit, nodes], dev)
+    if rank == 0:
+        T = max(x[0] for x in g)
+        tot_solved = sum(x[1] for x in g); tot_att = sum(x[2] for x in g)
+        Cc, N = synthetic.CONFIGS[a.config][0], synthetic.CONFIGS[a.config][1]
+        # roofline of the dominant kernel (ipm_kernel), rank 0: algorithmic flops / HIP-event time of its launches
+        flops = iters * f_iter(Cc, N) + rowit * F_ROW
+        ach = flops / ipm_s if ipm_s > 0 else 0.0
+        out = dict(metric="MIQP solves/sec to 1% gap, 2-agent x 20-step x 32-region", value=tot_solved / T, unit="MIQP solves/s",
+                   n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * T / a.steps, higher_is_better=True, scaling="weak",
+                   vs_baseline=None, dtype="f64", data="synthetic",
+                   config=dict(workload="%s: %d cars x %d steps x %d regions, %d env pieces, %d obstacles; %d instances per GPU and step, gap %g, time limit %g s"
+                               % ((a.config,) + synthetic.CONFIGS[a.config] + (B, a.gap, a.time_limit)),
+                               instances_attempted=int(tot_att), instances_solved_to_gap=int(tot_solved),
+                               bnb_nodes=int(sum(x[7] for x in g)), ipm_iterations=int(sum(x[5] for x in g))),
+                   roofline=dict(bound="mfma", achieved=ach / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s", frac=ach / FP64_PEAK, traffic=None,
+                                 kernel="ipm_kernel", launches=int(launches), avg_launch_ms=1e3 * ipm_s / max(1, launches),
+                                 flops_per_launch=flops / max(1, launches)))
+        if not a.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(batches[a.warmup][0], a.gap)
+        elif not a.no_cpu:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -872,22 +872,28 @@ static void fill_results(const dmodel* M, const signed char* comp, const double*
 typedef struct { double bound; long long seq; signed char* fix; int depth; } bnode;
 typedef struct { bnode* a; int n, cap; } heap_t;
 
-static int node_less(const bnode* x, const bnode* y) { return x->bound < y->bound || (x->bound == y->bound && x->seq < y->seq); }
+/* open list as a plain array: node selection is best-bound, interleaved with dives (deepest node, ties by
+ * bound) while no incumbent exists and on every 4th selection afterwards (standard B&B practice; the search
+ * order does not change what is proven, only how fast incumbents appear) */
 static void heap_push(heap_t* h, bnode nd) {
   if (h->n == h->cap) { h->cap = h->cap ? 2 * h->cap : 1024; h->a = (bnode*)realloc(h->a, sizeof(bnode) * h->cap); }
-  int i = h->n++; h->a[i] = nd;
-  while (i > 0) { int p = (i - 1) / 2; if (!node_less(&h->a[i], &h->a[p])) break; bnode t = h->a[i]; h->a[i] = h->a[p]; h->a[p] = t; i = p; }
+  h->a[h->n++] = nd;
 }
-static bnode heap_pop(heap_t* h) {
-  bnode top = h->a[0]; h->a[0] = h->a[--h->n];
-  int i = 0;
-  for (;;) {
-    int l = 2 * i + 1, r = l + 1, m = i;
-    if (l < h->n && node_less(&h->a[l], &h->a[m])) m = l;
-    if (r < h->n && node_less(&h->a[r], &h->a[m])) m = r;
-    if (m == i) break;
-    bnode t = h->a[i]; h->a[i] = h->a[m]; h->a[m] = t; i = m;
+static double heap_min_bound(const heap_t* h) {
+  double b = INFINITY;
+  for (int k = 0; k < h->n; ++k) if (h->a[k].bound < b) b = h->a[k].bound;
+  return b;
+}
+static bnode heap_pop(heap_t* h, int dive) {
+  int best = 0;
+  for (int k = 1; k < h->n; ++k) {
+    const bnode* x = &h->a[k]; const bnode* y = &h->a[best];
+    int better;
+    if (dive) better = x->depth > y->depth || (x->depth == y->depth && (x->bound < y->bound || (x->bound == y->bound && x->seq < y->seq)));
+    else better = x->bound < y->bound || (x->bound == y->bound && x->seq < y->seq);
+    if (better) best = k;
   }
+  bnode top = h->a[best]; h->a[best] = h->a[--h->n];
   return top;
 }
 
@@ -914,10 +920,13 @@ int orc_solve(const oinst* I, const orc_opts* o, miqp_raw_results_c* res, miqp_s
     memset(root.fix, -1, M->fixlen);
     heap_push(&H, root);
   }
+  long long pops = 0;
   while (H.n > 0) {
-    bnode nd = heap_pop(&H);
-    if (inc < INFINITY && (inc - nd.bound) <= gap * (1e-10 + fabs(inc))) { best_bound = nd.bound; free(nd.fix); break; }
-    if (props->nodes >= max_nodes || now_s() - t0 > tlim) { timed_out = 1; best_bound = nd.bound; free(nd.fix); break; }
+    double lb = heap_min_bound(&H);
+    if (inc < INFINITY && (inc - lb) <= gap * (1e-10 + fabs(inc))) { best_bound = lb; break; }
+    if (props->nodes >= max_nodes || now_s() - t0 > tlim) { timed_out = 1; best_bound = lb; break; }
+    bnode nd = heap_pop(&H, !(inc < INFINITY) || (pops++ % 4) == 3);
+    if (inc < INFINITY && (inc - nd.bound) <= gap * (1e-10 + fabs(inc))) { free(nd.fix); continue; }
     props->nodes++;
     node_rows(M, nd.fix, &rows);
     qpres q; qp_solve(M, rows.r, rows.n, &q);

@@ -33,7 +33,7 @@ struct DevBuf {
   signed char* pool_fix;         // [pool_cap][fixlen]
   int* pool_count; int pool_cap;
   // open lists per instance
-  double* open_bound; int* open_node; int* open_count; int open_cap;
+  double* open_bound; int* open_node; int* open_depth; int* open_count; int open_cap;
   // per instance state
   unsigned long long* inc_key;   // orderable(objective) with the batch slot in the low 20 bits
   unsigned long long* inc_seen;  // key whose solution has been copied to inc_fix / inc_Z
@@ -42,7 +42,7 @@ struct DevBuf {
   double* lower_bound; int* inst_done; int* inst_flags; double* inst_gap; double* inst_const;
   long long* inst_nodes; long long* inst_iters; int* inst_ninc;
   // batch of the current round
-  int* batch_count; int* batch_node; int* batch_inst; int batch_cap;
+  int* batch_count; int* batch_node; int* batch_inst; int* batch_depth; int batch_cap;
   double* batch_Z; double* batch_obj; double* batch_viol; int* batch_ok; int* batch_it; double* batch_bound;
   signed char* batch_comp;       // completed fix record of feasible nodes
   double* rowstate;              // [batch_cap][NFIELD][ROWCAP]
@@ -828,7 +828,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     if (lane < nalt) {
       size_t oi = (size_t)inst * B.open_cap + ob + lane;
       // a soft obstacle that is ignored costs WEIGHTS_SLACK_OBSTACLE (obstacle_environment_constraints.mod:85-91)
-      B.open_bound[oi] = obj - B.inst_const[inst]; B.open_node[oi] = nb + lane;
+      B.open_bound[oi] = obj - B.inst_const[inst]; B.open_node[oi] = nb + lane; B.open_depth[oi] = B.batch_depth[node] + 1;
     }
   }
 }
@@ -843,8 +843,10 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   extern __shared__ double lds[];
   const int cap = B.open_cap;
   int cap2 = 1; while (cap2 < cap) cap2 <<= 1;
-  double* kb = lds;                  // [cap2] bounds
+  double* kk = lds;                  // [cap2] sort key
+  double* kb = kk + cap2;            // [cap2] bound
   int* kn = (int*)(kb + cap2);       // [cap2] node ids
+  int* kd = kn + cap2;               // [cap2] depth
   __shared__ int sh_n, sh_take, sh_base;
   __shared__ double sh_inc;
   if (B.inst_done[inst]) return;
@@ -868,39 +870,53 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   const double inc = sh_inc < 1e300 ? B.inc_obj[inst] : 1e300;
   const double cst = B.inst_const[inst];
   const double gap = B.inst_gap[inst];
+  // node selection: best bound, interleaved with dives (deepest first) while no incumbent exists and on every
+  // 4th round afterwards; the order changes how fast incumbents appear, not what is proven
+  const bool dive = !(inc < 1e300) || (round & 3) == 3;
   int n = B.open_count[inst]; if (n > cap) n = cap;
-  // bounds in the open list exclude the instance constant
   double lb = 1e300;
   for (int k = tid; k < cap2; k += SEL_THREADS) {
-    double b = 1e300; int nd = -1;
-    if (k < n) { b = B.open_bound[(size_t)inst * cap + k]; nd = B.open_node[(size_t)inst * cap + k]; lb = fmin(lb, b); }
-    // prune: cannot improve the incumbent by more than the gap
-    if (k < n && inc < 1e300 && (inc - (b + cst)) <= gap * (1e-10 + fabs(inc))) { b = 1e300; nd = -1; }
-    kb[k] = b; kn[k] = nd;
+    double b = 1e300, key = 1e300; int nd = -1, dp = 0;
+    if (k < n) {
+      size_t oi = (size_t)inst * cap + k;
+      b = B.open_bound[oi]; nd = B.open_node[oi]; dp = B.open_depth[oi]; lb = fmin(lb, b);
+      // prune: cannot improve the incumbent by more than the gap (bounds exclude the instance constant)
+      if (inc < 1e300 && (inc - (b + cst)) <= gap * (1e-10 + fabs(inc))) { b = 1e300; nd = -1; }
+      else key = dive ? (-(double)dp * 1e9 + fmax(b, -1e8)) : b;
+    }
+    kk[k] = key; kb[k] = b; kn[k] = nd; kd[k] = dp;
   }
   __shared__ double red[SEL_THREADS];
   red[tid] = lb; __syncthreads();
   for (int s = SEL_THREADS / 2; s > 0; s >>= 1) { if (tid < s) red[tid] = fmin(red[tid], red[tid + s]); __syncthreads(); }
   lb = red[0];
-  // bitonic sort ascending by bound
+  // bitonic sort ascending by key
   for (int k2 = 2; k2 <= cap2; k2 <<= 1)
     for (int j = k2 >> 1; j > 0; j >>= 1) {
       for (int t = tid; t < cap2; t += SEL_THREADS) {
         int ixj = t ^ j;
         if (ixj > t) {
           bool up = (t & k2) == 0;
-          double a = kb[t], b = kb[ixj];
-          if ((a > b) == up) { kb[t] = b; kb[ixj] = a; int x = kn[t]; kn[t] = kn[ixj]; kn[ixj] = x; }
+          double a = kk[t], b = kk[ixj];
+          if ((a > b) == up) {
+            kk[t] = b; kk[ixj] = a;
+            double x = kb[t]; kb[t] = kb[ixj]; kb[ixj] = x;
+            int y = kn[t]; kn[t] = kn[ixj]; kn[ixj] = y;
+            y = kd[t]; kd[t] = kd[ixj]; kd[ixj] = y;
+          }
         }
       }
       __syncthreads();
     }
   if (tid == 0) {
-    int m = 0; while (m < cap2 && kb[m] < 1e299) m++;
+    int m = 0; while (m < cap2 && kk[m] < 1e299) m++;
     sh_n = m;
-    int take = m < B.nodes_per_round ? m : B.nodes_per_round;
-    sh_take = take;
-    sh_base = take > 0 ? atomicAdd(B.batch_count, take) : 0;
+    int act = *B.active_insts; if (act < 1) act = 1;
+    int w = B.batch_cap / act; if (w < B.nodes_per_round) w = B.nodes_per_round;
+    int take = m < w ? m : w;
+    int base = take > 0 ? atomicAdd(B.batch_count, take) : 0;
+    if (base + take > B.batch_cap) take = B.batch_cap > base ? B.batch_cap - base : 0;
+    sh_take = take; sh_base = base;
     double lbt = (n > 0 ? lb + cst : inc);
     if (inc < 1e300 && lbt > inc) lbt = inc;
     B.lower_bound[inst] = lbt;
@@ -911,14 +927,14 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   __syncthreads();
   int m = sh_n, take = sh_take, base = sh_base;
   for (int k = tid; k < take; k += SEL_THREADS) {
-    if (base + k < B.batch_cap) { B.batch_node[base + k] = kn[k]; B.batch_inst[base + k] = inst; B.batch_bound[base + k] = kb[k]; }
+    B.batch_node[base + k] = kn[k]; B.batch_inst[base + k] = inst; B.batch_bound[base + k] = kb[k]; B.batch_depth[base + k] = kd[k];
   }
   for (int k = tid; k < m - take; k += SEL_THREADS) {
-    B.open_bound[(size_t)inst * cap + k] = kb[take + k]; B.open_node[(size_t)inst * cap + k] = kn[take + k];
+    size_t oi = (size_t)inst * cap + k;
+    B.open_bound[oi] = kb[take + k]; B.open_node[oi] = kn[take + k]; B.open_depth[oi] = kd[take + k];
   }
   __syncthreads();
   if (tid == 0) B.open_count[inst] = m - take;
-  (void)round;
 }
 
 }  // namespace miqp

@@ -185,6 +185,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   if (!X.alloc(&B.pool_count, 1)) return false;
   if (!X.alloc(&B.open_bound, (size_t)n_inst * open_cap)) return false;
   if (!X.alloc(&B.open_node, (size_t)n_inst * open_cap)) return false;
+  if (!X.alloc(&B.open_depth, (size_t)n_inst * open_cap)) return false;
   if (!X.alloc(&B.open_count, n_inst)) return false;
   if (!X.alloc(&B.inc_key, n_inst)) return false;
   if (!X.alloc(&B.inc_seen, n_inst)) return false;
@@ -202,6 +203,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   if (!X.alloc(&B.batch_count, 1)) return false;
   if (!X.alloc(&B.batch_node, batch_cap)) return false;
   if (!X.alloc(&B.batch_inst, batch_cap)) return false;
+  if (!X.alloc(&B.batch_depth, batch_cap)) return false;
   if (!X.alloc(&B.batch_Z, (size_t)batch_cap * Y.N * Y.nz)) return false;
   if (!X.alloc(&B.batch_obj, batch_cap)) return false;
   if (!X.alloc(&B.batch_viol, batch_cap)) return false;
@@ -225,7 +227,7 @@ size_t eval_lds_bytes(const Layout& Y) {
   size_t d = (size_t)Y.N * Y.nz + (size_t)Y.C * Y.N * Y.P + (size_t)Y.C * Y.N;
   return d * 8 + (size_t)(2 * Y.C * Y.N + 64) * 4 + 64 * 8 + 2 * (size_t)Y.fixlen + 64;
 }
-size_t select_lds_bytes(int open_cap) { int c2 = 1; while (c2 < open_cap) c2 <<= 1; return (size_t)c2 * 12 + 16; }
+size_t select_lds_bytes(int open_cap) { int c2 = 1; while (c2 < open_cap) c2 <<= 1; return (size_t)c2 * 24 + 16; }
 
 template <int C> void launch_ipm(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { hipLaunchKernelGGL(ipm_kernel<C>, dim3(nblocks), dim3(64), lds, st, B); }
 template <int C> void launch_eval(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { hipLaunchKernelGGL(eval_kernel<C>, dim3(nblocks), dim3(64), lds, st, B); }
@@ -439,6 +441,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   HIP_OK(hipMemcpyAsync(B.open_bound, ob.data(), ob.size() * 8, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(B.open_node, on.data(), on.size() * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(B.open_count, oc.data(), n * 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemsetAsync(B.open_depth, 0, (size_t)n * open_cap * 4, st));
   HIP_OK(hipMemsetAsync(B.inc_key, 0xFF, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inc_seen, 0xFF, (size_t)n * 8, st));
   { std::vector<double> big(n, 1e300); HIP_OK(hipMemcpyAsync(B.inc_obj, big.data(), n * 8, hipMemcpyHostToDevice, st));

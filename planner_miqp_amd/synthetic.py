@@ -1,0 +1,107 @@
+"""Deterministic synthetic instances of the MIQP path: seed -> ModelParameters.
+
+Constants follow DefaultSettings() (src/miqp_planner_data.hpp:190-242) and the way MiqpPlanner fills
+ModelParameters (src/miqp_planner.cpp:95-133 solver/global block, :348-378 weights); the region tables are the
+fitted tables of the reference fixtures (planner_miqp_amd/data/region_tables_*.json).  Geometry: straight
+two-lane road, cars merging into the lane y = -1.75, optional constant-velocity rectangular obstacles."""
+import json
+import math
+import os
+
+import numpy as np
+
+from .ctypes_types import ModelParameters
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+_TABLES = {}
+
+CONFIGS = {
+    # name: (cars, steps, regions, environment pieces, obstacles)
+    "cfg2": (1, 20, 16, 1, 0),
+    "cfg3": (2, 20, 32, 2, 0),
+    "cfg4": (2, 20, 32, 2, 4),
+    "mini": (2, 8, 32, 1, 0),
+    "mini1": (1, 10, 32, 1, 1),
+}
+
+
+def tables(R):
+    if R not in _TABLES:
+        _TABLES[R] = json.load(open(os.path.join(_DATA, "region_tables_%d.json" % R)))
+    return _TABLES[R]
+
+
+def region_of(frac, vx, vy):
+    """common/parameter/regions.cpp:16-33 CalculateRegionIdx: sector that contains the velocity direction"""
+    th = math.atan2(vy, vx) % (2 * math.pi)
+    R = len(frac)
+    return int(th / (2 * math.pi / R)) % R
+
+
+def generate(config="cfg3", seed=0, gap=0.01, max_time=10.0):
+    C_, N, R, E, O = CONFIGS[config] if isinstance(config, str) else config
+    rng = np.random.Generator(np.random.MT19937(seed))
+    T = tables(R)
+    p = ModelParameters()
+    p.NumSteps, p.nr_regions, p.NumCars, p.nr_obstacles, p.nr_environments = N, R, C_, O, E
+    p.max_lines_obstacles = 4 if O > 0 else 0
+    p.max_solution_time, p.relative_mip_gap_tolerance = max_time, gap
+    p.ts = 0.25
+    eps = 1e-6
+    p.min_vel_x_y, p.max_vel_x_y = float(T["min_vel_x_y"]) - eps, float(T["max_vel_x_y"]) + eps
+    p.total_min_acc, p.total_max_acc = float(T["total_min_acc"]) - eps, float(T["total_max_acc"]) + eps
+    p.total_min_jerk, p.total_max_jerk = float(T["total_min_jerk"]) - eps, float(T["total_max_jerk"]) + eps
+    p.agent_safety_distance = np.zeros(N)
+    p.agent_safety_distance_slack = np.full(N, 3.0)
+    p.maximum_slack, p.WEIGHTS_SLACK, p.WEIGHTS_SLACK_OBSTACLE = 3.0, 30.0, 2000.0
+    p.minimum_region_change_speed = float(T["minimum_region_change_speed"])
+    lam = 0.5
+    scale = np.array([lam if c == 0 or C_ == 1 else (1 - lam) / (C_ - 1) for c in range(C_)])
+    if C_ == 1:
+        scale[:] = lam
+    p.WEIGHTS_POS_X = 2.0 * scale; p.WEIGHTS_POS_Y = 2.0 * scale
+    p.WEIGHTS_VEL_X = 0.0 * scale; p.WEIGHTS_VEL_Y = 0.0 * scale
+    p.WEIGHTS_ACC_X = 0.0 * scale; p.WEIGHTS_ACC_Y = 0.0 * scale
+    p.WEIGHTS_JERK_X = 1.0 * scale; p.WEIGHTS_JERK_Y = 1.0 * scale
+    p.WheelBase = np.full(C_, 2.8); p.CollisionRadius = np.full(C_, 1.0)
+    frac = np.array(T["fraction_parameters"], float).reshape(R, 4)
+    p.fraction_parameters = frac
+    for k in ["POLY_SINT_UB", "POLY_SINT_LB", "POLY_COSS_UB", "POLY_COSS_LB", "POLY_KAPPA_AX_MAX", "POLY_KAPPA_AX_MIN"]:
+        setattr(p, k, np.array(T[k], float).reshape(R, 3))
+    for k in ["min_acc_x", "max_acc_x", "min_acc_y", "max_acc_y", "min_jerk_x", "max_jerk_x", "min_jerk_y", "max_jerk_y"]:
+        setattr(p, k, np.tile(np.array(T[k], float).reshape(1, R), (C_, 1)))
+    x0 = np.zeros((C_, 6)); xr = np.zeros((C_, N)); yr = np.zeros((C_, N)); vxr = np.zeros((C_, N)); vyr = np.zeros((C_, N))
+    init = np.zeros(C_, int); poss = np.zeros((C_, R), int)
+    for c in range(C_):
+        lane = 1.75 if c % 2 == 0 else -1.75
+        sgn = -1.0 if lane > 0 else 1.0
+        px = 8.0 * c + rng.uniform(-2, 2); v0 = rng.uniform(4, 9); vdes = rng.uniform(5, 10)
+        x0[c] = [px, v0, 0.0, lane, 0.1 * sgn, 0.0]
+        xr[c] = px + vdes * p.ts * np.arange(N); yr[c] = -1.75; vxr[c] = vdes
+        j0 = region_of(frac, v0, 0.1 * sgn)
+        init[c] = j0 + 1
+        jr = region_of(frac, vdes, 0.0)
+        for j in (j0, jr, (jr - 1) % R):          # heading 0 lies on the border of regions R and 1
+            for dj in (-1, 0, 1):
+                poss[c, (j + dj) % R] = 1
+    p.IntitialState, p.x_ref, p.y_ref, p.vx_ref, p.vy_ref = x0, xr, yr, vxr, vyr
+    p.initial_region, p.possible_region = init, poss
+    if E == 1:
+        p.MultiEnvironmentConvexPolygon = [np.array([[-10, -5.25], [150, -5.25], [150, 5.25], [-10, 5.25]], float)]
+    elif E == 2:
+        p.MultiEnvironmentConvexPolygon = [np.array([[-10, -5.25], [75, -5.25], [75, 5.25], [-10, 5.25]], float),
+                                           np.array([[65, -5.25], [150, -5.25], [150, 5.25], [65, 5.25]], float)]
+    else:
+        p.MultiEnvironmentConvexPolygon = []
+    obs = []
+    for o in range(O):
+        ox = rng.uniform(20, 80); ov = rng.uniform(0, 6); oy = 1.75 if rng.uniform() < 0.5 else -1.75
+        hl, hw = 4.8 / 2 + 1.0, 1.8 / 2 + 1.0     # rectangle inflated by the collision radius
+        per_t = []
+        for i in range(N):
+            cx = ox + ov * p.ts * i
+            per_t.append(np.array([[cx - hl, oy - hw], [cx + hl, oy - hw], [cx + hl, oy + hw], [cx - hl, oy + hw]], float))
+        obs.append(per_t)
+    p.ObstacleConvexPolygon = obs
+    p.obstacle_is_soft = [0] * O
+    return p

@@ -43,5 +43,29 @@ def main():
     print("fixtures written", {k: len(v) for k, v in g.items() if isinstance(v, list)})
 
 
+
+
+def region_tables():
+    """planner_miqp_amd/data/region_tables_{16,32}.json: the fitted region tables (numeric data of
+    common/parameter/fitting_polynomial_parameters.hpp as they appear in the reference's .dat fixtures:
+    cplexmodel_testcase.dat = (32 regions, vmax 20), test_sos.dat = (16 regions, vmax 20)) used by the
+    synthetic instance generator."""
+    sys.path.insert(0, os.path.join(HERE, "..", "..", "tools"))
+    from miqp_py.dat import load_dat
+    out_dir = os.path.join(HERE, "..", "..", "planner_miqp_amd", "data")
+    os.makedirs(out_dir, exist_ok=True)
+    for f, R in (("cplexmodel_testcase.dat", 32), ("test_sos.dat", 16)):
+        d = load_dat(os.path.join(REF, "cplexmodel", f))
+        keys = ["fraction_parameters", "POLY_SINT_UB", "POLY_SINT_LB", "POLY_COSS_UB", "POLY_COSS_LB", "POLY_KAPPA_AX_MAX",
+                "POLY_KAPPA_AX_MIN", "min_acc_x", "max_acc_x", "min_acc_y", "max_acc_y", "min_jerk_x", "max_jerk_x",
+                "min_jerk_y", "max_jerk_y", "total_min_acc", "total_max_acc", "total_min_jerk", "total_max_jerk",
+                "min_vel_x_y", "max_vel_x_y", "minimum_region_change_speed"]
+        t = {k: d[k] for k in keys}
+        t["nr_regions"] = R
+        t["source"] = "cplexmodel/" + f
+        json.dump(t, open(os.path.join(out_dir, "region_tables_%d.json" % R), "w"))
+
+
 if __name__ == "__main__":
-    sys.exit(main())
+    main()
+    region_tables()

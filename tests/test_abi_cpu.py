@@ -1,0 +1,113 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol of include/miqp_gpu.h, host logic,
+sharding over gloo.  No compute call needs a GPU here."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import planner_miqp_amd as P
+from helpers import dat_path, load_params
+from planner_miqp_amd import synthetic
+from planner_miqp_amd.sharding import shard_indices
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    P.build_library()
+    return P.load_library()
+
+
+def test_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "miqp_gpu.h")).read()
+    names = set(re.findall(r"\b(miqp_[a-z_]+)\s*\(", hdr))
+    assert names, "no prototypes found"
+    for n in names:
+        assert hasattr(lib, n), n
+    from planner_miqp_amd.wrapper import EXPORTED_SYMBOLS
+    assert names == set(EXPORTED_SYMBOLS)
+
+
+def test_set_params_and_dims(lib):
+    import ctypes as C
+    p = load_params("cplexmodel_testcase.dat")
+    w = P.CplexWrapper()
+    w.resetParameters(p)
+    assert w._push_inputs() == 0
+    d = (C.c_int * 6)()
+    assert lib.miqp_solver_get_dims(w._h, d) == 0
+    assert list(d) == [1, 20, 32, 1, 1, 4]
+
+
+def test_load_dat_errors(lib):
+    w = P.CplexWrapper(parameterSource=P.ParameterSource.DATFILE)
+    w.setParameterDatFileAbsolute("/nonexistent/file.dat")
+    assert w.callCplex() == P.OptimizationStatus.FAILED_SEG_FAULT
+
+
+def test_no_cpu_fallback(lib):
+    """without a HIP device the product must fail loudly, never solve on the host"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    w = P.CplexWrapper(parameterSource=P.ParameterSource.DATFILE)
+    w.setParameterDatFileAbsolute(dat_path("cplexmodel_testcase.dat"))
+    assert w.callCplex() == P.OptimizationStatus.FAILED_SEG_FAULT
+    assert w.getRawResults() is None
+
+
+def test_product_does_not_reference_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "planner_miqp_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle/" not in txt.replace("no dependency on oracle/", "") and "liboracle" not in txt and "oracle_lib" not in txt, f
+
+
+def test_synthetic_generator_is_deterministic_and_valid(oracle):
+    a = synthetic.generate("cfg3", 7)
+    b = synthetic.generate("cfg3", 7)
+    assert np.array_equal(a.IntitialState, b.IntitialState) and np.array_equal(a.x_ref, b.x_ref)
+    h = oracle.from_params(a, 10)
+    s = oracle.sizes(h)
+    assert s["bin"] == 2 * 20 * (5 * 2 + 32 + 5) + 20 * 16 and s["cont"] == 2 * 20 * 12 + 20 * 4
+    oracle.free(h)
+
+
+def test_shard_indices_partition():
+    n = 37
+    seen = []
+    for r in range(4):
+        seen += shard_indices(n, r, 4)
+    assert sorted(seen) == list(range(n))
+
+
+def test_gloo_two_ranks_gather():
+    """the N>1 path of bench.py: independent shards, one gather of result counters (gloo, world_size 2)"""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from planner_miqp_amd.sharding import shard_indices, gather_counts
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+mine = shard_indices(10, r, w)
+g = gather_counts([float(len(mine)), float(sum(mine))])
+if r == 0:
+    assert sum(x[0] for x in g) == 10 and sum(x[1] for x in g) == 45, g
+    print("GATHER_OK")
+dist.destroy_process_group()
+''' % ROOT
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(code)
+        script = f.name
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", script], capture_output=True, text=True, env=env, timeout=300)
+    os.unlink(script)
+    assert "GATHER_OK" in out.stdout, out.stdout + out.stderr

@@ -1,0 +1,193 @@
+"""Parity of the HIP solver (through the C ABI) with the CPU oracle and the reference's known answers.
+All tests here need a real MI355X: run with  python -m pytest tests -m gpu."""
+import numpy as np
+import pytest
+
+import planner_miqp_amd as P
+from helpers import CONT_FIELDS, dat_path, k3, k3_results, load_params
+from planner_miqp_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+STATE_TOL = 1e-4      # north_star: trajectory states within 1e-4
+OBJ_TOL = 1e-5        # test/cplex_wrapper_test.cc:874 EXPECT_NEAR(..., 1e-5)
+
+
+def gpu_solve_dat(name, gap):
+    w = P.CplexWrapper("cplexmodel.mod", P.ParameterSource.DATFILE, 12, gap_override=gap)
+    w.setParameterDatFileAbsolute(dat_path(name))
+    st = w.callCplex()
+    return w, st
+
+
+def assert_states_close(a, b, tol=STATE_TOL, fields=CONT_FIELDS):
+    for n in fields:
+        d = np.abs(getattr(a, n) - getattr(b, n)).max()
+        assert d <= tol, (n, d)
+
+
+def test_testcase_matches_reference_and_oracle(oracle):
+    """test_problem_properties / test_hardcoded_data (cc:857-876): status 0, sizes, objective 9.57603 +- 1e-5;
+    plus: bit-equal regions and states within 1e-4 of the CPU oracle, result feasible for the raw OPL rows"""
+    w, st = gpu_solve_dat("cplexmodel_testcase.dat", 1e-6)
+    assert st == P.OptimizationStatus.SUCCESS
+    pr = w.getSolutionProperties()
+    g = k3()
+    assert abs(pr.objective - g["objective"]) <= OBJ_TOL
+    assert (pr.NrConstraints, pr.NrBinaryVariables, pr.NrFloatVariables) == (12361, 1240, 340)
+    assert pr.gap <= 1e-6 and pr.best_bound <= pr.objective + 1e-9 and pr.NrSolutionPool >= 1
+    res = w.getRawResults()
+    h = oracle.from_dat(dat_path("cplexmodel_testcase.dat"))
+    ost, ores, op = oracle.solve(h, (1, 20, 32, 1, 1, 4), gap=1e-6)
+    assert ost == 0 and abs(op.objective - pr.objective) <= 1e-6
+    assert np.array_equal(res.active_region, ores.active_region)
+    assert np.array_equal(res.active_region.reshape(-1), np.array(g["active_region"], dtype=np.int32))
+    assert_states_close(res, ores)
+    for n in ["deltacc", "deltacc_front", "notWithinEnvironmentRear", "region_change_not_allowed_combined"]:
+        assert np.array_equal(getattr(res, n), getattr(ores, n)), n
+    v, obj, worst = oracle.raw_eval(h, res)
+    assert v < 1e-5 and abs(obj - pr.objective) < 1e-6, worst
+    oracle.free(h)
+
+
+def test_k3_fixed_binaries_on_device(oracle):
+    """the device interior point kernel with K3's binaries asserted reproduces cc:283-456 and 9.57603"""
+    fx, g = k3_results()
+    w = P.CplexWrapper("cplexmodel.mod", P.ParameterSource.DATFILE, 12)
+    w.setParameterDatFileAbsolute(dat_path("cplexmodel_testcase.dat"))
+    rc, out, obj, it = w.solveFixed(fx)
+    assert rc == 0 and abs(obj - g["objective"]) <= OBJ_TOL
+    for n in CONT_FIELDS:
+        ref = np.array(g[n]).reshape(1, 20)
+        assert np.abs(getattr(out, n) - ref).max() <= 1e-4 + 5e-5 * np.abs(ref).max(), n
+    h = oracle.from_dat(dat_path("cplexmodel_testcase.dat"))
+    ost, ores, oobj, oit = oracle.solve_fixed(h, (1, 20, 32, 1, 1, 4), fx)
+    assert ost == 0 and abs(oobj - obj) <= 1e-7
+    assert_states_close(out, ores, 1e-5)
+    oracle.free(h)
+
+
+def test_hardcoded_data_versus_datfile():
+    """cc:474-505: CPPINPUTS and DATFILE sources give the same objective and gap"""
+    w1, st1 = gpu_solve_dat("cplexmodel_testcase.dat", 1e-6)
+    w2 = P.CplexWrapper("cplexmodel.mod", P.ParameterSource.CPPINPUTS, 12, gap_override=1e-6)
+    w2.resetParameters(load_params("cplexmodel_testcase.dat"))
+    st2 = w2.callCplex()
+    assert st1 == st2 == P.OptimizationStatus.SUCCESS
+    assert abs(w1.getSolutionProperties().objective - w2.getSolutionProperties().objective) < 1e-9
+
+
+def test_sos_and_priorities_do_not_change_the_answer(oracle):
+    """cc:604-635, :755-791: SOS1 / branching priorities leave objective and gap unchanged"""
+    objs = []
+    for sos, prio in ((False, False), (True, False), (False, True)):
+        w = P.CplexWrapper("cplexmodel.mod", P.ParameterSource.DATFILE, 12, gap_override=1e-5)
+        w.setParameterDatFileAbsolute(dat_path("test_sos.dat"))
+        w.setSpecialOrderedSets(sos); w.setUseBranchingPriorities(prio); w.setBranchingPriorityValueExtent(1, 19)
+        assert w.callCplex() == P.OptimizationStatus.SUCCESS
+        objs.append(w.getSolutionProperties().objective)
+    assert max(objs) - min(objs) < 1e-9
+    h = oracle.from_dat(dat_path("test_sos.dat"))
+    ost, ores, op = oracle.solve(h, (1, 20, 16, 0, 0, 0), gap=1e-5)
+    assert abs(op.objective - objs[0]) <= 2e-5 * abs(objs[0])
+    oracle.free(h)
+
+
+@pytest.mark.parametrize("cfg,seeds", [("mini1", range(6)), ("mini", range(6)), ("cfg2", range(4))])
+def test_synthetic_parity_tight_gap(oracle, cfg, seeds):
+    """seeded instances solved to 1e-7 by both: objective equal to 1e-6 relative, identical regions and
+    canonical binaries, states within 1e-4, device result feasible for the raw big-M model"""
+    for seed in seeds:
+        p = synthetic.generate(cfg, seed, gap=1e-7, max_time=60)
+        w = P.CplexWrapper(parameterSource=P.ParameterSource.CPPINPUTS)
+        w.resetParameters(p)
+        st = w.callCplex()
+        h = oracle.from_params(p, 10)
+        ost, ores, op = oracle.solve(h, oracle.dims(p), gap=1e-7, time_limit=120)
+        assert int(st) == ost, (cfg, seed, st, ost)
+        if ost != 0:
+            oracle.free(h); continue
+        pr = w.getSolutionProperties(); res = w.getRawResults()
+        assert abs(pr.objective - op.objective) <= 1e-6 * max(1.0, abs(op.objective)), (cfg, seed, pr.objective, op.objective)
+        assert np.array_equal(res.active_region, ores.active_region), (cfg, seed)
+        assert_states_close(res, ores)
+        for n in ["notWithinEnvironmentRear", "notWithinEnvironmentFrontUbUb", "deltacc", "deltacc_front", "car2car_collision",
+                  "region_change_not_allowed_combined", "region_change_not_allowed_x_positive"]:
+            assert np.array_equal(getattr(res, n), getattr(ores, n)), (cfg, seed, n)
+        v, obj, worst = oracle.raw_eval(h, res)
+        assert v < 1e-5 and abs(obj - pr.objective) <= 1e-6 * max(1.0, abs(obj)), (cfg, seed, worst)
+        oracle.free(h)
+
+
+def test_batch_equals_single_solves():
+    ps = [synthetic.generate("mini", s, gap=1e-6, max_time=60) for s in range(12)]
+    singles = []
+    for p in ps:
+        w = P.CplexWrapper(); w.resetParameters(p); assert w.callCplex() == P.OptimizationStatus.SUCCESS
+        singles.append(w.getSolutionProperties().objective)
+    ws = []
+    for p in ps:
+        w = P.CplexWrapper(); w.resetParameters(p); ws.append(w)
+    sts = P.solve_batch(ws)
+    assert all(s == P.OptimizationStatus.SUCCESS for s in sts)
+    for w, o in zip(ws, singles):
+        assert abs(w.getSolutionProperties().objective - o) <= 1e-6 * max(1.0, abs(o))
+
+
+def test_infeasible_instance_reports_no_solution():
+    """initial pose outside the environment: CPLEX status 'infeasible' -> FAILED_NO_SOLUT, NaN objective (cpp:231-240)"""
+    p = synthetic.generate("mini1", 0)
+    p.IntitialState = p.IntitialState.copy(); p.IntitialState[0, 3] = 9.0
+    w = P.CplexWrapper(); w.resetParameters(p)
+    assert w.callCplex() == P.OptimizationStatus.FAILED_NO_SOLUT
+    pr = w.getSolutionProperties()
+    assert np.isnan(pr.objective) and np.isnan(pr.gap)
+
+
+def test_time_limit_is_honoured():
+    """test_max_solution_time (cc:637-672): wall <= limit + 0.3 s; a time-limited incumbent is a SUCCESS (status 107)"""
+    import time
+    p = synthetic.generate("cfg3", 2, gap=1e-9, max_time=1.0)
+    w = P.CplexWrapper(); w.resetParameters(p)
+    t = time.time(); st = w.callCplex(); dt = time.time() - t
+    assert dt <= 1.0 + 0.3 + 0.5   # + buffer allocation of the first call
+    pr = w.getSolutionProperties()
+    assert (st == P.OptimizationStatus.SUCCESS and pr.status in (101, 102, 107)) or st == P.OptimizationStatus.FAILED_TIMEOUT
+
+
+def test_warmstart_is_accepted_as_incumbent():
+    """test_complete_warmstart_receding_horizon (cc:715-753): a feasible start vector is taken as incumbent"""
+    fx, g = k3_results()
+    w = P.CplexWrapper("cplexmodel.mod", P.ParameterSource.DATFILE, 12, gap_override=1e-6)
+    w.setParameterDatFileAbsolute(dat_path("cplexmodel_testcase.dat"))
+    w.addRecedingHorizonWarmstart(fx)
+    assert w.callCplex() == P.OptimizationStatus.SUCCESS
+    assert abs(w.getSolutionProperties().objective - g["objective"]) <= OBJ_TOL
+
+
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg4"])
+def test_full_size_properties(oracle, cfg):
+    """BASELINE configs at full size (2 cars x 20 steps x 32 regions [+ 4 obstacles]): size-independent
+    properties - status, bound <= objective, gap definition, feasibility of the returned vector for every raw
+    big-M row with the returned binaries, objective recomputed from the vector"""
+    ps = [synthetic.generate(cfg, s, gap=0.01, max_time=20) for s in range(8)]
+    ws = []
+    for p in ps:
+        w = P.CplexWrapper(); w.resetParameters(p); ws.append(w)
+    sts = P.solve_batch(ws)
+    nsolved = 0
+    for p, w, st in zip(ps, ws, sts):
+        pr = w.getSolutionProperties()
+        if st != P.OptimizationStatus.SUCCESS:
+            assert st in (P.OptimizationStatus.FAILED_TIMEOUT, P.OptimizationStatus.FAILED_NO_SOLUT)
+            continue
+        assert pr.best_bound <= pr.objective + 1e-9
+        assert abs(pr.gap - abs(pr.best_bound - pr.objective) / (1e-10 + abs(pr.objective))) < 1e-12
+        assert pr.status in (101, 102, 107) and (pr.status == 107 or pr.gap <= 0.01 + 1e-12)
+        nsolved += pr.status != 107
+        h = oracle.from_params(p, 10)
+        v, obj, worst = oracle.raw_eval(h, w.getRawResults())
+        assert v < 1e-5, (cfg, worst)
+        assert abs(obj - pr.objective) <= 1e-6 * max(1.0, abs(obj))
+        oracle.free(h)
+    assert nsolved >= 1
