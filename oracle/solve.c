@@ -23,6 +23,7 @@
 #define RHO_EL 1.0e5
 #define FEAS_TOL 1.0e-6
 #define QP_TOL 1.0e-10
+#define QP_TOL_FINAL 1.0e-13 /* polish of the returned incumbent */
 #define QP_MAXIT 80
 #define QP_SIGMA 0.1
 
@@ -319,7 +320,7 @@ static void build_AB(const oinst* I, double* A, double* B, int nx, int nu) {
 }
 
 /* rows must be usable in any order; they are bucketed by stage here */
-static int qp_solve(const dmodel* M, const orow* rows, int m, qpres* out) {
+static int qp_solve_tol(const dmodel* M, const orow* rows, int m, qpres* out, double qp_tol) {
   const oinst* I = M->I;
   const int N = I->N, nx = M->nx, nu = M->nu, nz = M->nz;
   double* A = (double*)malloc(sizeof(double) * nx * nx); double* B = (double*)malloc(sizeof(double) * nx * nu);
@@ -377,7 +378,7 @@ static int qp_solve(const dmodel* M, const orow* rows, int m, qpres* out) {
       if (rows[k].a == 0.0) { double t = tt[k], mu = RHO_EL - lam[k]; comp += t * mu; (void)c; }
     }
     comp /= (m + mel > 0 ? m + mel : 1);
-    if (comp < QP_TOL * fmax(1.0, fabs(obj)) && resid_fac * R0 < 1e-7) { ok = 1; break; }
+    if (comp < qp_tol * fmax(1.0, fabs(obj)) && resid_fac * R0 < 1e-7) { ok = 1; break; }
     double tau = QP_SIGMA * comp;
     /* backward sweep */
     memset(P, 0, sizeof(double) * nx * nx); memset(pv, 0, sizeof(double) * nx);
@@ -517,6 +518,8 @@ static int qp_solve(const dmodel* M, const orow* rows, int m, qpres* out) {
   free(Pn); free(pn);
   return ok;
 }
+
+static int qp_solve(const dmodel* M, const orow* rows, int m, qpres* out) { return qp_solve_tol(M, rows, m, out, QP_TOL); }
 
 /* ------------------------------------------------------------------ node relaxation rows */
 static void node_rows(const dmodel* M, const signed char* fix, rowvec* v) {
@@ -967,6 +970,19 @@ int orc_solve(const oinst* I, const orc_opts* o, miqp_raw_results_c* res, miqp_s
     status = MIQP_STATUS_SUCCESS;
     props->objective = inc; props->gap = fabs(best_bound - inc) / (1e-10 + fabs(inc));
     props->status = timed_out ? MIQP_CPX_STAT_TIME_LIM_FEAS : (props->gap <= 1e-9 ? MIQP_CPX_STAT_OPTIMAL : MIQP_CPX_STAT_OPTIMAL_TOL);
+    { /* polish: re-solve the incumbent's QP (all disjunctions fixed as completed) to a tight tolerance */
+      rowvec pr = {0, 0, 0}; node_rows(M, inc_fix, &pr);
+      qpres q; qp_solve_tol(M, pr.r, pr.n, &q, QP_TOL_FINAL);
+      props->NrIterations += q.it;
+      if (q.viol <= FEAS_TOL && (q.ok || q.it >= 10)) {
+        memcpy(incZ, q.Z, sizeof(double) * I->N * M->nz);
+        props->objective = q.obj + const_cost(M, inc_fix) + cobj0;
+        if (best_bound > props->objective) best_bound = props->objective;
+        props->best_bound = best_bound;
+        props->gap = fabs(best_bound - props->objective) / (1e-10 + fabs(props->objective));
+      }
+      free(q.Z); free(q.lam); free(pr.r);
+    }
     if (res) fill_results(M, inc_fix, incZ, res);
   } else {
     status = timed_out ? MIQP_STATUS_FAILED_TIMEOUT : MIQP_STATUS_FAILED_NO_SOLUT;
@@ -1028,7 +1044,7 @@ int orc_solve_fixed(const oinst* I, const miqp_raw_results_c* f, miqp_raw_result
           }
     }
   }
-  qpres q; qp_solve(M, rows.r, rows.n, &q);
+  qpres q; qp_solve_tol(M, rows.r, rows.n, &q, QP_TOL_FINAL);
   if (objective) *objective = q.obj;
   if (iters) *iters = q.it;
   int rc = (q.ok && q.viol <= FEAS_TOL) ? 0 : 1;

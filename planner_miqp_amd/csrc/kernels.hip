@@ -18,6 +18,7 @@ namespace miqp {
 constexpr double RHO_EL = 1.0e5;     // exact-penalty weight of the elastic rows
 constexpr double FEAS_TOL = 1.0e-6;
 constexpr double QP_TOL = 1.0e-10;
+constexpr double QP_TOL_FINAL = 1.0e-13;  // polish of the returned incumbent / solve_fixed
 constexpr double QP_SIGMA = 0.1;
 constexpr int QP_MAXIT = 80;
 constexpr int NFIELD = 6;            // per-row state: s, lambda, t, ds, dlambda, dt
@@ -48,6 +49,7 @@ struct DevBuf {
   double* rowstate;              // [batch_cap][NFIELD][ROWCAP]
   int* active_insts;             // number of instances not yet done
   int nodes_per_round; int n_inst;
+  double qp_tol;
   unsigned long long* stat_rowiters;
 };
 
@@ -216,78 +218,112 @@ __device__ inline double ab_entry(int q, int b, double ts) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int C>
-__global__ void __launch_bounds__(64) ipm_kernel(DevBuf B) {
+// block-wide reductions over NT threads (NT/64 waves); red has NT/64 doubles; two barriers each
+template <int NT> __device__ inline double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = 0.0;
+#pragma unroll
+  for (int k = 0; k < NT / 64; ++k) r += red[k];
+  return r;
+}
+template <int NT> __device__ inline double block_min(double v, double* red) {
+  v = wave_min(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = red[0];
+#pragma unroll
+  for (int k = 1; k < NT / 64; ++k) r = fmin(r, red[k]);
+  return r;
+}
+template <int NT> __device__ inline double block_max(double v, double* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = red[0];
+#pragma unroll
+  for (int k = 1; k < NT / 64; ++k) r = fmax(r, red[k]);
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  interior point kernel: one workgroup of NT threads per node
+template <int C, int NT>
+__global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
   constexpr int NX = 6 * C, NU = 2 * C, NZ = 8 * C, GS = NZ + 1;
   const Layout& Y = B.Y;
-  const int node = blockIdx.x, lane = threadIdx.x;
-  if (node >= *B.batch_count) return;
-  const int inst = B.batch_inst[node];
-  const double* D = B.inst_d + (size_t)inst * Y.dstride;
-  const int* T = B.inst_i + (size_t)inst * Y.istride;
+  const int tid = threadIdx.x;
+  const int nbatch = *B.batch_count;
   const int N = Y.N, NSLOT = Y.NSLOT;
-  const double ts = D[Y.d_glob + 7];
-
   extern __shared__ double lds[];
+  const int nrow = NSLOT > NT ? NSLOT : NT;  // LDS rows: one scratch row per thread, one row per slot of a stage
   double* Z = lds;                       // [N][NZ]
   double* dZ = Z + N * NZ;               // [N][NZ]
   double* Kg = dZ + N * NZ;              // [N][NU*NX]
   double* kg = Kg + N * NU * NX;         // [N][NU]
-  double* Gh = kg + N * NU;              // [slots rounded to 64][GS]
-  const int nsl64 = (NSLOT + 63) & ~63;
-  double* fs = Gh + nsl64 * GS;          // [nsl64]
-  double* Phi = fs + nsl64;              // [NZ*NZ]  (becomes S)
+  double* Gh = kg + N * NU;              // [nrow][GS]
+  double* fs = Gh + nrow * GS;           // [nrow]
+  double* Phi = fs + nrow;               // [NZ*NZ]  (becomes S)
   double* rr = Phi + NZ * NZ;            // [NZ]     (becomes sv)
   double* Tm = rr + NZ;                  // [NX*NZ]
   double* Pm = Tm + NX * NZ;             // [NX*NX]
   double* pv = Pm + NX * NX;             // [NX]
   double* Lc = pv + NX;                  // [NU*NU]
   double* Wd = Lc + NU * NU;             // [NZ]
-  signed char* fix = (signed char*)(Wd + NZ);  // [fixlen]
-
+  double* red = Wd + NZ;                 // [8]
+  signed char* fix = (signed char*)(red + 8);  // [fixlen]
+  // persistent-style: a resident block works through nodes blockIdx.x, blockIdx.x + gridDim.x, ... so that the
+  // per-row interior-point state (indexed by block, not by node) stays cache resident
+  for (int node = blockIdx.x; node < nbatch; node += gridDim.x) {
+  const int inst = B.batch_inst[node];
+  const double* D = B.inst_d + (size_t)inst * Y.dstride;
+  const int* T = B.inst_i + (size_t)inst * Y.istride;
+  const double ts = D[Y.d_glob + 7];
+  __syncthreads();
   {
     const signed char* src = B.pool_fix + (size_t)B.batch_node[node] * Y.fixlen;
-    for (int k = lane; k < Y.fixlen; k += 64) fix[k] = src[k];
-    for (int k = lane; k < NZ; k += 64) Wd[k] = D[Y.d_wd + k];
-    for (int k = lane; k < N * NZ; k += 64) { Z[k] = 0.0; dZ[k] = 0.0; }
+    for (int k = tid; k < Y.fixlen; k += NT) fix[k] = src[k];
+    for (int k = tid; k < NZ; k += NT) Wd[k] = D[Y.d_wd + k];
+    for (int k = tid; k < N * NZ; k += NT) { Z[k] = 0.0; dZ[k] = 0.0; }
   }
   __syncthreads();
-  if (lane < NX) Z[lane] = D[Y.d_x0 + lane];
+  if (tid < NX) Z[tid] = D[Y.d_x0 + tid];
   __syncthreads();
   for (int i = 0; i + 1 < N; ++i) {  // free rollout (u = 0)
-    if (lane < NX) {
+    if (tid < NX) {
       double acc = 0;
-      for (int q = 0; q < NX; ++q) acc += ab_entry<C>(lane, q, ts) * Z[i * NZ + q];
-      Z[(i + 1) * NZ + lane] = acc;
+      for (int q = 0; q < NX; ++q) acc += ab_entry<C>(tid, q, ts) * Z[i * NZ + q];
+      Z[(i + 1) * NZ + tid] = acc;
     }
     __syncthreads();
   }
-  double* RS = B.rowstate + (size_t)node * NFIELD * Y.ROWCAP;
+  double* RS = B.rowstate + (size_t)blockIdx.x * NFIELD * Y.ROWCAP;
   double* rs_s = RS, *rs_l = RS + Y.ROWCAP, *rs_t = RS + 2 * Y.ROWCAP, *rs_ds = RS + 3 * Y.ROWCAP,
          *rs_dl = RS + 4 * Y.ROWCAP, *rs_dt = RS + 5 * Y.ROWCAP;
   const double* Rf = D + Y.d_ref;
+  const int NROWS = N * NSLOT;
 
   // ---- initial row state, complementarity
   double csum = 0.0; int cnt = 0;
-  for (int i = 0; i < N; ++i)
-    for (int sb = 0; sb < NSLOT; sb += 64) {
-      int slot = sb + lane;
-      if (slot < NSLOT) {
-        double* g = Gh + lane * GS;
-        RowOut r = decode_row<C>(Y, D, T, fix, i, slot, g);
-        if (r.active) {
-          double c = r.rhs;
-          for (int q = 0; q < NZ; ++q) c -= g[q] * Z[i * NZ + q];
-          double s, lam, t = 0.0;
-          if (r.aq == 0.0) { lam = 1.0; s = fmax(c, 0.0) + 1.0; t = s - c; csum += s * lam + t * (RHO_EL - lam); cnt += 2; }
-          else { lam = fmax(1.0, -2.0 * c * r.aq + 1.0); s = c + lam / r.aq; csum += s * lam; cnt += 1; }
-          int idx = i * NSLOT + slot;
-          rs_s[idx] = s; rs_l[idx] = lam; rs_t[idx] = t;
-        }
-      }
+  for (int idx = tid; idx < NROWS; idx += NT) {
+    int i = idx / NSLOT, slot = idx - i * NSLOT;
+    double* g = Gh + tid * GS;
+    RowOut r = decode_row<C>(Y, D, T, fix, i, slot, g);
+    double s = 1.0, lam = 1.0, t = 1.0;
+    if (r.active) {
+      double c = r.rhs;
+      for (int q = 0; q < NZ; ++q) c -= g[q] * Z[i * NZ + q];
+      if (r.aq == 0.0) { lam = 1.0; s = fmax(c, 0.0) + 1.0; t = s - c; csum += s * lam + t * (RHO_EL - lam); cnt += 2; }
+      else { lam = fmax(1.0, -2.0 * c * r.aq + 1.0); s = c + lam / r.aq; t = 0.0; csum += s * lam; cnt += 1; }
     }
-  double comp = wave_sum(csum);
-  int ncomp = (int)wave_sum((double)cnt);
+    rs_s[idx] = s; rs_l[idx] = lam; rs_t[idx] = t; rs_ds[idx] = 0.0; rs_dl[idx] = 0.0; rs_dt[idx] = 0.0;
+  }
+  double comp = block_sum<NT>(csum, red);
+  int ncomp = (int)block_sum<NT>((double)cnt, red);
   if (ncomp < 1) ncomp = 1;
   comp /= ncomp;
 
@@ -297,66 +333,58 @@ __global__ void __launch_bounds__(64) ipm_kernel(DevBuf B) {
   for (it = 1; it <= QP_MAXIT; ++it) {
     {
       double o = 0.0;
-      for (int k = lane; k < N * NZ; k += 64) { double d = Z[k] - Rf[k]; o += Wd[k % NZ] * d * d; }
-      obj = wave_sum(o);
+      for (int k = tid; k < N * NZ; k += NT) { double d = Z[k] - Rf[k]; o += Wd[k % NZ] * d * d; }
+      obj = block_sum<NT>(o, red);
     }
-    if (comp < QP_TOL * fmax(1.0, fabs(obj)) && resid_fac * R0 < 1e-7) { ok = 1; break; }
+    if (comp < B.qp_tol * fmax(1.0, fabs(obj)) && resid_fac * R0 < 1e-7) { ok = 1; break; }
     const double tau = QP_SIGMA * comp;
     // ================= backward sweep
-    for (int k = lane; k < NX * NX; k += 64) Pm[k] = 0.0;
-    if (lane < NX) pv[lane] = 0.0;
+    for (int k = tid; k < NX * NX; k += NT) Pm[k] = 0.0;
+    if (tid < NX) pv[tid] = 0.0;
     double rmax = 0.0;
     for (int i = N - 1; i >= 0; --i) {
       __syncthreads();
-      for (int sb = 0; sb < nsl64; sb += 64) {
-        int slot = sb + lane;
+      for (int slot = tid; slot < NSLOT; slot += NT) {
         double* g = Gh + slot * GS;
         double fsv = 0.0;
-        bool act = false;
-        if (slot < NSLOT) {
-          RowOut r = decode_row<C>(Y, D, T, fix, i, slot, g);
-          act = r.active;
-          if (act) {
-            int idx = i * NSLOT + slot;
-            double s = rs_s[idx], lam = rs_l[idx], zz, r2mu = 0.0;
-            if (r.aq == 0.0) { double t = rs_t[idx], mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
-            else zz = 1.0 / r.aq;
-            double Dd = s / lam + zz, w = 1.0 / Dd;
-            double kap = ((tau - s * lam) / lam - r2mu) / Dd;
-            double sw = sqrt(w);
-            fsv = (lam + kap) / sw;
+        RowOut r = decode_row<C>(Y, D, T, fix, i, slot, g);
+        if (r.active) {
+          int idx = i * NSLOT + slot;
+          double s = rs_s[idx], lam = rs_l[idx], zz, r2mu = 0.0;
+          if (r.aq == 0.0) { double t = rs_t[idx], mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
+          else zz = 1.0 / r.aq;
+          double Dd = s / lam + zz, w = 1.0 / Dd;
+          double kap = ((tau - s * lam) / lam - r2mu) / Dd;
+          double sw = sqrt(w);
+          fsv = (lam + kap) / sw;
 #pragma unroll
-            for (int q = 0; q < NZ; ++q) g[q] *= sw;
-          }
-        }
-        if (!act) {
-#pragma unroll
-          for (int q = 0; q < NZ; ++q) g[q] = 0.0;
+          for (int q = 0; q < NZ; ++q) g[q] *= sw;
         }
         fs[slot] = fsv;
       }
       __syncthreads();
       // Phi = 2W + Gh' Gh ; rr = 2W(z - ref) + Gh' fs
-      for (int e = lane; e < NZ * NZ; e += 64) {
+      for (int e = tid; e < NZ * NZ; e += NT) {
         int a = e / NZ, b = e - a * NZ;
         double acc = (a == b) ? 2.0 * Wd[a] : 0.0;
         for (int sl = 0; sl < NSLOT; ++sl) acc += Gh[sl * GS + a] * Gh[sl * GS + b];
         Phi[e] = acc;
       }
-      if (lane < NZ) {
-        double acc = 2.0 * Wd[lane] * (Z[i * NZ + lane] - Rf[i * NZ + lane]);
-        for (int sl = 0; sl < NSLOT; ++sl) acc += Gh[sl * GS + lane] * fs[sl];
-        rr[lane] = acc;
+      if (tid >= NT - NZ) {  // the last NZ threads (another wave than the Phi-heavy first ones when NT > 64)
+        int a = tid - (NT - NZ);
+        double acc = 2.0 * Wd[a] * (Z[i * NZ + a] - Rf[i * NZ + a]);
+        for (int sl = 0; sl < NSLOT; ++sl) acc += Gh[sl * GS + a] * fs[sl];
+        rr[a] = acc;
         if (it == 1) rmax = fmax(rmax, fabs(acc));
       }
       __syncthreads();
       if (i == N - 1) {  // u_{N-1} = 0 (initial_conditions.mod:25-26)
-        for (int e = lane; e < NX * NX; e += 64) { int a = e / NX, b = e - a * NX; Pm[e] = Phi[a * NZ + b]; }
-        if (lane < NX) pv[lane] = rr[lane];
+        for (int e = tid; e < NX * NX; e += NT) { int a = e / NX, b = e - a * NX; Pm[e] = Phi[a * NZ + b]; }
+        if (tid < NX) pv[tid] = rr[tid];
         continue;
       }
       // T = P [A B]
-      for (int e = lane; e < NX * NZ; e += 64) {
+      for (int e = tid; e < NX * NZ; e += NT) {
         int a = e / NZ, b = e - a * NZ;
         double acc = 0.0;
         int q0 = b < NX ? 3 * (b / 3) : 3 * (b - NX);
@@ -365,22 +393,22 @@ __global__ void __launch_bounds__(64) ipm_kernel(DevBuf B) {
       }
       __syncthreads();
       // S = Phi + [A B]' T ; sv = rr + [A B]' p
-      for (int e = lane; e < NZ * NZ; e += 64) {
+      for (int e = tid; e < NZ * NZ; e += NT) {
         int a = e / NZ, b = e - a * NZ;
         double acc = Phi[e];
         int q0 = a < NX ? 3 * (a / 3) : 3 * (a - NX);
         for (int q = q0; q < q0 + 3; ++q) acc += ab_entry<C>(q, a, ts) * Tm[q * NZ + b];
         Phi[e] = acc;
       }
-      if (lane < NZ) {
-        int a = lane; double acc = rr[a];
+      if (tid < NZ) {
+        int a = tid; double acc = rr[a];
         int q0 = a < NX ? 3 * (a / 3) : 3 * (a - NX);
         for (int q = q0; q < q0 + 3; ++q) acc += ab_entry<C>(q, a, ts) * pv[q];
         rr[a] = acc;
       }
       __syncthreads();
-      // Cholesky of Suu (NU x NU), serial on lane 0 (tiny)
-      if (lane == 0) {
+      // Cholesky of Suu (NU x NU), serial on thread 0 (tiny)
+      if (tid == 0) {
         for (int a = 0; a < NU; ++a)
           for (int b = 0; b <= a; ++b) {
             double acc = Phi[(NX + a) * NZ + NX + b];
@@ -389,12 +417,12 @@ __global__ void __launch_bounds__(64) ipm_kernel(DevBuf B) {
           }
       }
       __syncthreads();
-      // K = Suu^-1 Sux, k = Suu^-1 su : one lane per right-hand side column
+      // K = Suu^-1 Sux, k = Suu^-1 su : one thread per right-hand side column
       double* Ki = Kg + i * NU * NX; double* ki = kg + i * NU;
-      if (lane <= NX) {
+      if (tid <= NX) {
         double y[NU];
         for (int a = 0; a < NU; ++a) {
-          double acc = lane < NX ? Phi[(NX + a) * NZ + lane] : rr[NX + a];
+          double acc = tid < NX ? Phi[(NX + a) * NZ + tid] : rr[NX + a];
           for (int q = 0; q < a; ++q) acc -= Lc[a * NU + q] * y[q];
           y[a] = acc / Lc[a * NU + a];
         }
@@ -403,89 +431,88 @@ __global__ void __launch_bounds__(64) ipm_kernel(DevBuf B) {
           for (int q = a + 1; q < NU; ++q) acc -= Lc[q * NU + a] * y[q];
           y[a] = acc / Lc[a * NU + a];
         }
-        for (int a = 0; a < NU; ++a) { if (lane < NX) Ki[a * NX + lane] = y[a]; else ki[a] = y[a]; }
+        for (int a = 0; a < NU; ++a) { if (tid < NX) Ki[a * NX + tid] = y[a]; else ki[a] = y[a]; }
       }
       __syncthreads();
       // P = Sxx - Sxu K (symmetrised), p = sx - Sxu k
-      for (int e = lane; e < NX * NX; e += 64) {
+      for (int e = tid; e < NX * NX; e += NT) {
         int a = e / NX, b = e - a * NX;
         double acc = Phi[a * NZ + b], acc2 = Phi[b * NZ + a];
         for (int q = 0; q < NU; ++q) { acc -= Phi[a * NZ + NX + q] * Ki[q * NX + b]; acc2 -= Phi[b * NZ + NX + q] * Ki[q * NX + a]; }
         Pm[e] = 0.5 * (acc + acc2);
       }
-      if (lane < NX) {
-        double acc = rr[lane];
-        for (int q = 0; q < NU; ++q) acc -= Phi[lane * NZ + NX + q] * ki[q];
-        pv[lane] = acc;
+      if (tid < NX) {
+        double acc = rr[tid];
+        for (int q = 0; q < NU; ++q) acc -= Phi[tid * NZ + NX + q] * ki[q];
+        pv[tid] = acc;
       }
     }
-    if (it == 1) R0 = wave_max(rmax);
+    if (it == 1) R0 = block_max<NT>(rmax, red);
     __syncthreads();
-    // ================= forward sweep
-    if (lane < NZ) dZ[lane] = 0.0;
+    // ================= forward sweep (first wave only; LDS traffic of one wave needs no workgroup barrier)
+    if (tid < NZ) dZ[tid] = 0.0;
     __syncthreads();
-    for (int i = 0; i + 1 < N; ++i) {
-      const double* Ki = Kg + i * NU * NX; const double* ki = kg + i * NU;
-      if (lane < NU) {
-        double acc = -ki[lane];
-        for (int q = 0; q < NX; ++q) acc -= Ki[lane * NX + q] * dZ[i * NZ + q];
-        dZ[i * NZ + NX + lane] = acc;
+    if (tid < 64) {
+      for (int i = 0; i + 1 < N; ++i) {
+        const double* Ki = Kg + i * NU * NX; const double* ki = kg + i * NU;
+        if (tid < NU) {
+          double acc = -ki[tid];
+          for (int q = 0; q < NX; ++q) acc -= Ki[tid * NX + q] * dZ[i * NZ + q];
+          dZ[i * NZ + NX + tid] = acc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (tid < NX) {
+          double acc = 0.0;
+          int q0 = 3 * (tid / 3);
+          for (int q = q0; q < q0 + 3; ++q) acc += ab_entry<C>(tid, q, ts) * dZ[i * NZ + q];
+          acc += ab_entry<C>(tid, NX + tid / 3, ts) * dZ[i * NZ + NX + tid / 3];
+          dZ[(i + 1) * NZ + tid] = acc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-      __syncthreads();
-      if (lane < NX) {
-        double acc = 0.0;
-        int q0 = 3 * (lane / 3);
-        for (int q = q0; q < q0 + 3; ++q) acc += ab_entry<C>(lane, q, ts) * dZ[i * NZ + q];
-        acc += ab_entry<C>(lane, NX + lane / 3, ts) * dZ[i * NZ + NX + lane / 3];
-        dZ[(i + 1) * NZ + lane] = acc;
-      }
-      __syncthreads();
+      if (tid < NU) dZ[(N - 1) * NZ + NX + tid] = 0.0;
     }
-    if (lane < NU) dZ[(N - 1) * NZ + NX + lane] = 0.0;
     __syncthreads();
     // ================= step length
     double amax = 1e300, a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    for (int i = 0; i < N; ++i)
-      for (int sb = 0; sb < NSLOT; sb += 64) {
-        int slot = sb + lane;
-        if (slot < NSLOT) {
-          double* g = Gh + lane * GS;
-          RowOut r = decode_row<C>(Y, D, T, fix, i, slot, g);
-          if (r.active) {
-            int idx = i * NSLOT + slot;
-            double gd = 0.0;
-            for (int q = 0; q < NZ; ++q) gd += g[q] * dZ[i * NZ + q];
-            double s = rs_s[idx], lam = rs_l[idx], zz, r2mu = 0.0, t = 0.0, mu = 0.0;
-            if (r.aq == 0.0) { t = rs_t[idx]; mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
-            else zz = 1.0 / r.aq;
-            double Dd = s / lam + zz, w = 1.0 / Dd;
-            double kap = ((tau - s * lam) / lam - r2mu) / Dd;
-            double dl = w * gd + kap;
-            double ds = ((tau - s * lam) - s * dl) / lam;
-            double dt = 0.0;
-            if (ds < 0) amax = fmin(amax, -s / ds);
-            if (dl < 0) amax = fmin(amax, -lam / dl);
-            a0 += s * lam; a1 += s * dl + lam * ds; a2 += ds * dl;
-            if (r.aq == 0.0) {
-              double dmu = -dl;
-              dt = ((tau - t * mu) - t * dmu) / mu;
-              if (dt < 0) amax = fmin(amax, -t / dt);
-              if (dmu < 0) amax = fmin(amax, -mu / dmu);
-              a0 += t * mu; a1 += t * dmu + mu * dt; a2 += dt * dmu;
-            }
-            rs_ds[idx] = ds; rs_dl[idx] = dl; rs_dt[idx] = dt;
-            rowiters++;
-          }
+    for (int idx = tid; idx < NROWS; idx += NT) {
+      int i = idx / NSLOT, slot = idx - i * NSLOT;
+      double* g = Gh + tid * GS;
+      RowOut r = decode_row<C>(Y, D, T, fix, i, slot, g);
+      double ds = 0.0, dl = 0.0, dt = 0.0;
+      if (r.active) {
+        double gd = 0.0;
+        for (int q = 0; q < NZ; ++q) gd += g[q] * dZ[i * NZ + q];
+        double s = rs_s[idx], lam = rs_l[idx], zz, r2mu = 0.0, t = 0.0, mu = 0.0;
+        if (r.aq == 0.0) { t = rs_t[idx]; mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
+        else zz = 1.0 / r.aq;
+        double Dd = s / lam + zz, w = 1.0 / Dd;
+        double kap = ((tau - s * lam) / lam - r2mu) / Dd;
+        dl = w * gd + kap;
+        ds = ((tau - s * lam) - s * dl) / lam;
+        if (ds < 0) amax = fmin(amax, -s / ds);
+        if (dl < 0) amax = fmin(amax, -lam / dl);
+        a0 += s * lam; a1 += s * dl + lam * ds; a2 += ds * dl;
+        if (r.aq == 0.0) {
+          double dmu = -dl;
+          dt = ((tau - t * mu) - t * dmu) / mu;
+          if (dt < 0) amax = fmin(amax, -t / dt);
+          if (dmu < 0) amax = fmin(amax, -mu / dmu);
+          a0 += t * mu; a1 += t * dmu + mu * dt; a2 += dt * dmu;
         }
+        rowiters++;
       }
-    amax = wave_min(amax);
-    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+      rs_ds[idx] = ds; rs_dl[idx] = dl; rs_dt[idx] = dt;
+    }
+    amax = block_min<NT>(amax, red);
+    a0 = block_sum<NT>(a0, red); a1 = block_sum<NT>(a1, red); a2 = block_sum<NT>(a2, red);
     double alpha = fmin(1.0, 0.995 * amax);
     comp = (a0 + alpha * a1 + alpha * alpha * a2) / ncomp;
     // ================= update
-    for (int k = lane; k < N * NZ; k += 64) Z[k] += alpha * dZ[k];
-    for (int idx = lane; idx < Y.ROWCAP; idx += 64) {
-      // inactive rows hold garbage that is never read; updating them is harmless
+    for (int k = tid; k < N * NZ; k += NT) Z[k] += alpha * dZ[k];
+    for (int idx = tid; idx < NROWS; idx += NT) {
       rs_s[idx] += alpha * rs_ds[idx]; rs_l[idx] += alpha * rs_dl[idx]; rs_t[idx] += alpha * rs_dt[idx];
     }
     resid_fac *= (1.0 - alpha);
@@ -494,35 +521,33 @@ __global__ void __launch_bounds__(64) ipm_kernel(DevBuf B) {
   }
   // ---- final measures: worst elastic violation, slack cost
   double viol = 0.0, scost = 0.0;
-  for (int i = 0; i < N; ++i)
-    for (int sb = 0; sb < NSLOT; sb += 64) {
-      int slot = sb + lane;
-      if (slot < NSLOT) {
-        double* g = Gh + lane * GS;
-        RowOut r = decode_row<C>(Y, D, T, fix, i, slot, g);
-        if (r.active) {
-          double c = r.rhs;
-          for (int q = 0; q < NZ; ++q) c -= g[q] * Z[i * NZ + q];
-          if (r.aq == 0.0) viol = fmax(viol, -c);
-          else { double t = rs_l[i * NSLOT + slot] / r.aq; scost += 0.5 * r.aq * t * t; }
-        }
-      }
+  for (int idx = tid; idx < NROWS; idx += NT) {
+    int i = idx / NSLOT, slot = idx - i * NSLOT;
+    double* g = Gh + tid * GS;
+    RowOut r = decode_row<C>(Y, D, T, fix, i, slot, g);
+    if (r.active) {
+      double c = r.rhs;
+      for (int q = 0; q < NZ; ++q) c -= g[q] * Z[i * NZ + q];
+      if (r.aq == 0.0) viol = fmax(viol, -c);
+      else { double t = rs_l[idx] / r.aq; scost += 0.5 * r.aq * t * t; }
     }
-  viol = wave_max(viol); scost = wave_sum(scost);
+  }
+  viol = block_max<NT>(viol, red); scost = block_sum<NT>(scost, red);
   {
     double o = 0.0;
-    for (int k = lane; k < N * NZ; k += 64) { double d = Z[k] - Rf[k]; o += Wd[k % NZ] * d * d; }
-    obj = wave_sum(o) + scost;
+    for (int k = tid; k < N * NZ; k += NT) { double d = Z[k] - Rf[k]; o += Wd[k % NZ] * d * d; }
+    obj = block_sum<NT>(o, red) + scost;
   }
   double* Zo = B.batch_Z + (size_t)node * N * NZ;
-  for (int k = lane; k < N * NZ; k += 64) Zo[k] = Z[k];
-  if (lane == 0) {
+  for (int k = tid; k < N * NZ; k += NT) Zo[k] = Z[k];
+  if (tid == 0) {
     B.batch_obj[node] = obj; B.batch_viol[node] = viol; B.batch_ok[node] = ok; B.batch_it[node] = it > QP_MAXIT ? QP_MAXIT : it;
     atomicAdd((unsigned long long*)&B.inst_iters[inst], (unsigned long long)(it > QP_MAXIT ? QP_MAXIT : it));
     atomicAdd((unsigned long long*)&B.inst_nodes[inst], 1ull);
   }
-  rowiters = (unsigned long long)wave_sum((double)rowiters);
-  if (lane == 0) atomicAdd(B.stat_rowiters, rowiters);
+  double rsum = block_sum<NT>((double)rowiters, red);
+  if (tid == 0) atomicAdd(B.stat_rowiters, (unsigned long long)rsum);
+  }  // node loop
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -16,6 +16,9 @@
 #include <vector>
 
 #include "../../include/miqp_gpu.h"
+#ifndef MIQP_IPM_NT
+#define MIQP_IPM_NT 64
+#endif
 #include "kernels.hip"
 
 using namespace miqp;
@@ -139,7 +142,7 @@ namespace {
 struct DevCtx {
   bool ready = false; int device = -1;
   hipStream_t stream = nullptr;
-  Layout Y{}; int n_inst = 0, open_cap = 0, batch_cap = 0, pool_cap = 0, npr = 0;
+  Layout Y{}; int n_inst = 0, open_cap = 0, batch_cap = 0, pool_cap = 0, npr = 0, ipm_grid_max = 1024;
   DevBuf B{};
   std::vector<void*> allocs;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -160,6 +163,8 @@ struct DevCtx {
 
 DevCtx g_ctx;
 
+size_t ipm_lds_bytes(const Layout& Y);
+
 bool same_layout(const Layout& a, const Layout& b) { return std::memcmp(&a, &b, sizeof(Layout)) == 0; }
 
 bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, int device) {
@@ -172,11 +177,14 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   if (!X.stream) HIP_OK(hipStreamCreate(&X.stream));
   if (!X.ev0) { HIP_OK(hipEventCreate(&X.ev0)); HIP_OK(hipEventCreate(&X.ev1)); }
   X.Y = Y; X.n_inst = n_inst; X.open_cap = open_cap; X.npr = npr; X.batch_cap = batch_cap;
+  { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); int cus = 256; if (hipGetDeviceProperties(&pr, dv) == hipSuccess) cus = pr.multiProcessorCount;
+    size_t l = ipm_lds_bytes(Y); int per = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(l, 1))); X.ipm_grid_max = cus * per; }
   // node pool: every processed node emits at most a handful of children; records are not recycled inside one solve
   size_t want = (size_t)n_inst * 16384; size_t maxrec = (size_t)3 << 30; maxrec /= (size_t)Y.fixlen;
   X.pool_cap = (int)std::min(want, std::min(maxrec, (size_t)1 << 20) * 1);
   if (X.pool_cap < n_inst * 64) X.pool_cap = n_inst * 64;
   DevBuf& B = X.B; std::memset(&B, 0, sizeof(B));
+  B.qp_tol = QP_TOL;
   B.Y = Y; B.pool_cap = X.pool_cap; B.open_cap = open_cap; B.batch_cap = batch_cap; B.nodes_per_round = npr; B.n_inst = n_inst;
   double* dd; int* ii;
   if (!X.alloc(&dd, (size_t)n_inst * Y.dstride)) return false; B.inst_d = dd;
@@ -211,16 +219,17 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   if (!X.alloc(&B.batch_it, batch_cap)) return false;
   if (!X.alloc(&B.batch_bound, batch_cap)) return false;
   if (!X.alloc(&B.batch_comp, (size_t)batch_cap * Y.fixlen)) return false;
-  if (!X.alloc(&B.rowstate, (size_t)batch_cap * NFIELD * Y.ROWCAP)) return false;
+  if (!X.alloc(&B.rowstate, (size_t)std::min(batch_cap, X.ipm_grid_max) * NFIELD * Y.ROWCAP)) return false;
   if (!X.alloc(&B.active_insts, 1)) return false;
   if (!X.alloc(&B.stat_rowiters, 1)) return false;
   X.ready = true;
   return true;
 }
 
+constexpr int IPM_NT = MIQP_IPM_NT;  // threads per node in the interior point kernel
 size_t ipm_lds_bytes(const Layout& Y) {
-  int NZ = Y.nz, NX = Y.nx, NU = Y.nu, N = Y.N, nsl64 = (Y.NSLOT + 63) & ~63;
-  size_t d = (size_t)2 * N * NZ + (size_t)N * NU * NX + (size_t)N * NU + (size_t)nsl64 * (NZ + 1) + nsl64 + NZ * NZ + NZ + NX * NZ + NX * NX + NX + NU * NU + NZ;
+  int NZ = Y.nz, NX = Y.nx, NU = Y.nu, N = Y.N, nrow = std::max(Y.NSLOT, IPM_NT);
+  size_t d = (size_t)2 * N * NZ + (size_t)N * NU * NX + (size_t)N * NU + (size_t)nrow * (NZ + 1) + nrow + NZ * NZ + NZ + NX * NZ + NX * NX + NX + NU * NU + NZ + 8;
   return d * 8 + (size_t)Y.fixlen + 16;
 }
 size_t eval_lds_bytes(const Layout& Y) {
@@ -229,15 +238,15 @@ size_t eval_lds_bytes(const Layout& Y) {
 }
 size_t select_lds_bytes(int open_cap) { int c2 = 1; while (c2 < open_cap) c2 <<= 1; return (size_t)c2 * 24 + 16; }
 
-template <int C> void launch_ipm(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { hipLaunchKernelGGL(ipm_kernel<C>, dim3(nblocks), dim3(64), lds, st, B); }
+template <int C> void launch_ipm(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { hipLaunchKernelGGL((ipm_kernel<C, IPM_NT>), dim3(nblocks), dim3(IPM_NT), lds, st, B); }
 template <int C> void launch_eval(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { hipLaunchKernelGGL(eval_kernel<C>, dim3(nblocks), dim3(64), lds, st, B); }
 
 bool set_kernel_lds(const Layout& Y, size_t ipm_lds, size_t eval_lds, size_t sel_lds) {
   if (Y.C == 1) {
-    HIP_OK(hipFuncSetAttribute((const void*)ipm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipm_lds));
+    HIP_OK(hipFuncSetAttribute((const void*)ipm_kernel<1, IPM_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipm_lds));
     HIP_OK(hipFuncSetAttribute((const void*)eval_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eval_lds));
   } else {
-    HIP_OK(hipFuncSetAttribute((const void*)ipm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipm_lds));
+    HIP_OK(hipFuncSetAttribute((const void*)ipm_kernel<2, IPM_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipm_lds));
     HIP_OK(hipFuncSetAttribute((const void*)eval_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eval_lds));
   }
   HIP_OK(hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
@@ -473,12 +482,30 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     if (wall_s() - t0 > tlim) { timed_out = true; break; }
     if (X.ipm_ev.size() < nev + 2) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); X.ipm_ev.push_back(a); X.ipm_ev.push_back(b); }
     HIP_OK(hipEventRecord(X.ipm_ev[nev], st));
-    if (Y.C == 1) launch_ipm<1>(B, bc, l_ipm, st); else launch_ipm<2>(B, bc, l_ipm, st);
+    { int gsz = std::min(bc, X.ipm_grid_max); if (Y.C == 1) launch_ipm<1>(B, gsz, l_ipm, st); else launch_ipm<2>(B, gsz, l_ipm, st); }
     HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
     nev += 2;
     if (Y.C == 1) launch_eval<1>(B, bc, l_eval, st); else launch_eval<2>(B, bc, l_eval, st);
     launched_nodes += bc; rounds++;
     if (O0.verbose > 1) std::fprintf(stderr, "[miqp_gpu] round %d: %d nodes\n", rounds, bc);
+  }
+  // ---- polish: the incumbent of every instance is re-solved (all disjunctions fixed as completed) to a tight
+  //      tolerance; its objective and states are what the caller receives
+  std::vector<double> h_pobj(n, 0.0), h_pviol(n, 1.0); std::vector<int> h_pok(n, 0), h_pit(n, 0);
+  {
+    HIP_OK(hipMemcpyAsync(B.pool_fix, B.inc_fix, (size_t)n * Y.fixlen, hipMemcpyDeviceToDevice, st));
+    std::vector<int> ids(n); for (int k = 0; k < n; ++k) ids[k] = k;
+    HIP_OK(hipMemcpyAsync(B.batch_node, ids.data(), n * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(B.batch_inst, ids.data(), n * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(B.batch_count, &n, 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));
+    DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL;
+    int nb = std::min(n, X.batch_cap);
+    { int gsz = std::min(nb, X.ipm_grid_max); if (Y.C == 1) launch_ipm<1>(Bp, gsz, l_ipm, st); else launch_ipm<2>(Bp, gsz, l_ipm, st); }
+    HIP_OK(hipMemcpyAsync(h_pobj.data(), B.batch_obj, nb * 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(h_pviol.data(), B.batch_viol, nb * 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(h_pok.data(), B.batch_ok, nb * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(h_pit.data(), B.batch_it, nb * 4, hipMemcpyDeviceToHost, st));
   }
   HIP_OK(hipEventRecord(X.ev1, st));
   HIP_OK(hipStreamSynchronize(st));
@@ -489,7 +516,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   double t_solve = wall_s() - t0;
 
   // ---- results
-  std::vector<double> h_inc(n), h_lb(n); std::vector<int> h_flags(n), h_ninc(n), h_oc(n); std::vector<long long> h_nodes(n), h_iters(n);
+  std::vector<double> h_inc(n), h_lb(n); std::vector<int> h_flags(n), h_ninc(n), h_oc(n), h_dn(n); std::vector<long long> h_nodes(n), h_iters(n);
   std::vector<unsigned long long> h_key(n);
   unsigned long long rowiters = 0;
   HIP_OK(hipMemcpy(h_inc.data(), B.inc_obj, n * 8, hipMemcpyDeviceToHost));
@@ -498,17 +525,29 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   HIP_OK(hipMemcpy(h_flags.data(), B.inst_flags, n * 4, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(h_ninc.data(), B.inst_ninc, n * 4, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(h_oc.data(), B.open_count, n * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(h_dn.data(), B.inst_done, n * 4, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(h_nodes.data(), B.inst_nodes, n * 8, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(h_iters.data(), B.inst_iters, n * 8, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(&rowiters, B.stat_rowiters, 8, hipMemcpyDeviceToHost));
   std::vector<signed char> h_fix((size_t)n * Y.fixlen); std::vector<double> h_Z((size_t)n * Y.N * Y.nz);
   HIP_OK(hipMemcpy(h_fix.data(), B.inc_fix, h_fix.size(), hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(h_Z.data(), B.inc_Z, h_Z.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<double> h_pZ((size_t)n * Y.N * Y.nz);
+  HIP_OK(hipMemcpy(h_pZ.data(), B.batch_Z, h_pZ.size() * 8, hipMemcpyDeviceToHost));
+  for (int k = 0; k < n; ++k) {
+    if (!(h_inc[k] < 1e299)) continue;
+    if (h_pviol[k] <= FEAS_TOL && (h_pok[k] || h_pit[k] >= 10)) {
+      int nign = 0; for (int q = 0; q < Y.C * Y.O * Y.N * 5; ++q) nign += h_fix[(size_t)k * Y.fixlen + Y.f_obs + q] >= Y.L;
+      h_inc[k] = h_pobj[k] + h_const[k] + nign * S[k]->inst.w_slack_obs;
+      std::copy(h_pZ.begin() + (size_t)k * Y.N * Y.nz, h_pZ.begin() + (size_t)(k + 1) * Y.N * Y.nz, h_Z.begin() + (size_t)k * Y.N * Y.nz);
+    }
+  }
   long long tot_iters = 0; for (int k = 0; k < n; ++k) tot_iters += h_iters[k];
   for (int k = 0; k < n; ++k) {
     miqp_solver* s = S[k];
     bool have = h_inc[k] < 1e299;
-    bool unfinished = timed_out || (h_flags[k] & 1) || h_oc[k] > 0;
+    bool unfinished = (h_flags[k] & 1) || h_oc[k] > 0 || !h_dn[k];
+    (void)timed_out;
     s->props.time = t_solve; s->props.NrIterations = (int)std::min<long long>(h_iters[k], 2147483647LL); s->props.nodes = h_nodes[k];
     s->props.NrSolutionPool = h_ninc[k];
     s->timing[0] = ms_all * 1e-3; s->timing[1] = ms_ipm * 1e-3; s->timing[2] = (double)(nev / 2); s->timing[3] = (double)launched_nodes;
@@ -649,7 +688,8 @@ int miqp_solver_solve_fixed(miqp_solver_t* s, const miqp_raw_results_c* fixed, m
   (void)hipMemcpyAsync(B.batch_node, &zero, 4, hipMemcpyHostToDevice, st);
   (void)hipMemcpyAsync(B.batch_inst, &zero, 4, hipMemcpyHostToDevice, st);
   (void)hipMemsetAsync(B.inst_nodes, 0, 8, st); (void)hipMemsetAsync(B.inst_iters, 0, 8, st); (void)hipMemsetAsync(B.stat_rowiters, 0, 8, st);
-  if (Y.C == 1) launch_ipm<1>(B, 1, ipm_lds_bytes(Y), st); else launch_ipm<2>(B, 1, ipm_lds_bytes(Y), st);
+  { DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL;
+    if (Y.C == 1) launch_ipm<1>(Bp, 1, ipm_lds_bytes(Y), st); else launch_ipm<2>(Bp, 1, ipm_lds_bytes(Y), st); }
   std::vector<double> Z((size_t)Y.N * Y.nz); double obj = 0, viol = 0; int ok = 0, it = 0;
   (void)hipMemcpyAsync(Z.data(), B.batch_Z, Z.size() * 8, hipMemcpyDeviceToHost, st);
   (void)hipMemcpyAsync(&obj, B.batch_obj, 8, hipMemcpyDeviceToHost, st);

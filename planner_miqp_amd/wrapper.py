@@ -14,7 +14,7 @@ _LIB = None
 
 
 def library_path():
-    return os.path.join(_HERE, "libmiqp_gpu.so")
+    return os.environ.get("MIQP_GPU_LIB", os.path.join(_HERE, "libmiqp_gpu.so"))
 
 
 def build_library(force=False):
