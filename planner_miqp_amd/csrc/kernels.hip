@@ -22,6 +22,8 @@ constexpr double QP_TOL_FINAL = 1.0e-13;  // polish of the returned incumbent / 
 constexpr double QP_SIGMA = 0.1;
 constexpr int QP_MAXIT = 80;
 constexpr int NFIELD = 6;            // per-row state: s, lambda, t, ds, dlambda, dt
+constexpr int NCACHE = 9;            // per-row cache: rhs, aq (-1: inactive), packed columns, 6 coefficients
+typedef double d4_t __attribute__((ext_vector_type(4)));
 
 enum { PT_R = 0, PT_U = 1, PT_L = 2 };
 __device__ __constant__ int ENV_PT_D[5][2] = {{PT_R, PT_R}, {PT_U, PT_U}, {PT_L, PT_U}, {PT_U, PT_L}, {PT_L, PT_L}};
@@ -46,7 +48,8 @@ struct DevBuf {
   int* batch_count; int* batch_node; int* batch_inst; int* batch_depth; int batch_cap;
   double* batch_Z; double* batch_obj; double* batch_viol; int* batch_ok; int* batch_it; double* batch_bound;
   signed char* batch_comp;       // completed fix record of feasible nodes
-  double* rowstate;              // [batch_cap][NFIELD][ROWCAP]
+  double* rowstate;              // [grid][NFIELD][ROWCAP]
+  double* rowcache;              // [grid][NCACHE][ROWCAP] decoded sparse rows of the node being solved
   int* active_insts;             // number of instances not yet done
   int nodes_per_round; int n_inst;
   double qp_tol;
@@ -254,13 +257,13 @@ template <int NT> __device__ inline double block_max(double v, double* red) {
 //  interior point kernel: one workgroup of NT threads per node
 template <int C, int NT>
 __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
-  constexpr int NX = 6 * C, NU = 2 * C, NZ = 8 * C, GS = NZ + 1;
+  constexpr int NX = 6 * C, NU = 2 * C, NZ = 8 * C, GS = 17;  // rows are zero padded to the 16 columns of the MFMA tile
   const Layout& Y = B.Y;
   const int tid = threadIdx.x;
   const int nbatch = *B.batch_count;
   const int N = Y.N, NSLOT = Y.NSLOT;
   extern __shared__ double lds[];
-  const int nrow = NSLOT > NT ? NSLOT : NT;  // LDS rows: one scratch row per thread, one row per slot of a stage
+  const int nrow = ((NSLOT + 3) & ~3) > NT ? ((NSLOT + 3) & ~3) : NT;  // LDS rows: scratch row per thread / row per slot of a stage
   double* Z = lds;                       // [N][NZ]
   double* dZ = Z + N * NZ;               // [N][NZ]
   double* Kg = dZ + N * NZ;              // [N][NU*NX]
@@ -307,19 +310,27 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
   const double* Rf = D + Y.d_ref;
   const int NROWS = N * NSLOT;
 
-  // ---- initial row state, complementarity
+  // ---- decode every row of the node once into the sparse row cache; initial row state, complementarity
+  double* RC = B.rowcache + (size_t)blockIdx.x * NCACHE * Y.ROWCAP;
+  double* rc_rhs = RC, *rc_aq = RC + Y.ROWCAP, *rc_col = RC + 2 * Y.ROWCAP, *rc_v = RC + 3 * Y.ROWCAP;
   double csum = 0.0; int cnt = 0;
   for (int idx = tid; idx < NROWS; idx += NT) {
     int i = idx / NSLOT, slot = idx - i * NSLOT;
     double* g = Gh + tid * GS;
     RowOut r = decode_row<C>(Y, D, T, fix, i, slot, g);
     double s = 1.0, lam = 1.0, t = 1.0;
+    unsigned long long cols = 0ull; int nn = 0;
     if (r.active) {
       double c = r.rhs;
-      for (int q = 0; q < NZ; ++q) c -= g[q] * Z[i * NZ + q];
+      for (int q = 0; q < NZ; ++q) {
+        double v = g[q];
+        if (v != 0.0 && nn < 6) { rc_v[(size_t)nn * Y.ROWCAP + idx] = v; cols |= (unsigned long long)q << (8 * nn); nn++; c -= v * Z[i * NZ + q]; }
+      }
       if (r.aq == 0.0) { lam = 1.0; s = fmax(c, 0.0) + 1.0; t = s - c; csum += s * lam + t * (RHO_EL - lam); cnt += 2; }
       else { lam = fmax(1.0, -2.0 * c * r.aq + 1.0); s = c + lam / r.aq; t = 0.0; csum += s * lam; cnt += 1; }
     }
+    cols |= (unsigned long long)nn << 56;
+    rc_rhs[idx] = r.rhs; rc_aq[idx] = r.active ? r.aq : -1.0; rc_col[idx] = __longlong_as_double((long long)cols);
     rs_s[idx] = s; rs_l[idx] = lam; rs_t[idx] = t; rs_ds[idx] = 0.0; rs_dl[idx] = 0.0; rs_dt[idx] = 0.0;
   }
   double comp = block_sum<NT>(csum, red);
@@ -344,33 +355,48 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     double rmax = 0.0;
     for (int i = N - 1; i >= 0; --i) {
       __syncthreads();
-      for (int slot = tid; slot < NSLOT; slot += NT) {
+      const int nsl4 = (NSLOT + 3) & ~3;
+      for (int slot = tid; slot < nsl4; slot += NT) {
         double* g = Gh + slot * GS;
         double fsv = 0.0;
-        RowOut r = decode_row<C>(Y, D, T, fix, i, slot, g);
-        if (r.active) {
-          int idx = i * NSLOT + slot;
-          double s = rs_s[idx], lam = rs_l[idx], zz, r2mu = 0.0;
-          if (r.aq == 0.0) { double t = rs_t[idx], mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
-          else zz = 1.0 / r.aq;
-          double Dd = s / lam + zz, w = 1.0 / Dd;
-          double kap = ((tau - s * lam) / lam - r2mu) / Dd;
-          double sw = sqrt(w);
-          fsv = (lam + kap) / sw;
 #pragma unroll
-          for (int q = 0; q < NZ; ++q) g[q] *= sw;
+        for (int q = 0; q < 16; ++q) g[q] = 0.0;
+        if (slot < NSLOT) {
+          int idx = i * NSLOT + slot;
+          double aq = rc_aq[idx];
+          if (aq >= 0.0) {
+            unsigned long long cols = (unsigned long long)__double_as_longlong(rc_col[idx]);
+            int nn = (int)(cols >> 56);
+            double s = rs_s[idx], lam = rs_l[idx], zz, r2mu = 0.0;
+            if (aq == 0.0) { double t = rs_t[idx], mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
+            else zz = 1.0 / aq;
+            double Dd = s / lam + zz, w = 1.0 / Dd;
+            double kap = ((tau - s * lam) / lam - r2mu) / Dd;
+            double sw = sqrt(w);
+            fsv = (lam + kap) / sw;
+            for (int k = 0; k < nn; ++k) g[(cols >> (8 * k)) & 255] = sw * rc_v[(size_t)k * Y.ROWCAP + idx];
+          }
         }
         fs[slot] = fsv;
       }
       __syncthreads();
-      // Phi = 2W + Gh' Gh ; rr = 2W(z - ref) + Gh' fs
-      for (int e = tid; e < NZ * NZ; e += NT) {
-        int a = e / NZ, b = e - a * NZ;
-        double acc = (a == b) ? 2.0 * Wd[a] : 0.0;
-        for (int sl = 0; sl < NSLOT; ++sl) acc += Gh[sl * GS + a] * Gh[sl * GS + b];
-        Phi[e] = acc;
+      // Phi = 2W + Gh' Gh on the matrix core: v_mfma_f64_16x16x4_f64, 4 rows of the scaled row block per instruction.
+      // A operand lane l = Gh[4kb + (l>>4)][l&15] = B operand (Gh' Gh is symmetric in its two factors);
+      // D layout of the f64 form: row = (l>>4) + 4*reg, col = l&15.
+      if (tid < 64) {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        const int lr = tid >> 4, lc = tid & 15;
+        for (int kb = 0; kb < nsl4; kb += 4) {
+          double a = Gh[(kb + lr) * GS + lc];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          int row = lr + 4 * rg;
+          if (row < NZ && lc < NZ) Phi[row * NZ + lc] = acc[rg] + (row == lc ? 2.0 * Wd[row] : 0.0);
+        }
       }
-      if (tid >= NT - NZ) {  // the last NZ threads (another wave than the Phi-heavy first ones when NT > 64)
+      if (tid >= NT - NZ) {  // rr = 2W(z - ref) + Gh' fs
         int a = tid - (NT - NZ);
         double acc = 2.0 * Wd[a] * (Z[i * NZ + a] - Rf[i * NZ + a]);
         for (int sl = 0; sl < NSLOT; ++sl) acc += Gh[sl * GS + a] * fs[sl];
@@ -478,16 +504,17 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     // ================= step length
     double amax = 1e300, a0 = 0.0, a1 = 0.0, a2 = 0.0;
     for (int idx = tid; idx < NROWS; idx += NT) {
-      int i = idx / NSLOT, slot = idx - i * NSLOT;
-      double* g = Gh + tid * GS;
-      RowOut r = decode_row<C>(Y, D, T, fix, i, slot, g);
+      int i = idx / NSLOT;
+      double aq = rc_aq[idx];
       double ds = 0.0, dl = 0.0, dt = 0.0;
-      if (r.active) {
+      if (aq >= 0.0) {
+        unsigned long long cols = (unsigned long long)__double_as_longlong(rc_col[idx]);
+        int nn = (int)(cols >> 56);
         double gd = 0.0;
-        for (int q = 0; q < NZ; ++q) gd += g[q] * dZ[i * NZ + q];
+        for (int k = 0; k < nn; ++k) gd += rc_v[(size_t)k * Y.ROWCAP + idx] * dZ[i * NZ + ((cols >> (8 * k)) & 255)];
         double s = rs_s[idx], lam = rs_l[idx], zz, r2mu = 0.0, t = 0.0, mu = 0.0;
-        if (r.aq == 0.0) { t = rs_t[idx]; mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
-        else zz = 1.0 / r.aq;
+        if (aq == 0.0) { t = rs_t[idx]; mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
+        else zz = 1.0 / aq;
         double Dd = s / lam + zz, w = 1.0 / Dd;
         double kap = ((tau - s * lam) / lam - r2mu) / Dd;
         dl = w * gd + kap;
@@ -495,7 +522,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
         if (ds < 0) amax = fmin(amax, -s / ds);
         if (dl < 0) amax = fmin(amax, -lam / dl);
         a0 += s * lam; a1 += s * dl + lam * ds; a2 += ds * dl;
-        if (r.aq == 0.0) {
+        if (aq == 0.0) {
           double dmu = -dl;
           dt = ((tau - t * mu) - t * dmu) / mu;
           if (dt < 0) amax = fmin(amax, -t / dt);
@@ -522,14 +549,15 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
   // ---- final measures: worst elastic violation, slack cost
   double viol = 0.0, scost = 0.0;
   for (int idx = tid; idx < NROWS; idx += NT) {
-    int i = idx / NSLOT, slot = idx - i * NSLOT;
-    double* g = Gh + tid * GS;
-    RowOut r = decode_row<C>(Y, D, T, fix, i, slot, g);
-    if (r.active) {
-      double c = r.rhs;
-      for (int q = 0; q < NZ; ++q) c -= g[q] * Z[i * NZ + q];
-      if (r.aq == 0.0) viol = fmax(viol, -c);
-      else { double t = rs_l[idx] / r.aq; scost += 0.5 * r.aq * t * t; }
+    int i = idx / NSLOT;
+    double aq = rc_aq[idx];
+    if (aq >= 0.0) {
+      unsigned long long cols = (unsigned long long)__double_as_longlong(rc_col[idx]);
+      int nn = (int)(cols >> 56);
+      double c = rc_rhs[idx];
+      for (int k = 0; k < nn; ++k) c -= rc_v[(size_t)k * Y.ROWCAP + idx] * Z[i * NZ + ((cols >> (8 * k)) & 255)];
+      if (aq == 0.0) viol = fmax(viol, -c);
+      else { double t = rs_l[idx] / aq; scost += 0.5 * aq * t * t; }
     }
   }
   viol = block_max<NT>(viol, red); scost = block_sum<NT>(scost, red);

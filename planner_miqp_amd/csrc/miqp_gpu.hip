@@ -220,6 +220,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   if (!X.alloc(&B.batch_bound, batch_cap)) return false;
   if (!X.alloc(&B.batch_comp, (size_t)batch_cap * Y.fixlen)) return false;
   if (!X.alloc(&B.rowstate, (size_t)std::min(batch_cap, X.ipm_grid_max) * NFIELD * Y.ROWCAP)) return false;
+  if (!X.alloc(&B.rowcache, (size_t)std::min(batch_cap, X.ipm_grid_max) * NCACHE * Y.ROWCAP)) return false;
   if (!X.alloc(&B.active_insts, 1)) return false;
   if (!X.alloc(&B.stat_rowiters, 1)) return false;
   X.ready = true;
@@ -228,8 +229,8 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
 
 constexpr int IPM_NT = MIQP_IPM_NT;  // threads per node in the interior point kernel
 size_t ipm_lds_bytes(const Layout& Y) {
-  int NZ = Y.nz, NX = Y.nx, NU = Y.nu, N = Y.N, nrow = std::max(Y.NSLOT, IPM_NT);
-  size_t d = (size_t)2 * N * NZ + (size_t)N * NU * NX + (size_t)N * NU + (size_t)nrow * (NZ + 1) + nrow + NZ * NZ + NZ + NX * NZ + NX * NX + NX + NU * NU + NZ + 8;
+  int NZ = Y.nz, NX = Y.nx, NU = Y.nu, N = Y.N, nrow = std::max((Y.NSLOT + 3) & ~3, IPM_NT);
+  size_t d = (size_t)2 * N * NZ + (size_t)N * NU * NX + (size_t)N * NU + (size_t)nrow * 17 + nrow + NZ * NZ + NZ + NX * NZ + NX * NX + NX + NU * NU + NZ + 8;
   return d * 8 + (size_t)Y.fixlen + 16;
 }
 size_t eval_lds_bytes(const Layout& Y) {
