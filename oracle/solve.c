@@ -609,8 +609,10 @@ static void sort_alts(int n, int* alts, double* vals) {
   }
 }
 
+static int g_branch_rule = 0; /* 0 earliest step, 1 latest step (experiments: ORC_BRANCH) */
 static void viol_consider(violation* best, int step, int kind, const int* key, int nalts, const int* alts) {
-  if (best->step >= 0 && (best->step < step || (best->step == step && best->kind <= kind))) return;
+  if (g_branch_rule == 0) { if (best->step >= 0 && (best->step < step || (best->step == step && best->kind <= kind))) return; }
+  else { if (best->step >= 0 && (best->step > step || (best->step == step && best->kind <= kind))) return; }
   best->step = step; best->kind = kind; memcpy(best->key, key, sizeof(int) * 5);
   best->nalts = nalts > 64 ? 64 : nalts; memcpy(best->alts, alts, sizeof(int) * best->nalts);
 }
@@ -904,6 +906,7 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
 
 int orc_solve(const oinst* I, const orc_opts* o, miqp_raw_results_c* res, miqp_solution_properties_c* props) {
   double t0 = now_s();
+  if (getenv("ORC_BRANCH")) g_branch_rule = atoi(getenv("ORC_BRANCH"));
   dmodel* M = dm_new(I);
   double gap = (o && o->gap >= 0) ? o->gap : I->gap;
   double tlim = (o && o->time_limit > 0) ? o->time_limit : I->tilim;
@@ -944,6 +947,7 @@ int orc_solve(const oinst* I, const orc_opts* o, miqp_raw_results_c* res, miqp_s
         props->NrSolutionPool++;
         if (verbose) fprintf(stderr, "  node %lld incumbent %.8f depth %d open %d\n", props->nodes, obj, nd.depth, H.n);
       } else {
+        if (verbose) { static long hist[4][64]; int kd = vb.key[0]=='r'?0:(vb.key[0]=='e'?1:(vb.key[0]=='o'?2:3)); int stp = kd==2?vb.key[3]:vb.key[2]; hist[kd][stp]++; if (props->nodes % 1000 == 0) { for (int k=0;k<4;++k){ fprintf(stderr,"kind %d:",k); for(int q=0;q<I->N;++q) fprintf(stderr," %ld",hist[k][q]); fprintf(stderr,"\n"); } } }
         for (int a = 0; a < vb.nalts; ++a) {
           bnode ch; ch.bound = obj; ch.seq = seq++; ch.depth = nd.depth + 1; ch.fix = (signed char*)malloc(M->fixlen);
           memcpy(ch.fix, nd.fix, M->fixlen);

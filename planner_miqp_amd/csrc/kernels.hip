@@ -35,6 +35,8 @@ struct DevBuf {
   // node pool
   signed char* pool_fix;         // [pool_cap][fixlen]
   int* pool_count; int pool_cap;
+  // recycled node records: queue of free slots; pops are limited to entries pushed before the current round
+  int* free_q; unsigned int* free_head; unsigned int* free_tail; unsigned int* free_limit;
   // open lists per instance
   double* open_bound; int* open_node; int* open_depth; int* open_count; int open_cap;
   // per instance state
@@ -641,6 +643,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   const Layout& Y = B.Y;
   const int node = blockIdx.x, lane = threadIdx.x;
   if (node >= *B.batch_count) return;
+#define FREE_NODE() do { if (lane == 0) { unsigned int q_ = atomicAdd(B.free_tail, 1u); B.free_q[q_ % (unsigned int)B.pool_cap] = B.batch_node[node]; } } while (0)
   const int inst = B.batch_inst[node];
   const double* D = B.inst_d + (size_t)inst * Y.dstride;
   const int* T = B.inst_i + (size_t)inst * Y.istride;
@@ -657,6 +660,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   signed char* comp = fix + Y.fixlen;                // [fixlen]
   __shared__ BranchDesc chosen;
   __shared__ int sh_base[3];
+  __shared__ int slots[64];
 
   const double* Zi = B.batch_Z + (size_t)node * N * NZ;
   const signed char* src = B.pool_fix + (size_t)B.batch_node[node] * Y.fixlen;
@@ -665,14 +669,14 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   __syncthreads();
   const double viol = B.batch_viol[node];
   const int okq = B.batch_ok[node];
-  if (viol > FEAS_TOL || !okq) return;  // infeasible relaxation
+  if (viol > FEAS_TOL || !okq) { FREE_NODE(); return; }  // infeasible relaxation
   // soft obstacles that this node ignores cost WEIGHTS_SLACK_OBSTACLE each (obstacle_environment_constraints.mod:85-91)
   int nign = 0;
   for (int k = lane; k < C * Y.O * N * 5; k += 64) nign += fix[Y.f_obs + k] >= Y.L ? 1 : 0;
   nign = (int)wave_sum((double)nign);
   const double obj = B.batch_obj[node] + B.inst_const[inst] + nign * D[Y.d_misc + 1];
   const double inc_now = inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]);
-  if (inc_now < 1e300 && !(obj < inc_now - 1e-12 * fabs(inc_now))) return;  // bound not better than the incumbent
+  if (inc_now < 1e300 && !(obj < inc_now - 1e-12 * fabs(inc_now))) { FREE_NODE(); return; }  // bound not better than the incumbent
   const double tol = FEAS_TOL;
   const int NCI = C * (N - 1);
   // ---------------- phase R: region alternatives per (c, i)
@@ -809,6 +813,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       B.batch_obj[node] = obj;
       atomicAdd(&B.inst_ninc[inst], 1);
     }
+    FREE_NODE();
     return;
   }
   unsigned long long bal = __ballot(mine.prio == best);
@@ -858,14 +863,24 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       while (b >= 0 && altval[b] > va) { altbuf[b + 1] = altbuf[b]; altval[b + 1] = altval[b]; b--; }
       altbuf[b + 1] = ia; altval[b + 1] = va;
     }
-    int nb = atomicAdd(B.pool_count, nalt);
     int ob = atomicAdd(&B.open_count[inst], nalt);
-    if (nb + nalt > B.pool_cap || ob + nalt > B.open_cap) { atomicOr(&B.inst_flags[inst], 1); nalt = 0; }
-    sh_base[0] = nb; sh_base[1] = ob; sh_base[2] = nalt;
+    bool okalloc = ob + nalt <= B.open_cap;
+    if (okalloc) {
+      unsigned int h = atomicAdd(B.free_head, (unsigned int)nalt);
+      if ((int)(*B.free_limit - h) >= nalt) {          // recycled records
+        for (int a = 0; a < nalt; ++a) slots[a] = B.free_q[(h + a) % (unsigned int)B.pool_cap];
+      } else {                                          // fresh records
+        int nb = atomicAdd(B.pool_count, nalt);
+        if (nb + nalt > B.pool_cap) okalloc = false;
+        for (int a = 0; a < nalt; ++a) slots[a] = nb + a;
+      }
+    }
+    if (!okalloc) { atomicOr(&B.inst_flags[inst], 1); nalt = 0; }
+    sh_base[1] = ob; sh_base[2] = nalt;
   }
   __syncthreads();
   nalt = sh_base[2];
-  if (nalt <= 0) return;
+  if (nalt <= 0) { FREE_NODE(); return; }
   {
     BranchDesc d = chosen;
     int off;
@@ -873,17 +888,19 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     else if (d.kind == 1) off = Y.f_env + (d.c * N + d.i) * 5 + d.pt;
     else if (d.kind == 2) off = Y.f_obs + ((d.c * Y.O + d.o) * N + d.i) * 5 + d.pt;
     else off = Y.f_c2c + (0 * N + d.i) * 4 + d.o;
-    int nb = sh_base[0], ob = sh_base[1];
+    int ob = sh_base[1];
     for (int a = 0; a < nalt; ++a) {
-      signed char* dst = B.pool_fix + (size_t)(nb + a) * Y.fixlen;
+      signed char* dst = B.pool_fix + (size_t)slots[a] * Y.fixlen;
       for (int k = lane; k < Y.fixlen; k += 64) dst[k] = (k == off) ? (signed char)altbuf[a] : fix[k];
     }
     if (lane < nalt) {
       size_t oi = (size_t)inst * B.open_cap + ob + lane;
       // a soft obstacle that is ignored costs WEIGHTS_SLACK_OBSTACLE (obstacle_environment_constraints.mod:85-91)
-      B.open_bound[oi] = obj - B.inst_const[inst]; B.open_node[oi] = nb + lane; B.open_depth[oi] = B.batch_depth[node] + 1;
+      B.open_bound[oi] = obj - B.inst_const[inst]; B.open_node[oi] = slots[lane]; B.open_depth[oi] = B.batch_depth[node] + 1;
     }
   }
+  FREE_NODE();
+#undef FREE_NODE
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -925,8 +942,9 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   const double gap = B.inst_gap[inst];
   // node selection: best bound, interleaved with dives (deepest first) while no incumbent exists and on every
   // 4th round afterwards; the order changes how fast incumbents appear, not what is proven
-  const bool dive = !(inc < 1e300) || (round & 3) == 3;
   int n = B.open_count[inst]; if (n > cap) n = cap;
+  // (a nearly full open list forces depth-first selection, whose frontier stays small)
+  const bool dive = !(inc < 1e300) || (round & 3) == 3 || n > cap / 2;
   double lb = 1e300;
   for (int k = tid; k < cap2; k += SEL_THREADS) {
     double b = 1e300, key = 1e300; int nd = -1, dp = 0;
@@ -934,7 +952,10 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
       size_t oi = (size_t)inst * cap + k;
       b = B.open_bound[oi]; nd = B.open_node[oi]; dp = B.open_depth[oi]; lb = fmin(lb, b);
       // prune: cannot improve the incumbent by more than the gap (bounds exclude the instance constant)
-      if (inc < 1e300 && (inc - (b + cst)) <= gap * (1e-10 + fabs(inc))) { b = 1e300; nd = -1; }
+      if (inc < 1e300 && (inc - (b + cst)) <= gap * (1e-10 + fabs(inc))) {
+        unsigned int q_ = atomicAdd(B.free_tail, 1u); B.free_q[q_ % (unsigned int)B.pool_cap] = nd;
+        b = 1e300; nd = -1;
+      }
       else key = dive ? (-(double)dp * 1e9 + fmax(b, -1e8)) : b;
     }
     kk[k] = key; kb[k] = b; kn[k] = nd; kd[k] = dp;
@@ -988,6 +1009,13 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   }
   __syncthreads();
   if (tid == 0) B.open_count[inst] = m - take;
+}
+
+// makes the records freed so far available to the next eval launch
+__global__ void roll_kernel(DevBuf B) {
+  unsigned int t = *B.free_tail, h = *B.free_head, l = *B.free_limit;
+  if ((int)(h - l) > 0) h = l;   // pops that overshot the limit took fresh records instead
+  *B.free_head = h; *B.free_limit = t;
 }
 
 }  // namespace miqp

@@ -180,9 +180,9 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); int cus = 256; if (hipGetDeviceProperties(&pr, dv) == hipSuccess) cus = pr.multiProcessorCount;
     size_t l = ipm_lds_bytes(Y); int per = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(l, 1))); X.ipm_grid_max = cus * per; }
   // node pool: every processed node emits at most a handful of children; records are not recycled inside one solve
-  size_t want = (size_t)n_inst * 16384; size_t maxrec = (size_t)3 << 30; maxrec /= (size_t)Y.fixlen;
-  X.pool_cap = (int)std::min(want, std::min(maxrec, (size_t)1 << 20) * 1);
-  if (X.pool_cap < n_inst * 64) X.pool_cap = n_inst * 64;
+  // node pool: live nodes are bounded by the open lists plus one round of children; processed records are recycled
+  size_t want = (size_t)n_inst * ((size_t)open_cap + (size_t)npr * 16 + 64); size_t maxrec = ((size_t)6 << 30) / (size_t)Y.fixlen;
+  X.pool_cap = (int)std::min(want, maxrec);
   DevBuf& B = X.B; std::memset(&B, 0, sizeof(B));
   B.qp_tol = QP_TOL;
   B.Y = Y; B.pool_cap = X.pool_cap; B.open_cap = open_cap; B.batch_cap = batch_cap; B.nodes_per_round = npr; B.n_inst = n_inst;
@@ -191,6 +191,10 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   if (!X.alloc(&ii, (size_t)n_inst * Y.istride)) return false; B.inst_i = ii;
   if (!X.alloc(&B.pool_fix, (size_t)X.pool_cap * Y.fixlen)) return false;
   if (!X.alloc(&B.pool_count, 1)) return false;
+  if (!X.alloc(&B.free_q, (size_t)X.pool_cap)) return false;
+  if (!X.alloc(&B.free_head, 1)) return false;
+  if (!X.alloc(&B.free_tail, 1)) return false;
+  if (!X.alloc(&B.free_limit, 1)) return false;
   if (!X.alloc(&B.open_bound, (size_t)n_inst * open_cap)) return false;
   if (!X.alloc(&B.open_node, (size_t)n_inst * open_cap)) return false;
   if (!X.alloc(&B.open_depth, (size_t)n_inst * open_cap)) return false;
@@ -448,6 +452,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     if (S[k]->has_ws && (int)S[k]->ws_fix.size() == Y.fixlen) HIP_OK(hipMemcpyAsync(B.pool_fix + (size_t)(n + k) * Y.fixlen, S[k]->ws_fix.data(), Y.fixlen, hipMemcpyHostToDevice, st));
   int pool0 = 2 * n;
   HIP_OK(hipMemcpyAsync(B.pool_count, &pool0, 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemsetAsync(B.free_head, 0, 4, st)); HIP_OK(hipMemsetAsync(B.free_tail, 0, 4, st)); HIP_OK(hipMemsetAsync(B.free_limit, 0, 4, st));
   HIP_OK(hipMemcpyAsync(B.open_bound, ob.data(), ob.size() * 8, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(B.open_node, on.data(), on.size() * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(B.open_count, oc.data(), n * 4, hipMemcpyHostToDevice, st));
@@ -475,6 +480,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   for (;;) {
     HIP_OK(hipMemsetAsync(B.batch_count, 0, 4, st));
     hipLaunchKernelGGL(select_kernel, dim3(n), dim3(SEL_THREADS), l_sel, st, B, rounds);
+    hipLaunchKernelGGL(roll_kernel, dim3(1), dim3(1), 0, st, B);
     int bc = 0;
     HIP_OK(hipMemcpyAsync(&bc, B.batch_count, 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
