@@ -38,7 +38,10 @@ struct DevBuf {
   // recycled node records: queue of free slots; pops are limited to entries pushed before the current round
   int* free_q; unsigned int* free_head; unsigned int* free_tail; unsigned int* free_limit;
   // open lists per instance
-  double* open_bound; int* open_node; int* open_depth; int* open_count; int open_cap;
+  // open lists: two buffers per instance (select reads buffer `open_sel`, writes the survivors to the other one,
+  // eval appends children to that other one); unsorted, selection by radix select on the 64-bit key
+  double* open_bound; int* open_node; int* open_depth; int* open_count; int open_cap; int open_sel;
+  unsigned long long* open_key;
   // per instance state
   unsigned long long* inc_key;   // orderable(objective) with the batch slot in the low 20 bits
   unsigned long long* inc_seen;  // key whose solution has been copied to inc_fix / inc_Z
@@ -280,7 +283,8 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
   double* Lc = pv + NX;                  // [NU*NU]
   double* Wd = Lc + NU * NU;             // [NZ]
   double* red = Wd + NZ;                 // [8]
-  signed char* fix = (signed char*)(red + 8);  // [fixlen]
+  double* ABm = red + 8;                 // [NX*NZ] = [A B] of the triple integrator chains
+  signed char* fix = (signed char*)(ABm + NX * NZ);  // [fixlen]
   // persistent-style: a resident block works through nodes blockIdx.x, blockIdx.x + gridDim.x, ... so that the
   // per-row interior-point state (indexed by block, not by node) stays cache resident
   for (int node = blockIdx.x; node < nbatch; node += gridDim.x) {
@@ -294,6 +298,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     for (int k = tid; k < Y.fixlen; k += NT) fix[k] = src[k];
     for (int k = tid; k < NZ; k += NT) Wd[k] = D[Y.d_wd + k];
     for (int k = tid; k < N * NZ; k += NT) { Z[k] = 0.0; dZ[k] = 0.0; }
+    for (int k = tid; k < NX * NZ; k += NT) ABm[k] = ab_entry<C>(k / NZ, k % NZ, ts);
   }
   __syncthreads();
   if (tid < NX) Z[tid] = D[Y.d_x0 + tid];
@@ -398,12 +403,16 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
           if (row < NZ && lc < NZ) Phi[row * NZ + lc] = acc[rg] + (row == lc ? 2.0 * Wd[row] : 0.0);
         }
       }
-      if (tid >= NT - NZ) {  // rr = 2W(z - ref) + Gh' fs
-        int a = tid - (NT - NZ);
-        double acc = 2.0 * Wd[a] * (Z[i * NZ + a] - Rf[i * NZ + a]);
-        for (int sl = 0; sl < NSLOT; ++sl) acc += Gh[sl * GS + a] * fs[sl];
-        rr[a] = acc;
-        if (it == 1) rmax = fmax(rmax, fabs(acc));
+      if (tid >= NT - 64) {  // rr = 2W(z - ref) + Gh' fs : 4 partial sums per component, combined by shuffles
+        int l = tid - (NT - 64), a = l & 15, part = l >> 4;
+        double acc = 0.0;
+        for (int sl = part; sl < NSLOT; sl += 4) acc += Gh[sl * GS + a] * fs[sl];
+        acc += __shfl_xor(acc, 16); acc += __shfl_xor(acc, 32);
+        if (part == 0 && a < NZ) {
+          acc += 2.0 * Wd[a] * (Z[i * NZ + a] - Rf[i * NZ + a]);
+          rr[a] = acc;
+          if (it == 1) rmax = fmax(rmax, fabs(acc));
+        }
       }
       __syncthreads();
       if (i == N - 1) {  // u_{N-1} = 0 (initial_conditions.mod:25-26)
@@ -416,7 +425,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
         int a = e / NZ, b = e - a * NZ;
         double acc = 0.0;
         int q0 = b < NX ? 3 * (b / 3) : 3 * (b - NX);
-        for (int q = q0; q < q0 + 3; ++q) acc += Pm[a * NX + q] * ab_entry<C>(q, b, ts);
+        for (int q = q0; q < q0 + 3; ++q) acc += Pm[a * NX + q] * ABm[q * NZ + b];
         Tm[e] = acc;
       }
       __syncthreads();
@@ -425,13 +434,13 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
         int a = e / NZ, b = e - a * NZ;
         double acc = Phi[e];
         int q0 = a < NX ? 3 * (a / 3) : 3 * (a - NX);
-        for (int q = q0; q < q0 + 3; ++q) acc += ab_entry<C>(q, a, ts) * Tm[q * NZ + b];
+        for (int q = q0; q < q0 + 3; ++q) acc += ABm[q * NZ + a] * Tm[q * NZ + b];
         Phi[e] = acc;
       }
       if (tid < NZ) {
         int a = tid; double acc = rr[a];
         int q0 = a < NX ? 3 * (a / 3) : 3 * (a - NX);
-        for (int q = q0; q < q0 + 3; ++q) acc += ab_entry<C>(q, a, ts) * pv[q];
+        for (int q = q0; q < q0 + 3; ++q) acc += ABm[q * NZ + a] * pv[q];
         rr[a] = acc;
       }
       __syncthreads();
@@ -493,8 +502,8 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
         if (tid < NX) {
           double acc = 0.0;
           int q0 = 3 * (tid / 3);
-          for (int q = q0; q < q0 + 3; ++q) acc += ab_entry<C>(tid, q, ts) * dZ[i * NZ + q];
-          acc += ab_entry<C>(tid, NX + tid / 3, ts) * dZ[i * NZ + NX + tid / 3];
+          for (int q = q0; q < q0 + 3; ++q) acc += ABm[tid * NZ + q] * dZ[i * NZ + q];
+          acc += ABm[tid * NZ + NX + tid / 3] * dZ[i * NZ + NX + tid / 3];
           dZ[(i + 1) * NZ + tid] = acc;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
@@ -894,7 +903,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       for (int k = lane; k < Y.fixlen; k += 64) dst[k] = (k == off) ? (signed char)altbuf[a] : fix[k];
     }
     if (lane < nalt) {
-      size_t oi = (size_t)inst * B.open_cap + ob + lane;
+      size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + ob + lane;
       // a soft obstacle that is ignored costs WEIGHTS_SLACK_OBSTACLE (obstacle_environment_constraints.mod:85-91)
       B.open_bound[oi] = obj - B.inst_const[inst]; B.open_node[oi] = slots[lane]; B.open_depth[oi] = B.batch_depth[node] + 1;
     }
@@ -907,25 +916,28 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
 //  select: per instance prune + sort + pick
 constexpr int SEL_THREADS = 256;
 
+// One workgroup per instance.  Reads the open list from buffer `B.open_sel`, prunes it against the incumbent,
+// selects the `take` smallest keys by an MSB-first 8-bit radix select (no full sort, lists live in HBM/L2),
+// emits them into the round's batch and writes the survivors to the other buffer.
 __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round) {
   const Layout& Y = B.Y;
   const int inst = blockIdx.x, tid = threadIdx.x;
-  extern __shared__ double lds[];
   const int cap = B.open_cap;
-  int cap2 = 1; while (cap2 < cap) cap2 <<= 1;
-  double* kk = lds;                  // [cap2] sort key
-  double* kb = kk + cap2;            // [cap2] bound
-  int* kn = (int*)(kb + cap2);       // [cap2] node ids
-  int* kd = kn + cap2;               // [cap2] depth
-  __shared__ int sh_n, sh_take, sh_base;
+  __shared__ int sh_take, sh_base, sh_m, sh_keep, sh_pick, sh_ties;
   __shared__ double sh_inc;
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned long long sh_prefix, sh_thr;
+  __shared__ double red[SEL_THREADS];
   if (B.inst_done[inst]) return;
+  const size_t src = ((size_t)B.open_sel * B.n_inst + inst) * cap, dst = ((size_t)(1 - B.open_sel) * B.n_inst + inst) * cap;
+  unsigned long long* keys = B.open_key + (size_t)inst * cap;
   // ---- incumbent bookkeeping: copy the solution of the atomicMin winner of the last round
   if (tid == 0) {
     unsigned long long key = B.inc_key[inst];
     sh_inc = inc_from_key(key);
     sh_take = -1;
     if (key != B.inc_seen[inst]) { sh_take = (int)(key & 0xFFFFFull); B.inc_seen[inst] = key; }
+    sh_m = 0; sh_keep = 0; sh_pick = 0; sh_ties = 0;
   }
   __syncthreads();
   if (sh_take >= 0) {
@@ -940,75 +952,99 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   const double inc = sh_inc < 1e300 ? B.inc_obj[inst] : 1e300;
   const double cst = B.inst_const[inst];
   const double gap = B.inst_gap[inst];
-  // node selection: best bound, interleaved with dives (deepest first) while no incumbent exists and on every
-  // 4th round afterwards; the order changes how fast incumbents appear, not what is proven
   int n = B.open_count[inst]; if (n > cap) n = cap;
-  // (a nearly full open list forces depth-first selection, whose frontier stays small)
+  // node selection: best bound, interleaved with dives (deepest first) while no incumbent exists, on every 4th
+  // round afterwards and whenever the list is more than half full (a depth-first frontier stays small);
+  // the order changes how fast incumbents appear, not what is proven
   const bool dive = !(inc < 1e300) || (round & 3) == 3 || n > cap / 2;
-  double lb = 1e300;
-  for (int k = tid; k < cap2; k += SEL_THREADS) {
-    double b = 1e300, key = 1e300; int nd = -1, dp = 0;
-    if (k < n) {
-      size_t oi = (size_t)inst * cap + k;
-      b = B.open_bound[oi]; nd = B.open_node[oi]; dp = B.open_depth[oi]; lb = fmin(lb, b);
-      // prune: cannot improve the incumbent by more than the gap (bounds exclude the instance constant)
-      if (inc < 1e300 && (inc - (b + cst)) <= gap * (1e-10 + fabs(inc))) {
-        unsigned int q_ = atomicAdd(B.free_tail, 1u); B.free_q[q_ % (unsigned int)B.pool_cap] = nd;
-        b = 1e300; nd = -1;
-      }
-      else key = dive ? (-(double)dp * 1e9 + fmax(b, -1e8)) : b;
+  // ---- pass 1: prune, keys, lower bound
+  double lb = 1e300; int mloc = 0;
+  for (int k = tid; k < n; k += SEL_THREADS) {
+    double b = B.open_bound[src + k]; int nd = B.open_node[src + k]; int dp = B.open_depth[src + k];
+    lb = fmin(lb, b);
+    unsigned long long key = ~0ull;
+    if (inc < 1e300 && (inc - (b + cst)) <= gap * (1e-10 + fabs(inc))) {  // cannot improve the incumbent by more than the gap
+      unsigned int q_ = atomicAdd(B.free_tail, 1u); B.free_q[q_ % (unsigned int)B.pool_cap] = nd;
+    } else {
+      double kv = dive ? (-(double)dp * 1e9 + fmax(b, -1e8)) : fmax(b, -1e300);
+      key = d2key(kv); if (key == ~0ull) key = ~0ull - 1;
+      mloc++;
     }
-    kk[k] = key; kb[k] = b; kn[k] = nd; kd[k] = dp;
+    keys[k] = key;
   }
-  __shared__ double red[SEL_THREADS];
   red[tid] = lb; __syncthreads();
   for (int s = SEL_THREADS / 2; s > 0; s >>= 1) { if (tid < s) red[tid] = fmin(red[tid], red[tid + s]); __syncthreads(); }
   lb = red[0];
-  // bitonic sort ascending by key
-  for (int k2 = 2; k2 <= cap2; k2 <<= 1)
-    for (int j = k2 >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < cap2; t += SEL_THREADS) {
-        int ixj = t ^ j;
-        if (ixj > t) {
-          bool up = (t & k2) == 0;
-          double a = kk[t], b = kk[ixj];
-          if ((a > b) == up) {
-            kk[t] = b; kk[ixj] = a;
-            double x = kb[t]; kb[t] = kb[ixj]; kb[ixj] = x;
-            int y = kn[t]; kn[t] = kn[ixj]; kn[ixj] = y;
-            y = kd[t]; kd[t] = kd[ixj]; kd[ixj] = y;
-          }
-        }
-      }
-      __syncthreads();
-    }
+  if (mloc) atomicAdd(&sh_m, mloc);
+  __syncthreads();
+  const int m = sh_m;
   if (tid == 0) {
-    int m = 0; while (m < cap2 && kk[m] < 1e299) m++;
-    sh_n = m;
     int act = *B.active_insts; if (act < 1) act = 1;
     int w = B.batch_cap / act; if (w < B.nodes_per_round) w = B.nodes_per_round;
     int take = m < w ? m : w;
+    int room = (cap - m) / 8; if (room < 1) room = 1;  // a processed node may emit up to ~8 children
+    if (take > room) take = room;
     int base = take > 0 ? atomicAdd(B.batch_count, take) : 0;
     if (base + take > B.batch_cap) take = B.batch_cap > base ? B.batch_cap - base : 0;
     sh_take = take; sh_base = base;
     double lbt = (n > 0 ? lb + cst : inc);
     if (inc < 1e300 && lbt > inc) lbt = inc;
     B.lower_bound[inst] = lbt;
-    if (m == 0) {  // tree exhausted or everything within the gap
-      B.inst_done[inst] = 1; atomicSub(B.active_insts, 1);
+    if (m == 0) { B.inst_done[inst] = 1; atomicSub(B.active_insts, 1); }
+    sh_prefix = 0ull; sh_thr = ~0ull;
+  }
+  __syncthreads();
+  const int take = sh_take, base = sh_base;
+  // ---- radix select: smallest key value T such that count(key <= T) >= take
+  if (take > 0 && take < m) {
+    int need = take;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+      hist[tid] = 0u;
+      __syncthreads();
+      const unsigned long long prefix = sh_prefix;
+      const unsigned long long himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+      for (int k = tid; k < n; k += SEL_THREADS) {
+        unsigned long long key = keys[k];
+        if (key != ~0ull && (key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255ull], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned int cum = 0; int bin = 0;
+        for (bin = 0; bin < 256; ++bin) { if (cum + hist[bin] >= (unsigned int)need) break; cum += hist[bin]; }
+        if (bin > 255) bin = 255;
+        sh_prefix = prefix | ((unsigned long long)bin << shift);
+        sh_pick = need - (int)cum;   // how many of the keys with this prefix are still needed
+      }
+      __syncthreads();
+      need = sh_pick;
+    }
+    if (tid == 0) { sh_thr = sh_prefix; sh_ties = need; sh_pick = 0; }
+    __syncthreads();
+  } else if (tid == 0) { sh_thr = take >= m ? (~0ull - 1) : 0ull; sh_ties = 0x7FFFFFFF; sh_pick = 0; }
+  __syncthreads();
+  // ---- pass 3: emit the selected nodes, keep the rest
+  const unsigned long long thr = sh_thr;
+  for (int k = tid; k < n; k += SEL_THREADS) {
+    unsigned long long key = keys[k];
+    if (key == ~0ull) continue;
+    double b = B.open_bound[src + k]; int nd = B.open_node[src + k]; int dp = B.open_depth[src + k];
+    bool pick = false;
+    if (take > 0) {
+      if (key < thr) pick = true;
+      else if (key == thr) { int t = atomicAdd(&sh_ties, -1); pick = t > 0; }
+    }
+    if (pick) {
+      int pos = atomicAdd(&sh_pick, 1);
+      if (pos < take) { B.batch_node[base + pos] = nd; B.batch_inst[base + pos] = inst; B.batch_bound[base + pos] = b; B.batch_depth[base + pos] = dp; }
+      else pick = false;
+    }
+    if (!pick) {
+      int pos = atomicAdd(&sh_keep, 1);
+      B.open_bound[dst + pos] = b; B.open_node[dst + pos] = nd; B.open_depth[dst + pos] = dp;
     }
   }
   __syncthreads();
-  int m = sh_n, take = sh_take, base = sh_base;
-  for (int k = tid; k < take; k += SEL_THREADS) {
-    B.batch_node[base + k] = kn[k]; B.batch_inst[base + k] = inst; B.batch_bound[base + k] = kb[k]; B.batch_depth[base + k] = kd[k];
-  }
-  for (int k = tid; k < m - take; k += SEL_THREADS) {
-    size_t oi = (size_t)inst * cap + k;
-    B.open_bound[oi] = kb[take + k]; B.open_node[oi] = kn[take + k]; B.open_depth[oi] = kd[take + k];
-  }
-  __syncthreads();
-  if (tid == 0) B.open_count[inst] = m - take;
+  if (tid == 0) B.open_count[inst] = sh_keep;
 }
 
 // makes the records freed so far available to the next eval launch

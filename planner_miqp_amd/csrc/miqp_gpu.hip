@@ -195,9 +195,10 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   if (!X.alloc(&B.free_head, 1)) return false;
   if (!X.alloc(&B.free_tail, 1)) return false;
   if (!X.alloc(&B.free_limit, 1)) return false;
-  if (!X.alloc(&B.open_bound, (size_t)n_inst * open_cap)) return false;
-  if (!X.alloc(&B.open_node, (size_t)n_inst * open_cap)) return false;
-  if (!X.alloc(&B.open_depth, (size_t)n_inst * open_cap)) return false;
+  if (!X.alloc(&B.open_bound, (size_t)2 * n_inst * open_cap)) return false;
+  if (!X.alloc(&B.open_node, (size_t)2 * n_inst * open_cap)) return false;
+  if (!X.alloc(&B.open_depth, (size_t)2 * n_inst * open_cap)) return false;
+  if (!X.alloc(&B.open_key, (size_t)n_inst * open_cap)) return false;
   if (!X.alloc(&B.open_count, n_inst)) return false;
   if (!X.alloc(&B.inc_key, n_inst)) return false;
   if (!X.alloc(&B.inc_seen, n_inst)) return false;
@@ -234,14 +235,14 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
 constexpr int IPM_NT = MIQP_IPM_NT;  // threads per node in the interior point kernel
 size_t ipm_lds_bytes(const Layout& Y) {
   int NZ = Y.nz, NX = Y.nx, NU = Y.nu, N = Y.N, nrow = std::max((Y.NSLOT + 3) & ~3, IPM_NT);
-  size_t d = (size_t)2 * N * NZ + (size_t)N * NU * NX + (size_t)N * NU + (size_t)nrow * 17 + nrow + NZ * NZ + NZ + NX * NZ + NX * NX + NX + NU * NU + NZ + 8;
+  size_t d = (size_t)2 * N * NZ + (size_t)N * NU * NX + (size_t)N * NU + (size_t)nrow * 17 + nrow + NZ * NZ + NZ + NX * NZ + NX * NX + NX + NU * NU + NZ + 8 + NX * NZ;
   return d * 8 + (size_t)Y.fixlen + 16;
 }
 size_t eval_lds_bytes(const Layout& Y) {
   size_t d = (size_t)Y.N * Y.nz + (size_t)Y.C * Y.N * Y.P + (size_t)Y.C * Y.N;
   return d * 8 + (size_t)(2 * Y.C * Y.N + 64) * 4 + 64 * 8 + 2 * (size_t)Y.fixlen + 64;
 }
-size_t select_lds_bytes(int open_cap) { int c2 = 1; while (c2 < open_cap) c2 <<= 1; return (size_t)c2 * 24 + 16; }
+size_t select_lds_bytes(int open_cap) { (void)open_cap; return 0; }
 
 template <int C> void launch_ipm(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { hipLaunchKernelGGL((ipm_kernel<C, IPM_NT>), dim3(nblocks), dim3(IPM_NT), lds, st, B); }
 template <int C> void launch_eval(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { hipLaunchKernelGGL(eval_kernel<C>, dim3(nblocks), dim3(64), lds, st, B); }
@@ -254,7 +255,7 @@ bool set_kernel_lds(const Layout& Y, size_t ipm_lds, size_t eval_lds, size_t sel
     HIP_OK(hipFuncSetAttribute((const void*)ipm_kernel<2, IPM_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipm_lds));
     HIP_OK(hipFuncSetAttribute((const void*)eval_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eval_lds));
   }
-  HIP_OK(hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+  (void)sel_lds;
   return true;
 }
 
@@ -413,7 +414,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   const Layout& Y = bs.Y;
   const miqp_solver_opts& O0 = S[0]->opts;
   int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(512, 4096 / n));
-  int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : 4096;
+  int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : 32768;
   if (open_cap < 64) open_cap = 64;
   if ((size_t)n * npr >= ((size_t)1 << 20)) npr = (int)((((size_t)1 << 20) - 1) / n);
   DevCtx& X = g_ctx;
@@ -456,7 +457,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   HIP_OK(hipMemcpyAsync(B.open_bound, ob.data(), ob.size() * 8, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(B.open_node, on.data(), on.size() * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(B.open_count, oc.data(), n * 4, hipMemcpyHostToDevice, st));
-  HIP_OK(hipMemsetAsync(B.open_depth, 0, (size_t)n * open_cap * 4, st));
+  HIP_OK(hipMemsetAsync(B.open_depth, 0, (size_t)2 * n * open_cap * 4, st));
   HIP_OK(hipMemsetAsync(B.inc_key, 0xFF, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inc_seen, 0xFF, (size_t)n * 8, st));
   { std::vector<double> big(n, 1e300); HIP_OK(hipMemcpyAsync(B.inc_obj, big.data(), n * 8, hipMemcpyHostToDevice, st));
@@ -479,6 +480,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   size_t nev = 0; int rounds = 0; long long launched_nodes = 0; bool timed_out = false;
   for (;;) {
     HIP_OK(hipMemsetAsync(B.batch_count, 0, 4, st));
+    B.open_sel = rounds & 1;
     hipLaunchKernelGGL(select_kernel, dim3(n), dim3(SEL_THREADS), l_sel, st, B, rounds);
     hipLaunchKernelGGL(roll_kernel, dim3(1), dim3(1), 0, st, B);
     int bc = 0;
@@ -492,7 +494,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     { int gsz = std::min(bc, X.ipm_grid_max); if (Y.C == 1) launch_ipm<1>(B, gsz, l_ipm, st); else launch_ipm<2>(B, gsz, l_ipm, st); }
     HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
     nev += 2;
-    if (Y.C == 1) launch_eval<1>(B, bc, l_eval, st); else launch_eval<2>(B, bc, l_eval, st);
+    { DevBuf Be = B; Be.open_sel = 1 - (rounds & 1); if (Y.C == 1) launch_eval<1>(Be, bc, l_eval, st); else launch_eval<2>(Be, bc, l_eval, st); }
     launched_nodes += bc; rounds++;
     if (O0.verbose > 1) std::fprintf(stderr, "[miqp_gpu] round %d: %d nodes\n", rounds, bc);
   }
