@@ -54,9 +54,9 @@ def cpu_baseline(params_list, gap, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="instances per GPU and step")
+    ap.add_argument("--batch", type=int, default=256, help="instances per GPU and step")
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--gap", type=float, default=0.01)
     ap.add_argument("--time-limit", type=float, default=10.0, help="max_solution_time per instance (reference default 10 s)")

@@ -573,7 +573,8 @@ static double const_cost(const dmodel* M, const signed char* fix) {
 }
 
 /* ------------------------------------------------------------------ completion */
-typedef struct { int step, kind; int key[5]; int nalts; int alts[64]; } violation;
+typedef struct { int step, kind; int key[5]; int nalts; int alts[64]; double mag; } violation;
+static double g_cur_viol = 0.0; /* violation of the least violated alternative of the disjunction being reported */
 
 static int region_cands(const dmodel* M, const signed char* fix, int c, int i, int* out) {
   const oinst* I = M->I;
@@ -612,7 +613,9 @@ static void sort_alts(int n, int* alts, double* vals) {
 static int g_branch_rule = 0; /* 0 earliest step, 1 latest step (experiments: ORC_BRANCH) */
 static void viol_consider(violation* best, int step, int kind, const int* key, int nalts, const int* alts) {
   if (g_branch_rule == 0) { if (best->step >= 0 && (best->step < step || (best->step == step && best->kind <= kind))) return; }
-  else { if (best->step >= 0 && (best->step > step || (best->step == step && best->kind <= kind))) return; }
+  else if (g_branch_rule == 1) { if (best->step >= 0 && (best->step > step || (best->step == step && best->kind <= kind))) return; }
+  else { if (best->step >= 0 && best->mag >= g_cur_viol) return; }
+  best->mag = g_cur_viol;
   best->step = step; best->kind = kind; memcpy(best->key, key, sizeof(int) * 5);
   best->nalts = nalts > 64 ? 64 : nalts; memcpy(best->alts, alts, sizeof(int) * best->nalts);
 }
@@ -643,6 +646,7 @@ static int complete(const dmodel* M, const signed char* fix, const double* Z, si
         if (v < bv) { bv = v; bi = cands[q]; }
       }
       if (bi < 0 || bv > tol) {
+        g_cur_viol = bv < 1e299 ? bv : 1e3;
         viol_region(M, fix, best, c, i);
         if (bi < 0) bi = n > 0 ? cands[0] : 0;
       }
@@ -660,7 +664,7 @@ static int complete(const dmodel* M, const signed char* fix, const double* Z, si
             if (pt > 0 && runfixed) {
               tmp.n = 0; env_rows(M, &tmp, c, i, pt, 0, j);
               double v = 0; for (int k = 0; k < tmp.n; ++k) v = fmax(v, row_val(M, &tmp.r[k], Z));
-              if (v > tol) viol_region(M, fix, best, c, i);
+              if (v > tol) { g_cur_viol = v; viol_region(M, fix, best, c, i); }
             }
             FIX_ENV(M, comp, c, i, pt) = 0;
             continue;
@@ -677,6 +681,7 @@ static int complete(const dmodel* M, const signed char* fix, const double* Z, si
           if (fx >= 0) okk = vals[fx] <= tol;
           else { sort_alts(ne, alts, vals); okk = vals[0] <= tol; FIX_ENV(M, comp, c, i, pt) = (signed char)alts[0]; }
           if (!okk) {
+            g_cur_viol = fx >= 0 ? vals[fx] : vals[0];
             if (pt > 0 && runfixed) viol_region(M, fix, best, c, i);
             else { int key[5] = {'e', c, i, pt, 0}; viol_consider(best, i, 1, key, ne, alts); }
           }
@@ -694,6 +699,7 @@ static int complete(const dmodel* M, const signed char* fix, const double* Z, si
           if (fx >= 0) okk = vals[fx] <= tol;
           else { sort_alts(I->L, alts, vals); okk = vals[0] <= tol; FIX_OBS(M, comp, c, o, i, pt) = (signed char)alts[0]; }
           if (!okk) {
+            g_cur_viol = fx >= 0 ? vals[fx] : vals[0];
             if (pt > 0 && runfixed) viol_region(M, fix, best, c, i);
             else {
               int na = I->L; if (I->obs_soft[o]) alts[na++] = I->L;
@@ -722,6 +728,7 @@ static int complete(const dmodel* M, const signed char* fix, const double* Z, si
         if (fx >= 0) okk = vals[fx] <= tol;
         else { sort_alts(4, alts, vals); okk = vals[0] <= tol; FIX_C2C(M, comp, p, i, g) = (signed char)alts[0]; }
         if (!okk) {
+          g_cur_viol = fx >= 0 ? vals[fx] : vals[0];
           if (unf >= 0) viol_region(M, fix, best, unf, i);
           else { int key[5] = {'a', p, i, g, 0}; viol_consider(best, i, 3, key, 4, alts); }
         }
