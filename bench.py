@@ -117,6 +117,10 @@ def main():
         # roofline of the dominant kernel (ipm_kernel), rank 0: algorithmic flops / HIP-event time of its launches
         flops = iters * f_iter(Cc, N) + rowit * F_ROW
         ach = flops / ipm_s if ipm_s > 0 else 0.0
+        traffic = None  # HBM bytes per launch come from the committed rocprofv3 PMC passes (cannot be collected live)
+        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tj) and a.config == "cfg3":
+            traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
         out = dict(metric="MIQP solves/sec to 1% gap, 2-agent x 20-step x 32-region", value=tot_solved / T, unit="MIQP solves/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * T / a.steps, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f64", data="synthetic",
@@ -124,7 +128,7 @@ def main():
                                % ((a.config,) + synthetic.CONFIGS[a.config] + (B, a.gap, a.time_limit)),
                                instances_attempted=int(tot_att), instances_solved_to_gap=int(tot_solved),
                                bnb_nodes=int(sum(x[7] for x in g)), ipm_iterations=int(sum(x[5] for x in g))),
-                   roofline=dict(bound="mfma", achieved=ach / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s", frac=ach / FP64_PEAK, traffic=None,
+                   roofline=dict(bound="mfma", achieved=ach / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s", frac=ach / FP64_PEAK, traffic=traffic,
                                  kernel="ipm_kernel", launches=int(launches), avg_launch_ms=1e3 * ipm_s / max(1, launches),
                                  flops_per_launch=flops / max(1, launches)))
         if not a.no_cpu and world == 1:
