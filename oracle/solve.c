@@ -22,10 +22,13 @@
 
 #define RHO_EL 1.0e5
 #define FEAS_TOL 1.0e-6
-#define QP_TOL 1.0e-10
+#define QP_TOL 1.0e-8
 #define QP_TOL_FINAL 1.0e-13 /* polish of the returned incumbent */
 #define QP_MAXIT 80
 #define QP_SIGMA 0.1
+#define QP_T0 1.0e-3
+#define QP_SIGMA_LO 0.1
+#define QP_SIGMA_HI 0.1
 
 enum { SX = 0, SVX, SAX, SY, SVY, SAY };
 enum { PT_R = 0, PT_U = 1, PT_L = 2 };
@@ -357,7 +360,12 @@ static int qp_solve_tol(const dmodel* M, const orow* rows, int m, qpres* out, do
   int mel = 0;
   for (int k = 0; k < m; ++k) {
     double c = -row_val(M, &rows[k], Z);
-    if (rows[k].a == 0.0) { lam[k] = 1.0; s[k] = (c > 0 ? c : 0) + 1.0; tt[k] = s[k] - c; mel++; }
+    if (rows[k].a == 0.0) {
+      double t0 = getenv("ORC_T0") ? atof(getenv("ORC_T0")) : QP_T0;
+      lam[k] = 1.0; mel++;
+      /* elastic slack starts small so that t*mu (mu ~ rho) is of the order of s*lambda */
+      if (c > t0) { tt[k] = t0; s[k] = c + t0; } else { s[k] = 100 * t0; tt[k] = s[k] - c; }
+    }
     else { double a = rows[k].a; lam[k] = fmax(1.0, -2 * c * a + 1.0); s[k] = c + lam[k] / a; }
   }
   double* Kg = (double*)calloc((size_t)N * nu * nx, sizeof(double)); double* kg = (double*)calloc((size_t)N * nu, sizeof(double));
@@ -367,7 +375,7 @@ static int qp_solve_tol(const dmodel* M, const orow* rows, int m, qpres* out, do
   double* T = (double*)malloc(sizeof(double) * nx * nz); double* S = (double*)malloc(sizeof(double) * nz * nz);
   double* sv = (double*)malloc(sizeof(double) * nz); double* Lc = (double*)malloc(sizeof(double) * nu * nu);
   double* Pn = (double*)malloc(sizeof(double) * nx * nx); double* pn = (double*)malloc(sizeof(double) * nx);
-  int it = 0, ok = 0; double resid_fac = 1.0, R0 = 0.0;
+  int it = 0, ok = 0; double resid_fac = 1.0, R0 = 0.0, alpha_prev = 0.0;
   for (it = 1; it <= QP_MAXIT; ++it) {
     double comp = 0, obj = 0;
     for (int i = 0; i < N; ++i)
@@ -379,7 +387,9 @@ static int qp_solve_tol(const dmodel* M, const orow* rows, int m, qpres* out, do
     }
     comp /= (m + mel > 0 ? m + mel : 1);
     if (comp < qp_tol * fmax(1.0, fabs(obj)) && resid_fac * R0 < 1e-7) { ok = 1; break; }
-    double tau = QP_SIGMA * comp;
+    /* centering: aggressive after a (nearly) full step, conservative after a blocked one */
+    double sigma = getenv("ORC_SIGMA_LO") ? (alpha_prev >= 0.9 ? atof(getenv("ORC_SIGMA_LO")) : atof(getenv("ORC_SIGMA_HI"))) : (alpha_prev >= 0.9 ? QP_SIGMA_LO : QP_SIGMA_HI);
+    double tau = sigma * comp;
     /* backward sweep */
     memset(P, 0, sizeof(double) * nx * nx); memset(pv, 0, sizeof(double) * nx);
     double rmax = 0;
@@ -500,7 +510,7 @@ static int qp_solve_tol(const dmodel* M, const orow* rows, int m, qpres* out, do
     if (getenv("ORC_QP_TRACE")) fprintf(stderr, "   it %d comp %.3e obj %.6f alpha %.4f resid %.2e\n", it, comp, obj, alpha, resid_fac * R0);
     for (int q = 0; q < N * nz; ++q) Z[q] += alpha * dZ[q];
     for (int k = 0; k < m; ++k) { s[k] += alpha * ds[k]; lam[k] += alpha * dlam[k]; tt[k] += alpha * dtt[k]; }
-    resid_fac *= (1.0 - alpha);
+    resid_fac *= (1.0 - alpha); alpha_prev = alpha;
     if (alpha < 1e-12) break;
   }
   double viol = 0, slack_cost = 0, obj = 0;
@@ -519,7 +529,8 @@ static int qp_solve_tol(const dmodel* M, const orow* rows, int m, qpres* out, do
   return ok;
 }
 
-static int qp_solve(const dmodel* M, const orow* rows, int m, qpres* out) { return qp_solve_tol(M, rows, m, out, QP_TOL); }
+static double g_node_tol = QP_TOL; /* node relaxations: accurate to a small fraction of the requested MIP gap */
+static int qp_solve(const dmodel* M, const orow* rows, int m, qpres* out) { return qp_solve_tol(M, rows, m, out, g_node_tol); }
 
 /* ------------------------------------------------------------------ node relaxation rows */
 static void node_rows(const dmodel* M, const signed char* fix, rowvec* v) {
@@ -639,12 +650,16 @@ static int complete(const dmodel* M, const signed char* fix, const double* Z, si
     for (int i = 1; i < N; ++i) {
       if (FIX_REG(M, fix, c, i) >= 0) { prevj = ALT_J(M, c, FIX_REG(M, fix, c, i)); continue; }
       int cands[64]; int n = region_cands(M, fix, c, i, cands);
-      int bi = -1; double bv = 1e300;
+      /* canonical choice (ties at sector borders are common): the first non-slow alternative, in (region, half-plane)
+       * order, whose rows hold within tol; else the slow alternative if it holds; else the least violated one */
+      int bi = -1; double bv = 1e300; int first_ok = -1, slow_ok = -1;
       for (int q = 0; q < n; ++q) {
         if (ALT_H(cands[q]) == 3 && ALT_J(M, c, cands[q]) != prevj) continue;
         double v = alt_viol_region(M, &tmp, c, i, cands[q], Z);
         if (v < bv) { bv = v; bi = cands[q]; }
+        if (v <= tol) { if (ALT_H(cands[q]) != 3) { if (first_ok < 0) first_ok = cands[q]; } else if (slow_ok < 0) slow_ok = cands[q]; }
       }
+      if (first_ok >= 0) { bi = first_ok; bv = 0.0; } else if (slow_ok >= 0) { bi = slow_ok; bv = 0.0; }
       if (bi < 0 || bv > tol) {
         g_cur_viol = bv < 1e299 ? bv : 1e3;
         viol_region(M, fix, best, c, i);
@@ -917,6 +932,7 @@ int orc_solve(const oinst* I, const orc_opts* o, miqp_raw_results_c* res, miqp_s
   dmodel* M = dm_new(I);
   double gap = (o && o->gap >= 0) ? o->gap : I->gap;
   double tlim = (o && o->time_limit > 0) ? o->time_limit : I->tilim;
+  g_node_tol = fmin(QP_TOL, fmax(1e-12, 1e-4 * gap));
   long long max_nodes = (o && o->max_nodes > 0) ? o->max_nodes : 2000000;
   int verbose = o ? o->verbose : 0;
   orc_sizes sz = orc_raw_sizes(I);

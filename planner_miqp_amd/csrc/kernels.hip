@@ -17,7 +17,8 @@ namespace miqp {
 
 constexpr double RHO_EL = 1.0e5;     // exact-penalty weight of the elastic rows
 constexpr double FEAS_TOL = 1.0e-6;
-constexpr double QP_TOL = 1.0e-10;
+constexpr double QP_TOL = 1.0e-8;      // node relaxations (bounds); the returned incumbent is polished to QP_TOL_FINAL
+constexpr double QP_T0 = 1.0e-3;       // initial elastic slack: t*mu (mu ~ rho) starts at the order of s*lambda
 constexpr double QP_TOL_FINAL = 1.0e-13;  // polish of the returned incumbent / solve_fixed
 constexpr double QP_SIGMA = 0.1;
 constexpr int QP_MAXIT = 80;
@@ -58,6 +59,7 @@ struct DevBuf {
   int* active_insts;             // number of instances not yet done
   int nodes_per_round; int n_inst;
   double qp_tol;
+  int* work_counter;             // next node of the batch to be solved (reset before every ipm launch)
   unsigned long long* stat_rowiters;
 };
 
@@ -287,7 +289,14 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
   signed char* fix = (signed char*)(ABm + NX * NZ);  // [fixlen]
   // persistent-style: a resident block works through nodes blockIdx.x, blockIdx.x + gridDim.x, ... so that the
   // per-row interior-point state (indexed by block, not by node) stays cache resident
-  for (int node = blockIdx.x; node < nbatch; node += gridDim.x) {
+  __shared__ int sh_node;
+  for (;;) {
+  // dynamic distribution: the next unsolved node of the batch (solve times vary 4x between nodes)
+  __syncthreads();
+  if (tid == 0) sh_node = atomicAdd(B.work_counter, 1);
+  __syncthreads();
+  const int node = sh_node;
+  if (node >= nbatch) break;
   const int inst = B.batch_inst[node];
   const double* D = B.inst_d + (size_t)inst * Y.dstride;
   const int* T = B.inst_i + (size_t)inst * Y.istride;
@@ -333,7 +342,11 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
         double v = g[q];
         if (v != 0.0 && nn < 6) { rc_v[(size_t)nn * Y.ROWCAP + idx] = v; cols |= (unsigned long long)q << (8 * nn); nn++; c -= v * Z[i * NZ + q]; }
       }
-      if (r.aq == 0.0) { lam = 1.0; s = fmax(c, 0.0) + 1.0; t = s - c; csum += s * lam + t * (RHO_EL - lam); cnt += 2; }
+      if (r.aq == 0.0) {
+        lam = 1.0;
+        if (c > QP_T0) { t = QP_T0; s = c + QP_T0; } else { s = 100.0 * QP_T0; t = s - c; }
+        csum += s * lam + t * (RHO_EL - lam); cnt += 2;
+      }
       else { lam = fmax(1.0, -2.0 * c * r.aq + 1.0); s = c + lam / r.aq; t = 0.0; csum += s * lam; cnt += 1; }
     }
     cols |= (unsigned long long)nn << 56;
@@ -699,14 +712,17 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       int np = T[Y.i_nposs + c];
       int nxt = (i + 1 < N) ? (int)fix[Y.f_reg + c * N + i + 1] : -1;
       int nxtq = (nxt >= 0 && (nxt & 3) == 3) ? (nxt >> 2) : -1;  // next step frozen to this region
-      double bv = 1e300; int bc = -1;
+      // canonical choice (ties at sector borders are common): the first non-slow alternative, in (region, half-plane)
+      // order, whose rows hold within tol; else the slow alternative if it holds; else the least violated one
+      double bv = 1e300; int bc = -1; bool found = false;
       for (int q = 0; q < np; ++q) {
         slowv[(c * N + i) * P + q] = (nxtq >= 0 && nxtq != q) ? 1e300 : region_alt_viol(Y, D, T, c, q, 3, s, wj);
         if (nxtq >= 0 && nxtq != q) continue;
         int nh = T[Y.i_nhs + c * P + q];
         for (int h = 0; h < nh; ++h) {
           double v = region_alt_viol(Y, D, T, c, q, h, s, wj);
-          if (v < bv) { bv = v; bc = q * 4 + h; }
+          if (!found && v <= tol) { found = true; bv = 0.0; bc = q * 4 + h; }
+          if (!found && v < bv) { bv = v; bc = q * 4 + h; }
         }
       }
       fastv[c * N + i] = bv; fastc[c * N + i] = bc; vflag[c * N + i] = 0;
@@ -721,7 +737,10 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       if (code < 0) {
         double bv = fastv[c * N + i]; int bc = fastc[c * N + i];
         for (int q = 0; q < np; ++q)
-          if (T[Y.i_regj + c * P + q] == prevj) { double v = slowv[(c * N + i) * P + q]; if (v < bv) { bv = v; bc = q * 4 + 3; } }
+          if (T[Y.i_regj + c * P + q] == prevj) {
+            double v = slowv[(c * N + i) * P + q];
+            if (bv > tol && (v <= tol || v < bv)) { bv = v <= tol ? 0.0 : v; bc = q * 4 + 3; }
+          }
         if (bc < 0 || bv > tol) { vflag[c * N + i] = 1; if (bc < 0) bc = 0; }
         comp[Y.f_reg + c * N + i] = (signed char)bc;
         code = bc;

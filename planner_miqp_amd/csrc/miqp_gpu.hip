@@ -226,6 +226,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   if (!X.alloc(&B.batch_comp, (size_t)batch_cap * Y.fixlen)) return false;
   if (!X.alloc(&B.rowstate, (size_t)std::min(batch_cap, X.ipm_grid_max) * NFIELD * Y.ROWCAP)) return false;
   if (!X.alloc(&B.rowcache, (size_t)std::min(batch_cap, X.ipm_grid_max) * NCACHE * Y.ROWCAP)) return false;
+  if (!X.alloc(&B.work_counter, 1)) return false;
   if (!X.alloc(&B.active_insts, 1)) return false;
   if (!X.alloc(&B.stat_rowiters, 1)) return false;
   X.ready = true;
@@ -244,7 +245,7 @@ size_t eval_lds_bytes(const Layout& Y) {
 }
 size_t select_lds_bytes(int open_cap) { (void)open_cap; return 0; }
 
-template <int C> void launch_ipm(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { hipLaunchKernelGGL((ipm_kernel<C, IPM_NT>), dim3(nblocks), dim3(IPM_NT), lds, st, B); }
+template <int C> void launch_ipm(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { (void)hipMemsetAsync(B.work_counter, 0, 4, st); hipLaunchKernelGGL((ipm_kernel<C, IPM_NT>), dim3(nblocks), dim3(IPM_NT), lds, st, B); }
 template <int C> void launch_eval(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { hipLaunchKernelGGL(eval_kernel<C>, dim3(nblocks), dim3(64), lds, st, B); }
 
 bool set_kernel_lds(const Layout& Y, size_t ipm_lds, size_t eval_lds, size_t sel_lds) {
@@ -445,6 +446,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     s->props = miqp_solution_properties_c{}; s->props.NrConstraints = rows; s->props.NrBinaryVariables = bin; s->props.NrFloatVariables = cont;
     s->props.NonZeroCoefficients = 0;
   }
+  { double gmin = 1.0; for (int k = 0; k < n; ++k) gmin = std::min(gmin, h_gap[k]);
+    B.qp_tol = std::min(QP_TOL, std::max(1e-12, 1e-4 * gmin)); }  // node relaxations: accurate to a small fraction of the MIP gap
   hipStream_t st = X.stream;
   HIP_OK(hipMemcpyAsync((void*)B.inst_d, hD.data(), hD.size() * 8, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync((void*)B.inst_i, hT.data(), hT.size() * 4, hipMemcpyHostToDevice, st));

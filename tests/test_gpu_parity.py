@@ -20,6 +20,18 @@ def gpu_solve_dat(name, gap):
     return w, st
 
 
+def assert_regions_canonical_equal(p, a, b, tol=1e-5):
+    """identical active regions, up to ties: where the labels differ the velocity must lie on the common border of
+    the two sectors (both labels describe the same continuous point; SURVEY.md section 7, hard part 3)"""
+    ra, rb = a.active_region.argmax(-1), b.active_region.argmax(-1)
+    F = np.asarray(p.fraction_parameters, float).reshape(-1, 4)
+    for c, i in np.argwhere(ra != rb):
+        for res, j in ((a, rb[c, i]), (b, ra[c, i])):
+            vx, vy = res.vel_x[c, i], res.vel_y[c, i]
+            n1, n3 = np.hypot(F[j, 0], F[j, 1]), np.hypot(F[j, 2], F[j, 3])
+            assert (F[j, 1] * vx - F[j, 0] * vy) / n1 <= tol and (F[j, 2] * vy - F[j, 3] * vx) / n3 <= tol, (c, i, ra[c, i], rb[c, i], vx, vy)
+
+
 def assert_states_close(a, b, tol=STATE_TOL, fields=CONT_FIELDS):
     for n in fields:
         d = np.abs(getattr(a, n) - getattr(b, n)).max()
@@ -109,7 +121,7 @@ def test_synthetic_parity_tight_gap(oracle, cfg, seeds):
             oracle.free(h); continue
         pr = w.getSolutionProperties(); res = w.getRawResults()
         assert abs(pr.objective - op.objective) <= 1e-6 * max(1.0, abs(op.objective)), (cfg, seed, pr.objective, op.objective)
-        assert np.array_equal(res.active_region, ores.active_region), (cfg, seed)
+        assert_regions_canonical_equal(p, res, ores)
         assert_states_close(res, ores)
         for n in ["notWithinEnvironmentRear", "notWithinEnvironmentFrontUbUb", "deltacc", "deltacc_front", "car2car_collision",
                   "region_change_not_allowed_combined", "region_change_not_allowed_x_positive"]:
