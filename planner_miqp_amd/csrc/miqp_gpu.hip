@@ -20,6 +20,7 @@
 #define MIQP_IPM_NT 64
 #endif
 #include "kernels.hip"
+#include "lp_export.hpp"
 
 using namespace miqp;
 
@@ -674,8 +675,8 @@ int miqp_solver_last_timing(const miqp_solver_t* s, double* out6) {
 }
 
 int miqp_solver_export_lp(const miqp_solver_t* s, const char* path) {
-  (void)s; (void)path;
-  return -1;  // LP export is a debug format of the reference; not built in this round
+  if (!s || !s->has_inst || !path) return -1;
+  return miqp::export_lp(s->inst, path);
 }
 
 int miqp_solver_solve_fixed(miqp_solver_t* s, const miqp_raw_results_c* fixed, miqp_raw_results_c* out, double* objective, int* iterations) {

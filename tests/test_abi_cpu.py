@@ -111,3 +111,21 @@ dist.destroy_process_group()
                           "--master-port", "29533", script], capture_output=True, text=True, env=env, timeout=300)
     os.unlink(script)
     assert "GATHER_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_lp_export_has_the_reference_model_sizes(lib, tmp_path):
+    """miqp_solver_export_lp (cplex.exportModel, src/cplex_wrapper.cpp:150-154): the LP dump of the testcase has the
+    row and binary counts CPLEX reports for the reference model (test/cplex_wrapper_test.cc:866-871)"""
+    w = P.CplexWrapper(parameterSource=P.ParameterSource.DATFILE)
+    w.setParameterDatFileAbsolute(dat_path("cplexmodel_testcase.dat"))
+    assert w._push_inputs() == 0
+    out = str(tmp_path / "testcase.lp")
+    assert lib.miqp_solver_export_lp(w._h, out.encode()) == 0
+    txt = open(out).read()
+    body = txt.split("Subject To")[1].split("Bounds")[0]
+    rows = [l for l in body.splitlines() if l.strip().startswith("c")]
+    assert len(rows) == 12361
+    nnz = sum(len(re.findall(r"[+-][0-9.eE+-]+ [A-Za-z_]", l)) for l in rows)
+    assert nnz == 29834
+    bins = [l for l in txt.split("Binaries")[1].split("End")[0].splitlines() if l.strip()]
+    assert len(bins) == 1240
