@@ -22,7 +22,7 @@ constexpr double QP_T0 = 1.0e-3;       // initial elastic slack: t*mu (mu ~ rho)
 constexpr double QP_TOL_FINAL = 1.0e-13;  // polish of the returned incumbent / solve_fixed
 constexpr double QP_SIGMA = 0.1;
 constexpr int QP_MAXIT = 80;
-constexpr int NFIELD = 6;            // per-row state: s, lambda, t, ds, dlambda, dt
+constexpr int NFIELD = 4;            // per-row state: s, lambda, t, g.dz
 constexpr int NCACHE = 9;            // per-row cache: rhs, aq (-1: inactive), packed columns, 6 coefficients
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
@@ -261,16 +261,31 @@ template <int NT> __device__ inline double block_max(double v, double* red) {
 }
 
 // ------------------------------------------------------------------------------------------------
-//  interior point kernel: one workgroup of NT threads per node
+//  Newton step of one row (elastic: aq == 0, quadratic-soft: aq > 0) given g.dz
+__device__ inline void row_step(double s, double lam, double t, double aq, double gd, double tau, double& ds, double& dl, double& dt) {
+  double zz, r2mu = 0.0, mu = 0.0;
+  if (aq == 0.0) { mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
+  else zz = 1.0 / aq;
+  double Dd = s / lam + zz;
+  double kap = ((tau - s * lam) / lam - r2mu) / Dd;
+  dl = gd / Dd + kap;
+  ds = ((tau - s * lam) - s * dl) / lam;
+  dt = aq == 0.0 ? ((tau - t * mu) + t * dl) / mu : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  interior point kernel: one wavefront per node.  The rows of the node are decoded once, compacted per stage
+//  (only active rows are stored) and kept as sparse rows (<= 6 non-zeros) in a block-indexed cache.
 template <int C, int NT>
 __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
+  static_assert(NT == 64, "one wavefront per node");
   constexpr int NX = 6 * C, NU = 2 * C, NZ = 8 * C, GS = 17;  // rows are zero padded to the 16 columns of the MFMA tile
   const Layout& Y = B.Y;
   const int tid = threadIdx.x;
   const int nbatch = *B.batch_count;
   const int N = Y.N, NSLOT = Y.NSLOT;
   extern __shared__ double lds[];
-  const int nrow = ((NSLOT + 3) & ~3) > NT ? ((NSLOT + 3) & ~3) : NT;  // LDS rows: scratch row per thread / row per slot of a stage
+  const int nrow = ((NSLOT + 3) & ~3) > NT ? ((NSLOT + 3) & ~3) : NT;  // LDS rows: scratch row per thread / row block of a stage
   double* Z = lds;                       // [N][NZ]
   double* dZ = Z + N * NZ;               // [N][NZ]
   double* Kg = dZ + N * NZ;              // [N][NU*NX]
@@ -286,10 +301,14 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
   double* Wd = Lc + NU * NU;             // [NZ]
   double* red = Wd + NZ;                 // [8]
   double* ABm = red + 8;                 // [NX*NZ] = [A B] of the triple integrator chains
-  signed char* fix = (signed char*)(ABm + NX * NZ);  // [fixlen]
-  // persistent-style: a resident block works through nodes blockIdx.x, blockIdx.x + gridDim.x, ... so that the
-  // per-row interior-point state (indexed by block, not by node) stays cache resident
+  int* sstart = (int*)(ABm + NX * NZ);   // [N+2] first compact row of every stage
+  signed char* fix = (signed char*)(sstart + ((N + 4) & ~1));  // [fixlen]
   __shared__ int sh_node;
+  // per-row data of the node being solved, indexed by resident block (stays L2 / Infinity-Cache resident)
+  double* RS = B.rowstate + (size_t)blockIdx.x * NFIELD * Y.ROWCAP;
+  double* rs_s = RS, *rs_l = RS + Y.ROWCAP, *rs_t = RS + 2 * Y.ROWCAP, *rs_g = RS + 3 * Y.ROWCAP;
+  double* RC = B.rowcache + (size_t)blockIdx.x * NCACHE * Y.ROWCAP;
+  double* rc_rhs = RC, *rc_aq = RC + Y.ROWCAP, *rc_col = RC + 2 * Y.ROWCAP, *rc_v = RC + 3 * Y.ROWCAP;
   for (;;) {
   // dynamic distribution: the next unsolved node of the batch (solve times vary 4x between nodes)
   __syncthreads();
@@ -301,7 +320,6 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
   const double* D = B.inst_d + (size_t)inst * Y.dstride;
   const int* T = B.inst_i + (size_t)inst * Y.istride;
   const double ts = D[Y.d_glob + 7];
-  __syncthreads();
   {
     const signed char* src = B.pool_fix + (size_t)B.batch_node[node] * Y.fixlen;
     for (int k = tid; k < Y.fixlen; k += NT) fix[k] = src[k];
@@ -315,44 +333,45 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
   for (int i = 0; i + 1 < N; ++i) {  // free rollout (u = 0)
     if (tid < NX) {
       double acc = 0;
-      for (int q = 0; q < NX; ++q) acc += ab_entry<C>(tid, q, ts) * Z[i * NZ + q];
+      for (int q = 0; q < NX; ++q) acc += ABm[tid * NZ + q] * Z[i * NZ + q];
       Z[(i + 1) * NZ + tid] = acc;
     }
     __syncthreads();
   }
-  double* RS = B.rowstate + (size_t)blockIdx.x * NFIELD * Y.ROWCAP;
-  double* rs_s = RS, *rs_l = RS + Y.ROWCAP, *rs_t = RS + 2 * Y.ROWCAP, *rs_ds = RS + 3 * Y.ROWCAP,
-         *rs_dl = RS + 4 * Y.ROWCAP, *rs_dt = RS + 5 * Y.ROWCAP;
   const double* Rf = D + Y.d_ref;
-  const int NROWS = N * NSLOT;
 
-  // ---- decode every row of the node once into the sparse row cache; initial row state, complementarity
-  double* RC = B.rowcache + (size_t)blockIdx.x * NCACHE * Y.ROWCAP;
-  double* rc_rhs = RC, *rc_aq = RC + Y.ROWCAP, *rc_col = RC + 2 * Y.ROWCAP, *rc_v = RC + 3 * Y.ROWCAP;
-  double csum = 0.0; int cnt = 0;
-  for (int idx = tid; idx < NROWS; idx += NT) {
-    int i = idx / NSLOT, slot = idx - i * NSLOT;
-    double* g = Gh + tid * GS;
-    RowOut r = decode_row<C>(Y, D, T, fix, i, slot, g);
-    double s = 1.0, lam = 1.0, t = 1.0;
-    unsigned long long cols = 0ull; int nn = 0;
-    if (r.active) {
-      double c = r.rhs;
-      for (int q = 0; q < NZ; ++q) {
-        double v = g[q];
-        if (v != 0.0 && nn < 6) { rc_v[(size_t)nn * Y.ROWCAP + idx] = v; cols |= (unsigned long long)q << (8 * nn); nn++; c -= v * Z[i * NZ + q]; }
+  // ---- decode every row of the node once; active rows are compacted per stage; initial row state
+  double csum = 0.0; int cnt = 0; int base = 0;
+  for (int i = 0; i < N; ++i) {
+    if (tid == 0) sstart[i] = base;
+    for (int sb = 0; sb < NSLOT; sb += NT) {
+      int slot = sb + tid;
+      double* g = Gh + tid * GS;
+      RowOut r; r.active = false; r.rhs = 0; r.aq = 0;
+      if (slot < NSLOT) r = decode_row<C>(Y, D, T, fix, i, slot, g);
+      unsigned long long mask = __ballot(r.active);
+      if (r.active) {
+        int idx = base + __popcll(mask & ((1ull << tid) - 1ull));
+        unsigned long long cols = 0ull; int nn = 0;
+        double c = r.rhs;
+        for (int q = 0; q < NZ; ++q) {
+          double v = g[q];
+          if (v != 0.0 && nn < 6) { rc_v[(size_t)nn * Y.ROWCAP + idx] = v; cols |= (unsigned long long)q << (8 * nn); nn++; c -= v * Z[i * NZ + q]; }
+        }
+        cols |= ((unsigned long long)i << 48) | ((unsigned long long)nn << 56);
+        double s, lam = 1.0, t;
+        if (r.aq == 0.0) {
+          if (c > QP_T0) { t = QP_T0; s = c + QP_T0; } else { s = 100.0 * QP_T0; t = s - c; }
+          csum += s * lam + t * (RHO_EL - lam); cnt += 2;
+        } else { lam = fmax(1.0, -2.0 * c * r.aq + 1.0); s = c + lam / r.aq; t = 0.0; csum += s * lam; cnt += 1; }
+        rc_rhs[idx] = r.rhs; rc_aq[idx] = r.aq; rc_col[idx] = __longlong_as_double((long long)cols);
+        rs_s[idx] = s; rs_l[idx] = lam; rs_t[idx] = t;
       }
-      if (r.aq == 0.0) {
-        lam = 1.0;
-        if (c > QP_T0) { t = QP_T0; s = c + QP_T0; } else { s = 100.0 * QP_T0; t = s - c; }
-        csum += s * lam + t * (RHO_EL - lam); cnt += 2;
-      }
-      else { lam = fmax(1.0, -2.0 * c * r.aq + 1.0); s = c + lam / r.aq; t = 0.0; csum += s * lam; cnt += 1; }
+      base += __popcll(mask);
     }
-    cols |= (unsigned long long)nn << 56;
-    rc_rhs[idx] = r.rhs; rc_aq[idx] = r.active ? r.aq : -1.0; rc_col[idx] = __longlong_as_double((long long)cols);
-    rs_s[idx] = s; rs_l[idx] = lam; rs_t[idx] = t; rs_ds[idx] = 0.0; rs_dl[idx] = 0.0; rs_dt[idx] = 0.0;
   }
+  if (tid == 0) sstart[N] = base;
+  const int NROWS = base;
   double comp = block_sum<NT>(csum, red);
   int ncomp = (int)block_sum<NT>((double)cnt, red);
   if (ncomp < 1) ncomp = 1;
@@ -375,39 +394,40 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     double rmax = 0.0;
     for (int i = N - 1; i >= 0; --i) {
       __syncthreads();
-      const int nsl4 = (NSLOT + 3) & ~3;
-      for (int slot = tid; slot < nsl4; slot += NT) {
-        double* g = Gh + slot * GS;
+      const int r0 = sstart[i], nr = sstart[i + 1] - r0;
+      const int nsl4 = (nr + 3) & ~3;
+      for (int r = tid; r < nsl4; r += NT) {
+        double* g = Gh + r * GS;
         double fsv = 0.0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) g[q] = 0.0;
-        if (slot < NSLOT) {
-          int idx = i * NSLOT + slot;
+        if (r < nr) {
+          int idx = r0 + r;
           double aq = rc_aq[idx];
-          if (aq >= 0.0) {
-            unsigned long long cols = (unsigned long long)__double_as_longlong(rc_col[idx]);
-            int nn = (int)(cols >> 56);
-            double s = rs_s[idx], lam = rs_l[idx], zz, r2mu = 0.0;
-            if (aq == 0.0) { double t = rs_t[idx], mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
-            else zz = 1.0 / aq;
-            double Dd = s / lam + zz, w = 1.0 / Dd;
-            double kap = ((tau - s * lam) / lam - r2mu) / Dd;
-            double sw = sqrt(w);
-            fsv = (lam + kap) / sw;
-            for (int k = 0; k < nn; ++k) g[(cols >> (8 * k)) & 255] = sw * rc_v[(size_t)k * Y.ROWCAP + idx];
-          }
+          unsigned long long cols = (unsigned long long)__double_as_longlong(rc_col[idx]);
+          int nn = (int)(cols >> 56);
+          double s = rs_s[idx], lam = rs_l[idx], zz, r2mu = 0.0;
+          if (aq == 0.0) { double t = rs_t[idx], mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
+          else zz = 1.0 / aq;
+          double Dd = s / lam + zz, w = 1.0 / Dd;
+          double kap = ((tau - s * lam) / lam - r2mu) / Dd;
+          double sw = sqrt(w);
+          fsv = (lam + kap) / sw;
+          for (int k = 0; k < nn; ++k) g[(cols >> (8 * k)) & 255] = sw * rc_v[(size_t)k * Y.ROWCAP + idx];
         }
-        fs[slot] = fsv;
+        fs[r] = fsv;
       }
       __syncthreads();
       // Phi = 2W + Gh' Gh on the matrix core: v_mfma_f64_16x16x4_f64, 4 rows of the scaled row block per instruction.
       // A operand lane l = Gh[4kb + (l>>4)][l&15] = B operand (Gh' Gh is symmetric in its two factors);
       // D layout of the f64 form: row = (l>>4) + 4*reg, col = l&15.
-      if (tid < 64) {
+      {
         d4_t acc = {0.0, 0.0, 0.0, 0.0};
         const int lr = tid >> 4, lc = tid & 15;
+        double racc = 0.0;
         for (int kb = 0; kb < nsl4; kb += 4) {
           double a = Gh[(kb + lr) * GS + lc];
+          racc += a * fs[kb + lr];                       // rr = Gh' fs, 4 partial sums per component
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
         }
 #pragma unroll
@@ -415,16 +435,11 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
           int row = lr + 4 * rg;
           if (row < NZ && lc < NZ) Phi[row * NZ + lc] = acc[rg] + (row == lc ? 2.0 * Wd[row] : 0.0);
         }
-      }
-      if (tid >= NT - 64) {  // rr = 2W(z - ref) + Gh' fs : 4 partial sums per component, combined by shuffles
-        int l = tid - (NT - 64), a = l & 15, part = l >> 4;
-        double acc = 0.0;
-        for (int sl = part; sl < NSLOT; sl += 4) acc += Gh[sl * GS + a] * fs[sl];
-        acc += __shfl_xor(acc, 16); acc += __shfl_xor(acc, 32);
-        if (part == 0 && a < NZ) {
-          acc += 2.0 * Wd[a] * (Z[i * NZ + a] - Rf[i * NZ + a]);
-          rr[a] = acc;
-          if (it == 1) rmax = fmax(rmax, fabs(acc));
+        racc += __shfl_xor(racc, 16); racc += __shfl_xor(racc, 32);
+        if (lr == 0 && lc < NZ) {
+          racc += 2.0 * Wd[lc] * (Z[i * NZ + lc] - Rf[i * NZ + lc]);
+          rr[lc] = racc;
+          if (it == 1) rmax = fmax(rmax, fabs(racc));
         }
       }
       __syncthreads();
@@ -499,72 +514,62 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     }
     if (it == 1) R0 = block_max<NT>(rmax, red);
     __syncthreads();
-    // ================= forward sweep (first wave only; LDS traffic of one wave needs no workgroup barrier)
+    // ================= forward sweep (one wavefront: LDS traffic in program order, no workgroup barrier needed)
     if (tid < NZ) dZ[tid] = 0.0;
     __syncthreads();
-    if (tid < 64) {
-      for (int i = 0; i + 1 < N; ++i) {
-        const double* Ki = Kg + i * NU * NX; const double* ki = kg + i * NU;
-        if (tid < NU) {
-          double acc = -ki[tid];
-          for (int q = 0; q < NX; ++q) acc -= Ki[tid * NX + q] * dZ[i * NZ + q];
-          dZ[i * NZ + NX + tid] = acc;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (tid < NX) {
-          double acc = 0.0;
-          int q0 = 3 * (tid / 3);
-          for (int q = q0; q < q0 + 3; ++q) acc += ABm[tid * NZ + q] * dZ[i * NZ + q];
-          acc += ABm[tid * NZ + NX + tid / 3] * dZ[i * NZ + NX + tid / 3];
-          dZ[(i + 1) * NZ + tid] = acc;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = 0; i + 1 < N; ++i) {
+      const double* Ki = Kg + i * NU * NX; const double* ki = kg + i * NU;
+      if (tid < NU) {
+        double acc = -ki[tid];
+        for (int q = 0; q < NX; ++q) acc -= Ki[tid * NX + q] * dZ[i * NZ + q];
+        dZ[i * NZ + NX + tid] = acc;
       }
-      if (tid < NU) dZ[(N - 1) * NZ + NX + tid] = 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (tid < NX) {
+        double acc = 0.0;
+        int q0 = 3 * (tid / 3);
+        for (int q = q0; q < q0 + 3; ++q) acc += ABm[tid * NZ + q] * dZ[i * NZ + q];
+        acc += ABm[tid * NZ + NX + tid / 3] * dZ[i * NZ + NX + tid / 3];
+        dZ[(i + 1) * NZ + tid] = acc;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    if (tid < NU) dZ[(N - 1) * NZ + NX + tid] = 0.0;
     __syncthreads();
-    // ================= step length
+    // ================= step length: ratio test over all rows; only g.dz is stored per row
     double amax = 1e300, a0 = 0.0, a1 = 0.0, a2 = 0.0;
     for (int idx = tid; idx < NROWS; idx += NT) {
-      int i = idx / NSLOT;
       double aq = rc_aq[idx];
-      double ds = 0.0, dl = 0.0, dt = 0.0;
-      if (aq >= 0.0) {
-        unsigned long long cols = (unsigned long long)__double_as_longlong(rc_col[idx]);
-        int nn = (int)(cols >> 56);
-        double gd = 0.0;
-        for (int k = 0; k < nn; ++k) gd += rc_v[(size_t)k * Y.ROWCAP + idx] * dZ[i * NZ + ((cols >> (8 * k)) & 255)];
-        double s = rs_s[idx], lam = rs_l[idx], zz, r2mu = 0.0, t = 0.0, mu = 0.0;
-        if (aq == 0.0) { t = rs_t[idx]; mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
-        else zz = 1.0 / aq;
-        double Dd = s / lam + zz, w = 1.0 / Dd;
-        double kap = ((tau - s * lam) / lam - r2mu) / Dd;
-        dl = w * gd + kap;
-        ds = ((tau - s * lam) - s * dl) / lam;
-        if (ds < 0) amax = fmin(amax, -s / ds);
-        if (dl < 0) amax = fmin(amax, -lam / dl);
-        a0 += s * lam; a1 += s * dl + lam * ds; a2 += ds * dl;
-        if (aq == 0.0) {
-          double dmu = -dl;
-          dt = ((tau - t * mu) - t * dmu) / mu;
-          if (dt < 0) amax = fmin(amax, -t / dt);
-          if (dmu < 0) amax = fmin(amax, -mu / dmu);
-          a0 += t * mu; a1 += t * dmu + mu * dt; a2 += dt * dmu;
-        }
-        rowiters++;
+      unsigned long long cols = (unsigned long long)__double_as_longlong(rc_col[idx]);
+      int nn = (int)(cols >> 56), i = (int)((cols >> 48) & 255);
+      double gd = 0.0;
+      for (int k = 0; k < nn; ++k) gd += rc_v[(size_t)k * Y.ROWCAP + idx] * dZ[i * NZ + ((cols >> (8 * k)) & 255)];
+      double s = rs_s[idx], lam = rs_l[idx], t = rs_t[idx], ds, dl, dt;
+      row_step(s, lam, t, aq, gd, tau, ds, dl, dt);
+      if (ds < 0) amax = fmin(amax, -s / ds);
+      if (dl < 0) amax = fmin(amax, -lam / dl);
+      a0 += s * lam; a1 += s * dl + lam * ds; a2 += ds * dl;
+      if (aq == 0.0) {
+        double mu = RHO_EL - lam, dmu = -dl;
+        if (dt < 0) amax = fmin(amax, -t / dt);
+        if (dmu < 0) amax = fmin(amax, -mu / dmu);
+        a0 += t * mu; a1 += t * dmu + mu * dt; a2 += dt * dmu;
       }
-      rs_ds[idx] = ds; rs_dl[idx] = dl; rs_dt[idx] = dt;
+      rs_g[idx] = gd;
     }
+    rowiters += (unsigned long long)NROWS;
     amax = block_min<NT>(amax, red);
     a0 = block_sum<NT>(a0, red); a1 = block_sum<NT>(a1, red); a2 = block_sum<NT>(a2, red);
     double alpha = fmin(1.0, 0.995 * amax);
     comp = (a0 + alpha * a1 + alpha * alpha * a2) / ncomp;
-    // ================= update
+    // ================= update (the step of every row is recomputed from its stored g.dz)
     for (int k = tid; k < N * NZ; k += NT) Z[k] += alpha * dZ[k];
     for (int idx = tid; idx < NROWS; idx += NT) {
-      rs_s[idx] += alpha * rs_ds[idx]; rs_l[idx] += alpha * rs_dl[idx]; rs_t[idx] += alpha * rs_dt[idx];
+      double s = rs_s[idx], lam = rs_l[idx], t = rs_t[idx], ds, dl, dt;
+      row_step(s, lam, t, rc_aq[idx], rs_g[idx], tau, ds, dl, dt);
+      rs_s[idx] = s + alpha * ds; rs_l[idx] = lam + alpha * dl; rs_t[idx] = t + alpha * dt;
     }
     resid_fac *= (1.0 - alpha);
     __syncthreads();
@@ -573,16 +578,13 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
   // ---- final measures: worst elastic violation, slack cost
   double viol = 0.0, scost = 0.0;
   for (int idx = tid; idx < NROWS; idx += NT) {
-    int i = idx / NSLOT;
     double aq = rc_aq[idx];
-    if (aq >= 0.0) {
-      unsigned long long cols = (unsigned long long)__double_as_longlong(rc_col[idx]);
-      int nn = (int)(cols >> 56);
-      double c = rc_rhs[idx];
-      for (int k = 0; k < nn; ++k) c -= rc_v[(size_t)k * Y.ROWCAP + idx] * Z[i * NZ + ((cols >> (8 * k)) & 255)];
-      if (aq == 0.0) viol = fmax(viol, -c);
-      else { double t = rs_l[idx] / aq; scost += 0.5 * aq * t * t; }
-    }
+    unsigned long long cols = (unsigned long long)__double_as_longlong(rc_col[idx]);
+    int nn = (int)(cols >> 56), i = (int)((cols >> 48) & 255);
+    double c = rc_rhs[idx];
+    for (int k = 0; k < nn; ++k) c -= rc_v[(size_t)k * Y.ROWCAP + idx] * Z[i * NZ + ((cols >> (8 * k)) & 255)];
+    if (aq == 0.0) viol = fmax(viol, -c);
+    else { double t = rs_l[idx] / aq; scost += 0.5 * aq * t * t; }
   }
   viol = block_max<NT>(viol, red); scost = block_sum<NT>(scost, red);
   {
@@ -596,9 +598,8 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     B.batch_obj[node] = obj; B.batch_viol[node] = viol; B.batch_ok[node] = ok; B.batch_it[node] = it > QP_MAXIT ? QP_MAXIT : it;
     atomicAdd((unsigned long long*)&B.inst_iters[inst], (unsigned long long)(it > QP_MAXIT ? QP_MAXIT : it));
     atomicAdd((unsigned long long*)&B.inst_nodes[inst], 1ull);
+    atomicAdd(B.stat_rowiters, rowiters);
   }
-  double rsum = block_sum<NT>((double)rowiters, red);
-  if (tid == 0) atomicAdd(B.stat_rowiters, (unsigned long long)rsum);
   }  // node loop
 }
 
