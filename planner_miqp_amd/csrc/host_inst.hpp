@@ -7,6 +7,7 @@
 //   cplexmodel/model_region_constraints.mod:43-114 region block (sector, front polynomials, boxes, curvature)
 //   cplexmodel/minimum_speed_constraints.mod:9-49 low-speed freeze -> non-slow half-planes per sector
 #pragma once
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -232,7 +233,7 @@ struct Layout {
   // double offsets
   int d_x0, d_wd, d_ref, d_glob, d_u0box, d_misc, d_dsep, d_ssl, d_smax, d_reg, d_env, d_obs, d_theta, dstride;
   // int offsets
-  int i_nposs, i_regj, i_nhs, i_hs, i_envn, i_obssoft, i_initj, istride;
+  int i_nposs, i_regj, i_nhs, i_hs, i_envn, i_obssoft, i_initj, i_dom, istride;
   // fix record (bytes)
   int f_reg, f_env, f_obs, f_c2c, fixlen;
 };
@@ -248,7 +249,7 @@ inline Layout make_layout(int C, int N, int R, int P, int E, int EL, int O, int 
   Y.d_env = o; o += E * EL * 3; Y.d_obs = o; o += O * N * L * 3; Y.d_theta = o; o += C * 4; Y.dstride = (o + 7) & ~7;
   o = 0;
   Y.i_nposs = o; o += C; Y.i_regj = o; o += C * P; Y.i_nhs = o; o += C * P; Y.i_hs = o; o += C * P * 4; Y.i_envn = o; o += E;
-  Y.i_obssoft = o; o += O; Y.i_initj = o; o += C; Y.istride = (o + 3) & ~3;
+  Y.i_obssoft = o; o += O; Y.i_initj = o; o += C; Y.i_dom = o; o += C * P * 4; Y.istride = (o + 3) & ~3;
   Y.f_reg = 0; Y.f_env = Y.f_reg + C * N; Y.f_obs = Y.f_env + C * N * 5; Y.f_c2c = Y.f_obs + C * O * N * 5;
   Y.fixlen = (Y.f_c2c + Y.NP * N * 4 + 15) & ~15;
   return Y;
@@ -294,6 +295,23 @@ inline int max_possible(const HostInst& I) {
 }
 inline int max_env_edges(const HostInst& I) {
   int m = 0; for (int e = 0; e < I.E; ++e) m = std::max(m, I.env_off[e + 1] - I.env_off[e]); return m;
+}
+
+// min of f(v) = a0 + a1*vx + a2*vy over the polygon {rows[k][0]*vx + rows[k][1]*vy <= rows[k][2]} (vertex enumeration);
+// +inf when the polygon is empty
+inline double min_affine_over_polygon(const std::vector<std::array<double, 3>>& rows, double a0, double a1, double a2) {
+  double best = 1e300; const double tol = 1e-9;
+  for (size_t a = 0; a < rows.size(); ++a)
+    for (size_t b = a + 1; b < rows.size(); ++b) {
+      double det = rows[a][0] * rows[b][1] - rows[a][1] * rows[b][0];
+      if (std::fabs(det) < 1e-14) continue;
+      double vx = (rows[a][2] * rows[b][1] - rows[a][1] * rows[b][2]) / det;
+      double vy = (rows[a][0] * rows[b][2] - rows[a][2] * rows[b][0]) / det;
+      bool ok = true;
+      for (auto& r : rows) if (r[0] * vx + r[1] * vy > r[2] + tol * (1.0 + std::fabs(r[2]))) { ok = false; break; }
+      if (ok) best = std::min(best, a0 + a1 * vx + a2 * vy);
+    }
+  return best;
 }
 
 // fills one instance's block of the device tables
@@ -350,6 +368,31 @@ inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int*
       int hs[2][2] = {{0, 1}, {0, 1}}; int nh = nonslow_halfplanes(F, hs);
       T[Y.i_nhs + c * Y.P + q] = nh;
       for (int h = 0; h < 2; ++h) { T[Y.i_hs + ((c * Y.P + q) * 2 + h) * 2] = hs[h][0]; T[Y.i_hs + ((c * Y.P + q) * 2 + h) * 2 + 1] = hs[h][1]; }
+      // corner dominance (exact presolve): pos_x_front_UB >= pos_x_front_LB and pos_y_front_UB >= pos_y_front_LB hold on the
+      // whole velocity set of the alternative (sector + half-plane or slow square, global bounds, reachable |vy|) ->
+      // of the rows of one polygon edge on the four front corners only the worst corner's row can be active
+      {
+        double vyb = 0.0; for (int cc = 0; cc < C; ++cc) vyb = std::max(vyb, std::fabs(I.x0[cc * 6 + 4]));
+        vyb += std::max(std::fabs(I.amax), std::fabs(I.amin)) * I.ts * N + 1.0;
+        for (int h = 0; h < 4; ++h) {
+          int flag = 0;
+          if (h < 3 && h >= nh) { T[Y.i_dom + (c * Y.P + q) * 4 + h] = 0; continue; }
+          std::vector<std::array<double, 3>> rows;
+          rows.push_back({-1.0, 0.0, -I.vmin}); rows.push_back({1.0, 0.0, I.vmax}); rows.push_back({0.0, -1.0, std::min(-I.vmin, vyb)});
+          rows.push_back({0.0, 1.0, vyb}); rows.push_back({0.0, -1.0, vyb});
+          if (h == 3) { rows.push_back({1, 0, I.vm}); rows.push_back({-1, 0, I.vm}); rows.push_back({0, 1, I.vm}); rows.push_back({0, -1, I.vm}); }
+          else {
+            rows.push_back({g[0], g[1], 0.0}); rows.push_back({g[2], g[3], 0.0});
+            double sg = hs[h][1]; if (hs[h][0] == 0) rows.push_back({-sg, 0.0, -I.vm}); else rows.push_back({0.0, -sg, -I.vm});
+          }
+          const double m = 1e-9;
+          double mx = min_affine_over_polygon(rows, g[19] - g[22], g[20] - g[23], g[21] - g[24]);
+          double my = min_affine_over_polygon(rows, g[25] - g[28], g[26] - g[29], g[27] - g[30]);
+          if (mx >= -m) flag |= 1;
+          if (my >= -m) flag |= 2;
+          T[Y.i_dom + (c * Y.P + q) * 4 + h] = flag;
+        }
+      }
     }
   }
   for (int e = 0; e < I.E; ++e) {

@@ -99,6 +99,21 @@ __device__ inline void add_point(double* g, double& rhs, int c, const double* rt
   if (ty != PT_R) { const double* p = rt + 25 + (ty == PT_U ? 0 : 3); rhs -= be * p[0]; g[6 * c + 1] += be * p[1]; g[6 * c + 4] += be * p[2]; }
 }
 
+// corner index of a front point with x/y types (tx, ty) in the environment / obstacle corner orders
+__device__ inline int env_corner(int tx, int ty) { return tx == PT_U ? (ty == PT_U ? 1 : 3) : (ty == PT_U ? 2 : 4); }
+__device__ inline int obs_corner(int tx, int ty) { return tx == PT_L ? (ty == PT_L ? 1 : 3) : (ty == PT_L ? 2 : 4); }
+
+// the row "al*X + be*Y <= gamma" on front corner (tx, ty) is implied by the same row on the worst corner (tx*, ty*)
+// when that corner carries the same row and UB >= LB is proven for every coordinate in which the corners differ
+__device__ inline bool corner_dominated(int tx, int ty, double al, double be, int domflag, int& txs, int& tys) {
+  txs = al > 0.0 ? PT_U : (al < 0.0 ? PT_L : tx);
+  tys = be > 0.0 ? PT_U : (be < 0.0 ? PT_L : ty);
+  if (txs == tx && tys == ty) return false;
+  if (txs != tx && !(domflag & 1)) return false;
+  if (tys != ty && !(domflag & 2)) return false;
+  return true;
+}
+
 struct RowOut { double rhs; double aq; bool active; };
 
 // rows of the relaxation of a node (only alternatives that are fixed); g is this lane's LDS row
@@ -168,6 +183,14 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
       int e = Y.E == 1 ? 0 : (int)fix[Y.f_env + (c * N + i) * 5 + pt];
       if (e < 0 || k >= T[Y.i_envn + e] || (pt > 0 && code < 0)) return r;
       const double* ed = D + Y.d_env + (e * Y.EL + k) * 3;
+      if (pt > 0) {  // exact presolve: rows on dominated corners of the front box are implied
+        int txs, tys;
+        if (corner_dominated(ENV_PT_D[pt][0], ENV_PT_D[pt][1], ed[0], ed[1], T[Y.i_dom + (c * Y.P + (code >> 2)) * 4 + (code & 3)], txs, tys)) {
+          int ps = env_corner(txs, tys);
+          int es = Y.E == 1 ? 0 : (int)fix[Y.f_env + (c * N + i) * 5 + ps];
+          if (es == e) return r;
+        }
+      }
       r.active = true; r.rhs = ed[2];
       add_point(g, r.rhs, c, rt, ENV_PT_D[pt][0], ENV_PT_D[pt][1], ed[0], ed[1]);
       return r;
@@ -178,6 +201,13 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
     int kk = (int)fix[Y.f_obs + ((c * Y.O + o) * N + i) * 5 + pt];
     if (kk < 0 || kk >= Y.L || (pt > 0 && code < 0)) return r;
     const double* ed = D + Y.d_obs + ((o * N + i) * Y.L + kk) * 3;
+    if (pt > 0) {
+      int txs, tys;
+      if (corner_dominated(OBS_PT_D[pt][0], OBS_PT_D[pt][1], ed[0], ed[1], T[Y.i_dom + (c * Y.P + (code >> 2)) * 4 + (code & 3)], txs, tys)) {
+        int ps = obs_corner(txs, tys);
+        if ((int)fix[Y.f_obs + ((c * Y.O + o) * N + i) * 5 + ps] == kk) return r;
+      }
+    }
     r.active = true; r.rhs = ed[2];
     add_point(g, r.rhs, c, rt, OBS_PT_D[pt][0], OBS_PT_D[pt][1], ed[0], ed[1]);
     return r;
