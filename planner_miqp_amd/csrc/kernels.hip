@@ -60,6 +60,7 @@ struct DevBuf {
   int nodes_per_round; int n_inst;
   double qp_tol;
   int* work_counter;             // next node of the batch to be solved (reset before every ipm launch)
+  unsigned long long* prof;      // [16] cycle counters of the phases of ipm_kernel (diagnostic build -DMIQP_PROFILE only)
   unsigned long long* stat_rowiters;
 };
 
@@ -290,6 +291,19 @@ template <int NT> __device__ inline double block_max(double v, double* red) {
   return r;
 }
 
+#ifdef MIQP_PROFILE
+#define PROF_T(var) long long var = clock64()
+#define PROF_ACC(k, t0, t1) pr_[k] += (unsigned long long)((t1) - (t0))
+#else
+#define PROF_T(var)
+#define PROF_ACC(k, t0, t1)
+#endif
+
+__device__ inline double readlane_d(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 // ------------------------------------------------------------------------------------------------
 //  Newton step of one row (elastic: aq == 0, quadratic-soft: aq > 0) given g.dz
 __device__ inline void row_step(double s, double lam, double t, double aq, double gd, double tau, double& ds, double& dl, double& dt) {
@@ -309,7 +323,10 @@ __device__ inline void row_step(double s, double lam, double t, double aq, doubl
 template <int C, int NT>
 __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
   static_assert(NT == 64, "one wavefront per node");
-  constexpr int NX = 6 * C, NU = 2 * C, NZ = 8 * C, GS = 17;  // rows are zero padded to the 16 columns of the MFMA tile
+  static_assert(C <= 2, "one 16x16 MFMA tile per stage");
+  constexpr int NX = 6 * C, NU = 2 * C, NZ = 8 * C, GS = 17;
+  constexpr int KB = (NX + 3) / 4;         // k blocks of the products with [A B]
+  constexpr int RU = NX / 4, GU0 = NX % 4;  // register / first lane group holding the input rows NX..NZ-1  // rows are zero padded to the 16 columns of the MFMA tile
   const Layout& Y = B.Y;
   const int tid = threadIdx.x;
   const int nbatch = *B.batch_count;
@@ -369,6 +386,13 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     __syncthreads();
   }
   const double* Rf = D + Y.d_ref;
+  double abr[KB];  // [A B] as MFMA operand: lane (g, c) holds AB[4kb + g][c]
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) abr[kb] = (4 * kb + (tid >> 4) < NX && (tid & 15) < NZ) ? ABm[(4 * kb + (tid >> 4)) * NZ + (tid & 15)] : 0.0;
+#ifdef MIQP_PROFILE
+  unsigned long long pr_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  PROF_T(tb0);
 
   // ---- decode every row of the node once; active rows are compacted per stage; initial row state
   double csum = 0.0; int cnt = 0; int base = 0;
@@ -402,6 +426,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
   }
   if (tid == 0) sstart[N] = base;
   const int NROWS = base;
+  PROF_T(tb1); PROF_ACC(0, tb0, tb1);
   double comp = block_sum<NT>(csum, red);
   int ncomp = (int)block_sum<NT>((double)cnt, red);
   if (ncomp < 1) ncomp = 1;
@@ -418,12 +443,18 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     }
     if (comp < B.qp_tol * fmax(1.0, fabs(obj)) && resid_fac * R0 < 1e-7) { ok = 1; break; }
     const double tau = QP_SIGMA * comp;
-    // ================= backward sweep
-    for (int k = tid; k < NX * NX; k += NT) Pm[k] = 0.0;
-    if (tid < NX) pv[tid] = 0.0;
+    // ================= backward sweep: Riccati recursion, the whole stage algebra stays in the registers of the wave.
+    // Matrices live in the D layout of v_mfma_f64_16x16x4_f64 (lane l: g = l>>4, c = l&15, register r <-> M[g+4r][c]).
+    // For a symmetric M that register file is directly the A operand of M*X (A[i=c][k=4kb+g] = M[4kb+g][c]) and the
+    // B operand of X*M, so  T = P [A B],  S = Phi + [A B]' T  and the rank-NU update  P = S - Sxu K  are MFMA chains
+    // without any LDS traffic; the NU x NU block is factored redundantly by every lane from v_readlane broadcasts.
+    const int lg = tid >> 4, lc = tid & 15;
+    d4_t Pd = {0.0, 0.0, 0.0, 0.0};
+    double pcol = 0.0;  // p[c], replicated over the four lane groups
     double rmax = 0.0;
     for (int i = N - 1; i >= 0; --i) {
       __syncthreads();
+      PROF_T(ts0);
       const int r0 = sstart[i], nr = sstart[i + 1] - r0;
       const int nsl4 = (nr + 3) & ~3;
       for (int r = tid; r < nsl4; r += NT) {
@@ -448,102 +479,118 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
         fs[r] = fsv;
       }
       __syncthreads();
-      // Phi = 2W + Gh' Gh on the matrix core: v_mfma_f64_16x16x4_f64, 4 rows of the scaled row block per instruction.
-      // A operand lane l = Gh[4kb + (l>>4)][l&15] = B operand (Gh' Gh is symmetric in its two factors);
-      // D layout of the f64 form: row = (l>>4) + 4*reg, col = l&15.
-      {
-        d4_t acc = {0.0, 0.0, 0.0, 0.0};
-        const int lr = tid >> 4, lc = tid & 15;
-        double racc = 0.0;
-        for (int kb = 0; kb < nsl4; kb += 4) {
-          double a = Gh[(kb + lr) * GS + lc];
-          racc += a * fs[kb + lr];                       // rr = Gh' fs, 4 partial sums per component
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          int row = lr + 4 * rg;
-          if (row < NZ && lc < NZ) Phi[row * NZ + lc] = acc[rg] + (row == lc ? 2.0 * Wd[row] : 0.0);
-        }
-        racc += __shfl_xor(racc, 16); racc += __shfl_xor(racc, 32);
-        if (lr == 0 && lc < NZ) {
-          racc += 2.0 * Wd[lc] * (Z[i * NZ + lc] - Rf[i * NZ + lc]);
-          rr[lc] = racc;
-          if (it == 1) rmax = fmax(rmax, fabs(racc));
-        }
+      PROF_T(ts1); PROF_ACC(1, ts0, ts1);
+      // Phi = 2W + Gh' Gh (4 rows of the scaled row block per MFMA; A operand = B operand), rr = 2W(z - ref) + Gh' fs
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      double racc = 0.0;
+      for (int kb = 0; kb < nsl4; kb += 16) {  // operands of up to 4 MFMAs are fetched before the dependent chain
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
+        a0 = Gh[(kb + lg) * GS + lc]; f0 = fs[kb + lg];
+        if (kb + 4 < nsl4) { a1 = Gh[(kb + 4 + lg) * GS + lc]; f1 = fs[kb + 4 + lg]; }
+        if (kb + 8 < nsl4) { a2 = Gh[(kb + 8 + lg) * GS + lc]; f2 = fs[kb + 8 + lg]; }
+        if (kb + 12 < nsl4) { a3 = Gh[(kb + 12 + lg) * GS + lc]; f3 = fs[kb + 12 + lg]; }
+        racc += a0 * f0 + a1 * f1 + a2 * f2 + a3 * f3;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc, 0, 0, 0);
+        if (kb + 4 < nsl4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc, 0, 0, 0);
+        if (kb + 8 < nsl4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, a2, acc, 0, 0, 0);
+        if (kb + 12 < nsl4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, a3, acc, 0, 0, 0);
       }
-      __syncthreads();
-      if (i == N - 1) {  // u_{N-1} = 0 (initial_conditions.mod:25-26)
-        for (int e = tid; e < NX * NX; e += NT) { int a = e / NX, b = e - a * NX; Pm[e] = Phi[a * NZ + b]; }
-        if (tid < NX) pv[tid] = rr[tid];
+      racc += __shfl_xor(racc, 16); racc += __shfl_xor(racc, 32);
+      double rrc = lc < NZ ? racc + 2.0 * Wd[lc] * (Z[i * NZ + lc] - Rf[i * NZ + lc]) : 0.0;  // rr[c], replicated over groups
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) if (lg + 4 * rg == lc && lc < NZ) acc[rg] += 2.0 * Wd[lc];
+      if (it == 1) rmax = fmax(rmax, fabs(rrc));
+      PROF_T(ts2); PROF_ACC(2, ts1, ts2);
+      if (i == N - 1) {  // u_{N-1} = 0 (initial_conditions.mod:25-26): P = Phi_xx, p = rr_x
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) Pd[rg] = (lg + 4 * rg < NX && lc < NX) ? acc[rg] : 0.0;
+        pcol = lc < NX ? rrc : 0.0;
         continue;
       }
       // T = P [A B]
-      for (int e = tid; e < NX * NZ; e += NT) {
-        int a = e / NZ, b = e - a * NZ;
-        double acc = 0.0;
-        int q0 = b < NX ? 3 * (b / 3) : 3 * (b - NX);
-        for (int q = q0; q < q0 + 3; ++q) acc += Pm[a * NX + q] * ABm[q * NZ + b];
-        Tm[e] = acc;
+      d4_t accT = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) accT = __builtin_amdgcn_mfma_f64_16x16x4f64(Pd[kb], abr[kb], accT, 0, 0, 0);
+      // S = Phi + [A B]' T   (acc becomes S)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(abr[kb], accT[kb], acc, 0, 0, 0);
+      // sv = rr + [A B]' p
+      double part = 0.0;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) part += abr[kb] * __shfl(pcol, 4 * kb + lg);
+      part += __shfl_xor(part, 16); part += __shfl_xor(part, 32);
+      const double svc = rrc + part;
+      PROF_T(ts3); PROF_ACC(3, ts2, ts3);
+      // Suu and su as wave-uniform values; Cholesky in registers (every lane, redundantly)
+      const double own = acc[RU];  // row NX + (g - GU0) of S for the lane groups that hold the u rows
+      double Lm[NU][NU], su[NU], dinv[NU];
+#pragma unroll
+      for (int q = 0; q < NU; ++q) {
+        su[q] = readlane_d(svc, NX + q);
+#pragma unroll
+        for (int q2 = 0; q2 <= q; ++q2) Lm[q][q2] = readlane_d(own, (GU0 + q) * 16 + NX + q2);
       }
-      __syncthreads();
-      // S = Phi + [A B]' T ; sv = rr + [A B]' p
-      for (int e = tid; e < NZ * NZ; e += NT) {
-        int a = e / NZ, b = e - a * NZ;
-        double acc = Phi[e];
-        int q0 = a < NX ? 3 * (a / 3) : 3 * (a - NX);
-        for (int q = q0; q < q0 + 3; ++q) acc += ABm[q * NZ + a] * Tm[q * NZ + b];
-        Phi[e] = acc;
-      }
-      if (tid < NZ) {
-        int a = tid; double acc = rr[a];
-        int q0 = a < NX ? 3 * (a / 3) : 3 * (a - NX);
-        for (int q = q0; q < q0 + 3; ++q) acc += ABm[q * NZ + a] * pv[q];
-        rr[a] = acc;
-      }
-      __syncthreads();
-      // Cholesky of Suu (NU x NU), serial on thread 0 (tiny)
-      if (tid == 0) {
-        for (int a = 0; a < NU; ++a)
-          for (int b = 0; b <= a; ++b) {
-            double acc = Phi[(NX + a) * NZ + NX + b];
-            for (int q = 0; q < b; ++q) acc -= Lc[a * NU + q] * Lc[b * NU + q];
-            if (a == b) Lc[a * NU + a] = sqrt(fmax(acc, 1e-300)); else Lc[a * NU + b] = acc / Lc[b * NU + b];
-          }
-      }
-      __syncthreads();
-      // K = Suu^-1 Sux, k = Suu^-1 su : one thread per right-hand side column
-      double* Ki = Kg + i * NU * NX; double* ki = kg + i * NU;
-      if (tid <= NX) {
-        double y[NU];
-        for (int a = 0; a < NU; ++a) {
-          double acc = tid < NX ? Phi[(NX + a) * NZ + tid] : rr[NX + a];
-          for (int q = 0; q < a; ++q) acc -= Lc[a * NU + q] * y[q];
-          y[a] = acc / Lc[a * NU + a];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+          double v = Lm[a][b];
+#pragma unroll
+          for (int q = 0; q < b; ++q) v -= Lm[a][q] * Lm[b][q];
+          if (a == b) { double d = sqrt(fmax(v, 1e-300)); Lm[a][a] = d; dinv[a] = 1.0 / d; } else Lm[a][b] = v * dinv[b];
         }
-        for (int a = NU - 1; a >= 0; --a) {
-          double acc = y[a];
-          for (int q = a + 1; q < NU; ++q) acc -= Lc[q * NU + a] * y[q];
-          y[a] = acc / Lc[a * NU + a];
+      }
+      // column c of Sux: S[NX+q][c] sits in lane (GU0+q, c); fetched from the three other lane groups
+      const double o1 = __shfl_xor(own, 16), o2 = __shfl_xor(own, 32), o3 = __shfl_xor(own, 48);
+      double col[NU], xk[NU], kk[NU];
+#pragma unroll
+      for (int q = 0; q < NU; ++q) { int m = lg ^ (GU0 + q); col[q] = m == 0 ? own : (m == 1 ? o1 : (m == 2 ? o2 : o3)); }
+      // K[:, c] = Suu^-1 Sux[:, c],  k = Suu^-1 su
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+        double v = col[a], w2 = su[a];
+#pragma unroll
+        for (int q = 0; q < a; ++q) { v -= Lm[a][q] * xk[q]; w2 -= Lm[a][q] * kk[q]; }
+        xk[a] = v * dinv[a]; kk[a] = w2 * dinv[a];
+      }
+#pragma unroll
+      for (int a = NU - 1; a >= 0; --a) {
+        double v = xk[a], w2 = kk[a];
+#pragma unroll
+        for (int q = a + 1; q < NU; ++q) { v -= Lm[q][a] * xk[q]; w2 -= Lm[q][a] * kk[q]; }
+        xk[a] = v * dinv[a]; kk[a] = w2 * dinv[a];
+      }
+      {
+        double* Ki = Kg + i * NU * NX; double* ki = kg + i * NU;
+        if (lg == 0 && lc < NX) {
+#pragma unroll
+          for (int q = 0; q < NU; ++q) Ki[q * NX + lc] = xk[q];
         }
-        for (int a = 0; a < NU; ++a) { if (tid < NX) Ki[a * NX + tid] = y[a]; else ki[a] = y[a]; }
+        if (tid == 0) {
+#pragma unroll
+          for (int q = 0; q < NU; ++q) ki[q] = kk[q];
+        }
       }
-      __syncthreads();
-      // P = Sxx - Sxu K (symmetrised), p = sx - Sxu k
-      for (int e = tid; e < NX * NX; e += NT) {
-        int a = e / NX, b = e - a * NX;
-        double acc = Phi[a * NZ + b], acc2 = Phi[b * NZ + a];
-        for (int q = 0; q < NU; ++q) { acc -= Phi[a * NZ + NX + q] * Ki[q * NX + b]; acc2 -= Phi[b * NZ + NX + q] * Ki[q * NX + a]; }
-        Pm[e] = 0.5 * (acc + acc2);
+      PROF_T(ts4); PROF_ACC(4, ts3, ts4);
+      // P = S - Sxu K : one MFMA (k = lane group), A[i=c][k=g] = -S[NX+q][c], B[k=g][j=c] = K[q][c]
+      {
+        const bool urow = lg >= GU0 && lg < GU0 + NU;
+        double bop = 0.0;
+#pragma unroll
+        for (int q = 0; q < NU; ++q) if (lg - GU0 == q) bop = xk[q];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(urow ? -own : 0.0, urow ? bop : 0.0, acc, 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) Pd[rg] = (lg + 4 * rg < NX && lc < NX) ? acc[rg] : 0.0;
+        double pn = svc;
+#pragma unroll
+        for (int q = 0; q < NU; ++q) pn -= col[q] * kk[q];
+        pcol = lc < NX ? pn : 0.0;
       }
-      if (tid < NX) {
-        double acc = rr[tid];
-        for (int q = 0; q < NU; ++q) acc -= Phi[tid * NZ + NX + q] * ki[q];
-        pv[tid] = acc;
-      }
+      PROF_T(ts5); PROF_ACC(5, ts4, ts5);
     }
     if (it == 1) R0 = block_max<NT>(rmax, red);
     __syncthreads();
+    PROF_T(tf0);
     // ================= forward sweep (one wavefront: LDS traffic in program order, no workgroup barrier needed)
     if (tid < NZ) dZ[tid] = 0.0;
     __syncthreads();
@@ -568,8 +615,10 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     }
     if (tid < NU) dZ[(N - 1) * NZ + NX + tid] = 0.0;
     __syncthreads();
+    PROF_T(tf1); PROF_ACC(6, tf0, tf1);
     // ================= step length: ratio test over all rows; only g.dz is stored per row
     double amax = 1e300, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll 4
     for (int idx = tid; idx < NROWS; idx += NT) {
       double aq = rc_aq[idx];
       unsigned long long cols = (unsigned long long)__double_as_longlong(rc_col[idx]);
@@ -594,8 +643,10 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     a0 = block_sum<NT>(a0, red); a1 = block_sum<NT>(a1, red); a2 = block_sum<NT>(a2, red);
     double alpha = fmin(1.0, 0.995 * amax);
     comp = (a0 + alpha * a1 + alpha * alpha * a2) / ncomp;
+    PROF_T(tf2); PROF_ACC(7, tf1, tf2);
     // ================= update (the step of every row is recomputed from its stored g.dz)
     for (int k = tid; k < N * NZ; k += NT) Z[k] += alpha * dZ[k];
+#pragma unroll 4
     for (int idx = tid; idx < NROWS; idx += NT) {
       double s = rs_s[idx], lam = rs_l[idx], t = rs_t[idx], ds, dl, dt;
       row_step(s, lam, t, rc_aq[idx], rs_g[idx], tau, ds, dl, dt);
@@ -603,6 +654,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     }
     resid_fac *= (1.0 - alpha);
     __syncthreads();
+    PROF_T(tf3); PROF_ACC(8, tf2, tf3);
     if (alpha < 1e-12) break;
   }
   // ---- final measures: worst elastic violation, slack cost
@@ -629,6 +681,10 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     atomicAdd((unsigned long long*)&B.inst_iters[inst], (unsigned long long)(it > QP_MAXIT ? QP_MAXIT : it));
     atomicAdd((unsigned long long*)&B.inst_nodes[inst], 1ull);
     atomicAdd(B.stat_rowiters, rowiters);
+#ifdef MIQP_PROFILE
+    for (int q = 0; q < 9; ++q) atomicAdd(&B.prof[q], pr_[q]);
+    atomicAdd(&B.prof[9], (unsigned long long)(it > QP_MAXIT ? QP_MAXIT : it)); atomicAdd(&B.prof[10], 1ull); atomicAdd(&B.prof[11], (unsigned long long)NROWS);
+#endif
   }
   }  // node loop
 }

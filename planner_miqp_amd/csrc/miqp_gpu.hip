@@ -228,6 +228,8 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   if (!X.alloc(&B.rowstate, (size_t)std::min(batch_cap, X.ipm_grid_max) * NFIELD * Y.ROWCAP)) return false;
   if (!X.alloc(&B.rowcache, (size_t)std::min(batch_cap, X.ipm_grid_max) * NCACHE * Y.ROWCAP)) return false;
   if (!X.alloc(&B.work_counter, 1)) return false;
+  if (!X.alloc(&B.prof, 16)) return false;
+  (void)hipMemset(B.prof, 0, 16 * 8);
   if (!X.alloc(&B.active_insts, 1)) return false;
   if (!X.alloc(&B.stat_rowiters, 1)) return false;
   X.ready = true;
@@ -524,6 +526,14 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   HIP_OK(hipStreamSynchronize(st));
   HIP_OK(hipGetLastError());
   float ms_all = 0; HIP_OK(hipEventElapsedTime(&ms_all, X.ev0, X.ev1));
+#ifdef MIQP_PROFILE
+  { unsigned long long pf[16]; HIP_OK(hipMemcpy(pf, B.prof, 16 * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemset(B.prof, 0, 16 * 8));
+    const char* nm[9] = {"build", "bw.rows", "bw.mfma", "bw.TS", "bw.cholK", "bw.P", "forward", "step", "update"};
+    double tot = 0; for (int q = 0; q < 9; ++q) tot += (double)pf[q];
+    std::fprintf(stderr, "[miqp_gpu profile] nodes %llu iters %llu rows/node %.0f cycles/node-iter %.0f :", pf[10], pf[9], (double)pf[11] / std::max(1ull, pf[10]), tot / std::max(1ull, pf[9]));
+    for (int q = 0; q < 9; ++q) std::fprintf(stderr, " %s %.1f%%", nm[q], 100.0 * pf[q] / tot);
+    std::fprintf(stderr, "\n"); }
+#endif
   double ms_ipm = 0;
   for (size_t e = 0; e + 1 < nev; e += 2) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, X.ipm_ev[e], X.ipm_ev[e + 1])); ms_ipm += ms; }
   double t_solve = wall_s() - t0;
