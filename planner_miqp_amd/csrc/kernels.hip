@@ -259,6 +259,16 @@ __device__ inline double ab_entry(int q, int b, double ts) {
 }
 
 // ------------------------------------------------------------------------------------------------
+struct RowRegs { double aq, col, s, lam, t, v[6]; };
+__device__ inline RowRegs load_row(const double* rc_aq, const double* rc_col, const double* rc_v, const double* rs_s, const double* rs_l,
+                                   const double* rs_t, int rowcap, int idx) {
+  RowRegs R;
+  R.aq = rc_aq[idx]; R.col = rc_col[idx]; R.s = rs_s[idx]; R.lam = rs_l[idx]; R.t = rs_t[idx];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) R.v[k] = rc_v[(size_t)k * rowcap + idx];
+  return R;
+}
+
 // block-wide reductions over NT threads (NT/64 waves); red has NT/64 doubles; two barriers each
 template <int NT> __device__ inline double block_sum(double v, double* red) {
   v = wave_sum(v);
@@ -339,13 +349,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
   double* kg = Kg + N * NU * NX;         // [N][NU]
   double* Gh = kg + N * NU;              // [nrow][GS]
   double* fs = Gh + nrow * GS;           // [nrow]
-  double* Phi = fs + nrow;               // [NZ*NZ]  (becomes S)
-  double* rr = Phi + NZ * NZ;            // [NZ]     (becomes sv)
-  double* Tm = rr + NZ;                  // [NX*NZ]
-  double* Pm = Tm + NX * NZ;             // [NX*NX]
-  double* pv = Pm + NX * NX;             // [NX]
-  double* Lc = pv + NX;                  // [NU*NU]
-  double* Wd = Lc + NU * NU;             // [NZ]
+  double* Wd = fs + nrow;                // [NZ]
   double* red = Wd + NZ;                 // [8]
   double* ABm = red + 8;                 // [NX*NZ] = [A B] of the triple integrator chains
   int* sstart = (int*)(ABm + NX * NZ);   // [N+2] first compact row of every stage
@@ -452,32 +456,39 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     d4_t Pd = {0.0, 0.0, 0.0, 0.0};
     double pcol = 0.0;  // p[c], replicated over the four lane groups
     double rmax = 0.0;
+    RowRegs pre; pre.aq = 0.0; pre.col = 0.0; pre.s = 1.0; pre.lam = 1.0; pre.t = 1.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pre.v[k] = 0.0;
+    { int rp = sstart[N - 1] + tid; if (rp < sstart[N]) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, rp); }
     for (int i = N - 1; i >= 0; --i) {
       __syncthreads();
       PROF_T(ts0);
       const int r0 = sstart[i], nr = sstart[i + 1] - r0;
       const int nsl4 = (nr + 3) & ~3;
-      for (int r = tid; r < nsl4; r += NT) {
+      for (int r = tid, ch = 0; r < nsl4; r += NT, ++ch) {
         double* g = Gh + r * GS;
         double fsv = 0.0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) g[q] = 0.0;
         if (r < nr) {
           int idx = r0 + r;
-          double aq = rc_aq[idx];
-          unsigned long long cols = (unsigned long long)__double_as_longlong(rc_col[idx]);
+          RowRegs R = ch == 0 ? pre : load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, idx);
+          unsigned long long cols = (unsigned long long)__double_as_longlong(R.col);
           int nn = (int)(cols >> 56);
-          double s = rs_s[idx], lam = rs_l[idx], zz, r2mu = 0.0;
-          if (aq == 0.0) { double t = rs_t[idx], mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
-          else zz = 1.0 / aq;
+          double s = R.s, lam = R.lam, zz, r2mu = 0.0;
+          if (R.aq == 0.0) { double t = R.t, mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
+          else zz = 1.0 / R.aq;
           double Dd = s / lam + zz, w = 1.0 / Dd;
           double kap = ((tau - s * lam) / lam - r2mu) / Dd;
           double sw = sqrt(w);
           fsv = (lam + kap) / sw;
-          for (int k = 0; k < nn; ++k) g[(cols >> (8 * k)) & 255] = sw * rc_v[(size_t)k * Y.ROWCAP + idx];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) if (k < nn) g[(cols >> (8 * k)) & 255] = sw * R.v[k];
         }
         fs[r] = fsv;
       }
+      // software prefetch: the rows of stage i-1 are requested now and arrive under the MFMA chains of stage i
+      if (i > 0) { int rp = sstart[i - 1] + tid; if (rp < r0) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, rp); }
       __syncthreads();
       PROF_T(ts1); PROF_ACC(1, ts0, ts1);
       // Phi = 2W + Gh' Gh (4 rows of the scaled row block per MFMA; A operand = B operand), rr = 2W(z - ref) + Gh' fs
@@ -523,21 +534,22 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
       PROF_T(ts3); PROF_ACC(3, ts2, ts3);
       // Suu and su as wave-uniform values; Cholesky in registers (every lane, redundantly)
       const double own = acc[RU];  // row NX + (g - GU0) of S for the lane groups that hold the u rows
-      double Lm[NU][NU], su[NU], dinv[NU];
+      double Lm[NU][NU], su[NU], dinv[NU], dvec[NU];
 #pragma unroll
       for (int q = 0; q < NU; ++q) {
         su[q] = readlane_d(svc, NX + q);
 #pragma unroll
         for (int q2 = 0; q2 <= q; ++q2) Lm[q][q2] = readlane_d(own, (GU0 + q) * 16 + NX + q2);
       }
+      // Suu = L D L' (unit lower L, no square roots); dinv = 1 / D
 #pragma unroll
       for (int a = 0; a < NU; ++a) {
 #pragma unroll
         for (int b = 0; b <= a; ++b) {
           double v = Lm[a][b];
 #pragma unroll
-          for (int q = 0; q < b; ++q) v -= Lm[a][q] * Lm[b][q];
-          if (a == b) { double d = sqrt(fmax(v, 1e-300)); Lm[a][a] = d; dinv[a] = 1.0 / d; } else Lm[a][b] = v * dinv[b];
+          for (int q = 0; q < b; ++q) v -= Lm[a][q] * Lm[b][q] * dvec[q];
+          if (a == b) { dvec[a] = fmax(v, 1e-300); dinv[a] = 1.0 / dvec[a]; } else Lm[a][b] = v * dinv[b];
         }
       }
       // column c of Sux: S[NX+q][c] sits in lane (GU0+q, c); fetched from the three other lane groups
@@ -545,20 +557,22 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
       double col[NU], xk[NU], kk[NU];
 #pragma unroll
       for (int q = 0; q < NU; ++q) { int m = lg ^ (GU0 + q); col[q] = m == 0 ? own : (m == 1 ? o1 : (m == 2 ? o2 : o3)); }
-      // K[:, c] = Suu^-1 Sux[:, c],  k = Suu^-1 su
+      // K[:, c] = Suu^-1 Sux[:, c],  k = Suu^-1 su   (forward with unit L, scale by 1/D, backward with unit L')
 #pragma unroll
       for (int a = 0; a < NU; ++a) {
         double v = col[a], w2 = su[a];
 #pragma unroll
         for (int q = 0; q < a; ++q) { v -= Lm[a][q] * xk[q]; w2 -= Lm[a][q] * kk[q]; }
-        xk[a] = v * dinv[a]; kk[a] = w2 * dinv[a];
+        xk[a] = v; kk[a] = w2;
       }
+#pragma unroll
+      for (int a = 0; a < NU; ++a) { xk[a] *= dinv[a]; kk[a] *= dinv[a]; }
 #pragma unroll
       for (int a = NU - 1; a >= 0; --a) {
         double v = xk[a], w2 = kk[a];
 #pragma unroll
         for (int q = a + 1; q < NU; ++q) { v -= Lm[q][a] * xk[q]; w2 -= Lm[q][a] * kk[q]; }
-        xk[a] = v * dinv[a]; kk[a] = w2 * dinv[a];
+        xk[a] = v; kk[a] = w2;
       }
       {
         double* Ki = Kg + i * NU * NX; double* ki = kg + i * NU;

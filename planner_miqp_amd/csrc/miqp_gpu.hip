@@ -239,7 +239,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
 constexpr int IPM_NT = MIQP_IPM_NT;  // threads per node in the interior point kernel
 size_t ipm_lds_bytes(const Layout& Y) {
   int NZ = Y.nz, NX = Y.nx, NU = Y.nu, N = Y.N, nrow = std::max((Y.NSLOT + 3) & ~3, IPM_NT);
-  size_t d = (size_t)2 * N * NZ + (size_t)N * NU * NX + (size_t)N * NU + (size_t)nrow * 17 + nrow + NZ * NZ + NZ + NX * NZ + NX * NX + NX + NU * NU + NZ + 8 + NX * NZ + (N + 6) / 2 + 1;
+  size_t d = (size_t)2 * N * NZ + (size_t)N * NU * NX + (size_t)N * NU + (size_t)nrow * 17 + nrow + NZ + 8 + NX * NZ + (N + 6) / 2 + 1;
   return d * 8 + (size_t)Y.fixlen + 16;
 }
 size_t eval_lds_bytes(const Layout& Y) {
