@@ -26,7 +26,8 @@ def build_library(force=False):
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-o", out, src]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fno-math-errno", "-freciprocal-math", "-fno-signed-zeros", "-fno-trapping-math",
+           "-fPIC", "-shared", "-std=c++17", "-o", out, src]
     subprocess.check_call(cmd)
     return out
 
