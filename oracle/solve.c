@@ -970,7 +970,7 @@ int orc_solve(const oinst* I, const orc_opts* o, miqp_raw_results_c* res, miqp_s
         props->NrSolutionPool++;
         if (verbose) fprintf(stderr, "  node %lld incumbent %.8f depth %d open %d\n", props->nodes, obj, nd.depth, H.n);
       } else {
-        if (verbose) { static long hist[4][64]; int kd = vb.key[0]=='r'?0:(vb.key[0]=='e'?1:(vb.key[0]=='o'?2:3)); int stp = kd==2?vb.key[3]:vb.key[2]; hist[kd][stp]++; if (props->nodes % 1000 == 0) { for (int k=0;k<4;++k){ fprintf(stderr,"kind %d:",k); for(int q=0;q<I->N;++q) fprintf(stderr," %ld",hist[k][q]); fprintf(stderr,"\n"); } } }
+        if (verbose) { static long hist[4][64]; static long hist_cnt = 0; int kd = vb.key[0]=='r'?0:(vb.key[0]=='e'?1:(vb.key[0]=='o'?2:3)); int stp = kd==2?vb.key[3]:vb.key[2]; hist[kd][stp]++; if (++hist_cnt % 1000 == 0) { for (int k=0;k<4;++k){ fprintf(stderr,"kind %d:",k); for(int q=0;q<I->N;++q) fprintf(stderr," %ld",hist[k][q]); fprintf(stderr,"\n"); } } }
         for (int a = 0; a < vb.nalts; ++a) {
           bnode ch; ch.bound = obj; ch.seq = seq++; ch.depth = nd.depth + 1; ch.fix = (signed char*)malloc(M->fixlen);
           memcpy(ch.fix, nd.fix, M->fixlen);

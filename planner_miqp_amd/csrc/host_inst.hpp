@@ -233,7 +233,7 @@ struct Layout {
   // double offsets
   int d_x0, d_wd, d_ref, d_glob, d_u0box, d_misc, d_dsep, d_ssl, d_smax, d_reg, d_env, d_obs, d_theta, dstride;
   // int offsets
-  int i_nposs, i_regj, i_nhs, i_hs, i_envn, i_obssoft, i_initj, i_dom, istride;
+  int i_nposs, i_regj, i_nhs, i_hs, i_envn, i_obssoft, i_initj, i_dom, i_allow, istride;
   // fix record (bytes)
   int f_reg, f_env, f_obs, f_c2c, fixlen;
 };
@@ -249,7 +249,7 @@ inline Layout make_layout(int C, int N, int R, int P, int E, int EL, int O, int 
   Y.d_env = o; o += E * EL * 3; Y.d_obs = o; o += O * N * L * 3; Y.d_theta = o; o += C * 4; Y.dstride = (o + 7) & ~7;
   o = 0;
   Y.i_nposs = o; o += C; Y.i_regj = o; o += C * P; Y.i_nhs = o; o += C * P; Y.i_hs = o; o += C * P * 4; Y.i_envn = o; o += E;
-  Y.i_obssoft = o; o += O; Y.i_initj = o; o += C; Y.i_dom = o; o += C * P * 4; Y.istride = (o + 3) & ~3;
+  Y.i_obssoft = o; o += O; Y.i_initj = o; o += C; Y.i_dom = o; o += C * P * 4; Y.i_allow = o; o += C * N * 2; Y.istride = (o + 3) & ~3;
   Y.f_reg = 0; Y.f_env = Y.f_reg + C * N; Y.f_obs = Y.f_env + C * N * 5; Y.f_c2c = Y.f_obs + C * O * N * 5;
   Y.fixlen = (Y.f_c2c + Y.NP * N * 4 + 15) & ~15;
   return Y;
@@ -393,6 +393,37 @@ inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int*
           T[Y.i_dom + (c * Y.P + q) * 4 + h] = flag;
         }
       }
+    }
+  }
+  // Reachability presolve (exact): with every acceleration in [total_min_acc, total_max_acc] (A3 rows) the velocity of
+  // step i lies in v0 + i*ts*[amin', amax'] (v_{k+1} = v_k + ts*(a_k + a_{k+1})/2).  A region alternative whose velocity
+  // set (sector and half-plane, or the slow square) misses that box can never hold -> it is never branched on.
+  for (int c = 0; c < C; ++c) {
+    const double alo = std::min(I.amin, std::min(I.x0[c * 6 + 2], I.x0[c * 6 + 5])), ahi = std::max(I.amax, std::max(I.x0[c * 6 + 2], I.x0[c * 6 + 5]));
+    const int np = T[Y.i_nposs + c];
+    for (int i = 0; i < N; ++i) {
+      unsigned long long mask = 0ull;
+      double t = i * I.ts;
+      double bx0 = std::max(I.vmin, I.x0[c * 6 + 1] + t * alo), bx1 = std::min(I.vmax, I.x0[c * 6 + 1] + t * ahi);
+      double by0 = std::max(I.vmin, I.x0[c * 6 + 4] + t * alo), by1 = I.x0[c * 6 + 4] + t * ahi;
+      const double pad = 1e-7;
+      for (int q = 0; q < np && i >= 1; ++q) {
+        const double* g = D + Y.d_reg + (c * Y.P + q) * REGSZ;
+        for (int h = 0; h < 4; ++h) {
+          if (h < 3 && h >= T[Y.i_nhs + c * Y.P + q]) continue;
+          std::vector<std::array<double, 3>> rows;
+          rows.push_back({-1.0, 0.0, -bx0 + pad}); rows.push_back({1.0, 0.0, bx1 + pad});
+          rows.push_back({0.0, -1.0, -by0 + pad}); rows.push_back({0.0, 1.0, by1 + pad});
+          if (h == 3) { rows.push_back({1, 0, I.vm + pad}); rows.push_back({-1, 0, I.vm + pad}); rows.push_back({0, 1, I.vm + pad}); rows.push_back({0, -1, I.vm + pad}); }
+          else {
+            rows.push_back({g[0], g[1], pad}); rows.push_back({g[2], g[3], pad});
+            const int* hs = T + Y.i_hs + ((c * Y.P + q) * 2 + h) * 2;
+            if (hs[0] == 0) rows.push_back({-(double)hs[1], 0.0, -I.vm + pad}); else rows.push_back({0.0, -(double)hs[1], -I.vm + pad});
+          }
+          if (min_affine_over_polygon(rows, 0.0, 0.0, 0.0) < 1e299) mask |= 1ull << (q * 4 + h);
+        }
+      }
+      T[Y.i_allow + (c * N + i) * 2] = (int)(mask & 0xFFFFFFFFull); T[Y.i_allow + (c * N + i) * 2 + 1] = (int)(mask >> 32);
     }
   }
   for (int e = 0; e < I.E; ++e) {

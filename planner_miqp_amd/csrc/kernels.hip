@@ -816,11 +816,13 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       // canonical choice (ties at sector borders are common): the first non-slow alternative, in (region, half-plane)
       // order, whose rows hold within tol; else the slow alternative if it holds; else the least violated one
       double bv = 1e300; int bc = -1; bool found = false;
+      const unsigned long long allow = ((unsigned long long)(unsigned int)T[Y.i_allow + (c * N + i) * 2 + 1] << 32) | (unsigned int)T[Y.i_allow + (c * N + i) * 2];
       for (int q = 0; q < np; ++q) {
-        slowv[(c * N + i) * P + q] = (nxtq >= 0 && nxtq != q) ? 1e300 : region_alt_viol(Y, D, T, c, q, 3, s, wj);
+        slowv[(c * N + i) * P + q] = ((nxtq >= 0 && nxtq != q) || !((allow >> (q * 4 + 3)) & 1ull)) ? 1e300 : region_alt_viol(Y, D, T, c, q, 3, s, wj);
         if (nxtq >= 0 && nxtq != q) continue;
         int nh = T[Y.i_nhs + c * P + q];
         for (int h = 0; h < nh; ++h) {
+          if (!((allow >> (q * 4 + h)) & 1ull)) continue;  // unreachable velocity set (host presolve)
           double v = region_alt_viol(Y, D, T, c, q, h, s, wj);
           if (!found && v <= tol) { found = true; bv = 0.0; bc = q * 4 + h; }
           if (!found && v < bv) { bv = v; bc = q * 4 + h; }
@@ -961,11 +963,13 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       if (i == 1) prevj = T[Y.i_initj + c]; else if (fix[Y.f_reg + c * N + i - 1] >= 0) prevj = T[Y.i_regj + c * P + (fix[Y.f_reg + c * N + i - 1] >> 2)];
       int nxt = (i + 1 < N) ? (int)fix[Y.f_reg + c * N + i + 1] : -1;
       int nxtq = (nxt >= 0 && (nxt & 3) == 3) ? (nxt >> 2) : -1;
+      const unsigned long long allow_b = ((unsigned long long)(unsigned int)T[Y.i_allow + (c * N + i) * 2 + 1] << 32) | (unsigned int)T[Y.i_allow + (c * N + i) * 2];
       for (int q = 0; q < np; ++q) {
         if (nxtq >= 0 && nxtq != q) continue;
         int nh = T[Y.i_nhs + c * P + q];
         for (int h = 0; h < 4; ++h) {
           if (h < 3 && h >= nh) continue;
+          if (!((allow_b >> (q * 4 + h)) & 1ull)) continue;
           if (h == 3 && prevj != -2 && prevj != T[Y.i_regj + c * P + q]) continue;
           if (nalt < 63) { altbuf[nalt] = q * 4 + h; altval[nalt] = region_alt_viol(Y, D, T, c, q, h, s, i <= N - 2); nalt++; }
         }
