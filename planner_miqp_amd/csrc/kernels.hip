@@ -59,6 +59,7 @@ struct DevBuf {
   int* active_insts;             // number of instances not yet done
   int nodes_per_round; int n_inst;
   double qp_tol;
+  int seq_kinds;                 // bit k set: first-deviation (time family) branching for disjunction kind k, else single step
   int* work_counter;             // next node of the batch to be solved (reset before every ipm launch)
   unsigned long long* prof;      // [16] cycle counters of the phases of ipm_kernel (diagnostic build -DMIQP_PROFILE only)
   unsigned long long* stat_rowiters;
@@ -784,6 +785,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   __shared__ BranchDesc chosen;
   __shared__ int sh_base[3];
   __shared__ int slots[64];
+  __shared__ int ck[64], ca[64], fam[4];
 
   const double* Zi = B.batch_Z + (size_t)node * N * NZ;
   const signed char* src = B.pool_fix + (size_t)B.batch_node[node] * Y.fixlen;
@@ -951,51 +953,68 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   int winner = __ffsll((long long)bal) - 1;
   if (lane == winner) chosen = mine;
   __syncthreads();
-  // ---------------- alternatives of the chosen disjunction, most promising first
+  // ---------------- first-deviation branching over the time family of the chosen disjunction.
+  // The same kind of decision exists at every step j (family: same car / obstacle / point / group).  With the completed
+  // choices ref_j of the still undecided steps as reference sequence, the children are
+  //     child_inf      : every undecided step j of the window takes ref_j
+  //     child (k, b)   : undecided steps j < k take ref_j, step k takes b != ref_k, later steps stay undecided
+  // which is an exhaustive and disjoint partition of all assignments on the window (decisions persist over time in this
+  // model, so child_inf usually carries the whole homotopy class and the deviating children are pruned quickly).
   int nalt = 0;
   if (lane == 0) {
-    BranchDesc d = chosen; int i = d.i;
-    const double* z = Z + i * NZ;
-    if (d.kind == 0) {
-      int c = d.c; int np = T[Y.i_nposs + c];
-      CarState s = {z[6 * c], z[6 * c + 1], z[6 * c + 2], z[6 * c + 3], z[6 * c + 4], z[6 * c + 5], z[6 * C + 2 * c], z[6 * C + 2 * c + 1]};
-      int prevj = -2;
-      if (i == 1) prevj = T[Y.i_initj + c]; else if (fix[Y.f_reg + c * N + i - 1] >= 0) prevj = T[Y.i_regj + c * P + (fix[Y.f_reg + c * N + i - 1] >> 2)];
-      int nxt = (i + 1 < N) ? (int)fix[Y.f_reg + c * N + i + 1] : -1;
-      int nxtq = (nxt >= 0 && (nxt & 3) == 3) ? (nxt >> 2) : -1;
-      const unsigned long long allow_b = ((unsigned long long)(unsigned int)T[Y.i_allow + (c * N + i) * 2 + 1] << 32) | (unsigned int)T[Y.i_allow + (c * N + i) * 2];
-      for (int q = 0; q < np; ++q) {
-        if (nxtq >= 0 && nxtq != q) continue;
-        int nh = T[Y.i_nhs + c * P + q];
-        for (int h = 0; h < 4; ++h) {
-          if (h < 3 && h >= nh) continue;
-          if (!((allow_b >> (q * 4 + h)) & 1ull)) continue;
-          if (h == 3 && prevj != -2 && prevj != T[Y.i_regj + c * P + q]) continue;
-          if (nalt < 63) { altbuf[nalt] = q * 4 + h; altval[nalt] = region_alt_viol(Y, D, T, c, q, h, s, i <= N - 2); nalt++; }
+    BranchDesc d = chosen; const int i = d.i;
+    int base, stride;
+    if (d.kind == 0) { base = Y.f_reg + d.c * N; stride = 1; }
+    else if (d.kind == 1) { base = Y.f_env + (d.c * N) * 5 + d.pt; stride = 5; }
+    else if (d.kind == 2) { base = Y.f_obs + ((d.c * Y.O + d.o) * N) * 5 + d.pt; stride = 5; }
+    else { base = Y.f_c2c + (0 * N) * 4 + d.o; stride = 4; }
+    // alternatives of step j other than ref_j; returns count, writes into tmp
+    auto alts_of = [&](int j, int* tmp) -> int {
+      int refv = (int)comp[base + j * stride]; int n = 0;
+      if (d.kind == 0) {
+        int c = d.c; int np = T[Y.i_nposs + c];
+        int pv_ = j == 1 ? -1 : (int)comp[base + (j - 1) * stride];          // previous step: decided or reference value
+        int prevj = j == 1 ? T[Y.i_initj + c] : T[Y.i_regj + c * P + (pv_ >> 2)];
+        int nxt = (j + 1 < N) ? (int)fix[base + (j + 1) * stride] : -1;
+        int nxtq = (nxt >= 0 && (nxt & 3) == 3) ? (nxt >> 2) : -1;
+        const unsigned long long allow_b = ((unsigned long long)(unsigned int)T[Y.i_allow + (c * N + j) * 2 + 1] << 32) | (unsigned int)T[Y.i_allow + (c * N + j) * 2];
+        for (int q = 0; q < np; ++q) {
+          if (nxtq >= 0 && nxtq != q) continue;
+          int nh = T[Y.i_nhs + c * P + q];
+          for (int h = 0; h < 4; ++h) {
+            if (h < 3 && h >= nh) continue;
+            if (!((allow_b >> (q * 4 + h)) & 1ull)) continue;
+            if (h == 3 && prevj != T[Y.i_regj + c * P + q]) continue;
+            if (q * 4 + h == refv) continue;
+            if (n < 16) tmp[n++] = q * 4 + h;
+          }
         }
+      } else if (d.kind == 1) { for (int e = 0; e < Y.E && n < 16; ++e) if (e != refv) tmp[n++] = e; }
+      else if (d.kind == 2) { int na = Y.L + (T[Y.i_obssoft + d.o] ? 1 : 0); for (int k = 0; k < na && n < 16; ++k) if (k != refv) tmp[n++] = k; }
+      else { for (int a2 = 0; a2 < 4; ++a2) if (a2 != refv) tmp[n++] = a2; }
+      return n;
+    };
+    // window of undecided steps: all of them when the children fit, else the steps from the violated one onwards
+    int tmp[16];
+    int jlo = 1, jhi = N - 1, total = 1;
+    for (int j = 1; j < N; ++j) if (fix[base + j * stride] < 0) total += alts_of(j, tmp);
+    if (!((B.seq_kinds >> d.kind) & 1)) { jlo = i; jhi = i; total = 1 + alts_of(i, tmp); }  // plain K-way branching on step i
+    else if (total > 63) {
+      jlo = i; total = 1; jhi = i - 1;
+      for (int j = i; j < N; ++j) {
+        if (fix[base + j * stride] >= 0) { jhi = j; continue; }
+        int n = alts_of(j, tmp);
+        if (total + n > 63) break;
+        total += n; jhi = j;
       }
-    } else if (d.kind == 1) {
-      int c = d.c; CarState s = {z[6 * c], z[6 * c + 1], z[6 * c + 2], z[6 * c + 3], z[6 * c + 4], z[6 * c + 5], 0, 0};
-      int code = (int)comp[Y.f_reg + c * N + i]; const double* rt = D + Y.d_reg + (c * P + (code >> 2)) * REGSZ;
-      double X, Yc; point_xy(s, rt, ENV_PT_D[d.pt][0], ENV_PT_D[d.pt][1], X, Yc);
-      for (int e = 0; e < Y.E && nalt < 64; ++e) { altbuf[nalt] = e; altval[nalt] = env_alt_viol(Y, D, T, e, X, Yc); nalt++; }
-    } else if (d.kind == 2) {
-      int c = d.c; CarState s = {z[6 * c], z[6 * c + 1], z[6 * c + 2], z[6 * c + 3], z[6 * c + 4], z[6 * c + 5], 0, 0};
-      int code = (int)comp[Y.f_reg + c * N + i]; const double* rt = D + Y.d_reg + (c * P + (code >> 2)) * REGSZ;
-      double X, Yc; point_xy(s, rt, OBS_PT_D[d.pt][0], OBS_PT_D[d.pt][1], X, Yc);
-      for (int k = 0; k < Y.L; ++k) { const double* ed = D + Y.d_obs + ((d.o * N + i) * Y.L + k) * 3; altbuf[nalt] = k; altval[nalt] = ed[0] * X + ed[1] * Yc - ed[2]; nalt++; }
-      if (T[Y.i_obssoft + d.o]) { altbuf[nalt] = Y.L; altval[nalt] = 1e299; nalt++; }
-    } else {
-      CarState s1 = {z[0], z[1], z[2], z[3], z[4], z[5], 0, 0}, s2 = {z[6], z[7], z[8], z[9], z[10], z[11], 0, 0};
-      int code1 = (int)comp[Y.f_reg + 0 * N + i], code2 = (int)comp[Y.f_reg + 1 * N + i];
-      const double* rt1 = D + Y.d_reg + (0 * P + (code1 >> 2)) * REGSZ; const double* rt2 = D + Y.d_reg + (1 * P + (code2 >> 2)) * REGSZ;
-      for (int a = 0; a < 4; ++a) { altbuf[nalt] = a; altval[nalt] = c2c_alt_viol(Y, D, 0, i, d.o, a, s1, rt1, s2, rt2); nalt++; }
     }
-    for (int a = 1; a < nalt; ++a) {  // insertion sort by violation
-      int ia = altbuf[a]; double va = altval[a]; int b = a - 1;
-      while (b >= 0 && altval[b] > va) { altbuf[b + 1] = altbuf[b]; altval[b + 1] = altval[b]; b--; }
-      altbuf[b + 1] = ia; altval[b + 1] = va;
+    ck[0] = N; ca[0] = 0; nalt = 1;                       // child_inf
+    for (int j = jlo; j <= jhi; ++j) {
+      if (fix[base + j * stride] >= 0) continue;
+      int n = alts_of(j, tmp);
+      for (int q = 0; q < n && nalt < 63; ++q) { ck[nalt] = j; ca[nalt] = tmp[q]; nalt++; }
     }
+    fam[0] = base; fam[1] = stride; fam[2] = jlo; fam[3] = jhi;
     int ob = atomicAdd(&B.open_count[inst], nalt);
     bool okalloc = ob + nalt <= B.open_cap;
     if (okalloc) {
@@ -1015,21 +1034,26 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   nalt = sh_base[2];
   if (nalt <= 0) { FREE_NODE(); return; }
   {
-    BranchDesc d = chosen;
-    int off;
-    if (d.kind == 0) off = Y.f_reg + d.c * N + d.i;
-    else if (d.kind == 1) off = Y.f_env + (d.c * N + d.i) * 5 + d.pt;
-    else if (d.kind == 2) off = Y.f_obs + ((d.c * Y.O + d.o) * N + d.i) * 5 + d.pt;
-    else off = Y.f_c2c + (0 * N + d.i) * 4 + d.o;
-    int ob = sh_base[1];
+    const int base = fam[0], stride = fam[1], jlo = fam[2], jhi = fam[3];
+    const int ob = sh_base[1];
     for (int a = 0; a < nalt; ++a) {
       signed char* dst = B.pool_fix + (size_t)slots[a] * Y.fixlen;
-      for (int k = lane; k < Y.fixlen; k += 64) dst[k] = (k == off) ? (signed char)altbuf[a] : fix[k];
+      const int kk = ck[a]; const signed char av = (signed char)ca[a];
+      for (int k = lane; k < Y.fixlen; k += 64) {
+        signed char v = fix[k];
+        int rel = k - base;
+        if (v < 0 && rel >= 0 && rel % stride == 0) {
+          int j = rel / stride;
+          if (j >= jlo && j <= jhi) { if (j < kk) v = comp[k]; else if (j == kk) v = av; }
+        }
+        dst[k] = v;
+      }
     }
     if (lane < nalt) {
       size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + ob + lane;
-      // a soft obstacle that is ignored costs WEIGHTS_SLACK_OBSTACLE (obstacle_environment_constraints.mod:85-91)
-      B.open_bound[oi] = obj - B.inst_const[inst]; B.open_node[oi] = slots[lane]; B.open_depth[oi] = B.batch_depth[node] + 1;
+      // depth word: (tree depth << 6) | preference among siblings (child_inf first) - used by the dive ordering
+      int pd = B.batch_depth[node] >> 6;
+      B.open_bound[oi] = obj - B.inst_const[inst]; B.open_node[oi] = slots[lane]; B.open_depth[oi] = ((pd + 1) << 6) | (63 - lane);
     }
   }
   FREE_NODE();
@@ -1106,7 +1130,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     int act = *B.active_insts; if (act < 1) act = 1;
     int w = B.batch_cap / act; if (w < B.nodes_per_round) w = B.nodes_per_round;
     int take = m < w ? m : w;
-    int room = (cap - m) / 8; if (room < 1) room = 1;  // a processed node may emit up to ~8 children
+    int room = (cap - m) / 64; if (room < 1) room = 1;  // a processed node may emit up to 63 children
     if (take > room) take = room;
     int base = take > 0 ? atomicAdd(B.batch_count, take) : 0;
     if (base + take > B.batch_cap) take = B.batch_cap > base ? B.batch_cap - base : 0;

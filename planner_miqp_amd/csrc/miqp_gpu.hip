@@ -182,10 +182,11 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
     size_t l = ipm_lds_bytes(Y); int per = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(l, 1))); X.ipm_grid_max = cus * per; }
   // node pool: every processed node emits at most a handful of children; records are not recycled inside one solve
   // node pool: live nodes are bounded by the open lists plus one round of children; processed records are recycled
-  size_t want = (size_t)n_inst * ((size_t)open_cap + (size_t)npr * 16 + 64); size_t maxrec = ((size_t)6 << 30) / (size_t)Y.fixlen;
+  size_t want = (size_t)n_inst * ((size_t)open_cap + (size_t)npr * 64 + 64); size_t maxrec = ((size_t)6 << 30) / (size_t)Y.fixlen;
   X.pool_cap = (int)std::min(want, maxrec);
   DevBuf& B = X.B; std::memset(&B, 0, sizeof(B));
   B.qp_tol = QP_TOL;
+  B.seq_kinds = std::getenv("MIQP_SEQ_KINDS") ? std::atoi(std::getenv("MIQP_SEQ_KINDS")) : 8;
   B.Y = Y; B.pool_cap = X.pool_cap; B.open_cap = open_cap; B.batch_cap = batch_cap; B.nodes_per_round = npr; B.n_inst = n_inst;
   double* dd; int* ii;
   if (!X.alloc(&dd, (size_t)n_inst * Y.dstride)) return false; B.inst_d = dd;
