@@ -59,9 +59,10 @@ struct DevBuf {
   int* active_insts;             // number of instances not yet done
   int nodes_per_round; int n_inst;
   double qp_tol;
+  int use_cutoff;                // 0: solve every node to convergence (polish of the incumbent, solve_fixed)
   int seq_kinds;                 // bit k set: first-deviation (time family) branching for disjunction kind k, else single step
   int* work_counter;             // next node of the batch to be solved (reset before every ipm launch)
-  unsigned long long* prof;      // [16] cycle counters of the phases of ipm_kernel (diagnostic build -DMIQP_PROFILE only)
+  unsigned long long* prof;      // [40] cycle counters of the phases of ipm_kernel (diagnostic build -DMIQP_PROFILE only)
   unsigned long long* stat_rowiters;
 };
 
@@ -318,14 +319,16 @@ __device__ inline double readlane_d(double v, int lane) {
 // ------------------------------------------------------------------------------------------------
 //  Newton step of one row (elastic: aq == 0, quadratic-soft: aq > 0) given g.dz
 __device__ inline void row_step(double s, double lam, double t, double aq, double gd, double tau, double& ds, double& dl, double& dt) {
-  double zz, r2mu = 0.0, mu = 0.0;
-  if (aq == 0.0) { mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
+  // three reciprocals per row: 1/lambda, 1/mu (or 1/aq), 1/D
+  const double il = 1.0 / lam;
+  const double r1 = tau - s * lam;
+  double zz, r2m = 0.0, im = 0.0, r2 = 0.0;
+  if (aq == 0.0) { const double mu = RHO_EL - lam; im = 1.0 / mu; zz = t * im; r2 = tau - t * mu; r2m = r2 * im; }
   else zz = 1.0 / aq;
-  double Dd = s / lam + zz;
-  double kap = ((tau - s * lam) / lam - r2mu) / Dd;
-  dl = gd / Dd + kap;
-  ds = ((tau - s * lam) - s * dl) / lam;
-  dt = aq == 0.0 ? ((tau - t * mu) + t * dl) / mu : 0.0;
+  const double w = 1.0 / (s * il + zz);
+  dl = (gd + r1 * il - r2m) * w;
+  ds = (r1 - s * dl) * il;
+  dt = aq == 0.0 ? (r2 + t * dl) * im : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -391,6 +394,14 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     __syncthreads();
   }
   const double* Rf = D + Y.d_ref;
+  // cutoff: a node whose dual bound already exceeds what can still improve the incumbent by more than the gap is
+  // abandoned (weak duality on the penalised QP; also catches infeasible nodes, whose penalty term is huge)
+  double cutoff = 1e300;
+  {
+    const double inc0 = inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]);
+    if (B.use_cutoff && inc0 < 1e300) cutoff = inc0 - B.inst_gap[inst] * (1e-10 + fabs(inc0)) - B.inst_const[inst];
+  }
+  double tsum = 0.0;   // sum of the elastic slacks of the current iterate
   double abr[KB];  // [A B] as MFMA operand: lane (g, c) holds AB[4kb + g][c]
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) abr[kb] = (4 * kb + (tid >> 4) < NX && (tid & 15) < NZ) ? ABm[(4 * kb + (tid >> 4)) * NZ + (tid & 15)] : 0.0;
@@ -421,7 +432,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
         double s, lam = 1.0, t;
         if (r.aq == 0.0) {
           if (c > QP_T0) { t = QP_T0; s = c + QP_T0; } else { s = 100.0 * QP_T0; t = s - c; }
-          csum += s * lam + t * (RHO_EL - lam); cnt += 2;
+          csum += s * lam + t * (RHO_EL - lam); cnt += 2; tsum += t;
         } else { lam = fmax(1.0, -2.0 * c * r.aq + 1.0); s = c + lam / r.aq; t = 0.0; csum += s * lam; cnt += 1; }
         rc_rhs[idx] = r.rhs; rc_aq[idx] = r.aq; rc_col[idx] = __longlong_as_double((long long)cols);
         rs_s[idx] = s; rs_l[idx] = lam; rs_t[idx] = t;
@@ -433,6 +444,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
   const int NROWS = base;
   PROF_T(tb1); PROF_ACC(0, tb0, tb1);
   double comp = block_sum<NT>(csum, red);
+  tsum = block_sum<NT>(tsum, red);
   int ncomp = (int)block_sum<NT>((double)cnt, red);
   if (ncomp < 1) ncomp = 1;
   comp /= ncomp;
@@ -447,6 +459,8 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
       obj = block_sum<NT>(o, red);
     }
     if (comp < B.qp_tol * fmax(1.0, fabs(obj)) && resid_fac * R0 < 1e-7) { ok = 1; break; }
+    // dual bound of the penalised problem: primal value - total complementarity (valid once the iterate is dual feasible)
+    if (it > 1 && resid_fac * R0 < 1e-9 * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }
     const double tau = QP_SIGMA * comp;
     // ================= backward sweep: Riccati recursion, the whole stage algebra stays in the registers of the wave.
     // Matrices live in the D layout of v_mfma_f64_16x16x4_f64 (lane l: g = l>>4, c = l&15, register r <-> M[g+4r][c]).
@@ -461,10 +475,10 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) pre.v[k] = 0.0;
     { int rp = sstart[N - 1] + tid; if (rp < sstart[N]) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, rp); }
-    for (int i = N - 1; i >= 0; --i) {
-      __syncthreads();
-      PROF_T(ts0);
-      const int r0 = sstart[i], nr = sstart[i + 1] - r0;
+
+    // scaled row block of stage j into LDS (Gh, fs); requests the rows of stage j-1 (software prefetch)
+    auto build_rows = [&](int j) {
+      const int r0 = sstart[j], nr = sstart[j + 1] - r0;
       const int nsl4 = (nr + 3) & ~3;
       for (int r = tid, ch = 0; r < nsl4; r += NT, ++ch) {
         double* g = Gh + r * GS;
@@ -476,24 +490,26 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
           RowRegs R = ch == 0 ? pre : load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, idx);
           unsigned long long cols = (unsigned long long)__double_as_longlong(R.col);
           int nn = (int)(cols >> 56);
-          double s = R.s, lam = R.lam, zz, r2mu = 0.0;
-          if (R.aq == 0.0) { double t = R.t, mu = RHO_EL - lam; zz = t / mu; r2mu = (tau - t * mu) / mu; }
+          const double s = R.s, lam = R.lam, il = 1.0 / lam;
+          double zz, r2mu = 0.0;
+          if (R.aq == 0.0) { const double t = R.t, mu = RHO_EL - lam, im = 1.0 / mu; zz = t * im; r2mu = (tau - t * mu) * im; }
           else zz = 1.0 / R.aq;
-          double Dd = s / lam + zz, w = 1.0 / Dd;
-          double kap = ((tau - s * lam) / lam - r2mu) / Dd;
-          double sw = sqrt(w);
-          fsv = (lam + kap) / sw;
+          const double w = 1.0 / (s * il + zz);
+          const double kap = ((tau - s * lam) * il - r2mu) * w;
+          const double isw = rsqrt(w), sw = w * isw;   // sqrt(w) and 1/sqrt(w) from one reciprocal square root
+          fsv = (lam + kap) * isw;
 #pragma unroll
           for (int k = 0; k < 6; ++k) if (k < nn) g[(cols >> (8 * k)) & 255] = sw * R.v[k];
         }
         fs[r] = fsv;
       }
-      // software prefetch: the rows of stage i-1 are requested now and arrive under the MFMA chains of stage i
-      if (i > 0) { int rp = sstart[i - 1] + tid; if (rp < r0) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, rp); }
+      if (j > 0) { int rp = sstart[j - 1] + tid; if (rp < r0) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, rp); }
       __syncthreads();
-      PROF_T(ts1); PROF_ACC(1, ts0, ts1);
-      // Phi = 2W + Gh' Gh (4 rows of the scaled row block per MFMA; A operand = B operand), rr = 2W(z - ref) + Gh' fs
-      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    };
+    // Phi_j = 2W + Gh' Gh (4 rows of the scaled row block per MFMA; A operand = B operand), rr_j = 2W(z - ref) + Gh' fs
+    auto phi_chain = [&](int j, d4_t& acc, double& rrc) {
+      const int nsl4 = (sstart[j + 1] - sstart[j] + 3) & ~3;
+      acc = d4_t{0.0, 0.0, 0.0, 0.0};
       double racc = 0.0;
       for (int kb = 0; kb < nsl4; kb += 16) {  // operands of up to 4 MFMAs are fetched before the dependent chain
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
@@ -508,17 +524,29 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
         if (kb + 12 < nsl4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, a3, acc, 0, 0, 0);
       }
       racc += __shfl_xor(racc, 16); racc += __shfl_xor(racc, 32);
-      double rrc = lc < NZ ? racc + 2.0 * Wd[lc] * (Z[i * NZ + lc] - Rf[i * NZ + lc]) : 0.0;  // rr[c], replicated over groups
+      rrc = lc < NZ ? racc + 2.0 * Wd[lc] * (Z[j * NZ + lc] - Rf[j * NZ + lc]) : 0.0;  // rr[c], replicated over groups
+      if (it == 1) rmax = fmax(rmax, fabs(rrc));
+    };
+
+    // Software pipeline over the stages: while the VALU chain of the elimination of stage i runs, the matrix core works
+    // on Phi_{i-1}; the row block of stage i-1 is built under the T/S chains of stage i.
+    d4_t accA; double rrA;
+    PROF_T(tp0);
+    build_rows(N - 1);
+    phi_chain(N - 1, accA, rrA);
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {  // u_{N-1} = 0 (initial_conditions.mod:25-26): P = Phi_xx (+ 2W), p = rr_x
+      double v = accA[rg] + ((lg + 4 * rg == lc && lc < NZ) ? 2.0 * Wd[lc] : 0.0);
+      Pd[rg] = (lg + 4 * rg < NX && lc < NX) ? v : 0.0;
+    }
+    pcol = lc < NX ? rrA : 0.0;
+    if (N >= 2) { build_rows(N - 2); phi_chain(N - 2, accA, rrA); }
+    PROF_T(tp1); PROF_ACC(1, tp0, tp1);
+    for (int i = N - 2; i >= 0; --i) {
+      PROF_T(ts2);
+      d4_t acc = accA; const double rrc = rrA;
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) if (lg + 4 * rg == lc && lc < NZ) acc[rg] += 2.0 * Wd[lc];
-      if (it == 1) rmax = fmax(rmax, fabs(rrc));
-      PROF_T(ts2); PROF_ACC(2, ts1, ts2);
-      if (i == N - 1) {  // u_{N-1} = 0 (initial_conditions.mod:25-26): P = Phi_xx, p = rr_x
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) Pd[rg] = (lg + 4 * rg < NX && lc < NX) ? acc[rg] : 0.0;
-        pcol = lc < NX ? rrc : 0.0;
-        continue;
-      }
       // T = P [A B]
       d4_t accT = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -532,8 +560,11 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
       for (int kb = 0; kb < KB; ++kb) part += abr[kb] * __shfl(pcol, 4 * kb + lg);
       part += __shfl_xor(part, 16); part += __shfl_xor(part, 32);
       const double svc = rrc + part;
+      // next stage: row block under the T/S chains, then its Phi chain is queued behind them
+      d4_t accB = {0.0, 0.0, 0.0, 0.0}; double rrB = 0.0;
+      if (i > 0) { build_rows(i - 1); phi_chain(i - 1, accB, rrB); }
       PROF_T(ts3); PROF_ACC(3, ts2, ts3);
-      // Suu and su as wave-uniform values; Cholesky in registers (every lane, redundantly)
+      // Suu and su as wave-uniform values; LDL' in registers (every lane, redundantly)
       const double own = acc[RU];  // row NX + (g - GU0) of S for the lane groups that hold the u rows
       double Lm[NU][NU], su[NU], dinv[NU], dvec[NU];
 #pragma unroll
@@ -601,6 +632,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
         for (int q = 0; q < NU; ++q) pn -= col[q] * kk[q];
         pcol = lc < NX ? pn : 0.0;
       }
+      accA = accB; rrA = rrB;
       PROF_T(ts5); PROF_ACC(5, ts4, ts5);
     }
     if (it == 1) R0 = block_max<NT>(rmax, red);
@@ -632,7 +664,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     __syncthreads();
     PROF_T(tf1); PROF_ACC(6, tf0, tf1);
     // ================= step length: ratio test over all rows; only g.dz is stored per row
-    double amax = 1e300, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    double rinv = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll 4
     for (int idx = tid; idx < NROWS; idx += NT) {
       double aq = rc_aq[idx];
@@ -642,31 +674,34 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
       for (int k = 0; k < nn; ++k) gd += rc_v[(size_t)k * Y.ROWCAP + idx] * dZ[i * NZ + ((cols >> (8 * k)) & 255)];
       double s = rs_s[idx], lam = rs_l[idx], t = rs_t[idx], ds, dl, dt;
       row_step(s, lam, t, aq, gd, tau, ds, dl, dt);
-      if (ds < 0) amax = fmin(amax, -s / ds);
-      if (dl < 0) amax = fmin(amax, -lam / dl);
+      // ratio test in reciprocal form: alpha_max = 1 / max_k(-dv_k / v_k)
+      rinv = fmax(rinv, fmax(-ds / s, -dl / lam));
       a0 += s * lam; a1 += s * dl + lam * ds; a2 += ds * dl;
       if (aq == 0.0) {
         double mu = RHO_EL - lam, dmu = -dl;
-        if (dt < 0) amax = fmin(amax, -t / dt);
-        if (dmu < 0) amax = fmin(amax, -mu / dmu);
+        rinv = fmax(rinv, fmax(-dt / t, -dmu / mu));
         a0 += t * mu; a1 += t * dmu + mu * dt; a2 += dt * dmu;
       }
       rs_g[idx] = gd;
     }
     rowiters += (unsigned long long)NROWS;
-    amax = block_min<NT>(amax, red);
+    rinv = block_max<NT>(rinv, red);
+    const double amax = rinv > 1e-300 ? 1.0 / rinv : 1e300;
     a0 = block_sum<NT>(a0, red); a1 = block_sum<NT>(a1, red); a2 = block_sum<NT>(a2, red);
     double alpha = fmin(1.0, 0.995 * amax);
     comp = (a0 + alpha * a1 + alpha * alpha * a2) / ncomp;
     PROF_T(tf2); PROF_ACC(7, tf1, tf2);
     // ================= update (the step of every row is recomputed from its stored g.dz)
+    double tnew = 0.0;
     for (int k = tid; k < N * NZ; k += NT) Z[k] += alpha * dZ[k];
 #pragma unroll 4
     for (int idx = tid; idx < NROWS; idx += NT) {
       double s = rs_s[idx], lam = rs_l[idx], t = rs_t[idx], ds, dl, dt;
       row_step(s, lam, t, rc_aq[idx], rs_g[idx], tau, ds, dl, dt);
       rs_s[idx] = s + alpha * ds; rs_l[idx] = lam + alpha * dl; rs_t[idx] = t + alpha * dt;
+      tnew += t + alpha * dt;   // quadratic-soft rows carry t = 0
     }
+    tsum = block_sum<NT>(tnew, red);
     resid_fac *= (1.0 - alpha);
     __syncthreads();
     PROF_T(tf3); PROF_ACC(8, tf2, tf3);
@@ -699,6 +734,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
 #ifdef MIQP_PROFILE
     for (int q = 0; q < 9; ++q) atomicAdd(&B.prof[q], pr_[q]);
     atomicAdd(&B.prof[9], (unsigned long long)(it > QP_MAXIT ? QP_MAXIT : it)); atomicAdd(&B.prof[10], 1ull); atomicAdd(&B.prof[11], (unsigned long long)NROWS);
+    { int hb = (it > QP_MAXIT ? QP_MAXIT : it) / 10; if (hb > 8) hb = 8; atomicAdd(&B.prof[16 + hb], 1ull); if (viol > FEAS_TOL) atomicAdd(&B.prof[25 + hb], 1ull); }
 #endif
   }
   }  // node loop
@@ -794,7 +830,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   __syncthreads();
   const double viol = B.batch_viol[node];
   const int okq = B.batch_ok[node];
-  if (viol > FEAS_TOL || !okq) { FREE_NODE(); return; }  // infeasible relaxation
+  if (viol > FEAS_TOL || okq != 1) { FREE_NODE(); return; }  // infeasible relaxation, or abandoned at the incumbent cutoff
   // soft obstacles that this node ignores cost WEIGHTS_SLACK_OBSTACLE each (obstacle_environment_constraints.mod:85-91)
   int nign = 0;
   for (int k = lane; k < C * Y.O * N * 5; k += 64) nign += fix[Y.f_obs + k] >= Y.L ? 1 : 0;

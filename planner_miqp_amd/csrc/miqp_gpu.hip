@@ -185,7 +185,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   size_t want = (size_t)n_inst * ((size_t)open_cap + (size_t)npr * 64 + 64); size_t maxrec = ((size_t)6 << 30) / (size_t)Y.fixlen;
   X.pool_cap = (int)std::min(want, maxrec);
   DevBuf& B = X.B; std::memset(&B, 0, sizeof(B));
-  B.qp_tol = QP_TOL;
+  B.qp_tol = QP_TOL; B.use_cutoff = 1;
   B.seq_kinds = std::getenv("MIQP_SEQ_KINDS") ? std::atoi(std::getenv("MIQP_SEQ_KINDS")) : 8;
   B.Y = Y; B.pool_cap = X.pool_cap; B.open_cap = open_cap; B.batch_cap = batch_cap; B.nodes_per_round = npr; B.n_inst = n_inst;
   double* dd; int* ii;
@@ -229,8 +229,8 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   if (!X.alloc(&B.rowstate, (size_t)std::min(batch_cap, X.ipm_grid_max) * NFIELD * Y.ROWCAP)) return false;
   if (!X.alloc(&B.rowcache, (size_t)std::min(batch_cap, X.ipm_grid_max) * NCACHE * Y.ROWCAP)) return false;
   if (!X.alloc(&B.work_counter, 1)) return false;
-  if (!X.alloc(&B.prof, 16)) return false;
-  (void)hipMemset(B.prof, 0, 16 * 8);
+  if (!X.alloc(&B.prof, 40)) return false;
+  (void)hipMemset(B.prof, 0, 40 * 8);
   if (!X.alloc(&B.active_insts, 1)) return false;
   if (!X.alloc(&B.stat_rowiters, 1)) return false;
   X.ready = true;
@@ -515,7 +515,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     HIP_OK(hipMemcpyAsync(B.batch_inst, ids.data(), n * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(B.batch_count, &n, 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipStreamSynchronize(st));
-    DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL;
+    DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL; Bp.use_cutoff = 0;
     int nb = std::min(n, X.batch_cap);
     { int gsz = std::min(nb, X.ipm_grid_max); if (Y.C == 1) launch_ipm<1>(Bp, gsz, l_ipm, st); else launch_ipm<2>(Bp, gsz, l_ipm, st); }
     HIP_OK(hipMemcpyAsync(h_pobj.data(), B.batch_obj, nb * 8, hipMemcpyDeviceToHost, st));
@@ -528,7 +528,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   HIP_OK(hipGetLastError());
   float ms_all = 0; HIP_OK(hipEventElapsedTime(&ms_all, X.ev0, X.ev1));
 #ifdef MIQP_PROFILE
-  { unsigned long long pf[16]; HIP_OK(hipMemcpy(pf, B.prof, 16 * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemset(B.prof, 0, 16 * 8));
+  { unsigned long long pf[40]; HIP_OK(hipMemcpy(pf, B.prof, 40 * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemset(B.prof, 0, 40 * 8));
+    std::fprintf(stderr, "[miqp_gpu profile] iteration histogram (bins of 10; all / infeasible):"); for (int q = 0; q < 9; ++q) std::fprintf(stderr, " %llu/%llu", pf[16 + q], pf[25 + q]); std::fprintf(stderr, "\n");
     const char* nm[9] = {"build", "bw.rows", "bw.mfma", "bw.TS", "bw.cholK", "bw.P", "forward", "step", "update"};
     double tot = 0; for (int q = 0; q < 9; ++q) tot += (double)pf[q];
     std::fprintf(stderr, "[miqp_gpu profile] nodes %llu iters %llu rows/node %.0f cycles/node-iter %.0f :", pf[10], pf[9], (double)pf[11] / std::max(1ull, pf[10]), tot / std::max(1ull, pf[9]));
@@ -712,7 +713,7 @@ int miqp_solver_solve_fixed(miqp_solver_t* s, const miqp_raw_results_c* fixed, m
   (void)hipMemcpyAsync(B.batch_node, &zero, 4, hipMemcpyHostToDevice, st);
   (void)hipMemcpyAsync(B.batch_inst, &zero, 4, hipMemcpyHostToDevice, st);
   (void)hipMemsetAsync(B.inst_nodes, 0, 8, st); (void)hipMemsetAsync(B.inst_iters, 0, 8, st); (void)hipMemsetAsync(B.stat_rowiters, 0, 8, st);
-  { DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL;
+  { DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL; Bp.use_cutoff = 0;
     if (Y.C == 1) launch_ipm<1>(Bp, 1, ipm_lds_bytes(Y), st); else launch_ipm<2>(Bp, 1, ipm_lds_bytes(Y), st); }
   std::vector<double> Z((size_t)Y.N * Y.nz); double obj = 0, viol = 0; int ok = 0, it = 0;
   (void)hipMemcpyAsync(Z.data(), B.batch_Z, Z.size() * 8, hipMemcpyDeviceToHost, st);
