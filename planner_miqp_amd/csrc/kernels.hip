@@ -13,9 +13,24 @@
 
 #include "host_inst.hpp"
 
+#ifndef MIQP_RHO
+#define MIQP_RHO 1.0e5
+#endif
+
+#ifndef MIQP_IPM_WPE
+#define MIQP_IPM_WPE 3   // wavefronts per SIMD the interior point kernel is register-allocated for (168 VGPRs; measured best of 2, 3, 4)
+#endif
+
+// timing ablations (diagnostic build -DMIQP_ABLATE: the host replays one full batch with parts of the kernel switched
+// off by the runtime mask DevBuf::abl and a fixed iteration count; the results of such launches are discarded)
+#ifdef MIQP_ABLATE
+#define MIQP_ABL (B.abl)
+#else
+#define MIQP_ABL 0
+#endif
 namespace miqp {
 
-constexpr double RHO_EL = 1.0e5;     // exact-penalty weight of the elastic rows
+constexpr double RHO_EL = MIQP_RHO;     // exact-penalty weight of the elastic rows
 constexpr double FEAS_TOL = 1.0e-6;
 constexpr double QP_TOL = 1.0e-8;      // node relaxations (bounds); the returned incumbent is polished to QP_TOL_FINAL
 constexpr double QP_T0 = 1.0e-3;       // initial elastic slack: t*mu (mu ~ rho) starts at the order of s*lambda
@@ -24,6 +39,11 @@ constexpr double QP_SIGMA = 0.1;
 constexpr int QP_MAXIT = 80;
 constexpr int NFIELD = 4;            // per-row state: s, lambda, t, g.dz
 constexpr int NCACHE = 9;            // per-row cache: rhs, aq (-1: inactive), packed columns, 6 coefficients
+constexpr int GROWS = 48;            // rows of a stage staged through LDS per chunk of the stage-Hessian contraction
+constexpr int GSTR = 17;             // LDS stride of a dense row (16 columns of the MFMA tile + 1: conflict-free)
+// LDS doubles behind Z of the interior point kernel: [dZ | row chunk | scaled residuals]; the decode phase reuses the
+// region as one dense scratch row per lane
+__host__ __device__ inline int ipm_scratch_doubles(int N, int NZ) { int a = N * NZ + GROWS * (GSTR + 1), b = 64 * GSTR; return a > b ? a : b; }
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 enum { PT_R = 0, PT_U = 1, PT_L = 2 };
@@ -56,11 +76,13 @@ struct DevBuf {
   signed char* batch_comp;       // completed fix record of feasible nodes
   double* rowstate;              // [grid][NFIELD][ROWCAP]
   double* rowcache;              // [grid][NCACHE][ROWCAP] decoded sparse rows of the node being solved
+  double* kgain;                 // [grid][N][NU][NX+2] feedback gains K and feed-forward k of the Riccati sweep
   int* active_insts;             // number of instances not yet done
   int nodes_per_round; int n_inst;
   double qp_tol;
   int use_cutoff;                // 0: solve every node to convergence (polish of the incumbent, solve_fixed)
   int seq_kinds;                 // bit k set: first-deviation (time family) branching for disjunction kind k, else single step
+  int abl;                       // ablation mask of the diagnostic build (0 otherwise)
   int* work_counter;             // next node of the batch to be solved (reset before every ipm launch)
   unsigned long long* prof;      // [40] cycle counters of the phases of ipm_kernel (diagnostic build -DMIQP_PROFILE only)
   unsigned long long* stat_rowiters;
@@ -274,6 +296,7 @@ __device__ inline RowRegs load_row(const double* rc_aq, const double* rc_col, co
 // block-wide reductions over NT threads (NT/64 waves); red has NT/64 doubles; two barriers each
 template <int NT> __device__ inline double block_sum(double v, double* red) {
   v = wave_sum(v);
+  if (NT == 64) return v;   // one wavefront: the butterfly already left the result in every lane
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
@@ -284,6 +307,7 @@ template <int NT> __device__ inline double block_sum(double v, double* red) {
 }
 template <int NT> __device__ inline double block_min(double v, double* red) {
   v = wave_min(v);
+  if (NT == 64) return v;   // one wavefront: the butterfly already left the result in every lane
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
@@ -294,6 +318,7 @@ template <int NT> __device__ inline double block_min(double v, double* red) {
 }
 template <int NT> __device__ inline double block_max(double v, double* red) {
   v = wave_max(v);
+  if (NT == 64) return v;   // one wavefront: the butterfly already left the result in every lane
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
@@ -316,16 +341,28 @@ __device__ inline double readlane_d(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// 1/x from v_rcp_f64 and one Newton step (relative error ~1e-13; the interior point directions tolerate far more, and
+// every place that needs the same quantity twice recomputes it with the same instructions)
+__device__ inline double frcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  return fma(r, fma(-x, r, 1.0), r);
+}
+// 1/sqrt(x) from v_rsq_f64 and one Newton step
+__device__ inline double frsq(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  return fma(0.5 * r, fma(-x * r, r, 1.0), r);
+}
+
 // ------------------------------------------------------------------------------------------------
 //  Newton step of one row (elastic: aq == 0, quadratic-soft: aq > 0) given g.dz
 __device__ inline void row_step(double s, double lam, double t, double aq, double gd, double tau, double& ds, double& dl, double& dt) {
   // three reciprocals per row: 1/lambda, 1/mu (or 1/aq), 1/D
-  const double il = 1.0 / lam;
+  const double il = frcp(lam);
   const double r1 = tau - s * lam;
   double zz, r2m = 0.0, im = 0.0, r2 = 0.0;
-  if (aq == 0.0) { const double mu = RHO_EL - lam; im = 1.0 / mu; zz = t * im; r2 = tau - t * mu; r2m = r2 * im; }
-  else zz = 1.0 / aq;
-  const double w = 1.0 / (s * il + zz);
+  if (aq == 0.0) { const double mu = RHO_EL - lam; im = frcp(mu); zz = t * im; r2 = tau - t * mu; r2m = r2 * im; }
+  else zz = frcp(aq);
+  const double w = frcp(s * il + zz);
   dl = (gd + r1 * il - r2m) * w;
   ds = (r1 - s * dl) * il;
   dt = aq == 0.0 ? (r2 + t * dl) * im : 0.0;
@@ -335,10 +372,10 @@ __device__ inline void row_step(double s, double lam, double t, double aq, doubl
 //  interior point kernel: one wavefront per node.  The rows of the node are decoded once, compacted per stage
 //  (only active rows are stored) and kept as sparse rows (<= 6 non-zeros) in a block-indexed cache.
 template <int C, int NT>
-__global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
+__global__ void __launch_bounds__(NT, MIQP_IPM_WPE) ipm_kernel(DevBuf B) {
   static_assert(NT == 64, "one wavefront per node");
   static_assert(C <= 2, "one 16x16 MFMA tile per stage");
-  constexpr int NX = 6 * C, NU = 2 * C, NZ = 8 * C, GS = 17;
+  constexpr int NX = 6 * C, NU = 2 * C, NZ = 8 * C, GS = GSTR;
   constexpr int KB = (NX + 3) / 4;         // k blocks of the products with [A B]
   constexpr int RU = NX / 4, GU0 = NX % 4;  // register / first lane group holding the input rows NX..NZ-1  // rows are zero padded to the 16 columns of the MFMA tile
   const Layout& Y = B.Y;
@@ -346,18 +383,17 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
   const int nbatch = *B.batch_count;
   const int N = Y.N, NSLOT = Y.NSLOT;
   extern __shared__ double lds[];
-  const int nrow = ((NSLOT + 3) & ~3) > NT ? ((NSLOT + 3) & ~3) : NT;  // LDS rows: scratch row per thread / row block of a stage
   double* Z = lds;                       // [N][NZ]
   double* dZ = Z + N * NZ;               // [N][NZ]
-  double* Kg = dZ + N * NZ;              // [N][NU*NX]
-  double* kg = Kg + N * NU * NX;         // [N][NU]
-  double* Gh = kg + N * NU;              // [nrow][GS]
-  double* fs = Gh + nrow * GS;           // [nrow]
-  double* Wd = fs + nrow;                // [NZ]
+  double* Gh = dZ + N * NZ;              // [GROWS][GS] scaled rows of the stage being contracted
+  double* fs = Gh + GROWS * GS;          // [GROWS]
+  double* Wd = Z + N * NZ + ipm_scratch_doubles(N, NZ);  // [NZ]
   double* red = Wd + NZ;                 // [8]
-  double* ABm = red + 8;                 // [NX*NZ] = [A B] of the triple integrator chains
-  int* sstart = (int*)(ABm + NX * NZ);   // [N+2] first compact row of every stage
+  int* sstart = (int*)(red + 8);         // [N+2] first compact row of every stage
   signed char* fix = (signed char*)(sstart + ((N + 4) & ~1));  // [fixlen]
+  double* dscr = dZ;                     // decode phase: one dense scratch row per lane
+  constexpr int KSTR = NX + 2;           // gain row: K[q][0..NX-1], k[q], pad
+  double* KG = B.kgain + (size_t)blockIdx.x * N * NU * KSTR;
   __shared__ int sh_node;
   // per-row data of the node being solved, indexed by resident block (stays L2 / Infinity-Cache resident)
   double* RS = B.rowstate + (size_t)blockIdx.x * NFIELD * Y.ROWCAP;
@@ -379,8 +415,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     const signed char* src = B.pool_fix + (size_t)B.batch_node[node] * Y.fixlen;
     for (int k = tid; k < Y.fixlen; k += NT) fix[k] = src[k];
     for (int k = tid; k < NZ; k += NT) Wd[k] = D[Y.d_wd + k];
-    for (int k = tid; k < N * NZ; k += NT) { Z[k] = 0.0; dZ[k] = 0.0; }
-    for (int k = tid; k < NX * NZ; k += NT) ABm[k] = ab_entry<C>(k / NZ, k % NZ, ts);
+    for (int k = tid; k < N * NZ; k += NT) Z[k] = 0.0;
   }
   __syncthreads();
   if (tid < NX) Z[tid] = D[Y.d_x0 + tid];
@@ -388,7 +423,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
   for (int i = 0; i + 1 < N; ++i) {  // free rollout (u = 0)
     if (tid < NX) {
       double acc = 0;
-      for (int q = 0; q < NX; ++q) acc += ABm[tid * NZ + q] * Z[i * NZ + q];
+      for (int q = 3 * (tid / 3); q < 3 * (tid / 3) + 3; ++q) acc += ab_entry<C>(tid, q, ts) * Z[i * NZ + q];
       Z[(i + 1) * NZ + tid] = acc;
     }
     __syncthreads();
@@ -404,7 +439,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
   double tsum = 0.0;   // sum of the elastic slacks of the current iterate
   double abr[KB];  // [A B] as MFMA operand: lane (g, c) holds AB[4kb + g][c]
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb) abr[kb] = (4 * kb + (tid >> 4) < NX && (tid & 15) < NZ) ? ABm[(4 * kb + (tid >> 4)) * NZ + (tid & 15)] : 0.0;
+  for (int kb = 0; kb < KB; ++kb) abr[kb] = (4 * kb + (tid >> 4) < NX && (tid & 15) < NZ) ? ab_entry<C>(4 * kb + (tid >> 4), tid & 15, ts) : 0.0;
 #ifdef MIQP_PROFILE
   unsigned long long pr_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -416,7 +451,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     if (tid == 0) sstart[i] = base;
     for (int sb = 0; sb < NSLOT; sb += NT) {
       int slot = sb + tid;
-      double* g = Gh + tid * GS;
+      double* g = dscr + tid * GS;
       RowOut r; r.active = false; r.rhs = 0; r.aq = 0;
       if (slot < NSLOT) r = decode_row<C>(Y, D, T, fix, i, slot, g);
       unsigned long long mask = __ballot(r.active);
@@ -458,9 +493,10 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
       for (int k = tid; k < N * NZ; k += NT) { double d = Z[k] - Rf[k]; o += Wd[k % NZ] * d * d; }
       obj = block_sum<NT>(o, red);
     }
-    if (comp < B.qp_tol * fmax(1.0, fabs(obj)) && resid_fac * R0 < 1e-7) { ok = 1; break; }
+    if (MIQP_ABL) { if (it > (((MIQP_ABL) & 512) ? 0 : 20)) { ok = 1; break; } }
+    else if (comp < B.qp_tol * fmax(1.0, fabs(obj)) && resid_fac * R0 < 1e-7) { ok = 1; break; }
     // dual bound of the penalised problem: primal value - total complementarity (valid once the iterate is dual feasible)
-    if (it > 1 && resid_fac * R0 < 1e-9 * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }
+    if (!(MIQP_ABL) && it > 1 && resid_fac * R0 < 1e-9 * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }
     const double tau = QP_SIGMA * comp;
     // ================= backward sweep: Riccati recursion, the whole stage algebra stays in the registers of the wave.
     // Matrices live in the D layout of v_mfma_f64_16x16x4_f64 (lane l: g = l>>4, c = l&15, register r <-> M[g+4r][c]).
@@ -471,60 +507,67 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     d4_t Pd = {0.0, 0.0, 0.0, 0.0};
     double pcol = 0.0;  // p[c], replicated over the four lane groups
     double rmax = 0.0;
+    double rfn = lc < NZ ? Rf[(N - 1) * NZ + lc] : 0.0;   // reference of the stage whose Phi is built next (prefetched)
     RowRegs pre; pre.aq = 0.0; pre.col = 0.0; pre.s = 1.0; pre.lam = 1.0; pre.t = 1.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) pre.v[k] = 0.0;
-    { int rp = sstart[N - 1] + tid; if (rp < sstart[N]) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, rp); }
+    { int rp = sstart[N - 1] + tid; if (!((MIQP_ABL) & 1024) && tid < GROWS && rp < sstart[N]) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, rp); }
 
-    // scaled row block of stage j into LDS (Gh, fs); requests the rows of stage j-1 (software prefetch)
-    auto build_rows = [&](int j) {
-      const int r0 = sstart[j], nr = sstart[j + 1] - r0;
-      const int nsl4 = (nr + 3) & ~3;
-      for (int r = tid, ch = 0; r < nsl4; r += NT, ++ch) {
-        double* g = Gh + r * GS;
-        double fsv = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) g[q] = 0.0;
-        if (r < nr) {
-          int idx = r0 + r;
-          RowRegs R = ch == 0 ? pre : load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, idx);
-          unsigned long long cols = (unsigned long long)__double_as_longlong(R.col);
-          int nn = (int)(cols >> 56);
-          const double s = R.s, lam = R.lam, il = 1.0 / lam;
-          double zz, r2mu = 0.0;
-          if (R.aq == 0.0) { const double t = R.t, mu = RHO_EL - lam, im = 1.0 / mu; zz = t * im; r2mu = (tau - t * mu) * im; }
-          else zz = 1.0 / R.aq;
-          const double w = 1.0 / (s * il + zz);
-          const double kap = ((tau - s * lam) * il - r2mu) * w;
-          const double isw = rsqrt(w), sw = w * isw;   // sqrt(w) and 1/sqrt(w) from one reciprocal square root
-          fsv = (lam + kap) * isw;
-#pragma unroll
-          for (int k = 0; k < 6; ++k) if (k < nn) g[(cols >> (8 * k)) & 255] = sw * R.v[k];
-        }
-        fs[r] = fsv;
-      }
-      if (j > 0) { int rp = sstart[j - 1] + tid; if (rp < r0) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, rp); }
-      __syncthreads();
-    };
-    // Phi_j = 2W + Gh' Gh (4 rows of the scaled row block per MFMA; A operand = B operand), rr_j = 2W(z - ref) + Gh' fs
+    // Phi_j = 2W + Gh' Gh, rr_j = 2W(z - ref) + Gh' fs.  The scaled rows of stage j pass through LDS in chunks of GROWS
+    // rows (one lane per row; the first chunk comes from the prefetch registers, and the rows of stage j-1 are
+    // requested as soon as they are free); 4 rows per MFMA with A operand = B operand.
     auto phi_chain = [&](int j, d4_t& acc, double& rrc) {
-      const int nsl4 = (sstart[j + 1] - sstart[j] + 3) & ~3;
+      const int rb = sstart[j], nrj = sstart[j + 1] - rb;
       acc = d4_t{0.0, 0.0, 0.0, 0.0};
       double racc = 0.0;
-      for (int kb = 0; kb < nsl4; kb += 16) {  // operands of up to 4 MFMAs are fetched before the dependent chain
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
-        a0 = Gh[(kb + lg) * GS + lc]; f0 = fs[kb + lg];
-        if (kb + 4 < nsl4) { a1 = Gh[(kb + 4 + lg) * GS + lc]; f1 = fs[kb + 4 + lg]; }
-        if (kb + 8 < nsl4) { a2 = Gh[(kb + 8 + lg) * GS + lc]; f2 = fs[kb + 8 + lg]; }
-        if (kb + 12 < nsl4) { a3 = Gh[(kb + 12 + lg) * GS + lc]; f3 = fs[kb + 12 + lg]; }
-        racc += a0 * f0 + a1 * f1 + a2 * f2 + a3 * f3;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc, 0, 0, 0);
-        if (kb + 4 < nsl4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc, 0, 0, 0);
-        if (kb + 8 < nsl4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, a2, acc, 0, 0, 0);
-        if (kb + 12 < nsl4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, a3, acc, 0, 0, 0);
+      for (int c0 = 0; c0 == 0 || c0 < nrj; c0 += GROWS) {
+        const int nr = nrj - c0 < GROWS ? nrj - c0 : GROWS;
+        const int nsl4 = (nr + 3) & ~3;
+        if (tid < (((MIQP_ABL) & 128) ? 0 : nsl4)) {
+          double* g = Gh + tid * GS;
+          double fsv = 0.0;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) g[q] = 0.0;
+          if (tid < nr) {
+            RowRegs R = c0 == 0 ? pre : load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, rb + c0 + tid);
+            unsigned long long cols = (unsigned long long)__double_as_longlong(R.col);
+            int nn = (int)(cols >> 56);
+            double sw;
+            if ((MIQP_ABL) & 2) { sw = R.s + R.lam + R.t; fsv = sw; }
+            else {
+            const double s = R.s, lam = R.lam, il = frcp(lam);
+            double zz, r2mu = 0.0;
+            if (R.aq == 0.0) { const double t = R.t, mu = RHO_EL - lam, im = frcp(mu); zz = t * im; r2mu = (tau - t * mu) * im; }
+            else zz = frcp(R.aq);
+            const double w = frcp(s * il + zz);
+            const double kap = ((tau - s * lam) * il - r2mu) * w;
+            const double isw = frsq(w); sw = w * isw;   // sqrt(w) and 1/sqrt(w) from one reciprocal square root
+            fsv = (lam + kap) * isw;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (k < nn) g[(cols >> (8 * k)) & 255] = sw * R.v[k];
+          }
+          fs[tid] = fsv;
+        }
+        if (c0 == 0 && j > 0) { int rp = sstart[j - 1] + tid; if (!((MIQP_ABL) & 1024) && tid < GROWS && rp < rb) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, rp); }
+        __syncthreads();
+        for (int kb = 0; kb < (((MIQP_ABL) & 4) ? 0 : nsl4); kb += 16) {  // operands of up to 4 MFMAs are fetched before the dependent chain
+          double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
+          a0 = Gh[(kb + lg) * GS + lc]; f0 = fs[kb + lg];
+          if (kb + 4 < nsl4) { a1 = Gh[(kb + 4 + lg) * GS + lc]; f1 = fs[kb + 4 + lg]; }
+          if (kb + 8 < nsl4) { a2 = Gh[(kb + 8 + lg) * GS + lc]; f2 = fs[kb + 8 + lg]; }
+          if (kb + 12 < nsl4) { a3 = Gh[(kb + 12 + lg) * GS + lc]; f3 = fs[kb + 12 + lg]; }
+          racc += a0 * f0 + a1 * f1 + a2 * f2 + a3 * f3;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc, 0, 0, 0);
+          if (kb + 4 < nsl4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc, 0, 0, 0);
+          if (kb + 8 < nsl4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, a2, acc, 0, 0, 0);
+          if (kb + 12 < nsl4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, a3, acc, 0, 0, 0);
+        }
+        if (c0 + GROWS < nrj) __syncthreads();   // the next chunk overwrites the staging rows
       }
       racc += __shfl_xor(racc, 16); racc += __shfl_xor(racc, 32);
-      rrc = lc < NZ ? racc + 2.0 * Wd[lc] * (Z[j * NZ + lc] - Rf[j * NZ + lc]) : 0.0;  // rr[c], replicated over groups
+      rrc = lc < NZ ? racc + 2.0 * Wd[lc] * (Z[j * NZ + lc] - rfn) : 0.0;  // rr[c], replicated over groups
+      if (j > 0 && lc < NZ) rfn = Rf[(j - 1) * NZ + lc];
       if (it == 1) rmax = fmax(rmax, fabs(rrc));
     };
 
@@ -532,7 +575,6 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     // on Phi_{i-1}; the row block of stage i-1 is built under the T/S chains of stage i.
     d4_t accA; double rrA;
     PROF_T(tp0);
-    build_rows(N - 1);
     phi_chain(N - 1, accA, rrA);
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {  // u_{N-1} = 0 (initial_conditions.mod:25-26): P = Phi_xx (+ 2W), p = rr_x
@@ -540,7 +582,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
       Pd[rg] = (lg + 4 * rg < NX && lc < NX) ? v : 0.0;
     }
     pcol = lc < NX ? rrA : 0.0;
-    if (N >= 2) { build_rows(N - 2); phi_chain(N - 2, accA, rrA); }
+    if (N >= 2) phi_chain(N - 2, accA, rrA);
     PROF_T(tp1); PROF_ACC(1, tp0, tp1);
     for (int i = N - 2; i >= 0; --i) {
       PROF_T(ts2);
@@ -550,10 +592,10 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
       // T = P [A B]
       d4_t accT = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) accT = __builtin_amdgcn_mfma_f64_16x16x4f64(Pd[kb], abr[kb], accT, 0, 0, 0);
+      for (int kb = 0; kb < (((MIQP_ABL) & 64) ? 0 : KB); ++kb) accT = __builtin_amdgcn_mfma_f64_16x16x4f64(Pd[kb], abr[kb], accT, 0, 0, 0);
       // S = Phi + [A B]' T   (acc becomes S)
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(abr[kb], accT[kb], acc, 0, 0, 0);
+      for (int kb = 0; kb < (((MIQP_ABL) & 64) ? 0 : KB); ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(abr[kb], accT[kb], acc, 0, 0, 0);
       // sv = rr + [A B]' p
       double part = 0.0;
 #pragma unroll
@@ -562,8 +604,13 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
       const double svc = rrc + part;
       // next stage: row block under the T/S chains, then its Phi chain is queued behind them
       d4_t accB = {0.0, 0.0, 0.0, 0.0}; double rrB = 0.0;
-      if (i > 0) { build_rows(i - 1); phi_chain(i - 1, accB, rrB); }
+      if (i > 0) phi_chain(i - 1, accB, rrB);
       PROF_T(ts3); PROF_ACC(3, ts2, ts3);
+      if ((MIQP_ABL) & 2048) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) Pd[rg] = (lg + 4 * rg < NX && lc < NX) ? acc[rg] : 0.0;
+        pcol = lc < NX ? svc : 0.0; accA = accB; rrA = rrB; continue;
+      }
       // Suu and su as wave-uniform values; LDL' in registers (every lane, redundantly)
       const double own = acc[RU];  // row NX + (g - GU0) of S for the lane groups that hold the u rows
       double Lm[NU][NU], su[NU], dinv[NU], dvec[NU];
@@ -574,6 +621,10 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
         for (int q2 = 0; q2 <= q; ++q2) Lm[q][q2] = readlane_d(own, (GU0 + q) * 16 + NX + q2);
       }
       // Suu = L D L' (unit lower L, no square roots); dinv = 1 / D
+      if ((MIQP_ABL) & 1) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) { dvec[a] = 1.0; dinv[a] = 1.0; }
+      } else {
 #pragma unroll
       for (int a = 0; a < NU; ++a) {
 #pragma unroll
@@ -581,8 +632,9 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
           double v = Lm[a][b];
 #pragma unroll
           for (int q = 0; q < b; ++q) v -= Lm[a][q] * Lm[b][q] * dvec[q];
-          if (a == b) { dvec[a] = fmax(v, 1e-300); dinv[a] = 1.0 / dvec[a]; } else Lm[a][b] = v * dinv[b];
+          if (a == b) { dvec[a] = fmax(v, 1e-300); dinv[a] = frcp(dvec[a]); } else Lm[a][b] = v * dinv[b];
         }
+      }
       }
       // column c of Sux: S[NX+q][c] sits in lane (GU0+q, c); fetched from the three other lane groups
       const double o1 = __shfl_xor(own, 16), o2 = __shfl_xor(own, 32), o3 = __shfl_xor(own, 48);
@@ -590,6 +642,10 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
 #pragma unroll
       for (int q = 0; q < NU; ++q) { int m = lg ^ (GU0 + q); col[q] = m == 0 ? own : (m == 1 ? o1 : (m == 2 ? o2 : o3)); }
       // K[:, c] = Suu^-1 Sux[:, c],  k = Suu^-1 su   (forward with unit L, scale by 1/D, backward with unit L')
+      if ((MIQP_ABL) & 1) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) { xk[a] = col[a] * 1e-3; kk[a] = su[a] * 1e-3; }
+      } else {
 #pragma unroll
       for (int a = 0; a < NU; ++a) {
         double v = col[a], w2 = su[a];
@@ -606,24 +662,15 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
         for (int q = a + 1; q < NU; ++q) { v -= Lm[q][a] * xk[q]; w2 -= Lm[q][a] * kk[q]; }
         xk[a] = v; kk[a] = w2;
       }
-      {
-        double* Ki = Kg + i * NU * NX; double* ki = kg + i * NU;
-        if (lg == 0 && lc < NX) {
-#pragma unroll
-          for (int q = 0; q < NU; ++q) Ki[q * NX + lc] = xk[q];
-        }
-        if (tid == 0) {
-#pragma unroll
-          for (int q = 0; q < NU; ++q) ki[q] = kk[q];
-        }
       }
       PROF_T(ts4); PROF_ACC(4, ts3, ts4);
       // P = S - Sxu K : one MFMA (k = lane group), A[i=c][k=g] = -S[NX+q][c], B[k=g][j=c] = K[q][c]
       {
         const bool urow = lg >= GU0 && lg < GU0 + NU;
-        double bop = 0.0;
+        double bop = 0.0, kop = 0.0;
 #pragma unroll
-        for (int q = 0; q < NU; ++q) if (lg - GU0 == q) bop = xk[q];
+        for (int q = 0; q < NU; ++q) if (lg - GU0 == q) { bop = xk[q]; kop = kk[q]; }
+        if (urow && lc <= NX) KG[(i * NU + (lg - GU0)) * KSTR + lc] = lc < NX ? bop : kop;   // gains of stage i (L2 resident)
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(urow ? -own : 0.0, urow ? bop : 0.0, acc, 0, 0, 0);
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) Pd[rg] = (lg + 4 * rg < NX && lc < NX) ? acc[rg] : 0.0;
@@ -640,25 +687,40 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     PROF_T(tf0);
     // ================= forward sweep (one wavefront: LDS traffic in program order, no workgroup barrier needed)
     if (tid < NZ) dZ[tid] = 0.0;
-    __syncthreads();
-    for (int i = 0; i + 1 < N; ++i) {
-      const double* Ki = Kg + i * NU * NX; const double* ki = kg + i * NU;
-      if (tid < NU) {
-        double acc = -ki[tid];
-        for (int q = 0; q < NX; ++q) acc -= Ki[tid * NX + q] * dZ[i * NZ + q];
-        dZ[i * NZ + NX + tid] = acc;
+    // [A B] row of lane tid < NX: x+[tid] = sum_m ca[m] x[q0 + m] + cb u[tid / 3]
+    double ca[3], cb;
+    { const int k3 = tid % 3;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) { int d = m - k3; ca[m] = d < 0 ? 0.0 : (d == 0 ? 1.0 : (d == 1 ? ts : 0.5 * ts * ts)); }
+      cb = k3 == 0 ? ts * ts * ts / 6.0 : (k3 == 1 ? 0.5 * ts * ts : ts); }
+    // the gains come back from L2 in bulk (the row staging area is free now): SPL stages per load, one wait each
+    double* KL = Gh;
+    constexpr int KSZ = NU * KSTR;
+    constexpr int SPL = (GROWS * (GS + 1)) / KSZ;
+    for (int s0 = 0; s0 + 1 < (((MIQP_ABL) & 8) ? 0 : N); s0 += SPL) {
+      __syncthreads();
+      { const int n = ((N - 1 - s0) < SPL ? (N - 1 - s0) : SPL) * KSZ;
+        for (int k = tid; k < n; k += NT) KL[k] = KG[s0 * KSZ + k]; }
+      __syncthreads();
+      const int s1 = s0 + SPL < N - 1 ? s0 + SPL : N - 1;
+      for (int i = s0; i < s1; ++i) {
+        if (tid < NU) {
+          const double* kv = KL + (i - s0) * KSZ + tid * KSTR;
+          double acc = -kv[NX];
+#pragma unroll
+          for (int q = 0; q < NX; ++q) acc -= kv[q] * dZ[i * NZ + q];
+          dZ[i * NZ + NX + tid] = acc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (tid < NX) {
+          const int q0 = 3 * (tid / 3);
+          double acc = ca[0] * dZ[i * NZ + q0] + ca[1] * dZ[i * NZ + q0 + 1] + ca[2] * dZ[i * NZ + q0 + 2] + cb * dZ[i * NZ + NX + tid / 3];
+          dZ[(i + 1) * NZ + tid] = acc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (tid < NX) {
-        double acc = 0.0;
-        int q0 = 3 * (tid / 3);
-        for (int q = q0; q < q0 + 3; ++q) acc += ABm[tid * NZ + q] * dZ[i * NZ + q];
-        acc += ABm[tid * NZ + NX + tid / 3] * dZ[i * NZ + NX + tid / 3];
-        dZ[(i + 1) * NZ + tid] = acc;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (tid < NU) dZ[(N - 1) * NZ + NX + tid] = 0.0;
     __syncthreads();
@@ -666,7 +728,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     // ================= step length: ratio test over all rows; only g.dz is stored per row
     double rinv = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll 4
-    for (int idx = tid; idx < NROWS; idx += NT) {
+    for (int idx = tid; idx < (((MIQP_ABL) & 16) ? 0 : NROWS); idx += NT) {
       double aq = rc_aq[idx];
       unsigned long long cols = (unsigned long long)__double_as_longlong(rc_col[idx]);
       int nn = (int)(cols >> 56), i = (int)((cols >> 48) & 255);
@@ -675,18 +737,18 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
       double s = rs_s[idx], lam = rs_l[idx], t = rs_t[idx], ds, dl, dt;
       row_step(s, lam, t, aq, gd, tau, ds, dl, dt);
       // ratio test in reciprocal form: alpha_max = 1 / max_k(-dv_k / v_k)
-      rinv = fmax(rinv, fmax(-ds / s, -dl / lam));
+      rinv = fmax(rinv, fmax(-ds * __builtin_amdgcn_rcp(s), -dl * __builtin_amdgcn_rcp(lam)));
       a0 += s * lam; a1 += s * dl + lam * ds; a2 += ds * dl;
       if (aq == 0.0) {
         double mu = RHO_EL - lam, dmu = -dl;
-        rinv = fmax(rinv, fmax(-dt / t, -dmu / mu));
+        rinv = fmax(rinv, fmax(-dt * __builtin_amdgcn_rcp(t), -dmu * __builtin_amdgcn_rcp(mu)));
         a0 += t * mu; a1 += t * dmu + mu * dt; a2 += dt * dmu;
       }
       rs_g[idx] = gd;
     }
     rowiters += (unsigned long long)NROWS;
     rinv = block_max<NT>(rinv, red);
-    const double amax = rinv > 1e-300 ? 1.0 / rinv : 1e300;
+    const double amax = rinv > 1e-300 ? 1.0 / rinv : 1e300;   // raw v_rcp_f64 in the ratios: far inside the 0.5 % margin below
     a0 = block_sum<NT>(a0, red); a1 = block_sum<NT>(a1, red); a2 = block_sum<NT>(a2, red);
     double alpha = fmin(1.0, 0.995 * amax);
     comp = (a0 + alpha * a1 + alpha * alpha * a2) / ncomp;
@@ -695,7 +757,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     double tnew = 0.0;
     for (int k = tid; k < N * NZ; k += NT) Z[k] += alpha * dZ[k];
 #pragma unroll 4
-    for (int idx = tid; idx < NROWS; idx += NT) {
+    for (int idx = tid; idx < (((MIQP_ABL) & 32) ? 0 : NROWS); idx += NT) {
       double s = rs_s[idx], lam = rs_l[idx], t = rs_t[idx], ds, dl, dt;
       row_step(s, lam, t, rc_aq[idx], rs_g[idx], tau, ds, dl, dt);
       rs_s[idx] = s + alpha * ds; rs_l[idx] = lam + alpha * dl; rs_t[idx] = t + alpha * dt;
@@ -705,7 +767,7 @@ __global__ void __launch_bounds__(NT) ipm_kernel(DevBuf B) {
     resid_fac *= (1.0 - alpha);
     __syncthreads();
     PROF_T(tf3); PROF_ACC(8, tf2, tf3);
-    if (alpha < 1e-12) break;
+    if (!(MIQP_ABL) && alpha < 1e-12) break;
   }
   // ---- final measures: worst elastic violation, slack cost
   double viol = 0.0, scost = 0.0;
@@ -892,8 +954,14 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   __syncthreads();
   // ---------------- phase L: leaf disjunctions; every lane keeps its most urgent violated disjunction
   BranchDesc mine; mine.prio = 0x7FFFFFFF; mine.kind = 0; mine.c = 0; mine.o = 0; mine.i = 0; mine.pt = 0;
-  auto consider = [&](int step, int kind, int c, int o, int pt) {
-    int prio = ((step * 4 + kind) << 12) | ((c & 7) << 9) | ((o & 31) << 4) | (pt & 15);
+  const int prio_mode = (B.seq_kinds >> 8) & 15;   // 0: earliest step first (default); others are experiments
+  auto consider = [&](int step, int kind, int c, int o, int pt, double vv) {
+    int major = step * 4 + kind;
+    if (prio_mode == 1) major = (3 - kind) * 32 + step;
+    else if (prio_mode == 2) major = kind * 32 + step;
+    else if (prio_mode == 3) major = 100000 - (int)(fmin(vv, 99.0) * 1000.0);
+    else if (prio_mode == 4) major = (31 - step) * 4 + kind;
+    int prio = (major << 12) | ((c & 7) << 9) | ((o & 31) << 4) | (pt & 15);
     if (prio < mine.prio) { mine.prio = prio; mine.kind = kind; mine.c = c; mine.o = o; mine.i = step; mine.pt = pt; }
   };
   for (int L0 = 0; L0 < NCI; L0 += 64) {
@@ -902,7 +970,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       int c = L / (N - 1), i = 1 + L % (N - 1);
       const double* z = Z + i * NZ;
       CarState s = {z[6 * c], z[6 * c + 1], z[6 * c + 2], z[6 * c + 3], z[6 * c + 4], z[6 * c + 5], z[6 * C + 2 * c], z[6 * C + 2 * c + 1]};
-      if (vflag[c * N + i]) consider(i, 0, c, 0, 0);
+      if (vflag[c * N + i]) consider(i, 0, c, 0, 0, fastv[c * N + i]);
       int code = (int)comp[Y.f_reg + c * N + i];
       const double* rt = D + Y.d_reg + (c * P + (code >> 2)) * REGSZ;
       bool runfixed = fix[Y.f_reg + c * N + i] < 0;
@@ -910,34 +978,34 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         for (int pt = 0; pt < 5; ++pt) {
           double X, Yc; point_xy(s, rt, ENV_PT_D[pt][0], ENV_PT_D[pt][1], X, Yc);
           if (Y.E == 1) {
-            if (pt > 0 && runfixed && env_alt_viol(Y, D, T, 0, X, Yc) > tol) consider(i, 0, c, 0, 0);
+            if (pt > 0 && runfixed) { double v = env_alt_viol(Y, D, T, 0, X, Yc); if (v > tol) consider(i, 0, c, 0, 0, v); }
             comp[Y.f_env + (c * N + i) * 5 + pt] = 0;
             continue;
           }
           int fx = (int)fix[Y.f_env + (c * N + i) * 5 + pt];
           if (fx >= 0 && !(pt > 0 && runfixed)) continue;
-          bool okk;
-          if (fx >= 0) okk = env_alt_viol(Y, D, T, fx, X, Yc) <= tol;
+          bool okk; double bv = 1e300;
+          if (fx >= 0) { bv = env_alt_viol(Y, D, T, fx, X, Yc); okk = bv <= tol; }
           else {
-            double bv = 1e300; int be = 0;
+            int be = 0;
             for (int e = 0; e < Y.E; ++e) { double v = env_alt_viol(Y, D, T, e, X, Yc); if (v < bv) { bv = v; be = e; } }
             okk = bv <= tol; comp[Y.f_env + (c * N + i) * 5 + pt] = (signed char)be;
           }
-          if (!okk) { if (pt > 0 && runfixed) consider(i, 0, c, 0, 0); else consider(i, 1, c, 0, pt); }
+          if (!okk) { if (pt > 0 && runfixed) consider(i, 0, c, 0, 0, bv); else consider(i, 1, c, 0, pt, bv); }
         }
       for (int o = 0; o < Y.O; ++o)
         for (int pt = 0; pt < 5; ++pt) {
           int fx = (int)fix[Y.f_obs + ((c * Y.O + o) * N + i) * 5 + pt];
           if (fx >= 0 && (fx >= Y.L || !(pt > 0 && runfixed))) continue;
           double X, Yc; point_xy(s, rt, OBS_PT_D[pt][0], OBS_PT_D[pt][1], X, Yc);
-          bool okk;
-          if (fx >= 0) { const double* ed = D + Y.d_obs + ((o * N + i) * Y.L + fx) * 3; okk = ed[0] * X + ed[1] * Yc - ed[2] <= tol; }
+          bool okk; double bv = 1e300;
+          if (fx >= 0) { const double* ed = D + Y.d_obs + ((o * N + i) * Y.L + fx) * 3; bv = ed[0] * X + ed[1] * Yc - ed[2]; okk = bv <= tol; }
           else {
-            double bv = 1e300; int bk = 0;
+            int bk = 0;
             for (int k = 0; k < Y.L; ++k) { const double* ed = D + Y.d_obs + ((o * N + i) * Y.L + k) * 3; double v = ed[0] * X + ed[1] * Yc - ed[2]; if (v < bv) { bv = v; bk = k; } }
             okk = bv <= tol; comp[Y.f_obs + ((c * Y.O + o) * N + i) * 5 + pt] = (signed char)bk;
           }
-          if (!okk) { if (pt > 0 && runfixed) consider(i, 0, c, 0, 0); else consider(i, 2, c, o, pt); }
+          if (!okk) { if (pt > 0 && runfixed) consider(i, 0, c, 0, 0, bv); else consider(i, 2, c, o, pt, bv); }
         }
     }
   }
@@ -956,14 +1024,14 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
           if (need1 && fix[Y.f_reg + 0 * N + i] < 0) unf = 0; else if (need2 && fix[Y.f_reg + 1 * N + i] < 0) unf = 1;
           int fx = (int)fix[Y.f_c2c + (0 * N + i) * 4 + g];
           if (fx >= 0 && unf < 0) continue;
-          bool okk;
-          if (fx >= 0) okk = c2c_alt_viol(Y, D, 0, i, g, fx, s1, rt1, s2, rt2) <= tol;
+          bool okk; double bv = 1e300;
+          if (fx >= 0) { bv = c2c_alt_viol(Y, D, 0, i, g, fx, s1, rt1, s2, rt2); okk = bv <= tol; }
           else {
-            double bv = 1e300; int ba = 0;
+            int ba = 0;
             for (int a = 0; a < 4; ++a) { double v = c2c_alt_viol(Y, D, 0, i, g, a, s1, rt1, s2, rt2); if (v < bv) { bv = v; ba = a; } }
             okk = bv <= tol; comp[Y.f_c2c + (0 * N + i) * 4 + g] = (signed char)ba;
           }
-          if (!okk) { if (unf >= 0) consider(i, 0, unf, 0, 0); else consider(i, 3, 0, g, 0); }
+          if (!okk) { if (unf >= 0) consider(i, 0, unf, 0, 0, bv); else consider(i, 3, 0, g, 0, bv); }
         }
       }
     }

@@ -179,7 +179,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   if (!X.ev0) { HIP_OK(hipEventCreate(&X.ev0)); HIP_OK(hipEventCreate(&X.ev1)); }
   X.Y = Y; X.n_inst = n_inst; X.open_cap = open_cap; X.npr = npr; X.batch_cap = batch_cap;
   { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); int cus = 256; if (hipGetDeviceProperties(&pr, dv) == hipSuccess) cus = pr.multiProcessorCount;
-    size_t l = ipm_lds_bytes(Y); int per = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(l, 1))); X.ipm_grid_max = cus * per; }
+    size_t l = ipm_lds_bytes(Y); int per = (int)std::max<size_t>(1, std::min<size_t>(4 * MIQP_IPM_WPE, (160 * 1024) / std::max<size_t>(l + 8, 1))); X.ipm_grid_max = cus * per; }
   // node pool: every processed node emits at most a handful of children; records are not recycled inside one solve
   // node pool: live nodes are bounded by the open lists plus one round of children; processed records are recycled
   size_t want = (size_t)n_inst * ((size_t)open_cap + (size_t)npr * 64 + 64); size_t maxrec = ((size_t)6 << 30) / (size_t)Y.fixlen;
@@ -228,6 +228,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   if (!X.alloc(&B.batch_comp, (size_t)batch_cap * Y.fixlen)) return false;
   if (!X.alloc(&B.rowstate, (size_t)std::min(batch_cap, X.ipm_grid_max) * NFIELD * Y.ROWCAP)) return false;
   if (!X.alloc(&B.rowcache, (size_t)std::min(batch_cap, X.ipm_grid_max) * NCACHE * Y.ROWCAP)) return false;
+  if (!X.alloc(&B.kgain, (size_t)std::min(batch_cap, X.ipm_grid_max) * Y.N * Y.nu * (Y.nx + 2))) return false;
   if (!X.alloc(&B.work_counter, 1)) return false;
   if (!X.alloc(&B.prof, 40)) return false;
   (void)hipMemset(B.prof, 0, 40 * 8);
@@ -239,8 +240,8 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
 
 constexpr int IPM_NT = MIQP_IPM_NT;  // threads per node in the interior point kernel
 size_t ipm_lds_bytes(const Layout& Y) {
-  int NZ = Y.nz, NX = Y.nx, NU = Y.nu, N = Y.N, nrow = std::max((Y.NSLOT + 3) & ~3, IPM_NT);
-  size_t d = (size_t)2 * N * NZ + (size_t)N * NU * NX + (size_t)N * NU + (size_t)nrow * 17 + nrow + NZ + 8 + NX * NZ + (N + 6) / 2 + 1;
+  int NZ = Y.nz, N = Y.N;
+  size_t d = (size_t)N * NZ + (size_t)ipm_scratch_doubles(N, NZ) + NZ + 8 + (N + 6) / 2 + 1;
   return d * 8 + (size_t)Y.fixlen + 16;
 }
 size_t eval_lds_bytes(const Layout& Y) {
@@ -418,7 +419,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   if (!bs.ok) { for (int k = 0; k < n; ++k) { if (S[k]) S[k]->err = bs.err; statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; } std::fprintf(stderr, "[miqp_gpu] %s\n", bs.err.c_str()); return false; }
   const Layout& Y = bs.Y;
   const miqp_solver_opts& O0 = S[0]->opts;
-  int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(512, 4096 / n));
+  int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(512, 16384 / n));
+  if (O0.nodes_per_round <= 0 && std::getenv("MIQP_NPR")) npr = std::max(1, std::atoi(std::getenv("MIQP_NPR")));  // tuning knob
   int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : 32768;
   if (open_cap < 64) open_cap = 64;
   if ((size_t)n * npr >= ((size_t)1 << 20)) npr = (int)((((size_t)1 << 20) - 1) / n);
@@ -501,9 +503,38 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     { int gsz = std::min(bc, X.ipm_grid_max); if (Y.C == 1) launch_ipm<1>(B, gsz, l_ipm, st); else launch_ipm<2>(B, gsz, l_ipm, st); }
     HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
     nev += 2;
+#ifdef MIQP_ABLATE
+    if (bc == X.batch_cap) {   // cost map: the same full batch replayed with parts of the kernel switched off
+      static bool done_abl = false;
+      if (!done_abl) {
+        done_abl = true;
+        const int masks[] = {256, 257, 258, 260, 264, 272, 288, 320, 384, 256 + 255, 256 + 255 + 1024, 256 + 255 + 2048, 256 + 255 + 1024 + 2048, 512};
+        for (int mk : masks) {
+          DevBuf Ba = B; Ba.abl = mk; Ba.use_cutoff = 0;
+          hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+          int gsz = std::min(bc, X.ipm_grid_max);
+          launch_ipm<2>(Ba, gsz, l_ipm, st);
+          HIP_OK(hipEventRecord(e0, st));
+          for (int r = 0; r < 3; ++r) launch_ipm<2>(Ba, gsz, l_ipm, st);
+          HIP_OK(hipEventRecord(e1, st)); HIP_OK(hipStreamSynchronize(st));
+          float ms = 0; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+          std::fprintf(stderr, "[miqp_gpu ablate] mask %3d: %.3f ms per launch of %d nodes x 20 iterations = %.2f us per 1000 node-iterations\n", mk, ms / 3, bc, 1e3 * ms / 3 / (bc * 20.0) * 1e3);
+        }
+        // the replay clobbered the batch results: solve the real batch again below
+        launch_ipm<2>(B, std::min(bc, X.ipm_grid_max), l_ipm, st);
+      }
+    }
+#endif
     { DevBuf Be = B; Be.open_sel = 1 - (rounds & 1); if (Y.C == 1) launch_eval<1>(Be, bc, l_eval, st); else launch_eval<2>(Be, bc, l_eval, st); }
     launched_nodes += bc; rounds++;
     if (O0.verbose > 1) std::fprintf(stderr, "[miqp_gpu] round %d: %d nodes\n", rounds, bc);
+    if (O0.verbose == 1 && rounds % 25 == 0) {  // progress of the first instance
+      double lb0 = 0, io0 = 0; int oc0 = 0; unsigned long long k0 = 0;
+      HIP_OK(hipMemcpyAsync(&lb0, B.lower_bound, 8, hipMemcpyDeviceToHost, st)); HIP_OK(hipMemcpyAsync(&io0, B.inc_obj, 8, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipMemcpyAsync(&oc0, B.open_count, 4, hipMemcpyDeviceToHost, st)); HIP_OK(hipMemcpyAsync(&k0, B.inc_key, 8, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipStreamSynchronize(st));
+      std::fprintf(stderr, "[miqp_gpu] t %.2f s round %d nodes %lld: instance 0 bound %.4f incumbent %.4f open %d\n", wall_s() - t0, rounds, launched_nodes, lb0, k0 >= 0xFFF0000000000000ull ? INFINITY : io0 + h_const[0], oc0);
+    }
   }
   // ---- polish: the incumbent of every instance is re-solved (all disjunctions fixed as completed) to a tight
   //      tolerance; its objective and states are what the caller receives
