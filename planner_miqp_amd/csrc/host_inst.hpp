@@ -235,14 +235,14 @@ struct Layout {
   // int offsets
   int i_nposs, i_regj, i_nhs, i_hs, i_envn, i_obssoft, i_initj, i_dom, i_allow, istride;
   // fix record (bytes)
-  int f_reg, f_env, f_obs, f_c2c, fixlen;
+  int f_reg, f_env, f_obs, f_c2c, f_c2n, fixlen;   // f_c2n: per (pair, step, group) bit mask of excluded car/car alternatives
 };
 
 inline Layout make_layout(int C, int N, int R, int P, int E, int EL, int O, int L) {
   Layout Y; std::memset(&Y, 0, sizeof(Y));
   Y.C = C; Y.N = N; Y.R = R; Y.P = P; Y.E = E; Y.EL = EL; Y.O = O; Y.L = L; Y.NP = C * (C - 1) / 2;
   Y.nx = 6 * C; Y.nu = 2 * C; Y.nz = 8 * C;
-  Y.SC = 16 + 5 * EL + 5 * O; Y.NSLOT = C * Y.SC + Y.NP * 8; Y.ROWCAP = N * Y.NSLOT;
+  Y.SC = 16 + 5 * EL + 5 * O; Y.NSLOT = C * Y.SC + Y.NP * 24; Y.ROWCAP = N * Y.NSLOT;
   int o = 0;
   Y.d_x0 = o; o += C * 6; Y.d_wd = o; o += Y.nz; Y.d_ref = o; o += N * Y.nz; Y.d_glob = o; o += 8; Y.d_u0box = o; o += C * 4;
   Y.d_misc = o; o += 4; Y.d_dsep = o; o += Y.NP * N; Y.d_ssl = o; o += N; Y.d_smax = o; o += N; Y.d_reg = o; o += C * P * REGSZ;
@@ -251,7 +251,8 @@ inline Layout make_layout(int C, int N, int R, int P, int E, int EL, int O, int 
   Y.i_nposs = o; o += C; Y.i_regj = o; o += C * P; Y.i_nhs = o; o += C * P; Y.i_hs = o; o += C * P * 4; Y.i_envn = o; o += E;
   Y.i_obssoft = o; o += O; Y.i_initj = o; o += C; Y.i_dom = o; o += C * P * 4; Y.i_allow = o; o += C * N * 2; Y.istride = (o + 3) & ~3;
   Y.f_reg = 0; Y.f_env = Y.f_reg + C * N; Y.f_obs = Y.f_env + C * N * 5; Y.f_c2c = Y.f_obs + C * O * N * 5;
-  Y.fixlen = (Y.f_c2c + Y.NP * N * 4 + 15) & ~15;
+  Y.f_c2n = Y.f_c2c + Y.NP * N * 4;
+  Y.fixlen = (Y.f_c2n + Y.NP * N * 4 + 15) & ~15;
   return Y;
 }
 

@@ -239,10 +239,19 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
   }
   if (C < 2 || i < 1) return r;
   int q = slot - C * Y.SC;
-  int p = q >> 3, grp = (q & 7) >> 1, which = q & 1;
-  int c1 = 0, c2 = 1;  // C == 2: the single pair
-  int alt = (int)fix[Y.f_c2c + (p * N + i) * 4 + grp];
-  if (alt < 0) return r;
+  // car/car rows (C == 2: the single pair).  Slots [0, 8 NP): the fixed alternative of every group (hard cap row and,
+  // for the soft groups, the quadratic-soft row).  Slots [8 NP, 24 NP): exclusion rows - alternative a of the group is
+  // asserted NOT to hold at zero slack (first-deviation children exclude the alternatives of their earlier siblings:
+  // a trajectory that satisfies one of those for free is covered, at no greater cost, by that sibling).
+  const bool excl = q >= Y.NP * 8;
+  int p, grp, which, alt;
+  if (!excl) { p = q >> 3; grp = (q & 7) >> 1; which = q & 1; alt = (int)fix[Y.f_c2c + (p * N + i) * 4 + grp]; if (alt < 0) return r; }
+  else {
+    int q2 = q - Y.NP * 8; p = q2 >> 4; grp = (q2 >> 2) & 3; alt = q2 & 3; which = 1;
+    int m = (int)fix[Y.f_c2n + (p * N + i) * 4 + grp];
+    if (m <= 0 || !((m >> alt) & 1)) return r;
+  }
+  int c1 = 0, c2 = 1;
   int code1 = (int)fix[Y.f_reg + c1 * N + i], code2 = (int)fix[Y.f_reg + c2 * N + i];
   bool need1 = grp >= 2, need2 = (grp == 1 || grp == 3);
   if ((need1 && code1 < 0) || (need2 && code2 < 0)) return r;
@@ -250,8 +259,10 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
   const double* rt2 = code2 >= 0 ? D + Y.d_reg + (c2 * Y.P + (code2 >> 2)) * REGSZ : nullptr;
   double Dsep = D[Y.d_dsep + p * N + i], S = D[Y.d_ssl + i], smax = D[Y.d_smax + i], wsl = D[Y.d_misc + 0];
   bool soft = (grp == 0 || grp == 3);
-  if (!soft && which == 1) return r;
-  if (soft && which == 1 && !(smax > 0 && wsl > 0)) return r;
+  if (!excl) {
+    if (!soft && which == 1) return r;
+    if (soft && which == 1 && !(smax > 0 && wsl > 0)) return r;
+  }
   bool isx = alt < 2, lo = (alt == 0 || alt == 2);
   int ca, cb, ta, tb;
   if (grp == 0) { ta = tb = PT_R; ca = lo ? c1 : c2; cb = lo ? c2 : c1; }
@@ -261,9 +272,14 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
   double al = isx ? 1.0 : 0.0, be = isx ? 0.0 : 1.0;
   r.active = true;
   r.rhs = soft ? (which == 0 ? -(Dsep + S) + smax : -(Dsep + S)) : -Dsep;
-  r.aq = (soft && which == 1) ? 2.0 * wsl : 0.0;
+  r.aq = (!excl && soft && which == 1) ? 2.0 * wsl : 0.0;
   add_point(g, r.rhs, ca, ca == c1 ? rt1 : rt2, ta, ta, al, be);
   add_point(g, r.rhs, cb, cb == c1 ? rt1 : rt2, tb, tb, -al, -be);
+  if (excl) {   // g.z >= rhs
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) g[k] = -g[k];
+    r.rhs = -r.rhs;
+  }
   return r;
 }
 
@@ -1143,6 +1159,14 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     for (int a = 0; a < nalt; ++a) {
       signed char* dst = B.pool_fix + (size_t)slots[a] * Y.fixlen;
       const int kk = ck[a]; const signed char av = (signed char)ca[a];
+      // exclusive children (car/car): the deviating child excludes, at zero slack, the reference alternative of step kk
+      // and the alternatives of its earlier siblings at that step
+      int negidx = -1, negm = 0;
+      if (chosen.kind == 3 && kk < N && (B.seq_kinds & 0x10000) == 0) {
+        negidx = Y.f_c2n + (0 * N + kk) * 4 + chosen.o;
+        negm = 1 << (int)comp[base + kk * stride];
+        for (int a2 = 1; a2 < a; ++a2) if (ck[a2] == kk) negm |= 1 << ca[a2];
+      }
       for (int k = lane; k < Y.fixlen; k += 64) {
         signed char v = fix[k];
         int rel = k - base;
@@ -1150,6 +1174,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
           int j = rel / stride;
           if (j >= jlo && j <= jhi) { if (j < kk) v = comp[k]; else if (j == kk) v = av; }
         }
+        if (k == negidx) v = (signed char)negm;
         dst[k] = v;
       }
     }

@@ -536,6 +536,24 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
       std::fprintf(stderr, "[miqp_gpu] t %.2f s round %d nodes %lld: instance 0 bound %.4f incumbent %.4f open %d\n", wall_s() - t0, rounds, launched_nodes, lb0, k0 >= 0xFFF0000000000000ull ? INFINITY : io0 + h_const[0], oc0);
     }
   }
+  if (const char* dp = std::getenv("MIQP_DUMP_OPEN")) {   // diagnostic: open list of instance 0 (bound, depth, fix record of the 400 lowest)
+    int oc0 = 0; HIP_OK(hipMemcpy(&oc0, B.open_count, 4, hipMemcpyDeviceToHost)); oc0 = std::min(oc0, open_cap);
+    const size_t src = ((size_t)(rounds & 1) * n + 0) * open_cap;
+    std::vector<double> hb(oc0); std::vector<int> hn(oc0), hd(oc0);
+    if (oc0 > 0) { HIP_OK(hipMemcpy(hb.data(), B.open_bound + src, (size_t)oc0 * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(hn.data(), B.open_node + src, (size_t)oc0 * 4, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(hd.data(), B.open_depth + src, (size_t)oc0 * 4, hipMemcpyDeviceToHost)); }
+    std::vector<int> ord(oc0); for (int k = 0; k < oc0; ++k) ord[k] = k;
+    std::sort(ord.begin(), ord.end(), [&](int x, int y) { return hb[x] < hb[y]; });
+    if (FILE* f = std::fopen(dp, "w")) {
+      std::fprintf(f, "%d %d %d %d %d %d %d\n", oc0, Y.fixlen, Y.f_reg, Y.f_env, Y.f_obs, Y.f_c2c, Y.N);
+      std::vector<signed char> rec(Y.fixlen);
+      for (int q = 0; q < std::min(oc0, 400); ++q) {
+        int k = ord[q]; HIP_OK(hipMemcpy(rec.data(), B.pool_fix + (size_t)hn[k] * Y.fixlen, Y.fixlen, hipMemcpyDeviceToHost));
+        std::fprintf(f, "%.9g %d", hb[k] + h_const[0], hd[k] >> 6); for (int x = 0; x < Y.fixlen; ++x) std::fprintf(f, " %d", (int)rec[x]); std::fprintf(f, "\n");
+      }
+      std::fclose(f);
+    }
+  }
   // ---- polish: the incumbent of every instance is re-solved (all disjunctions fixed as completed) to a tight
   //      tolerance; its objective and states are what the caller receives
   std::vector<double> h_pobj(n, 0.0), h_pviol(n, 1.0); std::vector<int> h_pok(n, 0), h_pit(n, 0);
