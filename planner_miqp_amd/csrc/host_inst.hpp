@@ -18,7 +18,7 @@
 
 namespace miqp {
 
-constexpr int MAXC = 2;          // cars supported by the device kernels in this round
+constexpr int MAXC = 4;          // cars supported by the device kernels (stage vector of at most 32 entries)
 constexpr int REGSZ = 32;        // doubles per (car, possible region) table entry
 constexpr double BIGM_JERK = 10.0, BIGM_ACC = 10.0;
 

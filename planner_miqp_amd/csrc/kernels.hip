@@ -43,7 +43,15 @@ constexpr int GROWS = 48;            // rows of a stage staged through LDS per c
 constexpr int GSTR = 17;             // LDS stride of a dense row (16 columns of the MFMA tile + 1: conflict-free)
 // LDS doubles behind Z of the interior point kernel: [dZ | row chunk | scaled residuals]; the decode phase reuses the
 // region as one dense scratch row per lane
-__host__ __device__ inline int ipm_scratch_doubles(int N, int NZ) { int a = N * NZ + GROWS * (GSTR + 1), b = 64 * GSTR; return a > b ? a : b; }
+// (more than two cars: the dense stage matrices S, P, T, the vectors and the gains of one stage live there instead)
+__host__ __device__ inline int ipm_stage_doubles(int C) {
+  int NX = 6 * C, NU = 2 * C, NZ = 8 * C;
+  return C <= 2 ? GROWS * (GSTR + 1) : NZ * NZ + NX * NX + NX * NZ + NZ + NX + NU * (NX + 1);
+}
+__host__ __device__ inline int ipm_scratch_doubles(int N, int C) {
+  int NZ = 8 * C, a = N * NZ + ipm_stage_doubles(C), b = 64 * (C <= 2 ? GSTR : NZ + 1);
+  return a > b ? a : b;
+}
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 enum { PT_R = 0, PT_U = 1, PT_L = 2 };
@@ -137,6 +145,13 @@ __device__ inline bool corner_dominated(int tx, int ty, double al, double be, in
   if (txs != tx && !(domflag & 1)) return false;
   if (tys != ty && !(domflag & 2)) return false;
   return true;
+}
+
+// cars (c1 < c2) of pair p in the order c1 = 0: c2 = 1..C-1, c1 = 1: ...
+__device__ inline void pair_cars(int p, int C, int& c1, int& c2) {
+  c1 = 0; int rem = p;
+  while (rem >= C - 1 - c1) { rem -= C - 1 - c1; ++c1; }
+  c2 = c1 + 1 + rem;
 }
 
 struct RowOut { double rhs; double aq; bool active; };
@@ -239,7 +254,7 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
   }
   if (C < 2 || i < 1) return r;
   int q = slot - C * Y.SC;
-  // car/car rows (C == 2: the single pair).  Slots [0, 8 NP): the fixed alternative of every group (hard cap row and,
+  // car/car rows.  Slots [0, 8 NP): the fixed alternative of every group (hard cap row and,
   // for the soft groups, the quadratic-soft row).  Slots [8 NP, 24 NP): exclusion rows - alternative a of the group is
   // asserted NOT to hold at zero slack (first-deviation children exclude the alternatives of their earlier siblings:
   // a trajectory that satisfies one of those for free is covered, at no greater cost, by that sibling).
@@ -251,7 +266,7 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
     int m = (int)fix[Y.f_c2n + (p * N + i) * 4 + grp];
     if (m <= 0 || !((m >> alt) & 1)) return r;
   }
-  int c1 = 0, c2 = 1;
+  int c1, c2; pair_cars(p, C, c1, c2);
   int code1 = (int)fix[Y.f_reg + c1 * N + i], code2 = (int)fix[Y.f_reg + c2 * N + i];
   bool need1 = grp >= 2, need2 = (grp == 1 || grp == 3);
   if ((need1 && code1 < 0) || (need2 && code2 < 0)) return r;
@@ -388,10 +403,11 @@ __device__ inline void row_step(double s, double lam, double t, double aq, doubl
 //  interior point kernel: one wavefront per node.  The rows of the node are decoded once, compacted per stage
 //  (only active rows are stored) and kept as sparse rows (<= 6 non-zeros) in a block-indexed cache.
 template <int C, int NT>
-__global__ void __launch_bounds__(NT, MIQP_IPM_WPE) ipm_kernel(DevBuf B) {
+__global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(DevBuf B) {
   static_assert(NT == 64, "one wavefront per node");
-  static_assert(C <= 2, "one 16x16 MFMA tile per stage");
-  constexpr int NX = 6 * C, NU = 2 * C, NZ = 8 * C, GS = GSTR;
+  static_assert(C <= 4, "stage vectors of at most 32 entries");
+  constexpr bool WIDE = C > 2;   // more than two cars: the stage does not fit one 16x16 MFMA tile -> dense LDS stage algebra
+  constexpr int NX = 6 * C, NU = 2 * C, NZ = 8 * C, GS = WIDE ? NZ + 1 : GSTR;
   constexpr int KB = (NX + 3) / 4;         // k blocks of the products with [A B]
   constexpr int RU = NX / 4, GU0 = NX % 4;  // register / first lane group holding the input rows NX..NZ-1  // rows are zero padded to the 16 columns of the MFMA tile
   const Layout& Y = B.Y;
@@ -403,7 +419,7 @@ __global__ void __launch_bounds__(NT, MIQP_IPM_WPE) ipm_kernel(DevBuf B) {
   double* dZ = Z + N * NZ;               // [N][NZ]
   double* Gh = dZ + N * NZ;              // [GROWS][GS] scaled rows of the stage being contracted
   double* fs = Gh + GROWS * GS;          // [GROWS]
-  double* Wd = Z + N * NZ + ipm_scratch_doubles(N, NZ);  // [NZ]
+  double* Wd = Z + N * NZ + ipm_scratch_doubles(N, C);  // [NZ]
   double* red = Wd + NZ;                 // [8]
   int* sstart = (int*)(red + 8);         // [N+2] first compact row of every stage
   signed char* fix = (signed char*)(sstart + ((N + 4) & ~1));  // [fixlen]
@@ -519,10 +535,11 @@ __global__ void __launch_bounds__(NT, MIQP_IPM_WPE) ipm_kernel(DevBuf B) {
     // For a symmetric M that register file is directly the A operand of M*X (A[i=c][k=4kb+g] = M[4kb+g][c]) and the
     // B operand of X*M, so  T = P [A B],  S = Phi + [A B]' T  and the rank-NU update  P = S - Sxu K  are MFMA chains
     // without any LDS traffic; the NU x NU block is factored redundantly by every lane from v_readlane broadcasts.
+    double rmax = 0.0;
+    if constexpr (!WIDE) {
     const int lg = tid >> 4, lc = tid & 15;
     d4_t Pd = {0.0, 0.0, 0.0, 0.0};
     double pcol = 0.0;  // p[c], replicated over the four lane groups
-    double rmax = 0.0;
     double rfn = lc < NZ ? Rf[(N - 1) * NZ + lc] : 0.0;   // reference of the stage whose Phi is built next (prefetched)
     RowRegs pre; pre.aq = 0.0; pre.col = 0.0; pre.s = 1.0; pre.lam = 1.0; pre.t = 1.0;
 #pragma unroll
@@ -698,6 +715,127 @@ __global__ void __launch_bounds__(NT, MIQP_IPM_WPE) ipm_kernel(DevBuf B) {
       accA = accB; rrA = rrB;
       PROF_T(ts5); PROF_ACC(5, ts4, ts5);
     }
+    } else {
+    // ================= backward sweep for more than two cars: dense stage algebra in LDS.  [A B] is block sparse (three
+    // entries per chain column), so T = P [A B] and S = Phi + [A B]' T cost three terms per element; the NU x NU block is
+    // factored redundantly by every lane, lane c solves column c of K, P = Sxx - Sxu' K.
+    double* Sm = dZ + N * NZ;        // [NZ][NZ]
+    double* Pm = Sm + NZ * NZ;       // [NX][NX]
+    double* Tm = Pm + NX * NX;       // [NX][NZ]
+    double* svv = Tm + NX * NZ;      // [NZ]
+    double* pv = svv + NZ;           // [NX]
+    double* Km = pv + NX;            // [NU][NX+1]
+    const double h1 = ts, h2 = 0.5 * ts * ts, h3 = ts * ts * ts / 6.0;
+    for (int j = N - 1; j >= 0; --j) {
+      for (int k = tid; k < NZ * NZ; k += NT) Sm[k] = 0.0;
+      __syncthreads();
+      if (tid < NZ) { Sm[tid * NZ + tid] = 2.0 * Wd[tid]; svv[tid] = 2.0 * Wd[tid] * (Z[j * NZ + tid] - Rf[j * NZ + tid]); }
+      __syncthreads();
+      for (int r = sstart[j] + tid; r < sstart[j + 1]; r += NT) {
+        RowRegs R = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, r);
+        unsigned long long cols = (unsigned long long)__double_as_longlong(R.col);
+        const int nn = (int)(cols >> 56);
+        const double s = R.s, lam = R.lam, il = frcp(lam);
+        double zz, r2mu = 0.0;
+        if (R.aq == 0.0) { const double t = R.t, mu = RHO_EL - lam, im = frcp(mu); zz = t * im; r2mu = (tau - t * mu) * im; }
+        else zz = frcp(R.aq);
+        const double w = frcp(s * il + zz);
+        const double lk = lam + ((tau - s * lam) * il - r2mu) * w;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          if (a < nn) {
+            const int ca_ = (int)((cols >> (8 * a)) & 255);
+            atomicAdd(&svv[ca_], R.v[a] * lk);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) if (b < nn) atomicAdd(&Sm[ca_ * NZ + (int)((cols >> (8 * b)) & 255)], w * R.v[a] * R.v[b]);
+          }
+        }
+      }
+      __syncthreads();
+      if (it == 1 && tid < NZ) rmax = fmax(rmax, fabs(svv[tid]));
+      if (j == N - 1) {   // u_{N-1} = 0 (initial_conditions.mod:25-26): P = Phi_xx, p = rr_x
+        for (int k = tid; k < NX * NX; k += NT) Pm[k] = Sm[(k / NX) * NZ + k % NX];
+        if (tid < NX) pv[tid] = svv[tid];
+        __syncthreads();
+        continue;
+      }
+      // T = P [A B]
+      for (int k = tid; k < NX * NZ; k += NT) {
+        const int i = k / NZ, b = k - i * NZ;
+        const double* Pi = Pm + i * NX;
+        double v;
+        if (b < NX) { const int ch = b / 3, kb = b - 3 * ch; v = Pi[b]; if (kb >= 1) v += h1 * Pi[b - 1]; if (kb >= 2) v += h2 * Pi[b - 2]; }
+        else { const int ch = b - NX; v = h3 * Pi[3 * ch] + h2 * Pi[3 * ch + 1] + h1 * Pi[3 * ch + 2]; }
+        Tm[k] = v;
+      }
+      __syncthreads();
+      // S = Phi + [A B]' T,  sv = rr + [A B]' p
+      for (int k = tid; k < NZ * NZ; k += NT) {
+        const int a = k / NZ, b = k - a * NZ;
+        double v;
+        if (a < NX) { const int ch = a / 3, ka = a - 3 * ch; v = Tm[a * NZ + b]; if (ka >= 1) v += h1 * Tm[(a - 1) * NZ + b]; if (ka >= 2) v += h2 * Tm[(a - 2) * NZ + b]; }
+        else { const int ch = a - NX; v = h3 * Tm[(3 * ch) * NZ + b] + h2 * Tm[(3 * ch + 1) * NZ + b] + h1 * Tm[(3 * ch + 2) * NZ + b]; }
+        Sm[k] += v;
+      }
+      if (tid < NZ) {
+        const int a = tid; double v;
+        if (a < NX) { const int ch = a / 3, ka = a - 3 * ch; v = pv[a]; if (ka >= 1) v += h1 * pv[a - 1]; if (ka >= 2) v += h2 * pv[a - 2]; }
+        else { const int ch = a - NX; v = h3 * pv[3 * ch] + h2 * pv[3 * ch + 1] + h1 * pv[3 * ch + 2]; }
+        svv[a] += v;
+      }
+      __syncthreads();
+      // Suu = L D L' in the registers of every lane
+      double Lm[NU][NU], dinv[NU], dvec[NU];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+          double v = Sm[(NX + a) * NZ + NX + b];
+#pragma unroll
+          for (int q = 0; q < b; ++q) v -= Lm[a][q] * Lm[b][q] * dvec[q];
+          if (a == b) { dvec[a] = fmax(v, 1e-300); dinv[a] = frcp(dvec[a]); } else Lm[a][b] = v * dinv[b];
+        }
+      }
+      // lane c < NX: K[:, c] = Suu^-1 Sux[:, c]; lane NX: k = Suu^-1 su
+      if (tid <= NX) {
+        double xk[NU];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+          double v = tid < NX ? Sm[(NX + a) * NZ + tid] : svv[NX + a];
+#pragma unroll
+          for (int q = 0; q < a; ++q) v -= Lm[a][q] * xk[q];
+          xk[a] = v;
+        }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) xk[a] *= dinv[a];
+#pragma unroll
+        for (int a = NU - 1; a >= 0; --a) {
+          double v = xk[a];
+#pragma unroll
+          for (int q = a + 1; q < NU; ++q) v -= Lm[q][a] * xk[q];
+          xk[a] = v;
+        }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) { Km[a * (NX + 1) + tid] = xk[a]; KG[(j * NU + a) * KSTR + tid] = xk[a]; }
+      }
+      __syncthreads();
+      // P = Sxx - Sxu' K,  p = sv_x - Sxu' k
+      for (int k = tid; k < NX * NX; k += NT) {
+        const int a = k / NX, b = k - a * NX;
+        double v = Sm[a * NZ + b];
+#pragma unroll
+        for (int q = 0; q < NU; ++q) v -= Sm[(NX + q) * NZ + a] * Km[q * (NX + 1) + b];
+        Pm[k] = v;
+      }
+      if (tid < NX) {
+        double v = svv[tid];
+#pragma unroll
+        for (int q = 0; q < NU; ++q) v -= Sm[(NX + q) * NZ + tid] * Km[q * (NX + 1) + NX];
+        pv[tid] = v;
+      }
+      __syncthreads();
+    }
+    }
     if (it == 1) R0 = block_max<NT>(rmax, red);
     __syncthreads();
     PROF_T(tf0);
@@ -710,9 +848,9 @@ __global__ void __launch_bounds__(NT, MIQP_IPM_WPE) ipm_kernel(DevBuf B) {
       for (int m = 0; m < 3; ++m) { int d = m - k3; ca[m] = d < 0 ? 0.0 : (d == 0 ? 1.0 : (d == 1 ? ts : 0.5 * ts * ts)); }
       cb = k3 == 0 ? ts * ts * ts / 6.0 : (k3 == 1 ? 0.5 * ts * ts : ts); }
     // the gains come back from L2 in bulk (the row staging area is free now): SPL stages per load, one wait each
-    double* KL = Gh;
+    double* KL = dZ + N * NZ;   // the stage area (row staging / dense stage matrices) is free during the forward sweep
     constexpr int KSZ = NU * KSTR;
-    constexpr int SPL = (GROWS * (GS + 1)) / KSZ;
+    constexpr int SPL = (WIDE ? NZ * NZ + NX * NX + NX * NZ : GROWS * (GSTR + 1)) / KSZ;
     for (int s0 = 0; s0 + 1 < (((MIQP_ABL) & 8) ? 0 : N); s0 += SPL) {
       __syncthreads();
       { const int n = ((N - 1 - s0) < SPL ? (N - 1 - s0) : SPL) * KSZ;
@@ -855,7 +993,7 @@ __device__ inline double env_alt_viol(const Layout& Y, const double* D, const in
   return v;
 }
 
-// zero-slack violation of c2c alternative (C == 2)
+// zero-slack violation of c2c alternative; (s1, rt1) / (s2, rt2) are the two cars of pair p
 __device__ inline double c2c_alt_viol(const Layout& Y, const double* D, int p, int i, int grp, int alt, const CarState& s1, const double* rt1,
                                       const CarState& s2, const double* rt2) {
   double Dsep = D[Y.d_dsep + p * Y.N + i], S = D[Y.d_ssl + i];
@@ -1025,29 +1163,31 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         }
     }
   }
-  if (C == 2) {
-    for (int L0 = 0; L0 < N - 1; L0 += 64) {
+  if (C >= 2) {
+    const int NPI = Y.NP * (N - 1);
+    for (int L0 = 0; L0 < NPI; L0 += 64) {
       int L = L0 + lane;
-      if (L < N - 1) {
-        int i = 1 + L; const double* z = Z + i * NZ;
-        CarState s1 = {z[0], z[1], z[2], z[3], z[4], z[5], z[6 * C], z[6 * C + 1]};
-        CarState s2 = {z[6], z[7], z[8], z[9], z[10], z[11], z[6 * C + 2], z[6 * C + 3]};
-        int code1 = (int)comp[Y.f_reg + 0 * N + i], code2 = (int)comp[Y.f_reg + 1 * N + i];
-        const double* rt1 = D + Y.d_reg + (0 * P + (code1 >> 2)) * REGSZ; const double* rt2 = D + Y.d_reg + (1 * P + (code2 >> 2)) * REGSZ;
+      if (L < NPI) {
+        int p = L / (N - 1), i = 1 + L % (N - 1); const double* z = Z + i * NZ;
+        int c1, c2; pair_cars(p, C, c1, c2);
+        CarState s1 = {z[6 * c1], z[6 * c1 + 1], z[6 * c1 + 2], z[6 * c1 + 3], z[6 * c1 + 4], z[6 * c1 + 5], z[6 * C + 2 * c1], z[6 * C + 2 * c1 + 1]};
+        CarState s2 = {z[6 * c2], z[6 * c2 + 1], z[6 * c2 + 2], z[6 * c2 + 3], z[6 * c2 + 4], z[6 * c2 + 5], z[6 * C + 2 * c2], z[6 * C + 2 * c2 + 1]};
+        int code1 = (int)comp[Y.f_reg + c1 * N + i], code2 = (int)comp[Y.f_reg + c2 * N + i];
+        const double* rt1 = D + Y.d_reg + (c1 * P + (code1 >> 2)) * REGSZ; const double* rt2 = D + Y.d_reg + (c2 * P + (code2 >> 2)) * REGSZ;
         for (int g = 0; g < 4; ++g) {
           bool need1 = g >= 2, need2 = (g == 1 || g == 3);
           int unf = -1;
-          if (need1 && fix[Y.f_reg + 0 * N + i] < 0) unf = 0; else if (need2 && fix[Y.f_reg + 1 * N + i] < 0) unf = 1;
-          int fx = (int)fix[Y.f_c2c + (0 * N + i) * 4 + g];
+          if (need1 && fix[Y.f_reg + c1 * N + i] < 0) unf = c1; else if (need2 && fix[Y.f_reg + c2 * N + i] < 0) unf = c2;
+          int fx = (int)fix[Y.f_c2c + (p * N + i) * 4 + g];
           if (fx >= 0 && unf < 0) continue;
           bool okk; double bv = 1e300;
-          if (fx >= 0) { bv = c2c_alt_viol(Y, D, 0, i, g, fx, s1, rt1, s2, rt2); okk = bv <= tol; }
+          if (fx >= 0) { bv = c2c_alt_viol(Y, D, p, i, g, fx, s1, rt1, s2, rt2); okk = bv <= tol; }
           else {
             int ba = 0;
-            for (int a = 0; a < 4; ++a) { double v = c2c_alt_viol(Y, D, 0, i, g, a, s1, rt1, s2, rt2); if (v < bv) { bv = v; ba = a; } }
-            okk = bv <= tol; comp[Y.f_c2c + (0 * N + i) * 4 + g] = (signed char)ba;
+            for (int a = 0; a < 4; ++a) { double v = c2c_alt_viol(Y, D, p, i, g, a, s1, rt1, s2, rt2); if (v < bv) { bv = v; ba = a; } }
+            okk = bv <= tol; comp[Y.f_c2c + (p * N + i) * 4 + g] = (signed char)ba;
           }
-          if (!okk) { if (unf >= 0) consider(i, 0, unf, 0, 0, bv); else consider(i, 3, 0, g, 0, bv); }
+          if (!okk) { if (unf >= 0) consider(i, 0, unf, 0, 0, bv); else consider(i, 3, p, g, 0, bv); }
         }
       }
     }
@@ -1087,7 +1227,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     if (d.kind == 0) { base = Y.f_reg + d.c * N; stride = 1; }
     else if (d.kind == 1) { base = Y.f_env + (d.c * N) * 5 + d.pt; stride = 5; }
     else if (d.kind == 2) { base = Y.f_obs + ((d.c * Y.O + d.o) * N) * 5 + d.pt; stride = 5; }
-    else { base = Y.f_c2c + (0 * N) * 4 + d.o; stride = 4; }
+    else { base = Y.f_c2c + (d.c * N) * 4 + d.o; stride = 4; }
     // alternatives of step j other than ref_j; returns count, writes into tmp
     auto alts_of = [&](int j, int* tmp) -> int {
       int refv = (int)comp[base + j * stride]; int n = 0;
@@ -1163,7 +1303,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       // and the alternatives of its earlier siblings at that step
       int negidx = -1, negm = 0;
       if (chosen.kind == 3 && kk < N && (B.seq_kinds & 0x10000) == 0) {
-        negidx = Y.f_c2n + (0 * N + kk) * 4 + chosen.o;
+        negidx = Y.f_c2n + (chosen.c * N + kk) * 4 + chosen.o;
         negm = 1 << (int)comp[base + kk * stride];
         for (int a2 = 1; a2 < a; ++a2) if (ck[a2] == kk) negm |= 1 << ca[a2];
       }

@@ -179,7 +179,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   if (!X.ev0) { HIP_OK(hipEventCreate(&X.ev0)); HIP_OK(hipEventCreate(&X.ev1)); }
   X.Y = Y; X.n_inst = n_inst; X.open_cap = open_cap; X.npr = npr; X.batch_cap = batch_cap;
   { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); int cus = 256; if (hipGetDeviceProperties(&pr, dv) == hipSuccess) cus = pr.multiProcessorCount;
-    size_t l = ipm_lds_bytes(Y); int per = (int)std::max<size_t>(1, std::min<size_t>(4 * MIQP_IPM_WPE, (160 * 1024) / std::max<size_t>(l + 8, 1))); X.ipm_grid_max = cus * per; }
+    size_t l = ipm_lds_bytes(Y); int per = (int)std::max<size_t>(1, std::min<size_t>(4 * (Y.C <= 2 ? MIQP_IPM_WPE : 1), (160 * 1024) / std::max<size_t>(l + 8, 1))); X.ipm_grid_max = cus * per; }
   // node pool: every processed node emits at most a handful of children; records are not recycled inside one solve
   // node pool: live nodes are bounded by the open lists plus one round of children; processed records are recycled
   size_t want = (size_t)n_inst * ((size_t)open_cap + (size_t)npr * 64 + 64); size_t maxrec = ((size_t)6 << 30) / (size_t)Y.fixlen;
@@ -241,7 +241,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
 constexpr int IPM_NT = MIQP_IPM_NT;  // threads per node in the interior point kernel
 size_t ipm_lds_bytes(const Layout& Y) {
   int NZ = Y.nz, N = Y.N;
-  size_t d = (size_t)N * NZ + (size_t)ipm_scratch_doubles(N, NZ) + NZ + 8 + (N + 6) / 2 + 1;
+  size_t d = (size_t)N * NZ + (size_t)ipm_scratch_doubles(N, Y.C) + NZ + 8 + (N + 6) / 2 + 1;
   return d * 8 + (size_t)Y.fixlen + 16;
 }
 size_t eval_lds_bytes(const Layout& Y) {
@@ -253,16 +253,24 @@ size_t select_lds_bytes(int open_cap) { (void)open_cap; return 0; }
 template <int C> void launch_ipm(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { (void)hipMemsetAsync(B.work_counter, 0, 4, st); hipLaunchKernelGGL((ipm_kernel<C, IPM_NT>), dim3(nblocks), dim3(IPM_NT), lds, st, B); }
 template <int C> void launch_eval(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { hipLaunchKernelGGL(eval_kernel<C>, dim3(nblocks), dim3(64), lds, st, B); }
 
-bool set_kernel_lds(const Layout& Y, size_t ipm_lds, size_t eval_lds, size_t sel_lds) {
-  if (Y.C == 1) {
-    HIP_OK(hipFuncSetAttribute((const void*)ipm_kernel<1, IPM_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipm_lds));
-    HIP_OK(hipFuncSetAttribute((const void*)eval_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eval_lds));
-  } else {
-    HIP_OK(hipFuncSetAttribute((const void*)ipm_kernel<2, IPM_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipm_lds));
-    HIP_OK(hipFuncSetAttribute((const void*)eval_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eval_lds));
-  }
-  (void)sel_lds;
+void launch_ipm_c(int C, const DevBuf& B, int nblocks, size_t lds, hipStream_t st) {
+  switch (C) { case 1: launch_ipm<1>(B, nblocks, lds, st); break; case 2: launch_ipm<2>(B, nblocks, lds, st); break;
+               case 3: launch_ipm<3>(B, nblocks, lds, st); break; default: launch_ipm<4>(B, nblocks, lds, st); }
+}
+void launch_eval_c(int C, const DevBuf& B, int nblocks, size_t lds, hipStream_t st) {
+  switch (C) { case 1: launch_eval<1>(B, nblocks, lds, st); break; case 2: launch_eval<2>(B, nblocks, lds, st); break;
+               case 3: launch_eval<3>(B, nblocks, lds, st); break; default: launch_eval<4>(B, nblocks, lds, st); }
+}
+
+template <int C> bool set_kernel_lds_c(size_t ipm_lds, size_t eval_lds) {
+  HIP_OK(hipFuncSetAttribute((const void*)ipm_kernel<C, IPM_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipm_lds));
+  HIP_OK(hipFuncSetAttribute((const void*)eval_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eval_lds));
   return true;
+}
+bool set_kernel_lds(const Layout& Y, size_t ipm_lds, size_t eval_lds, size_t sel_lds) {
+  (void)sel_lds;
+  switch (Y.C) { case 1: return set_kernel_lds_c<1>(ipm_lds, eval_lds); case 2: return set_kernel_lds_c<2>(ipm_lds, eval_lds);
+                 case 3: return set_kernel_lds_c<3>(ipm_lds, eval_lds); default: return set_kernel_lds_c<4>(ipm_lds, eval_lds); }
 }
 
 // ---------------------------------------------------------------- results (collectRawResults, cplex_wrapper.cpp:311-448)
@@ -404,7 +412,7 @@ BatchShape batch_layout(miqp_solver_t* const* S, int n) {
     if (I.C != I0.C || I.N != I0.N || I.O != I0.O || I.L != I0.L || I.E != I0.E || I.R != I0.R) { bs.err = "instances of one batch must share NumCars, NumSteps, nr_regions, nr_environments, nr_obstacles, max_lines_obstacles"; return bs; }
     P = std::max(P, max_possible(I)); EL = std::max(EL, max_env_edges(I));
   }
-  if (I0.C > MAXC) { bs.err = "NumCars > 2 is not supported by this build of the device kernels"; return bs; }
+  if (I0.C > MAXC) { bs.err = "NumCars > 4 is not supported by the device kernels"; return bs; }
   if (P > 15) { bs.err = "more than 15 possible regions per car"; return bs; }
   if (I0.E > 100 || I0.L > 100) { bs.err = "too many environment pieces / obstacle edges"; return bs; }
   bs.Y = make_layout(I0.C, I0.N, I0.R, P, I0.E, EL, I0.O, I0.L); bs.ok = true;
@@ -500,7 +508,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     if (wall_s() - t0 > tlim) { timed_out = true; break; }
     if (X.ipm_ev.size() < nev + 2) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); X.ipm_ev.push_back(a); X.ipm_ev.push_back(b); }
     HIP_OK(hipEventRecord(X.ipm_ev[nev], st));
-    { int gsz = std::min(bc, X.ipm_grid_max); if (Y.C == 1) launch_ipm<1>(B, gsz, l_ipm, st); else launch_ipm<2>(B, gsz, l_ipm, st); }
+    { int gsz = std::min(bc, X.ipm_grid_max); launch_ipm_c(Y.C, B, gsz, l_ipm, st); }
     HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
     nev += 2;
 #ifdef MIQP_ABLATE
@@ -525,7 +533,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
       }
     }
 #endif
-    { DevBuf Be = B; Be.open_sel = 1 - (rounds & 1); if (Y.C == 1) launch_eval<1>(Be, bc, l_eval, st); else launch_eval<2>(Be, bc, l_eval, st); }
+    { DevBuf Be = B; Be.open_sel = 1 - (rounds & 1); launch_eval_c(Y.C, Be, bc, l_eval, st); }
     launched_nodes += bc; rounds++;
     if (O0.verbose > 1) std::fprintf(stderr, "[miqp_gpu] round %d: %d nodes\n", rounds, bc);
     if (O0.verbose == 1 && rounds % 25 == 0) {  // progress of the first instance
@@ -566,7 +574,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     HIP_OK(hipStreamSynchronize(st));
     DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL; Bp.use_cutoff = 0;
     int nb = std::min(n, X.batch_cap);
-    { int gsz = std::min(nb, X.ipm_grid_max); if (Y.C == 1) launch_ipm<1>(Bp, gsz, l_ipm, st); else launch_ipm<2>(Bp, gsz, l_ipm, st); }
+    { int gsz = std::min(nb, X.ipm_grid_max); launch_ipm_c(Y.C, Bp, gsz, l_ipm, st); }
     HIP_OK(hipMemcpyAsync(h_pobj.data(), B.batch_obj, nb * 8, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(h_pviol.data(), B.batch_viol, nb * 8, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(h_pok.data(), B.batch_ok, nb * 4, hipMemcpyDeviceToHost, st));
@@ -763,7 +771,7 @@ int miqp_solver_solve_fixed(miqp_solver_t* s, const miqp_raw_results_c* fixed, m
   (void)hipMemcpyAsync(B.batch_inst, &zero, 4, hipMemcpyHostToDevice, st);
   (void)hipMemsetAsync(B.inst_nodes, 0, 8, st); (void)hipMemsetAsync(B.inst_iters, 0, 8, st); (void)hipMemsetAsync(B.stat_rowiters, 0, 8, st);
   { DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL; Bp.use_cutoff = 0;
-    if (Y.C == 1) launch_ipm<1>(Bp, 1, ipm_lds_bytes(Y), st); else launch_ipm<2>(Bp, 1, ipm_lds_bytes(Y), st); }
+    launch_ipm_c(Y.C, Bp, 1, ipm_lds_bytes(Y), st); }
   std::vector<double> Z((size_t)Y.N * Y.nz); double obj = 0, viol = 0; int ok = 0, it = 0;
   (void)hipMemcpyAsync(Z.data(), B.batch_Z, Z.size() * 8, hipMemcpyDeviceToHost, st);
   (void)hipMemcpyAsync(&obj, B.batch_obj, 8, hipMemcpyDeviceToHost, st);

@@ -22,6 +22,12 @@ CONFIGS = {
     "cfg4": (2, 20, 32, 2, 4),
     "mini": (2, 8, 32, 1, 0),
     "mini1": (1, 10, 32, 1, 1),
+    "mini3": (3, 6, 32, 1, 0),
+    "mini4": (4, 6, 32, 1, 0),
+    "mini3b": (3, 8, 32, 1, 0),
+    "mini4b": (4, 8, 32, 1, 0),
+    "cfg5s": (4, 10, 32, 2, 0),   # reduced stand-in of cfg5 (4 cars) that the CPU oracle finishes in seconds
+    "cfg5": (4, 30, 64, 2, 0),
 }
 
 

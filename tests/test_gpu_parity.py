@@ -105,7 +105,8 @@ def test_sos_and_priorities_do_not_change_the_answer(oracle):
     oracle.free(h)
 
 
-@pytest.mark.parametrize("cfg,seeds", [("mini1", range(6)), ("mini", range(6)), ("cfg2", range(4))])
+@pytest.mark.parametrize("cfg,seeds", [("mini1", range(6)), ("mini", range(6)), ("cfg2", range(4)), ("mini3", range(4)), ("mini4", range(3)),
+                                       ("mini3b", range(4)), ("mini4b", range(4))])
 def test_synthetic_parity_tight_gap(oracle, cfg, seeds):
     """seeded instances solved to 1e-7 by both: objective equal to 1e-6 relative, identical regions and
     canonical binaries, states within 1e-4, device result feasible for the raw big-M model"""
@@ -129,6 +130,24 @@ def test_synthetic_parity_tight_gap(oracle, cfg, seeds):
         v, obj, worst = oracle.raw_eval(h, res)
         assert v < 1e-5 and abs(obj - pr.objective) <= 1e-6 * max(1.0, abs(obj)), (cfg, seed, worst)
         oracle.free(h)
+
+
+def test_three_car_reference_fixture_beats_the_recorded_cplex_point(oracle):
+    """cplexmodel.dat (K5: 3 cars, 8 steps, 11 environment pieces; the reference's modelRun.txt point evaluates to
+    741.22 in the raw model): the device result within 5 s is feasible for the raw big-M model and not worse"""
+    p = load_params("cplexmodel.dat")
+    p.max_solution_time = 5.0
+    w = P.CplexWrapper(parameterSource=P.ParameterSource.CPPINPUTS)
+    w.resetParameters(p)
+    st = w.callCplex()
+    assert int(st) == 0
+    pr = w.getSolutionProperties(); res = w.getRawResults()
+    h = oracle.from_dat(dat_path("cplexmodel.dat"))
+    v, obj, worst = oracle.raw_eval(h, res, use_real_slack=True)
+    oracle.free(h)
+    assert v < 1e-5, worst
+    assert abs(obj - pr.objective) <= 1e-6 * max(1.0, abs(obj))
+    assert pr.objective <= 741.2226
 
 
 def test_batch_equals_single_solves():
