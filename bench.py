@@ -7,6 +7,7 @@ Inputs are generated and packed before the timed region; the solve call uploads 
 """
 import argparse
 import json
+import numpy as np
 import os
 import sys
 import time
@@ -95,14 +96,17 @@ def main():
         P.solve_batch(batches[s][1])
     sync()
     t0 = time.time()
-    solved = 0; attempted = 0; ipm_s = 0.0; launches = 0; iters = 0; rowit = 0; nodes = 0
+    solved = 0; attempted = 0; ipm_s = 0.0; launches = 0; iters = 0; rowit = 0; nodes = 0; lat = []
     for s in range(a.warmup, a.warmup + a.steps):
         ps, ws = batches[s]
         sts = P.solve_batch(ws)
         attempted += len(ws)
         for w, st in zip(ws, sts):
             pr = w.getSolutionProperties()
-            solved += int(st == P.OptimizationStatus.SUCCESS and pr.status in (101, 102))
+            ok = st == P.OptimizationStatus.SUCCESS and pr.status in (101, 102)
+            solved += int(ok)
+            if ok:
+                lat.append(pr.time)   # seconds from the start of the batch to this instance's proof
         tm = ws[0].lastTiming()
         ipm_s += tm["ipm_s"]; launches += tm["ipm_launches"]; iters += tm["ipm_iters"]; rowit += tm["row_iters"]; nodes += tm["nodes"]
     sync()
@@ -127,7 +131,8 @@ def main():
                    config=dict(workload="%s: %d cars x %d steps x %d regions, %d env pieces, %d obstacles; %d instances per GPU and step, gap %g, time limit %g s"
                                % ((a.config,) + synthetic.CONFIGS[a.config] + (B, a.gap, a.time_limit)),
                                instances_attempted=int(tot_att), instances_solved_to_gap=int(tot_solved),
-                               bnb_nodes=int(sum(x[7] for x in g)), ipm_iterations=int(sum(x[5] for x in g))),
+                               bnb_nodes=int(sum(x[7] for x in g)), ipm_iterations=int(sum(x[5] for x in g)),
+                               solve_latency_s_rank0=dict(p50=float(np.percentile(lat, 50)), p95=float(np.percentile(lat, 95)), max=float(max(lat))) if lat else None),
                    roofline=dict(bound="mfma", achieved=ach / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s", frac=ach / FP64_PEAK, traffic=traffic,
                                  kernel="ipm_kernel", launches=int(launches), avg_launch_ms=1e3 * ipm_s / max(1, launches),
                                  flops_per_launch=flops / max(1, launches)))

@@ -421,8 +421,10 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   double* fs = Gh + GROWS * GS;          // [GROWS]
   double* Wd = Z + N * NZ + ipm_scratch_doubles(N, C);  // [NZ]
   double* red = Wd + NZ;                 // [8]
-  int* sstart = (int*)(red + 8);         // [N+2] first compact row of every stage
-  signed char* fix = (signed char*)(sstart + ((N + 4) & ~1));  // [fixlen]
+  double* dgq = red + 8;                 // [2][16] diagonal / gradient contributions of the single-entry rows of a stage
+  int* sstart = (int*)(dgq + 32);        // [N+2] first multi-entry row of every stage (rows grow up from index 0)
+  int* sst = sstart + ((N + 4) & ~1);    // [N+2] single-entry rows before every stage (they grow down from ROWCAP-1)
+  signed char* fix = (signed char*)(sst + ((N + 4) & ~1));  // [fixlen]
   double* dscr = dZ;                     // decode phase: one dense scratch row per lane
   constexpr int KSTR = NX + 2;           // gain row: K[q][0..NX-1], k[q], pad
   double* KG = B.kgain + (size_t)blockIdx.x * N * NU * KSTR;
@@ -478,37 +480,46 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   PROF_T(tb0);
 
   // ---- decode every row of the node once; active rows are compacted per stage; initial row state
-  double csum = 0.0; int cnt = 0; int base = 0;
+  // Rows with one non-zero and no quadratic slack (the boxes: most rows of a node) are kept apart from the general
+  // rows: they touch only the diagonal of the stage Hessian and need one coefficient.
+  double csum = 0.0; int cnt = 0; int base = 0, sbase = 0;
   for (int i = 0; i < N; ++i) {
-    if (tid == 0) sstart[i] = base;
+    if (tid == 0) { sstart[i] = base; sst[i] = sbase; }
     for (int sb = 0; sb < NSLOT; sb += NT) {
       int slot = sb + tid;
       double* g = dscr + tid * GS;
       RowOut r; r.active = false; r.rhs = 0; r.aq = 0;
       if (slot < NSLOT) r = decode_row<C>(Y, D, T, fix, i, slot, g);
-      unsigned long long mask = __ballot(r.active);
+      unsigned long long cols = 0ull; int nn = 0;
+      double c = r.rhs;
       if (r.active) {
-        int idx = base + __popcll(mask & ((1ull << tid) - 1ull));
-        unsigned long long cols = 0ull; int nn = 0;
-        double c = r.rhs;
         for (int q = 0; q < NZ; ++q) {
           double v = g[q];
-          if (v != 0.0 && nn < 6) { rc_v[(size_t)nn * Y.ROWCAP + idx] = v; cols |= (unsigned long long)q << (8 * nn); nn++; c -= v * Z[i * NZ + q]; }
+          if (v != 0.0 && nn < 6) { cols |= (unsigned long long)q << (8 * nn); nn++; c -= v * Z[i * NZ + q]; }
         }
+      }
+      const bool sgl = r.active && nn == 1 && r.aq == 0.0, mul = r.active && !sgl;
+      const unsigned long long maskM = __ballot(mul), maskS = __ballot(sgl), lt = (1ull << tid) - 1ull;
+      if (r.active) {
+        const int idx = mul ? base + __popcll(maskM & lt) : Y.ROWCAP - 1 - (sbase + __popcll(maskS & lt));
+        for (int k = 0; k < nn; ++k) rc_v[(size_t)k * Y.ROWCAP + idx] = g[(cols >> (8 * k)) & 255];
         cols |= ((unsigned long long)i << 48) | ((unsigned long long)nn << 56);
         double s, lam = 1.0, t;
         if (r.aq == 0.0) {
           if (c > QP_T0) { t = QP_T0; s = c + QP_T0; } else { s = 100.0 * QP_T0; t = s - c; }
           csum += s * lam + t * (RHO_EL - lam); cnt += 2; tsum += t;
         } else { lam = fmax(1.0, -2.0 * c * r.aq + 1.0); s = c + lam / r.aq; t = 0.0; csum += s * lam; cnt += 1; }
-        rc_rhs[idx] = r.rhs; rc_aq[idx] = r.aq; rc_col[idx] = __longlong_as_double((long long)cols);
+        rc_rhs[idx] = r.rhs; rc_col[idx] = __longlong_as_double((long long)cols);
+        if (mul) rc_aq[idx] = r.aq;
         rs_s[idx] = s; rs_l[idx] = lam; rs_t[idx] = t;
       }
-      base += __popcll(mask);
+      base += __popcll(maskM); sbase += __popcll(maskS);
     }
   }
-  if (tid == 0) sstart[N] = base;
-  const int NROWS = base;
+  if (tid == 0) { sstart[N] = base; sst[N] = sbase; }
+  const int NM = base, NS = sbase, NROWS = NM + NS;
+  // row r of the node (general rows first): its index in the row arrays
+  auto ridx = [&](int r) { return r < NM ? r : Y.ROWCAP - 1 - (r - NM); };
   PROF_T(tb1); PROF_ACC(0, tb0, tb1);
   double comp = block_sum<NT>(csum, red);
   tsum = block_sum<NT>(tsum, red);
@@ -546,13 +557,21 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     for (int k = 0; k < 6; ++k) pre.v[k] = 0.0;
     { int rp = sstart[N - 1] + tid; if (!((MIQP_ABL) & 1024) && tid < GROWS && rp < sstart[N]) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, rp); }
 
-    // Phi_j = 2W + Gh' Gh, rr_j = 2W(z - ref) + Gh' fs.  The scaled rows of stage j pass through LDS in chunks of GROWS
+    // single-entry rows of the stage whose Phi is built next: coefficient, column word, s, lambda, t
+    double sv_ = 0.0, sc_ = 0.0, ss_ = 1.0, sl_ = 1.0, st_ = 1.0;
+    auto load_single = [&](int q) { const int idx = Y.ROWCAP - 1 - q; sv_ = rc_v[idx]; sc_ = rc_col[idx]; ss_ = rs_s[idx]; sl_ = rs_l[idx]; st_ = rs_t[idx]; };
+    { int q = sst[N - 1] + tid; if (!((MIQP_ABL) & 1024) && q < sst[N]) load_single(q); }
+
+    // Phi_j = 2W + diag(single-entry rows) + Gh' Gh, rr_j = 2W(z - ref) + (single-entry rows) + Gh' fs.  Single-entry
+    // rows add w v^2 / v (lambda + kappa) to one diagonal / gradient entry (LDS f64 atomics, one lane per row).
+    // The scaled general rows of stage j pass through LDS in chunks of GROWS
     // rows (one lane per row; the first chunk comes from the prefetch registers, and the rows of stage j-1 are
     // requested as soon as they are free); 4 rows per MFMA with A operand = B operand.
     auto phi_chain = [&](int j, d4_t& acc, double& rrc) {
       const int rb = sstart[j], nrj = sstart[j + 1] - rb;
       acc = d4_t{0.0, 0.0, 0.0, 0.0};
       double racc = 0.0;
+      if (tid < 32) dgq[tid] = 0.0;
       for (int c0 = 0; c0 == 0 || c0 < nrj; c0 += GROWS) {
         const int nr = nrj - c0 < GROWS ? nrj - c0 : GROWS;
         const int nsl4 = (nr + 3) & ~3;
@@ -584,6 +603,20 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
         }
         if (c0 == 0 && j > 0) { int rp = sstart[j - 1] + tid; if (!((MIQP_ABL) & 1024) && tid < GROWS && rp < rb) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, rp); }
         __syncthreads();
+        if (c0 == 0) {
+          const int sb = sst[j], nsj = sst[j + 1] - sb;
+          for (int q0 = 0; q0 < nsj; q0 += NT) {
+            if (q0 > 0 && q0 + tid < nsj) load_single(sb + q0 + tid);
+            if (q0 + tid < nsj) {
+              const double s = ss_, lam = sl_, t = st_, il = frcp(lam), mu = RHO_EL - lam, im = frcp(mu);
+              const double w = frcp(s * il + t * im);
+              const double lk = lam + ((tau - s * lam) * il - (tau - t * mu) * im) * w;
+              const int col = (int)((unsigned long long)__double_as_longlong(sc_) & 255ull);
+              atomicAdd(&dgq[col], w * sv_ * sv_); atomicAdd(&dgq[16 + col], sv_ * lk);
+            }
+          }
+          if (j > 0) { int q = sst[j - 1] + tid; if (!((MIQP_ABL) & 1024) && q < sb) load_single(q); }
+        }
         for (int kb = 0; kb < (((MIQP_ABL) & 4) ? 0 : nsl4); kb += 16) {  // operands of up to 4 MFMAs are fetched before the dependent chain
           double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
           a0 = Gh[(kb + lg) * GS + lc]; f0 = fs[kb + lg];
@@ -599,7 +632,11 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
         if (c0 + GROWS < nrj) __syncthreads();   // the next chunk overwrites the staging rows
       }
       racc += __shfl_xor(racc, 16); racc += __shfl_xor(racc, 32);
-      rrc = lc < NZ ? racc + 2.0 * Wd[lc] * (Z[j * NZ + lc] - rfn) : 0.0;  // rr[c], replicated over groups
+      __syncthreads();   // the single-entry contributions are complete
+      { const double dd = lc < NZ ? 2.0 * Wd[lc] + dgq[lc] : 0.0;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) if (lg + 4 * rg == lc) acc[rg] += dd; }
+      rrc = lc < NZ ? racc + dgq[16 + lc] + 2.0 * Wd[lc] * (Z[j * NZ + lc] - rfn) : 0.0;  // rr[c], replicated over groups
       if (j > 0 && lc < NZ) rfn = Rf[(j - 1) * NZ + lc];
       if (it == 1) rmax = fmax(rmax, fabs(rrc));
     };
@@ -611,7 +648,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     phi_chain(N - 1, accA, rrA);
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {  // u_{N-1} = 0 (initial_conditions.mod:25-26): P = Phi_xx (+ 2W), p = rr_x
-      double v = accA[rg] + ((lg + 4 * rg == lc && lc < NZ) ? 2.0 * Wd[lc] : 0.0);
+      double v = accA[rg];
       Pd[rg] = (lg + 4 * rg < NX && lc < NX) ? v : 0.0;
     }
     pcol = lc < NX ? rrA : 0.0;
@@ -620,8 +657,6 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     for (int i = N - 2; i >= 0; --i) {
       PROF_T(ts2);
       d4_t acc = accA; const double rrc = rrA;
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) if (lg + 4 * rg == lc && lc < NZ) acc[rg] += 2.0 * Wd[lc];
       // T = P [A B]
       d4_t accT = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -731,8 +766,12 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
       __syncthreads();
       if (tid < NZ) { Sm[tid * NZ + tid] = 2.0 * Wd[tid]; svv[tid] = 2.0 * Wd[tid] * (Z[j * NZ + tid] - Rf[j * NZ + tid]); }
       __syncthreads();
-      for (int r = sstart[j] + tid; r < sstart[j + 1]; r += NT) {
+      const int nmj = sstart[j + 1] - sstart[j], nsj = sst[j + 1] - sst[j];
+      for (int r0 = tid; r0 < nmj + nsj; r0 += NT) {
+        const bool sgl = r0 >= nmj;
+        const int r = sgl ? Y.ROWCAP - 1 - (sst[j] + r0 - nmj) : sstart[j] + r0;
         RowRegs R = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, r);
+        if (sgl) R.aq = 0.0;
         unsigned long long cols = (unsigned long long)__double_as_longlong(R.col);
         const int nn = (int)(cols >> 56);
         const double s = R.s, lam = R.lam, il = frcp(lam);
@@ -882,8 +921,9 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     // ================= step length: ratio test over all rows; only g.dz is stored per row
     double rinv = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll 4
-    for (int idx = tid; idx < (((MIQP_ABL) & 16) ? 0 : NROWS); idx += NT) {
-      double aq = rc_aq[idx];
+    for (int r = tid; r < (((MIQP_ABL) & 16) ? 0 : NROWS); r += NT) {
+      const int idx = ridx(r);
+      double aq = r < NM ? rc_aq[idx] : 0.0;
       unsigned long long cols = (unsigned long long)__double_as_longlong(rc_col[idx]);
       int nn = (int)(cols >> 56), i = (int)((cols >> 48) & 255);
       double gd = 0.0;
@@ -911,9 +951,10 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     double tnew = 0.0;
     for (int k = tid; k < N * NZ; k += NT) Z[k] += alpha * dZ[k];
 #pragma unroll 4
-    for (int idx = tid; idx < (((MIQP_ABL) & 32) ? 0 : NROWS); idx += NT) {
+    for (int r = tid; r < (((MIQP_ABL) & 32) ? 0 : NROWS); r += NT) {
+      const int idx = ridx(r);
       double s = rs_s[idx], lam = rs_l[idx], t = rs_t[idx], ds, dl, dt;
-      row_step(s, lam, t, rc_aq[idx], rs_g[idx], tau, ds, dl, dt);
+      row_step(s, lam, t, r < NM ? rc_aq[idx] : 0.0, rs_g[idx], tau, ds, dl, dt);
       rs_s[idx] = s + alpha * ds; rs_l[idx] = lam + alpha * dl; rs_t[idx] = t + alpha * dt;
       tnew += t + alpha * dt;   // quadratic-soft rows carry t = 0
     }
@@ -925,8 +966,9 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   }
   // ---- final measures: worst elastic violation, slack cost
   double viol = 0.0, scost = 0.0;
-  for (int idx = tid; idx < NROWS; idx += NT) {
-    double aq = rc_aq[idx];
+  for (int r = tid; r < NROWS; r += NT) {
+    const int idx = ridx(r);
+    double aq = r < NM ? rc_aq[idx] : 0.0;
     unsigned long long cols = (unsigned long long)__double_as_longlong(rc_col[idx]);
     int nn = (int)(cols >> 56), i = (int)((cols >> 48) & 255);
     double c = rc_rhs[idx];

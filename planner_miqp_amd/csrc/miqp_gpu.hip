@@ -182,7 +182,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
     size_t l = ipm_lds_bytes(Y); int per = (int)std::max<size_t>(1, std::min<size_t>(4 * (Y.C <= 2 ? MIQP_IPM_WPE : 1), (160 * 1024) / std::max<size_t>(l + 8, 1))); X.ipm_grid_max = cus * per; }
   // node pool: every processed node emits at most a handful of children; records are not recycled inside one solve
   // node pool: live nodes are bounded by the open lists plus one round of children; processed records are recycled
-  size_t want = (size_t)n_inst * ((size_t)open_cap + (size_t)npr * 64 + 64); size_t maxrec = ((size_t)6 << 30) / (size_t)Y.fixlen;
+  size_t want = (size_t)n_inst * ((size_t)open_cap + (size_t)npr * 64 + 64); size_t maxrec = ((size_t)48 << 30) / (size_t)Y.fixlen;   // node records: up to 48 GB of the 288 GB
   X.pool_cap = (int)std::min(want, maxrec);
   DevBuf& B = X.B; std::memset(&B, 0, sizeof(B));
   B.qp_tol = QP_TOL; B.use_cutoff = 1;
@@ -241,7 +241,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
 constexpr int IPM_NT = MIQP_IPM_NT;  // threads per node in the interior point kernel
 size_t ipm_lds_bytes(const Layout& Y) {
   int NZ = Y.nz, N = Y.N;
-  size_t d = (size_t)N * NZ + (size_t)ipm_scratch_doubles(N, Y.C) + NZ + 8 + (N + 6) / 2 + 1;
+  size_t d = (size_t)N * NZ + (size_t)ipm_scratch_doubles(N, Y.C) + NZ + 8 + 32 + 2 * ((N + 6) / 2 + 1);
   return d * 8 + (size_t)Y.fixlen + 16;
 }
 size_t eval_lds_bytes(const Layout& Y) {
@@ -429,7 +429,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   const miqp_solver_opts& O0 = S[0]->opts;
   int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(512, 16384 / n));
   if (O0.nodes_per_round <= 0 && std::getenv("MIQP_NPR")) npr = std::max(1, std::atoi(std::getenv("MIQP_NPR")));  // tuning knob
-  int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : 32768;
+  int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (std::getenv("MIQP_OPEN_CAP") ? std::atoi(std::getenv("MIQP_OPEN_CAP")) : std::max(32768, std::min(1 << 20, (1 << 24) / n)));
   if (open_cap < 64) open_cap = 64;
   if ((size_t)n * npr >= ((size_t)1 << 20)) npr = (int)((((size_t)1 << 20) - 1) / n);
   DevCtx& X = g_ctx;
@@ -443,7 +443,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   std::vector<double> h_const(n, 0.0), h_gap(n), h_tlim(n);
   std::vector<int> h_done(n, 0);
   std::vector<signed char> roots((size_t)n * Y.fixlen, (signed char)-1);
-  std::vector<double> ob((size_t)n * open_cap, 0.0); std::vector<int> on((size_t)n * open_cap, 0), oc(n, 1);
+  std::vector<double> ob((size_t)n * 2, 0.0); std::vector<int> on((size_t)n * 2, 0), oc(n, 1);   // the first two open entries of every instance
   int active = 0;
   for (int k = 0; k < n; ++k) {
     miqp_solver* s = S[k]; s->lay = Y; s->has_sol = false;
@@ -452,9 +452,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     double cobj = 0; bool feas0 = step0_check(G, cobj);
     h_const[k] = cobj; h_gap[k] = s->opts.gap_override >= 0 ? s->opts.gap_override : s->inst.gap; h_tlim[k] = s->inst.tilim;
     if (!feas0) { h_done[k] = 1; oc[k] = 0; } else active++;
-    ob[(size_t)k * open_cap] = -1e300; on[(size_t)k * open_cap] = k;
+    ob[(size_t)k * 2] = -1e300; on[(size_t)k * 2] = k;
     if (s->has_ws && (int)s->ws_fix.size() == Y.fixlen && feas0) {  // MIP start: its binaries as a second root candidate
-      oc[k] = 2; ob[(size_t)k * open_cap + 1] = -1e300; on[(size_t)k * open_cap + 1] = n + k;
+      oc[k] = 2; ob[(size_t)k * 2 + 1] = -1e300; on[(size_t)k * 2 + 1] = n + k;
     }
     int rows, bin, cont, nnz; raw_sizes(s->inst, rows, bin, cont, nnz);
     s->props = miqp_solution_properties_c{}; s->props.NrConstraints = rows; s->props.NrBinaryVariables = bin; s->props.NrFloatVariables = cont;
@@ -471,8 +471,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   int pool0 = 2 * n;
   HIP_OK(hipMemcpyAsync(B.pool_count, &pool0, 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemsetAsync(B.free_head, 0, 4, st)); HIP_OK(hipMemsetAsync(B.free_tail, 0, 4, st)); HIP_OK(hipMemsetAsync(B.free_limit, 0, 4, st));
-  HIP_OK(hipMemcpyAsync(B.open_bound, ob.data(), ob.size() * 8, hipMemcpyHostToDevice, st));
-  HIP_OK(hipMemcpyAsync(B.open_node, on.data(), on.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpy2DAsync(B.open_bound, (size_t)open_cap * 8, ob.data(), 16, 16, n, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpy2DAsync(B.open_node, (size_t)open_cap * 4, on.data(), 8, 8, n, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(B.open_count, oc.data(), n * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemsetAsync(B.open_depth, 0, (size_t)2 * n * open_cap * 4, st));
   HIP_OK(hipMemsetAsync(B.inc_key, 0xFF, (size_t)n * 8, st));
@@ -494,6 +494,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   double t0 = wall_s();
   double tlim = 0; for (int k = 0; k < n; ++k) tlim = std::max(tlim, h_tlim[k]);
   HIP_OK(hipEventRecord(X.ev0, st));
+  std::vector<int> h_done_now(n, 0); std::vector<double> h_tdone(n, -1.0);
   size_t nev = 0; int rounds = 0; long long launched_nodes = 0; bool timed_out = false;
   for (;;) {
     HIP_OK(hipMemsetAsync(B.batch_count, 0, 4, st));
@@ -502,7 +503,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     hipLaunchKernelGGL(roll_kernel, dim3(1), dim3(1), 0, st, B);
     int bc = 0;
     HIP_OK(hipMemcpyAsync(&bc, B.batch_count, 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(h_done_now.data(), B.inst_done, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
+    { const double tn = wall_s() - t0; for (int k = 0; k < n; ++k) if (h_done_now[k] && h_tdone[k] < 0) h_tdone[k] = tn; }   // completion time of every instance
     if (bc <= 0) break;
     if (bc > X.batch_cap) bc = X.batch_cap;
     if (wall_s() - t0 > tlim) { timed_out = true; break; }
@@ -630,7 +633,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     bool have = h_inc[k] < 1e299;
     bool unfinished = (h_flags[k] & 1) || h_oc[k] > 0 || !h_dn[k];
     (void)timed_out;
-    s->props.time = t_solve; s->props.NrIterations = (int)std::min<long long>(h_iters[k], 2147483647LL); s->props.nodes = h_nodes[k];
+    s->props.time = h_tdone[k] >= 0 ? h_tdone[k] : t_solve;   // batch: time from the start of the batch to the instance's proof s->props.NrIterations = (int)std::min<long long>(h_iters[k], 2147483647LL); s->props.nodes = h_nodes[k];
     s->props.NrSolutionPool = h_ninc[k];
     s->timing[0] = ms_all * 1e-3; s->timing[1] = ms_ipm * 1e-3; s->timing[2] = (double)(nev / 2); s->timing[3] = (double)launched_nodes;
     s->timing[4] = (double)tot_iters; s->timing[5] = (double)rowiters;
