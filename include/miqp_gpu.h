@@ -75,6 +75,23 @@ int miqp_solver_get_dims(const miqp_solver_t* s, int* out6);
 /* cplex.exportModel(".lp") debug output                        src/cplex_wrapper.cpp:150-154 */
 int miqp_solver_export_lp(const miqp_solver_t* s, const char* path);
 
+/* opl.printExternalData(): the loaded parameters as OPL external data (.dat syntax, re-readable by
+ * miqp_solver_load_dat and by OPL)                              src/cplex_wrapper.cpp:141-149
+ * (test_hardcoded_data_versus_datfile, test/cplex_wrapper_test.cc:474-505) */
+int miqp_solver_write_dat(const miqp_solver_t* s, const char* path);
+
+/* opl.printSolution(): every decision variable of the last solution as `name = [...]` blocks
+ * (layout of cplexmodel/modelRun.txt)                           src/cplex_wrapper.cpp:212-219 */
+int miqp_solver_write_solution(const miqp_solver_t* s, const char* path);
+
+/* cplex.writeMIPStarts(): the last solution as a CPLEX MIP start (.mst XML, variable names of the LP export)
+ *                                                               src/cplex_wrapper.cpp:206-209, 221-228 */
+int miqp_solver_write_mst(const miqp_solver_t* s, const char* path);
+
+/* cplex.readMIPStarts(): loads an .mst written by miqp_solver_write_mst (or by CPLEX for the exported .lp) as the
+ * MIP start of the next solve; returns 0 when the start was accepted  src/cplex_wrapper.cpp:128-138 */
+int miqp_solver_read_mst(miqp_solver_t* s, const char* path);
+
 /* continuous QP with the binaries of `fixed` asserted, solved by the device interior-point kernel
  * (used by the parity tests to compare the QP machinery with the CPU oracle and with K3);
  * returns 0 when feasible */

@@ -20,6 +20,7 @@
 #define MIQP_IPM_NT 64
 #endif
 #include "kernels.hip"
+#include "wire_formats.hpp"
 #include "lp_export.hpp"
 
 using namespace miqp;
@@ -749,6 +750,61 @@ int miqp_solver_last_timing(const miqp_solver_t* s, double* out6) {
 int miqp_solver_export_lp(const miqp_solver_t* s, const char* path) {
   if (!s || !s->has_inst || !path) return -1;
   return miqp::export_lp(s->inst, path);
+}
+
+namespace {
+// caller-independent RawResults record sized for the instance of `s`
+struct OwnedResults {
+  miqp_raw_results_c r{}; std::vector<std::vector<double>> d; std::vector<std::vector<int>> i;
+  explicit OwnedResults(const HostInst& I) {
+    const int C = I.C, N = I.N, R = I.R, E = I.E, O = I.O, L = I.L, K = I.C - 1;
+    r.N = N; r.NrEnvironments = E; r.NrRegions = R; r.NrObstacles = O; r.MaxLinesObstacles = L; r.NrCarToCarCollisions = K; r.NrCars = C;
+    auto D = [&](size_t n) { d.emplace_back(n ? n : 1, 9999999.0); return d.back().data(); };
+    auto J = [&](size_t n) { i.emplace_back(n ? n : 1, 9999999); return i.back().data(); };
+    d.reserve(16); i.reserve(24);
+    const size_t cn = (size_t)C * N;
+    r.u_x = D(cn); r.u_y = D(cn); r.pos_x = D(cn); r.vel_x = D(cn); r.acc_x = D(cn); r.pos_y = D(cn); r.vel_y = D(cn); r.acc_y = D(cn);
+    r.pos_x_front_UB = D(cn); r.pos_x_front_LB = D(cn); r.pos_y_front_UB = D(cn); r.pos_y_front_LB = D(cn);
+    r.notWithinEnvironmentRear = J(cn * E); r.notWithinEnvironmentFrontUbUb = J(cn * E); r.notWithinEnvironmentFrontLbUb = J(cn * E);
+    r.notWithinEnvironmentFrontUbLb = J(cn * E); r.notWithinEnvironmentFrontLbLb = J(cn * E); r.active_region = J(cn * R);
+    r.region_change_not_allowed_x_positive = J(cn); r.region_change_not_allowed_y_positive = J(cn); r.region_change_not_allowed_x_negative = J(cn);
+    r.region_change_not_allowed_y_negative = J(cn); r.region_change_not_allowed_combined = J(cn);
+    r.deltacc = J(cn * O * L); r.deltacc_front = J(cn * O * L * 4); r.car2car_collision = J((size_t)K * K * N * 16); r.slackvars = J((size_t)K * K * N * 4);
+    r.slackvarsObstacle = J(cn * O); r.slackvarsObstacle_front = J(cn * O * 4); r.slackvars_real = D((size_t)K * K * N * 4);
+  }
+};
+}  // namespace
+
+int miqp_solver_write_dat(const miqp_solver_t* s, const char* path) {
+  if (!s || !s->has_inst || !path) return -1;
+  FILE* f = std::fopen(path, "w"); if (!f) return -2;
+  bool ok = miqp::write_dat(s->inst, f);
+  return (std::fclose(f) == 0 && ok) ? 0 : -3;
+}
+
+int miqp_solver_write_solution(const miqp_solver_t* s, const char* path) {
+  if (!s || !s->has_sol || !path) return -1;
+  OwnedResults R(s->inst);
+  if (miqp_solver_get_results(s, &R.r) != 0) return -2;
+  FILE* f = std::fopen(path, "w"); if (!f) return -2;
+  bool ok = miqp::write_solution(R.r, s->props.objective, f);
+  return (std::fclose(f) == 0 && ok) ? 0 : -3;
+}
+
+int miqp_solver_write_mst(const miqp_solver_t* s, const char* path) {
+  if (!s || !s->has_sol || !path) return -1;
+  OwnedResults R(s->inst);
+  if (miqp_solver_get_results(s, &R.r) != 0) return -2;
+  FILE* f = std::fopen(path, "w"); if (!f) return -2;
+  bool ok = miqp::write_mst(R.r, s->props.objective, f);
+  return (std::fclose(f) == 0 && ok) ? 0 : -3;
+}
+
+int miqp_solver_read_mst(miqp_solver_t* s, const char* path) {
+  if (!s || !s->has_inst || !path) return -1;
+  OwnedResults R(s->inst);
+  if (miqp::read_mst(path, R.r) <= 0) return -2;
+  return miqp_solver_set_warmstart(s, &R.r, MIQP_WARMSTART_LAST_SOLUTION);
 }
 
 int miqp_solver_solve_fixed(miqp_solver_t* s, const miqp_raw_results_c* fixed, miqp_raw_results_c* out, double* objective, int* iterations) {

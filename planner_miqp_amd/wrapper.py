@@ -53,6 +53,8 @@ def load_library():
     L.miqp_solver_get_properties.restype = C.c_int; L.miqp_solver_get_properties.argtypes = [vp, C.POINTER(SolutionPropertiesC)]
     L.miqp_solver_get_dims.restype = C.c_int; L.miqp_solver_get_dims.argtypes = [vp, C.POINTER(C.c_int)]
     L.miqp_solver_export_lp.restype = C.c_int; L.miqp_solver_export_lp.argtypes = [vp, C.c_char_p]
+    for fn in (L.miqp_solver_write_dat, L.miqp_solver_write_solution, L.miqp_solver_write_mst, L.miqp_solver_read_mst):
+        fn.restype = C.c_int; fn.argtypes = [vp, C.c_char_p]
     L.miqp_solver_solve_fixed.restype = C.c_int
     L.miqp_solver_solve_fixed.argtypes = [vp, C.POINTER(RawResultsC), C.POINTER(RawResultsC), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.miqp_solver_last_timing.restype = C.c_int; L.miqp_solver_last_timing.argtypes = [vp, C.POINTER(C.c_double)]
@@ -65,7 +67,8 @@ EXPORTED_SYMBOLS = ["miqp_solver_create", "miqp_solver_destroy", "miqp_solver_se
                     "miqp_solver_override_settings", "miqp_solver_set_warmstart", "miqp_solver_solve",
                     "miqp_solver_solve_batch", "miqp_solver_get_results", "miqp_solver_get_properties",
                     "miqp_solver_get_dims", "miqp_solver_export_lp", "miqp_solver_solve_fixed",
-                    "miqp_solver_last_timing", "miqp_gpu_version"]
+                    "miqp_solver_last_timing", "miqp_gpu_version", "miqp_solver_write_dat", "miqp_solver_write_solution",
+                    "miqp_solver_write_mst", "miqp_solver_read_mst"]
 
 
 class OptimizationStatus(enum.IntEnum):  # src/cplex_wrapper.hpp:54-59
@@ -119,6 +122,8 @@ class CplexWrapper:
         self.debugOutputFilePath_ = ""
         self.debugOutputFilePrefix_ = ""
         self.print_debug_outputs_ = False
+        self.debugOutputParameterFilePath_ = ""
+        self.tmpWarmstartFile_ = "/tmp/warmstart_debug_res.mst"   # src/cplex_wrapper.hpp:104 (shared by all instances)
 
     def __del__(self):
         try:
@@ -175,7 +180,10 @@ class CplexWrapper:
         self.doWarmstart_ = wt if wt == WarmstartType.LAST_SOLUTION_WARMSTART else WarmstartType.BOTH_WARMSTART_STRATEGIES
 
     def deleteLastSolutionWarmstartFile(self):
+        """src/cplex_wrapper.cpp:482-488"""
         self._last = None
+        if os.path.exists(self.tmpWarmstartFile_):
+            os.remove(self.tmpWarmstartFile_)
 
     # ---- solve
     def _push_inputs(self):
@@ -191,12 +199,39 @@ class CplexWrapper:
         ws = None
         if self.doWarmstart_ in (WarmstartType.RECEDING_HORIZON_WARMSTART, WarmstartType.BOTH_WARMSTART_STRATEGIES):
             ws = self._warm
-        if ws is None and self.doWarmstart_ in (WarmstartType.LAST_SOLUTION_WARMSTART, WarmstartType.BOTH_WARMSTART_STRATEGIES):
-            ws = getattr(self, "_last", None)
         if ws is not None:
             wc = ws.to_c()
             self._L.miqp_solver_set_warmstart(self._h, C.byref(wc), int(self.doWarmstart_))
+        elif self.doWarmstart_ in (WarmstartType.LAST_SOLUTION_WARMSTART, WarmstartType.BOTH_WARMSTART_STRATEGIES):
+            # cplex.readMIPStarts(tmpWarmstartFile_) when the file exists (src/cplex_wrapper.cpp:128-138)
+            if os.path.exists(self.tmpWarmstartFile_):
+                self._L.miqp_solver_read_mst(self._h, self.tmpWarmstartFile_.encode())
         return 0
+
+    def _stamp(self, timestamp):
+        return "%.15g" % float(timestamp)
+
+    def _debug_before(self, timestamp):
+        """parameters_<t>.txt (OPL external data) and lpexport_<t>.lp (src/cplex_wrapper.cpp:141-155)"""
+        if not self.print_debug_outputs_:
+            return
+        base = os.path.join(self.debugOutputFilePath_, self.debugOutputFilePrefix_)
+        self.debugOutputParameterFilePath_ = base + "parameters_" + self._stamp(timestamp) + ".txt"
+        self._L.miqp_solver_write_dat(self._h, self.debugOutputParameterFilePath_.encode())
+        self._L.miqp_solver_export_lp(self._h, (base + "lpexport_" + self._stamp(timestamp) + ".lp").encode())
+
+    def _debug_after(self, timestamp, status):
+        """MIP start of the last solution and solution_<t>.txt / warmstartsolution_<t>.mst (src/cplex_wrapper.cpp:206-229)"""
+        if status != OptimizationStatus.SUCCESS:
+            return
+        last = self.doWarmstart_ in (WarmstartType.LAST_SOLUTION_WARMSTART, WarmstartType.BOTH_WARMSTART_STRATEGIES)
+        if last:
+            self._L.miqp_solver_write_mst(self._h, self.tmpWarmstartFile_.encode())
+        if self.print_debug_outputs_:
+            base = os.path.join(self.debugOutputFilePath_, self.debugOutputFilePrefix_)
+            self._L.miqp_solver_write_solution(self._h, (base + "solution_" + self._stamp(timestamp) + ".txt").encode())
+            if last:
+                self._L.miqp_solver_write_mst(self._h, (base + "warmstartsolution_" + self._stamp(timestamp) + ".mst").encode())
 
     def _collect(self, status):
         if status == OptimizationStatus.SUCCESS:
@@ -212,8 +247,10 @@ class CplexWrapper:
     def callCplex(self, timestamp=0.0):
         if self._push_inputs() != 0:
             return OptimizationStatus.FAILED_SEG_FAULT
-        st = self._L.miqp_solver_solve(self._h, float(timestamp))
-        return self._collect(st)
+        self._debug_before(timestamp)
+        st = self._collect(self._L.miqp_solver_solve(self._h, float(timestamp)))
+        self._debug_after(timestamp, st)
+        return st
 
     def getRawResults(self):
         return self._results
@@ -224,10 +261,16 @@ class CplexWrapper:
         return SolutionProperties(p)
 
     def getTmpWarmstartFile(self):
-        return "/tmp/warmstart_debug_res.mst"
+        return self.tmpWarmstartFile_
 
     def getDebugOutputParameterFilePath(self):
-        return ""
+        return self.debugOutputParameterFilePath_
+
+    def writeDat(self, path):
+        """the parameters of the next solve as OPL external data (no device needed)"""
+        if self._push_inputs() != 0:
+            return -1
+        return self._L.miqp_solver_write_dat(self._h, path.encode())
 
     # ---- extras of this implementation
     def solveFixed(self, fixed: RawResults):

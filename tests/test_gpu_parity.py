@@ -1,5 +1,7 @@
 """Parity of the HIP solver (through the C ABI) with the CPU oracle and the reference's known answers.
 All tests here need a real MI355X: run with  python -m pytest tests -m gpu."""
+import os
+
 import numpy as np
 import pytest
 
@@ -148,6 +150,47 @@ def test_three_car_reference_fixture_beats_the_recorded_cplex_point(oracle):
     assert v < 1e-5, worst
     assert abs(obj - pr.objective) <= 1e-6 * max(1.0, abs(obj))
     assert pr.objective <= 741.2226
+
+
+def test_debug_outputs_round_trip(tmp_path):
+    """test_hardcoded_data_versus_datfile (test/cplex_wrapper_test.cc:474-505): the parameter file written by the debug
+    output of a CPPINPUTS solve, read back as DATFILE, gives the same status, objective and gap; the solution print and the
+    LP export are written next to it (src/cplex_wrapper.cpp:141-155, 212-219)"""
+    p = load_params("cplexmodel_testcase.dat")
+    p.relative_mip_gap_tolerance = 1e-3
+    cw = P.CplexWrapper("cplexmodel.mod", P.ParameterSource.CPPINPUTS, 12)
+    cw.resetParameters(p)
+    cw.setDebugOutputFilePath(str(tmp_path)); cw.setDebugOutputFilePrefix("rt_"); cw.setDebugOutputPrint(True)
+    assert int(cw.callCplex()) == 0
+    datfile = cw.getDebugOutputParameterFilePath()
+    assert datfile.endswith("rt_parameters_0.txt") and (tmp_path / "rt_lpexport_0.lp").exists() and (tmp_path / "rt_solution_0.txt").exists()
+    cw2 = P.CplexWrapper("cplexmodel.mod", P.ParameterSource.DATFILE, 12)
+    cw2.setParameterDatFileAbsolute(datfile)
+    assert int(cw2.callCplex()) == 0
+    a, b = cw.getSolutionProperties(), cw2.getSolutionProperties()
+    # EXPECT_DOUBLE_EQ: within 4 units in the last place
+    assert a.status == b.status and abs(a.objective - b.objective) <= 4 * np.spacing(abs(a.objective)) and abs(a.gap - b.gap) <= 4 * np.spacing(max(abs(a.gap), 1e-300))
+    txt = open(tmp_path / "rt_solution_0.txt").read()
+    assert "pos_x = [[" in txt and "active_region = [[[" in txt
+
+
+def test_last_solution_warmstart_through_mst_file(tmp_path):
+    """LAST_SOLUTION_WARMSTART (src/cplex_wrapper.cpp:128-138, 206-209): the solve writes an .mst, the next solve reads
+    it as MIP start; the start is accepted as first incumbent (objective not worse, far fewer nodes)"""
+    p = synthetic.generate("cfg3", 3, gap=0.01, max_time=10)
+    w = P.CplexWrapper(); w.tmpWarmstartFile_ = str(tmp_path / "ws.mst")
+    w.resetParameters(p); w.setLastSolutionWarmstart(); w.deleteLastSolutionWarmstartFile()
+    assert int(w.callCplex()) == 0
+    first = w.getSolutionProperties()
+    assert os.path.exists(w.getTmpWarmstartFile()) and "<CPLEXSolution" in open(w.getTmpWarmstartFile()).read()
+    w2 = P.CplexWrapper(); w2.tmpWarmstartFile_ = w.tmpWarmstartFile_
+    w2.resetParameters(p); w2.setLastSolutionWarmstart()
+    assert int(w2.callCplex()) == 0
+    second = w2.getSolutionProperties()
+    assert second.objective <= first.objective * (1 + 1e-9)
+    assert second.NrSolutionPool >= 1
+    w2.deleteLastSolutionWarmstartFile()
+    assert not os.path.exists(w.getTmpWarmstartFile())
 
 
 def test_batch_equals_single_solves():
