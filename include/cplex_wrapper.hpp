@@ -79,7 +79,7 @@ class CplexWrapper {
   void setLastSolutionWarmstart(WarmstartType wt = LAST_SOLUTION_WARMSTART) {
     doWarmstart_ = wt != LAST_SOLUTION_WARMSTART ? BOTH_WARMSTART_STRATEGIES : wt;
   }
-  void deleteLastSolutionWarmstartFile() { lastSolution_.reset(); }
+  void deleteLastSolutionWarmstartFile() { lastSolution_.reset(); std::remove(tmpWarmstartFile_.c_str()); }  // cplex_wrapper.cpp:482-488
   void setParameterDatFileRelative(const char* datfile) { datfile_ = std::string("cplexmodel/") + datfile; }
   void setParameterDatFileAbsolute(const char* datfile) { datfile_ = datfile; }
   void resetParameters(std::shared_ptr<ModelParameters> parameters) { parameters_ = parameters; }
@@ -99,12 +99,27 @@ class CplexWrapper {
       if (parameterSource_ == DATFILE) { if (miqp_solver_load_dat(h_, datfile_.c_str()) != 0) return FAILED_SEG_FAULT; }
       else { if (!parameters_ || !pushParameters()) return FAILED_SEG_FAULT; }
       if (doWarmstart_ == RECEDING_HORIZON_WARMSTART || doWarmstart_ == BOTH_WARMSTART_STRATEGIES) pushWarmstart(*warmstartValues_);
-      else if (doWarmstart_ == LAST_SOLUTION_WARMSTART && lastSolution_) pushWarmstart(*lastSolution_);
+      else if (doWarmstart_ == LAST_SOLUTION_WARMSTART || doWarmstart_ == BOTH_WARMSTART_STRATEGIES)
+        miqp_solver_read_mst(h_, tmpWarmstartFile_.c_str());   // readMIPStarts when the file exists (cplex_wrapper.cpp:128-138)
+      const std::string base = debugOutputFilePath_ + "/" + debugOutputFilePrefix_, stamp = stampOf(timestemp);
+      if (print_debug_outputs_) {  // cplex_wrapper.cpp:141-155
+        debugOutputParameterFilePath_ = base + "parameters_" + stamp + ".txt";
+        miqp_solver_write_dat(h_, debugOutputParameterFilePath_.c_str());
+        miqp_solver_export_lp(h_, (base + "lpexport_" + stamp + ".lp").c_str());
+      }
       int st = miqp_solver_solve(h_, timestemp);
       miqp_solution_properties_c p{}; miqp_solver_get_properties(h_, &p);
       solutionProperties_ = {p.status, p.gap, p.objective, p.time, p.NrConstraints, p.NrBinaryVariables, p.NrFloatVariables,
                              p.NonZeroCoefficients, p.NrIterations, p.NrSolutionPool};
-      if (st == SUCCESS) { pullResults(); lastSolution_ = std::make_shared<RawResults>(*rawResults_); }
+      if (st == SUCCESS) {
+        pullResults(); lastSolution_ = std::make_shared<RawResults>(*rawResults_);
+        const bool last = doWarmstart_ == LAST_SOLUTION_WARMSTART || doWarmstart_ == BOTH_WARMSTART_STRATEGIES;
+        if (last) miqp_solver_write_mst(h_, tmpWarmstartFile_.c_str());                     // cplex_wrapper.cpp:206-209
+        if (print_debug_outputs_) {                                                           // cplex_wrapper.cpp:212-229
+          miqp_solver_write_solution(h_, (base + "solution_" + stamp + ".txt").c_str());
+          if (last) miqp_solver_write_mst(h_, (base + "warmstartsolution_" + stamp + ".mst").c_str());
+        }
+      }
       return static_cast<OptimizationStatus>(st);
     } catch (...) {
       return FAILED_SEG_FAULT;  // src/cplex_wrapper.cpp:97-109,162-180: every exception maps to this code
@@ -119,11 +134,13 @@ class CplexWrapper {
   std::string getDebugOutputParameterFilePath() const { return debugOutputParameterFilePath_; }
   void setSpecialOrderedSets(bool in) { useSpecialOrderedSets_ = in; }       // search hint of CPLEX: no effect on the result
   void setUseBranchingPriorities(bool in) { useBranchingPriorities_ = in; }  // idem
-  std::string getTmpWarmstartFile() { return "/tmp/warmstart_debug_res.mst"; }
+  std::string getTmpWarmstartFile() { return tmpWarmstartFile_; }
   void setBranchingPriorityValueExtent(int value, int extent) { prioValue_ = value; prioExtent_ = extent; }
   void setBufferCplexOutputsToStream(bool) {}
 
  private:
+  static std::string stampOf(double t) { char b[64]; std::snprintf(b, sizeof(b), "%.15g", t); return b; }  // << setprecision(15)
+  std::string tmpWarmstartFile_ = "/tmp/warmstart_debug_res.mst";  // src/cplex_wrapper.hpp:104
   template <class V> static std::vector<double> vec(const V& v) { return std::vector<double>(v.data(), v.data() + v.size()); }
   static std::vector<double> rowMajor(const Eigen::MatrixXd& m) {
     std::vector<double> o((size_t)m.rows() * m.cols());
