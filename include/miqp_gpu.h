@@ -103,6 +103,31 @@ int miqp_solver_solve_fixed(miqp_solver_t* s, const miqp_raw_results_c* fixed, m
  * out[3] = node relaxations solved, out[4] = IPM iterations (summed over nodes), out[5] = rows x iterations */
 int miqp_solver_last_timing(const miqp_solver_t* s, double* out6);
 
+/* ---- planner core: the host logic directly above the solve ---- */
+
+/* ParameterPreparer::CalculateFractionParameters             common/parameter/parameter_preparer.cpp:37-52; out[R*4] */
+int miqp_fraction_parameters(int nr_regions, float max_velocity_fitting, double* out);
+/* ParameterPreparer::CalculateMeanAngleVector                 parameter_preparer.cpp:96-113; out[R] */
+int miqp_mean_angles(const double* fraction_parameters, int nr_regions, double* out);
+/* CalculateAccLimitsPerCar / CalculateJerkLimitsPerCar (RotateLimitVectors)   parameter_preparer.cpp:54-94, 115-143
+ * acc: (acc_min, acc_max, -acc_lat, +acc_lat); jerk: (-jerk_max, jerk_max, -jerk_lat, +jerk_lat); four arrays of R */
+int miqp_limits_per_region(const double* fraction_parameters, int nr_regions, float long_min, float long_max, float lat_min, float lat_max,
+                           double* min_x, double* max_x, double* min_y, double* max_y);
+/* CalculateRegionIdx                                          common/parameter/regions.cpp:16-33; returns the count */
+int miqp_calculate_region_idx(const double* fraction_parameters, int nr_regions, float vx, float vy, int* out);
+/* ReserveNeighborRegions on one row of nr_regions flags       regions.cpp:75-112 */
+int miqp_reserve_neighbor_regions(int* row, int nr_regions, int expansions);
+/* CalculatePossibleRegions                                    regions.cpp:114-127; flags[R] */
+int miqp_calculate_possible_regions(const double* fraction_parameters, int nr_regions, const double* theta_ref, int n, int* flags);
+/* MiqpPlanner::CalculateWarmstart: last solution shifted by one step (with its quirks)   src/miqp_planner.cpp:787-1051 */
+int miqp_calculate_warmstart(const miqp_raw_results_c* last, miqp_raw_results_c* out, double ts, double minimum_region_change_speed);
+/* MiqpPlanner::Plan, region-combination retry loop            src/miqp_planner.cpp:634-645, 692-766
+ * initial_region[C] / possible_region[C*R] are the caller's arrays (p is re-pointed to them) and are updated in place as
+ * the reference updates its ModelParameters; returns 1 when a combination solved (Plan() == true),
+ * *status_out = last OptimizationStatus */
+int miqp_plan(miqp_solver_t* s, miqp_model_params_c* p, int* initial_region, int* possible_region, const miqp_raw_results_c* warmstart,
+              int warmstart_type, double timestamp, int* status_out);
+
 const char* miqp_gpu_version(void);
 
 #ifdef __cplusplus

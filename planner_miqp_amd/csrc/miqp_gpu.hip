@@ -21,6 +21,7 @@
 #endif
 #include "kernels.hip"
 #include "wire_formats.hpp"
+#include "planner_core.hpp"
 #include "lp_export.hpp"
 
 using namespace miqp;
@@ -365,18 +366,22 @@ bool fix_from_results(const HostInst& I, const Layout& Y, const int* T, const mi
     for (int i = 1; i < N; ++i) {
       int j = -1; for (int jj = 0; jj < R; ++jj) if (f->active_region[(c * N + i) * R + jj] == 1) j = jj;
       int q = -1; for (int k = 0; k < T[Y.i_nposs + c]; ++k) if (T[Y.i_regj + c * Y.P + k] == j) q = k;
-      if (q < 0) return false;
-      int h = 3;
-      if (f->region_change_not_allowed_combined[c * N + i] != 1) {
-        h = 0;
-        for (int k = 0; k < T[Y.i_nhs + c * Y.P + q]; ++k) {
-          const int* hs = T + Y.i_hs + ((c * Y.P + q) * 2 + k) * 2;
-          int b = hs[0] == 0 ? (hs[1] > 0 ? f->region_change_not_allowed_x_positive[c * N + i] : f->region_change_not_allowed_x_negative[c * N + i])
-                             : (hs[1] > 0 ? f->region_change_not_allowed_y_positive[c * N + i] : f->region_change_not_allowed_y_negative[c * N + i]);
-          if (b == 0) { h = k; break; }
+      // a step without a (possible) active region stays undecided: the start is then a partial assignment that the
+      // search completes (CPLEX repairs / completes partial MIP starts; the shifted receding-horizon start has an
+      // all-zero last region row, src/miqp_planner.cpp:982)
+      if (q >= 0) {
+        int h = 3;
+        if (f->region_change_not_allowed_combined[c * N + i] != 1) {
+          h = 0;
+          for (int k = 0; k < T[Y.i_nhs + c * Y.P + q]; ++k) {
+            const int* hs = T + Y.i_hs + ((c * Y.P + q) * 2 + k) * 2;
+            int b = hs[0] == 0 ? (hs[1] > 0 ? f->region_change_not_allowed_x_positive[c * N + i] : f->region_change_not_allowed_x_negative[c * N + i])
+                               : (hs[1] > 0 ? f->region_change_not_allowed_y_positive[c * N + i] : f->region_change_not_allowed_y_negative[c * N + i]);
+            if (b == 0) { h = k; break; }
+          }
         }
+        fix[Y.f_reg + c * N + i] = (signed char)(q * 4 + h);
       }
-      fix[Y.f_reg + c * N + i] = (signed char)(q * 4 + h);
       const int* nw[5] = {f->notWithinEnvironmentRear, f->notWithinEnvironmentFrontUbUb, f->notWithinEnvironmentFrontLbUb,
                           f->notWithinEnvironmentFrontUbLb, f->notWithinEnvironmentFrontLbLb};
       for (int pt = 0; pt < 5; ++pt) {
@@ -750,6 +755,72 @@ int miqp_solver_last_timing(const miqp_solver_t* s, double* out6) {
 int miqp_solver_export_lp(const miqp_solver_t* s, const char* path) {
   if (!s || !s->has_inst || !path) return -1;
   return miqp::export_lp(s->inst, path);
+}
+
+// ---------------------------------------------------------------- planner core (rows f1 / f2 of SURVEY.md section 8)
+int miqp_fraction_parameters(int nr_regions, float max_velocity_fitting, double* out) {
+  if (nr_regions < 1 || !out) return -1;
+  miqp::fraction_parameters(nr_regions, max_velocity_fitting, out); return 0;
+}
+int miqp_mean_angles(const double* fraction_parameters, int nr_regions, double* out) {
+  if (!fraction_parameters || nr_regions < 1 || !out) return -1;
+  miqp::mean_angles(fraction_parameters, nr_regions, out); return 0;
+}
+int miqp_limits_per_region(const double* fraction_parameters, int nr_regions, float long_min, float long_max, float lat_min, float lat_max,
+                           double* min_x, double* max_x, double* min_y, double* max_y) {
+  if (!fraction_parameters || nr_regions < 1 || !min_x || !max_x || !min_y || !max_y) return -1;
+  miqp::limits_per_region(fraction_parameters, nr_regions, long_min, long_max, lat_min, lat_max, min_x, max_x, min_y, max_y); return 0;
+}
+int miqp_calculate_region_idx(const double* fraction_parameters, int nr_regions, float vx, float vy, int* out) {
+  if (!fraction_parameters || nr_regions < 1 || !out) return -1;
+  return miqp::calculate_region_idx(fraction_parameters, nr_regions, vx, vy, out);
+}
+int miqp_reserve_neighbor_regions(int* row, int nr_regions, int expansions) {
+  if (!row || nr_regions < 1) return -1;
+  return miqp::reserve_neighbor_regions(row, nr_regions, expansions) ? 1 : 0;
+}
+int miqp_calculate_possible_regions(const double* fraction_parameters, int nr_regions, const double* theta_ref, int n, int* flags) {
+  if (!fraction_parameters || nr_regions < 1 || !theta_ref || !flags) return -1;
+  miqp::calculate_possible_regions(fraction_parameters, nr_regions, theta_ref, n, flags); return 0;
+}
+int miqp_calculate_warmstart(const miqp_raw_results_c* last, miqp_raw_results_c* out, double ts, double minimum_region_change_speed) {
+  if (!last || !out || last->N != out->N || last->NrCars != out->NrCars || last->NrRegions != out->NrRegions || last->N < 2) return -1;
+  miqp::calculate_warmstart(*last, *out, ts, minimum_region_change_speed); return 0;
+}
+
+// MiqpPlanner::Plan, the part between the environment update and the trajectory read-out (src/miqp_planner.cpp:634-645,
+// 692-766): initial regions of every car from its initial velocity, all combinations, one solve per combination until
+// one succeeds; the start region is made possible for the attempt and rolled back when the attempt fails.
+int miqp_plan(miqp_solver_t* s, miqp_model_params_c* p, int* initial_region, int* possible_region, const miqp_raw_results_c* warmstart, int warmstart_type,
+              double timestamp, int* status_out) {
+  if (!s || !p || !initial_region || !possible_region || p->NumCars < 1 || p->nr_regions < 1) return 0;
+  p->initial_region = initial_region; p->possible_region = possible_region;
+  const int C = p->NumCars, R = p->nr_regions;
+  std::vector<std::vector<int>> per_car(C), combos;
+  std::vector<int> idx(R);
+  for (int c = 0; c < C; ++c) {
+    int m = miqp::calculate_region_idx(p->fraction_parameters, R, (float)p->IntitialState[c * 6 + 1], (float)p->IntitialState[c * 6 + 4], idx.data());
+    per_car[c].assign(idx.begin(), idx.begin() + m);
+    if (m < 1) return 0;
+  }
+  miqp::region_combinations(per_car, combos);
+  int status = MIQP_STATUS_FAILED_NO_SOLUT;
+  std::vector<char> rollback(C, 0);
+  for (auto& comb : combos) {
+    for (int c = 0; c < C; ++c) {
+      initial_region[c] = comb[c] + 1;   // OPL is 1-based
+      if (possible_region[c * R + comb[c]] == 0) { possible_region[c * R + comb[c]] = 1; rollback[c] = 1; } else rollback[c] = 0;
+    }
+    if (miqp_solver_set_params(s, p) != 0) { status = MIQP_STATUS_FAILED_SEG_FAULT; break; }
+    if ((warmstart_type == MIQP_WARMSTART_RECEDING_HORIZON || warmstart_type == MIQP_WARMSTART_BOTH) && warmstart)
+      miqp_solver_set_warmstart(s, warmstart, warmstart_type);
+    status = miqp_solver_solve(s, timestamp);
+    if (status == MIQP_STATUS_SUCCESS) break;
+    if (status == MIQP_STATUS_FAILED_SEG_FAULT || status == MIQP_STATUS_FAILED_TIMEOUT) break;
+    for (int c = 0; c < C; ++c) if (rollback[c]) possible_region[c * R + comb[c]] = 0;
+  }
+  if (status_out) *status_out = status;
+  return status == MIQP_STATUS_SUCCESS ? 1 : 0;
 }
 
 namespace {

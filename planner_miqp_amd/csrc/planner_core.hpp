@@ -1,0 +1,175 @@
+// planner_core.hpp - bark-free restatement of the host logic that sits directly on top of the solve path:
+//   * region tables and region bookkeeping   common/parameter/parameter_preparer.cpp:37-143, regions.cpp:16-127
+//   * receding-horizon warm start (shift by one step)                src/miqp_planner.cpp:787-1051
+//   * the region-combination retry loop of MiqpPlanner::Plan         src/miqp_planner.cpp:633-766
+// Plain arrays in, plain arrays out; float where the reference computes in float (the rotated limits, the region test).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/miqp_types.h"
+
+namespace miqp {
+
+// fraction_parameters: sector k is bounded by the rays through (F[k][0], F[k][1]) and (F[k][2], F[k][3])
+// (ParameterPreparer::CalculateFractionParameters, parameter_preparer.cpp:37-52; maxVelocityFitting is a float there)
+inline void fraction_parameters(int R, float vmax_fit, double* out) {
+  for (int k = 0; k < R; ++k) {
+    const double step = (2.0 * M_PI - 0.0) / R;   // Eigen setLinSpaced(0, 2 pi) over R + 1 points: low + k * step, head(R)
+    double a0 = 0.0 + k * step;
+    out[k * 4 + 0] = vmax_fit * std::cos(a0); out[k * 4 + 1] = vmax_fit * std::sin(a0);
+  }
+  for (int k = 0; k < R; ++k) { int n = (k + 1) % R; out[k * 4 + 2] = out[n * 4 + 0]; out[k * 4 + 3] = out[n * 4 + 1]; }
+}
+
+inline double wrap_2pi(double a) { a = std::fmod(a, 2.0 * M_PI); if (a < 0) a += 2.0 * M_PI; return a; }
+
+// ParameterPreparer::CalculateMeanAngleVector (parameter_preparer.cpp:96-113)
+inline void mean_angles(const double* F, int R, double* out) {
+  for (int k = 0; k < R; ++k) {
+    double a1 = wrap_2pi(std::atan2(F[k * 4 + 1], F[k * 4 + 0])), a2 = wrap_2pi(std::atan2(F[k * 4 + 3], F[k * 4 + 2]));
+    if (k + 1 == R) a2 += M_PI * 2.0;
+    out[k] = 0.5 * (a1 + a2);
+  }
+}
+
+// RotateLimitVectors (parameter_preparer.cpp:115-143): the box of the four rotated corner sums, in float
+inline void rotate_limits(float long_min, float long_max, float lat_min, float lat_max, float angle, float& min_x, float& max_x, float& min_y, float& max_y) {
+  auto rot = [&](float x, float y, float& ox, float& oy) { ox = x * std::cos(angle) - y * std::sin(angle); oy = x * std::sin(angle) + y * std::cos(angle); };
+  float x[4], y[4];
+  rot(long_max, lat_max, x[0], y[0]); rot(long_max, lat_min, x[1], y[1]); rot(long_min, lat_max, x[2], y[2]); rot(long_min, lat_min, x[3], y[3]);
+  max_x = std::max(std::max(x[0], x[1]), std::max(x[2], x[3])); min_x = std::min(std::min(x[0], x[1]), std::min(x[2], x[3]));
+  max_y = std::max(std::max(y[0], y[2]), std::max(y[3], y[1])); min_y = std::min(std::min(y[0], y[2]), std::min(y[3], y[1]));
+  if (max_x < min_x) std::swap(max_x, min_x);
+  if (max_y < min_y) std::swap(max_y, min_y);
+}
+
+// CalculateAccLimitsPerCar / CalculateJerkLimitsPerCar (parameter_preparer.cpp:54-94): out[4][R] = min_x, max_x, min_y, max_y
+inline void limits_per_region(const double* F, int R, float long_min, float long_max, float lat_min, float lat_max, double* min_x, double* max_x, double* min_y, double* max_y) {
+  std::vector<double> ang(R); mean_angles(F, R, ang.data());
+  for (int k = 0; k < R; ++k) {
+    float a, b, c, d; rotate_limits(long_min, long_max, lat_min, lat_max, (float)ang[k], a, b, c, d);
+    min_x[k] = a; max_x[k] = b; min_y[k] = c; max_y[k] = d;
+  }
+}
+
+// CalculateRegionIdx (regions.cpp:16-33): every sector whose two half-planes hold within eps = 1e-3 (float vx, vy);
+// returns the count, indices ascending (the multimap iterates the non-initial entries in insertion order)
+inline int calculate_region_idx(const double* F, int R, float vx, float vy, int* out) {
+  const float eps = 1e-3f; int n = 0;
+  for (int k = 0; k < R; ++k) {
+    bool below_ub = F[k * 4 + 2] * vy <= F[k * 4 + 3] * vx + eps;
+    bool above_lb = F[k * 4 + 0] * vy >= F[k * 4 + 1] * vx - eps;
+    if (below_ub && above_lb) out[n++] = k;
+  }
+  return n;
+}
+
+// ReserveNeighborRegions (regions.cpp:75-112) on one row of R flags, including its quirk: `first`/`last` start as
+// numeric_limits<int>::quiet_NaN() == 0 and isnan(int) is never true, so a row without a 0/1 border sets region 0
+inline bool reserve_neighbor_regions(int* row, int R, int expansions) {
+  for (int e = 0; e < (expansions > 1 ? expansions : 1); ++e) {
+    int first = 0, last = 0;
+    for (int i = 0; i < R; ++i)
+      if (row[i] == 1) {
+        if (i >= 1 && row[i - 1] == 0) first = i - 1;
+        if (i + 1 < R && row[i + 1] == 0) last = i + 1;
+        if (i == 0 && row[R - 1] == 0) first = R - 1;
+        if (i == R - 1 && row[0] == 0) last = 0;
+      }
+    row[first] = 1; row[last] = 1;
+  }
+  return true;
+}
+
+// CalculatePossibleRegions (regions.cpp:114-127): union of the regions of the headings theta[k]
+inline void calculate_possible_regions(const double* F, int R, const double* theta, int n, int* flags) {
+  std::vector<int> idx(R);
+  for (int k = 0; k < R; ++k) flags[k] = 0;
+  for (int k = 0; k < n; ++k) { int m = calculate_region_idx(F, R, (float)std::cos(theta[k]), (float)std::sin(theta[k]), idx.data()); for (int q = 0; q < m; ++q) flags[idx[q]] = 1; }
+}
+
+// CalculateRegionCombinations (regions.cpp:45-62): cartesian product, car 0 slowest; per car the candidate marked as
+// initial region (SetInitialRegion) comes first, the others ascending
+inline void region_combinations(const std::vector<std::vector<int>>& per_car, std::vector<std::vector<int>>& out) {
+  out.clear(); std::vector<int> cur;
+  struct Rec { static void go(const std::vector<std::vector<int>>& pc, size_t c, std::vector<int>& cur, std::vector<std::vector<int>>& out) {
+    if (c == pc.size()) { out.push_back(cur); return; }
+    for (int r : pc[c]) { cur.push_back(r); go(pc, c + 1, cur, out); cur.pop_back(); } } };
+  Rec::go(per_car, 0, cur, out);
+}
+
+// ---------------------------------------------------------------- MiqpPlanner::CalculateWarmstart (miqp_planner.cpp:787-1051)
+// `w` (same sizes as `rr`, caller allocated) receives the last solution shifted by one step.  Quirks kept:
+// the last step of every binary family except the region-change flags is copied UNSHIFTED from the last step of `rr`
+// (:951-963, 997-1001, 1029-1046); the last-step active_region row stays all zero because `:982` is an expression
+// without effect; slackvarsObstacle* are not touched (they keep whatever `w` held); u of the last step is zero and the
+// last state is one explicit Euler step of the shifted step N-2 (:884-918).
+inline void calculate_warmstart(const miqp_raw_results_c& rr, miqp_raw_results_c& w, double ts, double min_region_change_speed) {
+  const int C = rr.NrCars, N = rr.N, R = rr.NrRegions, E = rr.NrEnvironments, O = rr.NrObstacles, L = rr.MaxLinesObstacles, K = rr.NrCarToCarCollisions;
+  auto shift2d = [&](double* dst, const double* src) { for (int c = 0; c < C; ++c) for (int i = 0; i + 1 < N; ++i) dst[c * N + i] = src[c * N + i + 1]; };
+  auto shift2i = [&](int* dst, const int* src) { for (int c = 0; c < C; ++c) for (int i = 0; i + 1 < N; ++i) dst[c * N + i] = src[c * N + i + 1]; };
+  shift2d(w.u_x, rr.u_x); shift2d(w.u_y, rr.u_y); shift2d(w.pos_x, rr.pos_x); shift2d(w.vel_x, rr.vel_x); shift2d(w.acc_x, rr.acc_x);
+  shift2d(w.pos_y, rr.pos_y); shift2d(w.vel_y, rr.vel_y); shift2d(w.acc_y, rr.acc_y);
+  shift2d(w.pos_x_front_UB, rr.pos_x_front_UB); shift2d(w.pos_x_front_LB, rr.pos_x_front_LB);
+  shift2d(w.pos_y_front_UB, rr.pos_y_front_UB); shift2d(w.pos_y_front_LB, rr.pos_y_front_LB);
+  shift2i(w.region_change_not_allowed_combined, rr.region_change_not_allowed_combined);
+  shift2i(w.region_change_not_allowed_x_negative, rr.region_change_not_allowed_x_negative);
+  shift2i(w.region_change_not_allowed_x_positive, rr.region_change_not_allowed_x_positive);
+  shift2i(w.region_change_not_allowed_y_negative, rr.region_change_not_allowed_y_negative);
+  shift2i(w.region_change_not_allowed_y_positive, rr.region_change_not_allowed_y_positive);
+  for (int c = 0; c < C; ++c) {
+    const int a = c * N + N - 1, b = c * N + N - 2;
+    w.u_x[a] = 0; w.u_y[a] = 0;
+    w.pos_x[a] = w.pos_x[b] + ts * w.vel_x[b]; w.pos_y[a] = w.pos_y[b] + ts * w.vel_y[b];
+    w.vel_x[a] = w.vel_x[b] + ts * w.acc_x[b]; w.vel_y[a] = w.vel_y[b] + ts * w.acc_y[b];
+    w.acc_x[a] = w.acc_x[b] + ts * w.u_x[b]; w.acc_y[a] = w.acc_y[b] + ts * w.u_y[b];
+    w.pos_x_front_UB[a] = w.pos_x_front_UB[b] + ts * w.vel_x[b]; w.pos_x_front_LB[a] = w.pos_x_front_LB[b] + ts * w.vel_x[b];
+    w.pos_y_front_UB[a] = w.pos_y_front_UB[b] + ts * w.vel_y[b]; w.pos_y_front_LB[a] = w.pos_y_front_LB[b] + ts * w.vel_y[b];
+    const int xp = w.vel_x[a] <= min_region_change_speed, yp = w.vel_y[a] <= min_region_change_speed;
+    const int xn = w.vel_x[a] >= -min_region_change_speed, yn = w.vel_y[a] >= -min_region_change_speed;
+    w.region_change_not_allowed_x_positive[a] = xp; w.region_change_not_allowed_y_positive[a] = yp;
+    w.region_change_not_allowed_x_negative[a] = xn; w.region_change_not_allowed_y_negative[a] = yn;
+    w.region_change_not_allowed_combined[a] = (xp + yp + xn + yn) > 3;
+  }
+  if (E > 0) {
+    int* dst[5] = {w.notWithinEnvironmentRear, w.notWithinEnvironmentFrontUbUb, w.notWithinEnvironmentFrontUbLb, w.notWithinEnvironmentFrontLbUb, w.notWithinEnvironmentFrontLbLb};
+    const int* src[5] = {rr.notWithinEnvironmentRear, rr.notWithinEnvironmentFrontUbUb, rr.notWithinEnvironmentFrontUbLb, rr.notWithinEnvironmentFrontLbUb, rr.notWithinEnvironmentFrontLbLb};
+    for (int f = 0; f < 5; ++f)
+      for (int q = 0; q < C * E; ++q) { for (int i = 0; i + 1 < N; ++i) dst[f][q * N + i] = src[f][q * N + i + 1]; dst[f][q * N + N - 1] = src[f][q * N + N - 1]; }
+  }
+  for (int c = 0; c < C; ++c) {
+    for (int i = 0; i + 1 < N; ++i) for (int j = 0; j < R; ++j) w.active_region[(c * N + i) * R + j] = rr.active_region[(c * N + i + 1) * R + j];
+    for (int j = 0; j < R; ++j) w.active_region[(c * N + N - 1) * R + j] = 0;
+  }
+  if (K > 0) {
+    for (int q = 0; q < K * K; ++q) {
+      for (int i = 0; i + 1 < N; ++i) for (int s = 0; s < 16; ++s) w.car2car_collision[(q * N + i) * 16 + s] = rr.car2car_collision[(q * N + i + 1) * 16 + s];
+      for (int s = 0; s < 16; ++s) w.car2car_collision[(q * N + N - 1) * 16 + s] = rr.car2car_collision[(q * N + N - 1) * 16 + s];
+      for (int i = 0; i + 1 < N; ++i) for (int s = 0; s < 4; ++s) {
+        w.slackvars[(q * N + i) * 4 + s] = rr.slackvars[(q * N + i + 1) * 4 + s];
+        if (w.slackvars_real && rr.slackvars_real) w.slackvars_real[(q * N + i) * 4 + s] = rr.slackvars_real[(q * N + i + 1) * 4 + s];
+      }
+      for (int s = 0; s < 4; ++s) {
+        w.slackvars[(q * N + N - 1) * 4 + s] = rr.slackvars[(q * N + N - 1) * 4 + s];
+        if (w.slackvars_real && rr.slackvars_real) w.slackvars_real[(q * N + N - 1) * 4 + s] = rr.slackvars_real[(q * N + N - 1) * 4 + s];
+      }
+    }
+  }
+  if (O > 0) {
+    for (int q = 0; q < C * O; ++q) {
+      for (int i = 0; i + 1 < N; ++i) for (int k = 0; k < L; ++k) {
+        w.deltacc[(q * N + i) * L + k] = rr.deltacc[(q * N + i + 1) * L + k];
+        for (int s = 0; s < 4; ++s) w.deltacc_front[((q * N + i) * L + k) * 4 + s] = rr.deltacc_front[((q * N + i + 1) * L + k) * 4 + s];
+      }
+      for (int k = 0; k < L; ++k) {
+        w.deltacc[(q * N + N - 1) * L + k] = rr.deltacc[(q * N + N - 1) * L + k];
+        for (int s = 0; s < 4; ++s) w.deltacc_front[((q * N + N - 1) * L + k) * 4 + s] = rr.deltacc_front[((q * N + N - 1) * L + k) * 4 + s];
+      }
+    }
+  }
+}
+
+}  // namespace miqp

@@ -68,7 +68,9 @@ EXPORTED_SYMBOLS = ["miqp_solver_create", "miqp_solver_destroy", "miqp_solver_se
                     "miqp_solver_solve_batch", "miqp_solver_get_results", "miqp_solver_get_properties",
                     "miqp_solver_get_dims", "miqp_solver_export_lp", "miqp_solver_solve_fixed",
                     "miqp_solver_last_timing", "miqp_gpu_version", "miqp_solver_write_dat", "miqp_solver_write_solution",
-                    "miqp_solver_write_mst", "miqp_solver_read_mst"]
+                    "miqp_solver_write_mst", "miqp_solver_read_mst", "miqp_fraction_parameters", "miqp_mean_angles",
+                    "miqp_limits_per_region", "miqp_calculate_region_idx", "miqp_reserve_neighbor_regions",
+                    "miqp_calculate_possible_regions", "miqp_calculate_warmstart", "miqp_plan"]
 
 
 class OptimizationStatus(enum.IntEnum):  # src/cplex_wrapper.hpp:54-59

@@ -1,0 +1,137 @@
+"""Planner core against the expectations of the reference's own CPLEX-free unit tests:
+common/tests/parameter_preparer_test.cc, common/tests/regions_test.cc.  No GPU needed."""
+import numpy as np
+import pytest
+
+import planner_miqp_amd as P
+from planner_miqp_amd import planner_core as K
+from planner_miqp_amd.ctypes_types import RawResults
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    P.build_library()
+
+
+def preparer(R=32, vfit=20, vmin=2):
+    # parameter_preparer_test.cc:19-27: accLonMax 2, accLonMin -4, jerkLonMax 3, accLat 1.6, jerkLat 1.4
+    return K.ParameterPreparer(R, vfit, vmin, 2, -4, 3, 1.6, 1.4)
+
+
+def test_mean_angle_vector():
+    """parameter_preparer_test.cc:17-40"""
+    exp = [0.0982, 0.2945, 0.4909, 0.6872, 0.8836, 1.0799, 1.2763, 1.4726, 1.6690, 1.8653, 2.0617, 2.2580, 2.4544, 2.6507, 2.8471, 3.0434,
+           3.2398, 3.4361, 3.6325, 3.8288, 4.0252, 4.2215, 4.4179, 4.6142, 4.8106, 5.0069, 5.2033, 5.3996, 5.5960, 5.7923, 5.9887, 6.1850]
+    assert np.abs(preparer().GetMeanAngleVector() - np.array(exp)).max() < 1e-3
+
+
+JX = [3.1228, 3.2772, 3.3057, 3.2072, 2.9854, 2.6489, 2.2106, 1.6873, 1.6873, 2.2106, 2.6489, 2.9854, 3.2072, 3.3057, 3.2772, 3.1228]
+JY = [1.6873, 2.2106, 2.6489, 2.9854, 3.2072, 3.3057, 3.2772, 3.1228, 3.1228, 3.2772, 3.3057, 3.2072, 2.9854, 2.6489, 2.2106, 1.6873]
+
+
+def test_jerk_limits():
+    """parameter_preparer_test.cc:42-89 (the 32 values are the 16 above repeated)"""
+    lim = preparer().CalculateJerkLimitsPerCar()
+    assert np.abs(lim["max_x"] - np.array(JX + JX)).max() < 1e-3 and np.abs(lim["min_x"] + np.array(JX + JX)).max() < 1e-3
+    assert np.abs(lim["max_y"] - np.array(JY + JY)).max() < 1e-3 and np.abs(lim["min_y"] + np.array(JY + JY)).max() < 1e-3
+
+
+def test_acc_limits():
+    """parameter_preparer_test.cc:91-135; the same numbers are the min/max_acc tables of cplexmodel_testcase.dat"""
+    max_x = [2.1472, 2.3783, 2.5181, 2.5611, 2.5056, 2.3539, 2.1117, 1.7883, 1.9844, 2.6922, 3.2967, 3.7744, 4.1071, 4.2819, 4.2922, 4.1376,
+             4.1376, 4.2922, 4.2819, 4.1071, 3.7744, 3.2967, 2.6922, 1.9844, 1.7883, 2.1117, 2.3539, 2.5056, 2.5611, 2.5181, 2.3783, 2.1472]
+    min_x = [-4.1376, -4.2922, -4.2819, -4.1071, -3.7744, -3.2967, -2.6922, -1.9844, -1.7883, -2.1117, -2.3539, -2.5056, -2.5611, -2.5181,
+             -2.3783, -2.1472, -2.1472, -2.3783, -2.5181, -2.5611, -2.5056, -2.3539, -2.1117, -1.7883, -1.9844, -2.6922, -3.2967, -3.7744,
+             -4.1071, -4.2819, -4.2922, -4.1376]
+    max_y = [1.7883, 2.1117, 2.3539, 2.5056, 2.5611, 2.5181, 2.3783, 2.1472, 2.1472, 2.3783, 2.5181, 2.5611, 2.5056, 2.3539, 2.1117, 1.7883,
+             1.9844, 2.6922, 3.2967, 3.7744, 4.1071, 4.2819, 4.2922, 4.1376, 4.1376, 4.2922, 4.2819, 4.1071, 3.7744, 3.2967, 2.6922, 1.9844]
+    min_y = [-1.9844, -2.6922, -3.2967, -3.7744, -4.1071, -4.2819, -4.2922, -4.1376, -4.1376, -4.2922, -4.2819, -4.1071, -3.7744, -3.2967,
+             -2.6922, -1.9844, -1.7883, -2.1117, -2.3539, -2.5056, -2.5611, -2.5181, -2.3783, -2.1472, -2.1472, -2.3783, -2.5181, -2.5611,
+             -2.5056, -2.3539, -2.1117, -1.7883]
+    lim = preparer().CalculateAccLimitsPerCar()
+    for k, e in (("max_x", max_x), ("min_x", min_x), ("max_y", max_y), ("min_y", min_y)):
+        assert np.abs(lim[k] - np.array(e)).max() < 1e-3, k
+    from helpers import load_params
+    p = load_params("cplexmodel_testcase.dat")
+    assert np.abs(np.asarray(p.max_acc_x).ravel() - lim["max_x"]).max() < 1e-4 and np.abs(np.asarray(p.min_acc_y).ravel() - lim["min_y"]).max() < 1e-4
+
+
+def test_fraction_parameters_16_exact():
+    """parameter_preparer_test.cc:184-222 requires a Frobenius distance below 1e-30, i.e. identical doubles"""
+    exp = [20.0, 0.0, 18.477590650225736, 7.653668647301796, 18.477590650225736, 7.653668647301796, 14.142135623730951, 14.14213562373095,
+           14.142135623730951, 14.14213562373095, 7.653668647301797, 18.477590650225736, 7.653668647301797, 18.477590650225736,
+           1.2246467991473533e-15, 20.0, 1.2246467991473533e-15, 20.0, -7.653668647301794, 18.477590650225736, -7.653668647301794,
+           18.477590650225736, -14.14213562373095, 14.142135623730951, -14.14213562373095, 14.142135623730951, -18.477590650225736,
+           7.653668647301798, -18.477590650225736, 7.653668647301798, -20.0, 2.4492935982947065e-15, -20.0, 2.4492935982947065e-15,
+           -18.477590650225736, -7.653668647301793, -18.477590650225736, -7.653668647301793, -14.142135623730955, -14.14213562373095,
+           -14.142135623730955, -14.14213562373095, -7.6536686473018065, -18.47759065022573, -7.6536686473018065, -18.47759065022573,
+           -3.673940397442059e-15, -20.0, -3.673940397442059e-15, -20.0, 7.6536686473018, -18.477590650225732, 7.6536686473018,
+           -18.477590650225732, 14.142135623730947, -14.142135623730955, 14.142135623730947, -14.142135623730955, 18.47759065022573,
+           -7.653668647301808, 18.47759065022573, -7.653668647301808, 20.0, 0.0]
+    fp = preparer(16).GetFractionParameters()
+    assert np.linalg.norm(fp - np.array(exp).reshape(16, 4)) < 1e-30
+
+
+def test_fraction_parameters_32_match_the_fixture():
+    """parameter_preparer_test.cc:137-182 (tolerance 1e-3 on the norm); the .dat fixture carries the same table"""
+    from helpers import load_params
+    p = load_params("cplexmodel_testcase.dat")
+    assert np.linalg.norm(preparer(32).GetFractionParameters() - np.asarray(p.fraction_parameters).reshape(32, 4)) < 1e-3
+
+
+def test_calculate_region_idx():
+    """regions_test.cc:19-61, 187-203"""
+    F = preparer().GetFractionParameters()
+    assert K.calculate_region_idx(F, 0.1, 0.01) == [0]
+    assert K.calculate_region_idx(F, 0.1951, 0.9808) == [6, 7]
+    assert K.calculate_region_idx(F, 0.1, 0.9) == [7]
+    assert K.calculate_region_idx(F, -0.1, -0.9) == [23]
+    assert K.calculate_region_idx(F, 0.1, -0.01) == [31]
+
+
+def test_calculate_possible_regions():
+    """regions_test.cc:97-185: heading 0.1 rad lies in region 0; headings 0.3 / 0.5 / 0.7 give regions 1, 2, 3 and not 0"""
+    F = preparer().GetFractionParameters()
+    assert 0 in K.calculate_possible_regions(F, [0.1, 0.1, 0.1])
+    assert 31 in K.calculate_possible_regions(F, [-0.1, -0.1, -0.1])
+    r = K.calculate_possible_regions(F, [0.3, 0.5, 0.7])
+    assert 0 not in r and {1, 2, 3} <= r
+
+
+def test_reserve_neighbor_regions():
+    """regions_test.cc:205-288"""
+    r = np.zeros((2, 32), dtype=np.int32); r[0, 2] = r[0, 3] = 1; r[1, 4] = r[1, 5] = 1
+    assert K.reserve_neighbor_regions(r, 0, 1) and r[0, :6].tolist() == [0, 1, 1, 1, 1, 0]
+    assert K.reserve_neighbor_regions(r, 1, 1) and r[1, 2:8].tolist() == [0, 1, 1, 1, 1, 0]
+    r = np.zeros((2, 32), dtype=np.int32); r[0, 0] = r[0, 1] = 1; r[1, 30] = r[1, 31] = 1
+    assert K.reserve_neighbor_regions(r, 0, 1) and r[0, 30:].tolist() == [0, 1] and r[0, :4].tolist() == [1, 1, 1, 0]
+    assert K.reserve_neighbor_regions(r, 1, 1) and r[1, 28:].tolist() == [0, 1, 1, 1] and r[1, :2].tolist() == [1, 0]
+    r = np.zeros((1, 32), dtype=np.int32); r[0, 0] = r[0, 1] = 1
+    assert K.reserve_neighbor_regions(r, 0, 2) and r[0, 29:].tolist() == [0, 1, 1] and r[0, :5].tolist() == [1, 1, 1, 1, 0]
+
+
+def test_calculate_warmstart_shift_and_quirks():
+    """MiqpPlanner::CalculateWarmstart (src/miqp_planner.cpp:787-1051): shift by one step, Euler step for the last
+    state, region-change flags recomputed, last-step binaries copied unshifted, last active_region row all zero"""
+    rng = np.random.default_rng(5)
+    Cn, N, R, E, O, L = 2, 6, 8, 2, 1, 4
+    a = RawResults(Cn, N, R, E, O, L)
+    for n in ["u_x", "u_y", "pos_x", "vel_x", "acc_x", "pos_y", "vel_y", "acc_y", "pos_x_front_UB", "pos_x_front_LB", "pos_y_front_UB", "pos_y_front_LB"]:
+        getattr(a, n)[...] = rng.normal(size=(Cn, N))
+    for n in ["notWithinEnvironmentRear", "notWithinEnvironmentFrontUbUb", "notWithinEnvironmentFrontLbUb", "notWithinEnvironmentFrontUbLb",
+              "notWithinEnvironmentFrontLbLb", "active_region", "region_change_not_allowed_x_positive", "region_change_not_allowed_combined",
+              "deltacc", "deltacc_front", "car2car_collision", "slackvars"]:
+        arr = getattr(a, n); arr[...] = rng.integers(0, 2, size=arr.shape)
+    ts, vm = 0.25, 2.0
+    w = K.calculate_warmstart(a, ts, vm)
+    for n in ["u_x", "pos_x", "vel_y", "acc_y", "pos_x_front_UB", "pos_y_front_LB"]:
+        assert np.array_equal(getattr(w, n)[:, :N - 1], getattr(a, n)[:, 1:]), n
+    assert np.all(w.u_x[:, N - 1] == 0) and np.all(w.u_y[:, N - 1] == 0)
+    assert np.allclose(w.pos_x[:, N - 1], w.pos_x[:, N - 2] + ts * w.vel_x[:, N - 2]) and np.allclose(w.vel_y[:, N - 1], w.vel_y[:, N - 2] + ts * w.acc_y[:, N - 2])
+    assert np.allclose(w.acc_x[:, N - 1], w.acc_x[:, N - 2] + ts * w.u_x[:, N - 2]) and np.allclose(w.pos_y_front_UB[:, N - 1], w.pos_y_front_UB[:, N - 2] + ts * w.vel_y[:, N - 2])
+    assert np.array_equal(w.region_change_not_allowed_x_positive[:, N - 1], (w.vel_x[:, N - 1] <= vm).astype(np.int32))
+    assert np.array_equal(w.notWithinEnvironmentRear[:, :, :N - 1], a.notWithinEnvironmentRear[:, :, 1:])
+    assert np.array_equal(w.notWithinEnvironmentRear[:, :, N - 1], a.notWithinEnvironmentRear[:, :, N - 1])      # copied unshifted (:951-963)
+    assert np.array_equal(w.active_region[:, :N - 1], a.active_region[:, 1:]) and not w.active_region[:, N - 1].any()  # :982 has no effect
+    assert np.array_equal(w.car2car_collision[:, :, :N - 1], a.car2car_collision[:, :, 1:]) and np.array_equal(w.car2car_collision[:, :, N - 1], a.car2car_collision[:, :, N - 1])
+    assert np.array_equal(w.deltacc[:, :, :N - 1], a.deltacc[:, :, 1:]) and np.array_equal(w.deltacc_front[:, :, N - 1], a.deltacc_front[:, :, N - 1])
