@@ -529,7 +529,7 @@ static int qp_solve_tol(const dmodel* M, const orow* rows, int m, qpres* out, do
   return ok;
 }
 
-static double g_node_tol = QP_TOL; /* node relaxations: accurate to a small fraction of the requested MIP gap */
+static __thread double g_node_tol = QP_TOL; /* node relaxations: accurate to a small fraction of the requested MIP gap */
 static int qp_solve(const dmodel* M, const orow* rows, int m, qpres* out) { return qp_solve_tol(M, rows, m, out, g_node_tol); }
 
 /* ------------------------------------------------------------------ node relaxation rows */
@@ -585,7 +585,7 @@ static double const_cost(const dmodel* M, const signed char* fix) {
 
 /* ------------------------------------------------------------------ completion */
 typedef struct { int step, kind; int key[5]; int nalts; int alts[64]; double mag; } violation;
-static double g_cur_viol = 0.0; /* violation of the least violated alternative of the disjunction being reported */
+static __thread double g_cur_viol = 0.0; /* violation of the least violated alternative of the disjunction being reported */
 
 static int region_cands(const dmodel* M, const signed char* fix, int c, int i, int* out) {
   const oinst* I = M->I;
