@@ -233,7 +233,7 @@ struct Layout {
   // double offsets
   int d_x0, d_wd, d_ref, d_glob, d_u0box, d_misc, d_dsep, d_ssl, d_smax, d_reg, d_env, d_obs, d_theta, dstride;
   // int offsets
-  int i_nposs, i_regj, i_nhs, i_hs, i_envn, i_obssoft, i_initj, i_dom, i_allow, istride;
+  int i_nposs, i_regj, i_nhs, i_hs, i_envn, i_obssoft, i_initj, i_dom, i_allow, i_boxskip, istride;
   // fix record (bytes)
   int f_reg, f_env, f_obs, f_c2c, f_c2n, fixlen;   // f_c2n: per (pair, step, group) bit mask of excluded car/car alternatives
 };
@@ -249,7 +249,7 @@ inline Layout make_layout(int C, int N, int R, int P, int E, int EL, int O, int 
   Y.d_env = o; o += E * EL * 3; Y.d_obs = o; o += O * N * L * 3; Y.d_theta = o; o += C * 4; Y.dstride = (o + 7) & ~7;
   o = 0;
   Y.i_nposs = o; o += C; Y.i_regj = o; o += C * P; Y.i_nhs = o; o += C * P; Y.i_hs = o; o += C * P * 4; Y.i_envn = o; o += E;
-  Y.i_obssoft = o; o += O; Y.i_initj = o; o += C; Y.i_dom = o; o += C * P * 4; Y.i_allow = o; o += C * N * 2; Y.istride = (o + 3) & ~3;
+  Y.i_obssoft = o; o += O; Y.i_initj = o; o += C; Y.i_dom = o; o += C * P * 4; Y.i_allow = o; o += C * N * 2; Y.i_boxskip = o; o += C * N; Y.istride = (o + 3) & ~3;
   Y.f_reg = 0; Y.f_env = Y.f_reg + C * N; Y.f_obs = Y.f_env + C * N * 5; Y.f_c2c = Y.f_obs + C * O * N * 5;
   Y.f_c2n = Y.f_c2c + Y.NP * N * 4;
   Y.fixlen = (Y.f_c2n + Y.NP * N * 4 + 15) & ~15;
@@ -425,6 +425,39 @@ inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int*
         }
       }
       T[Y.i_allow + (c * N + i) * 2] = (int)(mask & 0xFFFFFFFFull); T[Y.i_allow + (c * N + i) * 2 + 1] = (int)(mask >> 32);
+    }
+  }
+  // Box presolve (exact): interval propagation of (a, v) per axis from the initial state with the jerk and acceleration
+  // bounds that hold for every region (a+ = a + ts u, v+ = v + ts (a + a+)/2).  A velocity / acceleration bound row of
+  // step i that the reachable interval already satisfies is implied by the rows of the earlier steps and is not
+  // generated (bit rr of i_boxskip: rows 0..6 of decode_row).
+  for (int c = 0; c < C; ++c) {
+    const int np = T[Y.i_nposs + c];
+    double abox[4] = {I.amin, I.amax, I.amin, I.amax};     // lo_x, hi_x, lo_y, hi_y that every alternative respects
+    double atest[4] = {I.amin, I.amax, I.amin, I.amax};    // tightest right-hand sides a row can carry
+    for (int q = 0; q < np; ++q) { const double* g = D + Y.d_reg + (c * Y.P + q) * REGSZ;
+      atest[0] = std::max(atest[0], g[11]); atest[1] = std::min(atest[1], g[12]); atest[2] = std::max(atest[2], g[13]); atest[3] = std::min(atest[3], g[14]); }
+    double alo[2] = {I.x0[c * 6 + 2], I.x0[c * 6 + 5]}, ahi[2] = {alo[0], alo[1]};
+    double vlo[2] = {I.x0[c * 6 + 1], I.x0[c * 6 + 4]}, vhi[2] = {vlo[0], vlo[1]};
+    const double jlo = std::min(I.jmin, std::min(D[Y.d_u0box + c * 4], D[Y.d_u0box + c * 4 + 2])), jhi = std::max(I.jmax, std::max(D[Y.d_u0box + c * 4 + 1], D[Y.d_u0box + c * 4 + 3]));
+    const double pad = 1e-9;
+    for (int i = 1; i < N; ++i) {
+      int skip = 0;
+      for (int ax = 0; ax < 2; ++ax) {
+        double nlo = alo[ax] + I.ts * jlo, nhi = ahi[ax] + I.ts * jhi;           // a_i before its own box
+        double wlo = vlo[ax] + 0.5 * I.ts * (alo[ax] + nlo), whi = vhi[ax] + 0.5 * I.ts * (ahi[ax] + nhi);
+        // acceleration rows of step i: rr 3 (ax <= hi), 4 (ax >= lo), 5 / 6 for y
+        if (nhi <= atest[2 * ax + 1] - pad) skip |= 1 << (ax == 0 ? 3 : 5);
+        if (nlo >= atest[2 * ax] + pad) skip |= 1 << (ax == 0 ? 4 : 6);
+        nlo = std::max(nlo, abox[2 * ax]); nhi = std::min(nhi, abox[2 * ax + 1]);
+        wlo = vlo[ax] + 0.5 * I.ts * (alo[ax] + nlo); whi = vhi[ax] + 0.5 * I.ts * (ahi[ax] + nhi);
+        // velocity rows: rr 0 (vx >= vmin), 1 (vy >= vmin), 2 (vx <= vmax)
+        if (wlo >= I.vmin + pad) skip |= 1 << (ax == 0 ? 0 : 1);
+        if (ax == 0 && whi <= I.vmax - pad) skip |= 1 << 2;
+        alo[ax] = nlo; ahi[ax] = nhi;
+        vlo[ax] = std::max(wlo, I.vmin); vhi[ax] = ax == 0 ? std::min(whi, I.vmax) : whi;
+      }
+      T[Y.i_boxskip + c * N + i] = skip;
     }
   }
   for (int e = 0; e < I.E; ++e) {

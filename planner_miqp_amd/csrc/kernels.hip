@@ -170,7 +170,7 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
     int code = i >= 1 ? (int)fix[Y.f_reg + c * N + i] : -1;
     const double* rt = code >= 0 ? D + Y.d_reg + (c * Y.P + (code >> 2)) * REGSZ : nullptr;
     if (rr < 7) {
-      if (i < 1) return r;
+      if (i < 1 || ((T[Y.i_boxskip + c * N + i] >> rr) & 1)) return r;   // implied by the earlier steps (host box presolve)
       r.active = true;
       switch (rr) {
         case 0: g[6 * c + 1] = -1; r.rhs = -G[0]; break;
