@@ -33,9 +33,24 @@ namespace miqp {
 constexpr double RHO_EL = MIQP_RHO;     // exact-penalty weight of the elastic rows
 constexpr double FEAS_TOL = 1.0e-6;
 constexpr double QP_TOL = 1.0e-8;      // node relaxations (bounds); the returned incumbent is polished to QP_TOL_FINAL
-constexpr double QP_T0 = 1.0e-3;       // initial elastic slack: t*mu (mu ~ rho) starts at the order of s*lambda
+#ifndef MIQP_T0
+#define MIQP_T0 1.0e-3
+#endif
+#ifndef MIQP_LAM0
+#define MIQP_LAM0 2000.0   // initial multiplier of every elastic row: s*lambda and t*(rho - lambda) start at comparable size (swept 0.3 .. 3e4)
+#endif
+#ifndef MIQP_S0
+#define MIQP_S0 100.0
+#endif
+#ifndef MIQP_STEPFRAC
+#define MIQP_STEPFRAC 0.995
+#endif
+#ifndef MIQP_SIGMA0
+#define MIQP_SIGMA0 0.3
+#endif
+constexpr double QP_T0 = MIQP_T0;       // initial elastic slack: t*mu (mu ~ rho) starts at the order of s*lambda
 constexpr double QP_TOL_FINAL = 1.0e-13;  // polish of the returned incumbent / solve_fixed
-constexpr double QP_SIGMA = 0.1;       // centering parameter of the first iteration
+constexpr double QP_SIGMA = MIQP_SIGMA0;       // centering parameter of the first iteration
 constexpr double QP_SIGMA_LO = 0.02, QP_SIGMA_HI = 0.5;
 constexpr int QP_MAXIT = 80;
 constexpr int NFIELD = 4;            // per-row state: s, lambda, t, g.dz
@@ -505,9 +520,9 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
         const int idx = mul ? base + __popcll(maskM & lt) : Y.ROWCAP - 1 - (sbase + __popcll(maskS & lt));
         for (int k = 0; k < nn; ++k) rc_v[(size_t)k * Y.ROWCAP + idx] = g[(cols >> (8 * k)) & 255];
         cols |= ((unsigned long long)i << 48) | ((unsigned long long)nn << 56);
-        double s, lam = 1.0, t;
+        double s, lam = MIQP_LAM0, t;
         if (r.aq == 0.0) {
-          if (c > QP_T0) { t = QP_T0; s = c + QP_T0; } else { s = 100.0 * QP_T0; t = s - c; }
+          if (c > QP_T0) { t = QP_T0; s = c + QP_T0; } else { s = MIQP_S0 * QP_T0; t = s - c; }
           csum += s * lam + t * (RHO_EL - lam); cnt += 2; tsum += t;
         } else { lam = fmax(1.0, -2.0 * c * r.aq + 1.0); s = c + lam / r.aq; t = 0.0; csum += s * lam; cnt += 1; }
         rc_rhs[idx] = r.rhs; rc_col[idx] = __longlong_as_double((long long)cols);
@@ -946,7 +961,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     rinv = block_max<NT>(rinv, red);
     const double amax = rinv > 1e-300 ? 1.0 / rinv : 1e300;   // raw v_rcp_f64 in the ratios: far inside the 0.5 % margin below
     a0 = block_sum<NT>(a0, red); a1 = block_sum<NT>(a1, red); a2 = block_sum<NT>(a2, red);
-    double alpha = fmin(1.0, 0.995 * amax);
+    double alpha = fmin(1.0, MIQP_STEPFRAC * amax);
     comp = (a0 + alpha * a1 + alpha * alpha * a2) / ncomp;
     PROF_T(tf2); PROF_ACC(7, tf1, tf2);
     // ================= update (the step of every row is recomputed from its stored g.dz)
