@@ -233,7 +233,7 @@ struct Layout {
   // double offsets
   int d_x0, d_wd, d_ref, d_glob, d_u0box, d_misc, d_dsep, d_ssl, d_smax, d_reg, d_env, d_obs, d_theta, dstride;
   // int offsets
-  int i_nposs, i_regj, i_nhs, i_hs, i_envn, i_obssoft, i_initj, i_dom, i_allow, i_boxskip, istride;
+  int i_nposs, i_regj, i_nhs, i_hs, i_envn, i_obssoft, i_initj, i_dom, i_allow, i_boxskip, i_c2callow, istride;
   // fix record (bytes)
   int f_reg, f_env, f_obs, f_c2c, f_c2n, fixlen;   // f_c2n: per (pair, step, group) bit mask of excluded car/car alternatives
 };
@@ -249,7 +249,7 @@ inline Layout make_layout(int C, int N, int R, int P, int E, int EL, int O, int 
   Y.d_env = o; o += E * EL * 3; Y.d_obs = o; o += O * N * L * 3; Y.d_theta = o; o += C * 4; Y.dstride = (o + 7) & ~7;
   o = 0;
   Y.i_nposs = o; o += C; Y.i_regj = o; o += C * P; Y.i_nhs = o; o += C * P; Y.i_hs = o; o += C * P * 4; Y.i_envn = o; o += E;
-  Y.i_obssoft = o; o += O; Y.i_initj = o; o += C; Y.i_dom = o; o += C * P * 4; Y.i_allow = o; o += C * N * 2; Y.i_boxskip = o; o += C * N; Y.istride = (o + 3) & ~3;
+  Y.i_obssoft = o; o += O; Y.i_initj = o; o += C; Y.i_dom = o; o += C * P * 4; Y.i_allow = o; o += C * N * 2; Y.i_boxskip = o; o += C * N; Y.i_c2callow = o; o += Y.NP * N; Y.istride = (o + 3) & ~3;
   Y.f_reg = 0; Y.f_env = Y.f_reg + C * N; Y.f_obs = Y.f_env + C * N * 5; Y.f_c2c = Y.f_obs + C * O * N * 5;
   Y.f_c2n = Y.f_c2c + Y.NP * N * 4;
   Y.fixlen = (Y.f_c2n + Y.NP * N * 4 + 15) & ~15;
@@ -431,6 +431,7 @@ inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int*
   // bounds that hold for every region (a+ = a + ts u, v+ = v + ts (a + a+)/2).  A velocity / acceleration bound row of
   // step i that the reachable interval already satisfies is implied by the rows of the earlier steps and is not
   // generated (bit rr of i_boxskip: rows 0..6 of decode_row).
+  std::vector<double> preach((size_t)C * N * 4, 0.0);   // reachable position box per car and step: x lo, x hi, y lo, y hi
   for (int c = 0; c < C; ++c) {
     const int np = T[Y.i_nposs + c];
     double abox[4] = {I.amin, I.amax, I.amin, I.amax};     // lo_x, hi_x, lo_y, hi_y that every alternative respects
@@ -441,9 +442,15 @@ inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int*
     double vlo[2] = {I.x0[c * 6 + 1], I.x0[c * 6 + 4]}, vhi[2] = {vlo[0], vlo[1]};
     const double jlo = std::min(I.jmin, std::min(D[Y.d_u0box + c * 4], D[Y.d_u0box + c * 4 + 2])), jhi = std::max(I.jmax, std::max(D[Y.d_u0box + c * 4 + 1], D[Y.d_u0box + c * 4 + 3]));
     const double pad = 1e-9;
+    double plo[2] = {I.x0[c * 6 + 0], I.x0[c * 6 + 3]}, phi[2] = {plo[0], plo[1]};
+    for (int k = 0; k < 2; ++k) { preach[((size_t)c * N) * 4 + 2 * k] = plo[k]; preach[((size_t)c * N) * 4 + 2 * k + 1] = phi[k]; }
     for (int i = 1; i < N; ++i) {
       int skip = 0;
       for (int ax = 0; ax < 2; ++ax) {
+        // x+ = x + ts v + ts^2/2 a + ts^3/6 u with the intervals of step i-1 (monotone in every term)
+        plo[ax] += I.ts * vlo[ax] + 0.5 * I.ts * I.ts * alo[ax] + I.ts * I.ts * I.ts / 6.0 * jlo;
+        phi[ax] += I.ts * vhi[ax] + 0.5 * I.ts * I.ts * ahi[ax] + I.ts * I.ts * I.ts / 6.0 * jhi;
+        preach[((size_t)c * N + i) * 4 + 2 * ax] = plo[ax]; preach[((size_t)c * N + i) * 4 + 2 * ax + 1] = phi[ax];
         double nlo = alo[ax] + I.ts * jlo, nhi = ahi[ax] + I.ts * jhi;           // a_i before its own box
         double wlo = vlo[ax] + 0.5 * I.ts * (alo[ax] + nlo), whi = vhi[ax] + 0.5 * I.ts * (ahi[ax] + nhi);
         // acceleration rows of step i: rr 3 (ax <= hi), 4 (ax >= lo), 5 / 6 for y
@@ -460,6 +467,28 @@ inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int*
       T[Y.i_boxskip + c * N + i] = skip;
     }
   }
+  // Car/car alternatives that no reachable pair of positions can satisfy (exact): alternative a of group g at step i
+  // asks  coord(A) - coord(B) <= -(separation) for a rear or front point of each car; front points lie within one wheel
+  // base of the rear point.  Bit (4 g + a) of i_c2callow[pair][step] is set when the alternative is possible.
+  { int p = 0;
+    for (int c1 = 0; c1 < C; ++c1) for (int c2 = c1 + 1; c2 < C; ++c2, ++p)
+      for (int i = 0; i < N; ++i) {
+        int mask = 0;
+        for (int g = 0; g < 4; ++g) for (int a = 0; a < 4; ++a) {
+          const bool isx = a < 2, lo = (a == 0 || a == 2), soft = (g == 0 || g == 3);
+          int ca, cb; bool fa, fb;   // cars and "is a front point" of the two sides, as in decode_row
+          if (g == 0) { ca = lo ? c1 : c2; cb = lo ? c2 : c1; fa = fb = false; }
+          else if (g == 1) { if (lo) { ca = c1; fa = false; cb = c2; fb = true; } else { ca = c2; fa = true; cb = c1; fb = false; } }
+          else if (g == 2) { if (lo) { ca = c2; fa = false; cb = c1; fb = true; } else { ca = c1; fa = true; cb = c2; fb = false; } }
+          else { if (lo) { ca = c2; cb = c1; } else { ca = c1; cb = c2; } fa = fb = true; }
+          const double sep = I.rad[c1] + I.rad[c2] + I.safety[i] + (soft ? I.safety_slack[i] - std::max(0.0, std::min(I.safety_slack[i], I.max_slack)) : 0.0);
+          const int ax = isx ? 0 : 1;
+          const double amin_ = preach[((size_t)ca * N + i) * 4 + 2 * ax] - (fa ? I.wb[ca] : 0.0);
+          const double bmax_ = preach[((size_t)cb * N + i) * 4 + 2 * ax + 1] + (fb ? I.wb[cb] : 0.0);
+          if (amin_ - bmax_ <= -sep + 1e-6) mask |= 1 << (4 * g + a);
+        }
+        T[Y.i_c2callow + p * N + i] = mask;
+      } }
   for (int e = 0; e < I.E; ++e) {
     int n = I.env_off[e + 1] - I.env_off[e]; T[Y.i_envn + e] = n;
     for (int k = 0; k < n; ++k) {  // inside: cross >= 0  <=>  dy*X - dx*Y <= dy*x1 - dx*y1

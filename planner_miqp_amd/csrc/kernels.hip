@@ -1246,7 +1246,8 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
           if (fx >= 0) { bv = c2c_alt_viol(Y, D, p, i, g, fx, s1, rt1, s2, rt2); okk = bv <= tol; }
           else {
             int ba = 0;
-            for (int a = 0; a < 4; ++a) { double v = c2c_alt_viol(Y, D, p, i, g, a, s1, rt1, s2, rt2); if (v < bv) { bv = v; ba = a; } }
+            const int am = (T[Y.i_c2callow + p * N + i] >> (4 * g)) & 15;   // alternatives some reachable positions can satisfy (host presolve)
+            for (int a = 0; a < 4; ++a) { if (am && !((am >> a) & 1)) continue; double v = c2c_alt_viol(Y, D, p, i, g, a, s1, rt1, s2, rt2); if (v < bv) { bv = v; ba = a; } }
             okk = bv <= tol; comp[Y.f_c2c + (p * N + i) * 4 + g] = (signed char)ba;
           }
           if (!okk) { if (unf >= 0) consider(i, 0, unf, 0, 0, bv); else consider(i, 3, p, g, 0, bv); }
@@ -1313,7 +1314,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         }
       } else if (d.kind == 1) { for (int e = 0; e < Y.E && n < 16; ++e) if (e != refv) tmp[n++] = e; }
       else if (d.kind == 2) { int na = Y.L + (T[Y.i_obssoft + d.o] ? 1 : 0); for (int k = 0; k < na && n < 16; ++k) if (k != refv) tmp[n++] = k; }
-      else { for (int a2 = 0; a2 < 4; ++a2) if (a2 != refv) tmp[n++] = a2; }
+      else { const int am = (T[Y.i_c2callow + d.c * N + j] >> (4 * d.o)) & 15; for (int a2 = 0; a2 < 4; ++a2) if (a2 != refv && ((am >> a2) & 1)) tmp[n++] = a2; }
       return n;
     };
     // window of undecided steps: all of them when the children fit, else the steps from the violated one onwards
