@@ -639,7 +639,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     bool have = h_inc[k] < 1e299;
     bool unfinished = (h_flags[k] & 1) || h_oc[k] > 0 || !h_dn[k];
     (void)timed_out;
-    s->props.time = h_tdone[k] >= 0 ? h_tdone[k] : t_solve;   // batch: time from the start of the batch to the instance's proof s->props.NrIterations = (int)std::min<long long>(h_iters[k], 2147483647LL); s->props.nodes = h_nodes[k];
+    s->props.time = h_tdone[k] >= 0 ? h_tdone[k] : t_solve;   // batch: time from the start of the batch to the instance's proof
+    s->props.NrIterations = (int)std::min<long long>(h_iters[k], 2147483647LL); s->props.nodes = h_nodes[k];
     s->props.NrSolutionPool = h_ninc[k];
     s->timing[0] = ms_all * 1e-3; s->timing[1] = ms_ipm * 1e-3; s->timing[2] = (double)(nev / 2); s->timing[3] = (double)launched_nodes;
     s->timing[4] = (double)tot_iters; s->timing[5] = (double)rowiters;

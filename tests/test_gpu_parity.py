@@ -50,6 +50,7 @@ def test_testcase_matches_reference_and_oracle(oracle):
     assert abs(pr.objective - g["objective"]) <= OBJ_TOL
     assert (pr.NrConstraints, pr.NrBinaryVariables, pr.NrFloatVariables) == (12361, 1240, 340)
     assert pr.gap <= 1e-6 and pr.best_bound <= pr.objective + 1e-9 and pr.NrSolutionPool >= 1
+    assert pr.nodes >= 1 and pr.NrIterations >= pr.nodes and 0 < pr.time < 60   # search statistics are reported
     res = w.getRawResults()
     h = oracle.from_dat(dat_path("cplexmodel_testcase.dat"))
     ost, ores, op = oracle.solve(h, (1, 20, 32, 1, 1, 4), gap=1e-6)
