@@ -1,12 +1,13 @@
 // kernels.hip - CDNA4 (gfx950) device code of the MIQP solver.
 //
-//   ipm_kernel<C>     one 64-lane wavefront per B&B node: stage-banded primal-dual interior point on the node's
-//                     QP relaxation (rows decoded on the fly from compact per-instance tables, stage Hessians
-//                     assembled in LDS, Riccati recursion over the N stages).
-//   eval_kernel<C>    one wavefront per node: completion of undecided disjunctions, incumbent update
+//   select_kernel     one workgroup per instance: prune the open list against the incumbent, pick the `take` best
+//                     bounds by an 8-bit radix select over the HBM-resident list (dives: deepest first), termination.
+//   ipm_kernel<C>     one 64-lane wavefront per B&B node (nodes handed out dynamically): the rows of the node are
+//                     decoded once from the per-instance tables; stage-banded primal-dual interior point with a Riccati
+//                     recursion whose stage algebra stays in MFMA registers (C <= 2) or in dense LDS matrices (C = 3, 4).
+//   eval_kernel<C>    one wavefront per node: canonical completion of the undecided disjunctions, incumbent update
 //                     (64-bit atomicMin), choice of the branching disjunction (wave reduction), child emission.
-//   select_kernel     one workgroup per instance: prune, bitonic sort of the open list by bound in LDS, pick the
-//                     best nodes for the next round, instance termination test.
+//   roll_kernel       publishes the node records freed in this round to the next one.
 //
 // The model being solved is the disjunctive form of cplexmodel/*.mod described in host_inst.hpp / DESIGN.md.
 #include <hip/hip_runtime.h>
@@ -340,40 +341,10 @@ __device__ inline RowRegs load_row(const double* rc_aq, const double* rc_col, co
   return R;
 }
 
-// block-wide reductions over NT threads (NT/64 waves); red has NT/64 doubles; two barriers each
-template <int NT> __device__ inline double block_sum(double v, double* red) {
-  v = wave_sum(v);
-  if (NT == 64) return v;   // one wavefront: the butterfly already left the result in every lane
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double r = 0.0;
-#pragma unroll
-  for (int k = 0; k < NT / 64; ++k) r += red[k];
-  return r;
-}
-template <int NT> __device__ inline double block_min(double v, double* red) {
-  v = wave_min(v);
-  if (NT == 64) return v;   // one wavefront: the butterfly already left the result in every lane
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double r = red[0];
-#pragma unroll
-  for (int k = 1; k < NT / 64; ++k) r = fmin(r, red[k]);
-  return r;
-}
-template <int NT> __device__ inline double block_max(double v, double* red) {
-  v = wave_max(v);
-  if (NT == 64) return v;   // one wavefront: the butterfly already left the result in every lane
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double r = red[0];
-#pragma unroll
-  for (int k = 1; k < NT / 64; ++k) r = fmax(r, red[k]);
-  return r;
-}
+// reductions over the one wavefront that solves a node (the xor butterfly leaves the result in every lane)
+template <int NT> __device__ inline double block_sum(double v, double*) { static_assert(NT == 64, "one wavefront per node"); return wave_sum(v); }
+template <int NT> __device__ inline double block_min(double v, double*) { static_assert(NT == 64, "one wavefront per node"); return wave_min(v); }
+template <int NT> __device__ inline double block_max(double v, double*) { static_assert(NT == 64, "one wavefront per node"); return wave_max(v); }
 
 #ifdef MIQP_PROFILE
 #define PROF_T(var) long long var = clock64()

@@ -249,6 +249,56 @@ def test_infeasible_instance_reports_no_solution():
     assert np.isnan(pr.objective) and np.isnan(pr.gap)
 
 
+def test_soft_obstacle_can_be_ignored_at_its_price(oracle):
+    """obstacle_is_soft (obstacle_environment_constraints.mod:85-91): a soft obstacle adds the alternative 'ignored' at
+    WEIGHTS_SLACK_OBSTACLE per point; device and oracle agree on objective and on the slack binaries"""
+    hits = 0
+    for seed in range(6):
+        p = synthetic.generate("mini1", seed, gap=1e-7, max_time=60)
+        p.obstacle_is_soft = [1]
+        p.WEIGHTS_SLACK_OBSTACLE = 0.5       # cheap enough that driving through can pay off
+        cx, cy, hl, hw = float(p.IntitialState[0, 0]) + 9.0, -1.75, 3.4, 1.9    # static box on the reference path
+        box = np.array([[cx - hl, cy - hw], [cx + hl, cy - hw], [cx + hl, cy + hw], [cx - hl, cy + hw]])
+        p.ObstacleConvexPolygon = [[box.copy() for _ in range(p.NumSteps)]]
+        w = P.CplexWrapper(); w.resetParameters(p)
+        st = w.callCplex()
+        h = oracle.from_params(p, 10)
+        ost, ores, op = oracle.solve(h, oracle.dims(p), gap=1e-7, time_limit=120)
+        assert int(st) == ost
+        if ost == 0:
+            pr = w.getSolutionProperties(); res = w.getRawResults()
+            assert abs(pr.objective - op.objective) <= 1e-6 * max(1.0, abs(op.objective)), (seed, pr.objective, op.objective)
+            assert np.array_equal(res.slackvarsObstacle, ores.slackvarsObstacle) and np.array_equal(res.slackvarsObstacle_front, ores.slackvarsObstacle_front)
+            hits += int(res.slackvarsObstacle.sum() + res.slackvarsObstacle_front.sum() > 0)
+            v, obj, worst = oracle.raw_eval(h, res)
+            assert v < 1e-5 and abs(obj - pr.objective) <= 1e-6 * max(1.0, abs(obj)), worst
+        oracle.free(h)
+    assert hits >= 1, "no instance used the soft alternative: the test would not exercise it"
+
+
+def test_rejected_inputs_fail_loudly():
+    """sizes the device kernels do not take are refused with FAILED_SEG_FAULT (never approximated): 5 cars; a batch whose
+    instances differ in shape; an instance whose initial region is not a possible region"""
+    p5 = synthetic.generate((5, 6, 32, 1, 0), 0)
+    w = P.CplexWrapper(); w.resetParameters(p5)
+    assert w.callCplex() == P.OptimizationStatus.FAILED_SEG_FAULT
+    a, b = synthetic.generate("mini", 0), synthetic.generate("mini3", 0)
+    wa, wb = P.CplexWrapper(), P.CplexWrapper()
+    wa.resetParameters(a); wb.resetParameters(b)
+    assert all(s == P.OptimizationStatus.FAILED_SEG_FAULT for s in P.solve_batch([wa, wb]))
+    assert P.solve_batch([wa])[0] == P.OptimizationStatus.SUCCESS          # the same solver object still works afterwards
+
+
+def test_override_solver_settings():
+    """overrideSolverSettingsDataSource (src/cplex_wrapper.cpp:893-896): only the solver knobs are taken over"""
+    p = synthetic.generate("mini", 1, gap=0.5, max_time=30)
+    q = synthetic.generate("mini", 2, gap=1e-6, max_time=7)
+    w = P.CplexWrapper(); w.resetParameters(p)
+    w.overrideSolverSettingsDataSource(q)
+    assert p.relative_mip_gap_tolerance == 1e-6 and p.max_solution_time == 7
+    assert int(w.callCplex()) == 0 and w.getSolutionProperties().gap <= 1e-6
+
+
 def test_time_limit_is_honoured():
     """test_max_solution_time (cc:637-672): wall <= limit + 0.3 s; a time-limited incumbent is a SUCCESS (status 107)"""
     import time
