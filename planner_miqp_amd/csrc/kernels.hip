@@ -111,6 +111,7 @@ struct DevBuf {
   int* work_counter;             // next node of the batch to be solved (reset before every ipm launch)
   unsigned long long* prof;      // [40] cycle counters of the phases of ipm_kernel (diagnostic build -DMIQP_PROFILE only)
   unsigned long long* stat_rowiters;
+  signed char* pool_origin;      // diagnostic build: 2*kind + (deviating child) of the branching that created a node record
 };
 
 __device__ inline unsigned long long d2key(double v) {
@@ -984,6 +985,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     for (int q = 0; q < 9; ++q) atomicAdd(&B.prof[q], pr_[q]);
     atomicAdd(&B.prof[9], (unsigned long long)(it > QP_MAXIT ? QP_MAXIT : it)); atomicAdd(&B.prof[10], 1ull); atomicAdd(&B.prof[11], (unsigned long long)NROWS);
     { int hb = (it > QP_MAXIT ? QP_MAXIT : it) / 10; if (hb > 8) hb = 8; atomicAdd(&B.prof[16 + hb], 1ull); if (viol > FEAS_TOL) atomicAdd(&B.prof[25 + hb], 1ull); }
+    { int og = (int)B.pool_origin[B.batch_node[node]] & 7; atomicAdd(&B.prof[40 + og], 1ull); if (viol > FEAS_TOL) atomicAdd(&B.prof[48 + og], 1ull); if (ok == 2) atomicAdd(&B.prof[56 + og], 1ull); }
 #endif
   }
   }  // node loop
@@ -1351,6 +1353,9 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         if (k == negidx) v = (signed char)negm;
         dst[k] = v;
       }
+#ifdef MIQP_PROFILE
+      if (lane == 0) B.pool_origin[slots[a]] = (signed char)(2 * chosen.kind + (a > 0 ? 1 : 0));
+#endif
     }
     if (lane < nalt) {
       size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + ob + lane;

@@ -232,10 +232,14 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   if (!X.alloc(&B.rowcache, (size_t)std::min(batch_cap, X.ipm_grid_max) * NCACHE * Y.ROWCAP)) return false;
   if (!X.alloc(&B.kgain, (size_t)std::min(batch_cap, X.ipm_grid_max) * Y.N * Y.nu * (Y.nx + 2))) return false;
   if (!X.alloc(&B.work_counter, 1)) return false;
-  if (!X.alloc(&B.prof, 40)) return false;
+  if (!X.alloc(&B.prof, 64)) return false;
   (void)hipMemset(B.prof, 0, 40 * 8);
   if (!X.alloc(&B.active_insts, 1)) return false;
   if (!X.alloc(&B.stat_rowiters, 1)) return false;
+#ifdef MIQP_PROFILE
+  if (!X.alloc(&B.pool_origin, (size_t)X.pool_cap)) return false;
+  HIP_OK(hipMemset(B.pool_origin, 0, (size_t)X.pool_cap));
+#endif
   X.ready = true;
   return true;
 }
@@ -594,7 +598,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   HIP_OK(hipGetLastError());
   float ms_all = 0; HIP_OK(hipEventElapsedTime(&ms_all, X.ev0, X.ev1));
 #ifdef MIQP_PROFILE
-  { unsigned long long pf[40]; HIP_OK(hipMemcpy(pf, B.prof, 40 * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemset(B.prof, 0, 40 * 8));
+  { unsigned long long pf[64]; HIP_OK(hipMemcpy(pf, B.prof, 64 * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemset(B.prof, 0, 64 * 8));
+    { const char* on[8] = {"region.first", "region.other", "env.first", "env.other", "obs.first", "obs.other", "c2c.inf", "c2c.dev"};
+      std::fprintf(stderr, "[miqp_gpu profile] nodes by origin (all / infeasible / cut off):"); for (int q = 0; q < 8; ++q) std::fprintf(stderr, " %s %llu/%llu/%llu", on[q], pf[40 + q], pf[48 + q], pf[56 + q]); std::fprintf(stderr, "\n"); }
     std::fprintf(stderr, "[miqp_gpu profile] iteration histogram (bins of 10; all / infeasible):"); for (int q = 0; q < 9; ++q) std::fprintf(stderr, " %llu/%llu", pf[16 + q], pf[25 + q]); std::fprintf(stderr, "\n");
     const char* nm[9] = {"build", "bw.rows", "bw.mfma", "bw.TS", "bw.cholK", "bw.P", "forward", "step", "update"};
     double tot = 0; for (int q = 0; q < 9; ++q) tot += (double)pf[q];
