@@ -464,6 +464,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   for (int kb = 0; kb < KB; ++kb) abr[kb] = (4 * kb + (tid >> 4) < NX && (tid & 15) < NZ) ? ab_entry<C>(4 * kb + (tid >> 4), tid & 15, ts) : 0.0;
 #ifdef MIQP_PROFILE
   unsigned long long pr_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int first_proxy = 0;
 #endif
   PROF_T(tb0);
 
@@ -528,6 +529,9 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     if (MIQP_ABL) { if (it > (((MIQP_ABL) & 512) ? 0 : 20)) { ok = 1; break; } }
     else if (comp < B.qp_tol * fmax(1.0, fabs(obj)) && resid_fac * R0 < 1e-7) { ok = 1; break; }
     // dual bound of the penalised problem: primal value - total complementarity (valid once the iterate is dual feasible)
+#ifdef MIQP_PROFILE
+    if (it > 1 && first_proxy == 0 && obj + RHO_EL * tsum - (double)ncomp * comp > cutoff + 1e-9 * fabs(cutoff)) first_proxy = it;
+#endif
     if (!(MIQP_ABL) && it > 1 && resid_fac * R0 < 1e-9 * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }
     const double tau = sigma * comp;
     // ================= backward sweep: Riccati recursion, the whole stage algebra stays in the registers of the wave.
@@ -985,6 +989,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     for (int q = 0; q < 9; ++q) atomicAdd(&B.prof[q], pr_[q]);
     atomicAdd(&B.prof[9], (unsigned long long)(it > QP_MAXIT ? QP_MAXIT : it)); atomicAdd(&B.prof[10], 1ull); atomicAdd(&B.prof[11], (unsigned long long)NROWS);
     { int hb = (it > QP_MAXIT ? QP_MAXIT : it) / 10; if (hb > 8) hb = 8; atomicAdd(&B.prof[16 + hb], 1ull); if (viol > FEAS_TOL) atomicAdd(&B.prof[25 + hb], 1ull); }
+    if (ok == 2) { atomicAdd(&B.prof[36], (unsigned long long)first_proxy); atomicAdd(&B.prof[37], (unsigned long long)it); atomicAdd(&B.prof[38], 1ull); }
     { int og = (int)B.pool_origin[B.batch_node[node]] & 7; atomicAdd(&B.prof[40 + og], 1ull); if (viol > FEAS_TOL) atomicAdd(&B.prof[48 + og], 1ull); if (ok == 2) atomicAdd(&B.prof[56 + og], 1ull); }
 #endif
   }

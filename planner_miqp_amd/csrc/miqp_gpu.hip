@@ -437,7 +437,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   if (!bs.ok) { for (int k = 0; k < n; ++k) { if (S[k]) S[k]->err = bs.err; statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; } std::fprintf(stderr, "[miqp_gpu] %s\n", bs.err.c_str()); return false; }
   const Layout& Y = bs.Y;
   const miqp_solver_opts& O0 = S[0]->opts;
-  int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(512, 16384 / n));
+  int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(512, 32768 / n));
   if (O0.nodes_per_round <= 0 && std::getenv("MIQP_NPR")) npr = std::max(1, std::atoi(std::getenv("MIQP_NPR")));  // tuning knob
   int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (std::getenv("MIQP_OPEN_CAP") ? std::atoi(std::getenv("MIQP_OPEN_CAP")) : std::max(32768, std::min(1 << 20, (1 << 24) / n)));
   if (open_cap < 64) open_cap = 64;
@@ -600,6 +600,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
 #ifdef MIQP_PROFILE
   { unsigned long long pf[64]; HIP_OK(hipMemcpy(pf, B.prof, 64 * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemset(B.prof, 0, 64 * 8));
     { const char* on[8] = {"region.first", "region.other", "env.first", "env.other", "obs.first", "obs.other", "c2c.inf", "c2c.dev"};
+      std::fprintf(stderr, "[miqp_gpu profile] cut-off nodes %llu: unguarded estimate first above the cutoff at iteration %.2f on average, guarded exit at %.2f\n", pf[38], (double)pf[36] / std::max(1ull, pf[38]), (double)pf[37] / std::max(1ull, pf[38]));
       std::fprintf(stderr, "[miqp_gpu profile] nodes by origin (all / infeasible / cut off):"); for (int q = 0; q < 8; ++q) std::fprintf(stderr, " %s %llu/%llu/%llu", on[q], pf[40 + q], pf[48 + q], pf[56 + q]); std::fprintf(stderr, "\n"); }
     std::fprintf(stderr, "[miqp_gpu profile] iteration histogram (bins of 10; all / infeasible):"); for (int q = 0; q < 9; ++q) std::fprintf(stderr, " %llu/%llu", pf[16 + q], pf[25 + q]); std::fprintf(stderr, "\n");
     const char* nm[9] = {"build", "bw.rows", "bw.mfma", "bw.TS", "bw.cholK", "bw.P", "forward", "step", "update"};
