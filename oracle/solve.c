@@ -308,7 +308,7 @@ static double row_val(const dmodel* M, const orow* r, const double* Z) {
 }
 
 /* ------------------------------------------------------------------ QP: stage-banded primal-dual IPM */
-typedef struct { double* Z; double obj; double viol; int it; int ok; double slack_cost; double* lam; } qpres;
+typedef struct { double* Z; double obj; double viol; int it; int ok; double slack_cost; double* lam; double dgap; } qpres;
 
 static void build_AB(const oinst* I, double* A, double* B, int nx, int nu) {
   double ts = I->ts;
@@ -375,7 +375,7 @@ static int qp_solve_tol(const dmodel* M, const orow* rows, int m, qpres* out, do
   double* T = (double*)malloc(sizeof(double) * nx * nz); double* S = (double*)malloc(sizeof(double) * nz * nz);
   double* sv = (double*)malloc(sizeof(double) * nz); double* Lc = (double*)malloc(sizeof(double) * nu * nu);
   double* Pn = (double*)malloc(sizeof(double) * nx * nx); double* pn = (double*)malloc(sizeof(double) * nx);
-  int it = 0, ok = 0; double resid_fac = 1.0, R0 = 0.0, alpha_prev = 0.0;
+  int it = 0, ok = 0; double resid_fac = 1.0, R0 = 0.0, alpha_prev = 0.0, dgap = 0.0;
   for (it = 1; it <= QP_MAXIT; ++it) {
     double comp = 0, obj = 0;
     for (int i = 0; i < N; ++i)
@@ -385,6 +385,7 @@ static int qp_solve_tol(const dmodel* M, const orow* rows, int m, qpres* out, do
       comp += s[k] * lam[k];
       if (rows[k].a == 0.0) { double t = tt[k], mu = RHO_EL - lam[k]; comp += t * mu; (void)c; }
     }
+    dgap = comp; /* total complementarity = primal value - dual value of the iterate */
     comp /= (m + mel > 0 ? m + mel : 1);
     if (comp < qp_tol * fmax(1.0, fabs(obj)) && resid_fac * R0 < 1e-7) { ok = 1; break; }
     /* centering: aggressive after a (nearly) full step, conservative after a blocked one */
@@ -522,7 +523,7 @@ static int qp_solve_tol(const dmodel* M, const orow* rows, int m, qpres* out, do
     else { double t = lam[k] / rows[k].a; slack_cost += 0.5 * rows[k].a * t * t; }
   }
   out->Z = Z; out->obj = obj + slack_cost; out->viol = viol; out->it = it > QP_MAXIT ? QP_MAXIT : it; out->ok = ok;
-  out->slack_cost = slack_cost; out->lam = lam;
+  out->slack_cost = slack_cost; out->lam = lam; out->dgap = dgap;
   free(A); free(B); free(Wd); free(Rf); free(start); free(order); free(s); free(ds); free(dlam); free(w); free(kap);
   free(gd); free(tt); free(dtt); free(Kg); free(kg); free(dZ); free(Phi); free(rr); free(P); free(pv); free(T); free(S); free(sv); free(Lc);
   free(Pn); free(pn);
@@ -950,29 +951,33 @@ int orc_solve(const oinst* I, const orc_opts* o, miqp_raw_results_c* res, miqp_s
     heap_push(&H, root);
   }
   long long pops = 0;
+  double dropped_min = INFINITY; /* smallest bound of a node that was dropped because it lies within the gap */
   while (H.n > 0) {
     double lb = heap_min_bound(&H);
     if (inc < INFINITY && (inc - lb) <= gap * (1e-10 + fabs(inc))) { best_bound = lb; break; }
     if (props->nodes >= max_nodes || now_s() - t0 > tlim) { timed_out = 1; best_bound = lb; break; }
     bnode nd = heap_pop(&H, !(inc < INFINITY) || (pops++ % 4) == 3);
-    if (inc < INFINITY && (inc - nd.bound) <= gap * (1e-10 + fabs(inc))) { free(nd.fix); continue; }
+    if (inc < INFINITY && (inc - nd.bound) <= gap * (1e-10 + fabs(inc))) { if (nd.bound < dropped_min) dropped_min = nd.bound; free(nd.fix); continue; }
     props->nodes++;
     node_rows(M, nd.fix, &rows);
     qpres q; qp_solve(M, rows.r, rows.n, &q);
     props->NrIterations += q.it;
     double obj = q.obj + const_cost(M, nd.fix) + cobj0;
+    /* what the node proves is the dual value of its relaxation: the primal value of the interior point iterate minus
+       the remaining complementarity */
+    double objlb = obj - fmax(0.0, q.dgap);
     if (q.viol > FEAS_TOL || !q.ok) {
       if (verbose > 1) fprintf(stderr, "  node %lld infeasible viol %.2e ok %d it %d\n", props->nodes, q.viol, q.ok, q.it);
-    } else if (!(inc < INFINITY) || obj < inc - 1e-12 * fabs(inc)) {
+    } else if (!(inc < INFINITY) || objlb < inc - 1e-12 * fabs(inc)) {
       violation vb;
       if (complete(M, nd.fix, q.Z, comp, &vb, FEAS_TOL)) {
-        inc = obj; memcpy(inc_fix, comp, M->fixlen); memcpy(incZ, q.Z, sizeof(double) * I->N * M->nz);
+        if (!(inc < INFINITY) || obj < inc) { inc = obj; memcpy(inc_fix, comp, M->fixlen); memcpy(incZ, q.Z, sizeof(double) * I->N * M->nz); }
         props->NrSolutionPool++;
         if (verbose) fprintf(stderr, "  node %lld incumbent %.8f depth %d open %d\n", props->nodes, obj, nd.depth, H.n);
       } else {
         if (verbose) { static long hist[4][64]; static long hist_cnt = 0; int kd = vb.key[0]=='r'?0:(vb.key[0]=='e'?1:(vb.key[0]=='o'?2:3)); int stp = kd==2?vb.key[3]:vb.key[2]; hist[kd][stp]++; if (++hist_cnt % 1000 == 0) { for (int k=0;k<4;++k){ fprintf(stderr,"kind %d:",k); for(int q=0;q<I->N;++q) fprintf(stderr," %ld",hist[k][q]); fprintf(stderr,"\n"); } } }
         for (int a = 0; a < vb.nalts; ++a) {
-          bnode ch; ch.bound = obj; ch.seq = seq++; ch.depth = nd.depth + 1; ch.fix = (signed char*)malloc(M->fixlen);
+          bnode ch; ch.bound = objlb; ch.seq = seq++; ch.depth = nd.depth + 1; ch.fix = (signed char*)malloc(M->fixlen);
           memcpy(ch.fix, nd.fix, M->fixlen);
           switch (vb.key[0]) {
             case 'r': FIX_REG(M, ch.fix, vb.key[1], vb.key[2]) = (signed char)vb.alts[a]; break;
@@ -987,6 +992,7 @@ int orc_solve(const oinst* I, const orc_opts* o, miqp_raw_results_c* res, miqp_s
     free(q.Z); free(q.lam); free(nd.fix);
   }
   if (!timed_out && H.n == 0 && best_bound == -INFINITY) best_bound = inc; /* tree exhausted */
+  if (best_bound > dropped_min) best_bound = dropped_min;
   if (inc < INFINITY && best_bound > inc) best_bound = inc;
   for (int k = 0; k < H.n; ++k) free(H.a[k].fix);
   free(H.a); free(rows.r);

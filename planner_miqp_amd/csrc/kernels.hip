@@ -981,7 +981,9 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   double* Zo = B.batch_Z + (size_t)node * N * NZ;
   for (int k = tid; k < N * NZ; k += NT) Zo[k] = Z[k];
   if (tid == 0) {
-    B.batch_obj[node] = obj; B.batch_viol[node] = viol; B.batch_ok[node] = ok; B.batch_it[node] = it > QP_MAXIT ? QP_MAXIT : it;
+    B.batch_obj[node] = obj; B.batch_viol[node] = viol; B.batch_ok[node] = ok;
+    B.batch_bound[node] = (double)ncomp * comp;   // primal - dual value of the final iterate (total complementarity)
+    B.batch_it[node] = it > QP_MAXIT ? QP_MAXIT : it;
     atomicAdd((unsigned long long*)&B.inst_iters[inst], (unsigned long long)(it > QP_MAXIT ? QP_MAXIT : it));
     atomicAdd((unsigned long long*)&B.inst_nodes[inst], 1ull);
     atomicAdd(B.stat_rowiters, rowiters);
@@ -1091,9 +1093,12 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   int nign = 0;
   for (int k = lane; k < C * Y.O * N * 5; k += 64) nign += fix[Y.f_obs + k] >= Y.L ? 1 : 0;
   nign = (int)wave_sum((double)nign);
-  const double obj = B.batch_obj[node] + B.inst_const[inst] + nign * D[Y.d_misc + 1];
+  const double obj = B.batch_obj[node] + B.inst_const[inst] + nign * D[Y.d_misc + 1];   // primal value: what an incumbent costs
+  // what the node proves: the dual value of its relaxation (the primal value of an interior point iterate lies above the
+  // optimum of the relaxation by the remaining complementarity)
+  const double objlb = obj - fmax(0.0, B.batch_bound[node]);
   const double inc_now = inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]);
-  if (inc_now < 1e300 && !(obj < inc_now - 1e-12 * fabs(inc_now))) { FREE_NODE(); return; }  // bound not better than the incumbent
+  if (inc_now < 1e300 && !(objlb < inc_now - 1e-12 * fabs(inc_now))) { FREE_NODE(); return; }  // bound not better than the incumbent
   const double tol = FEAS_TOL;
   const int NCI = C * (N - 1);
   // ---------------- phase R: region alternatives per (c, i)
@@ -1366,7 +1371,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + ob + lane;
       // depth word: (tree depth << 6) | preference among siblings (child_inf first) - used by the dive ordering
       int pd = B.batch_depth[node] >> 6;
-      B.open_bound[oi] = obj - B.inst_const[inst]; B.open_node[oi] = slots[lane]; B.open_depth[oi] = ((pd + 1) << 6) | (63 - lane);
+      B.open_bound[oi] = objlb - B.inst_const[inst]; B.open_node[oi] = slots[lane]; B.open_depth[oi] = ((pd + 1) << 6) | (63 - lane);
     }
   }
   FREE_NODE();

@@ -655,7 +655,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
       s->status = MIQP_STATUS_SUCCESS; s->has_sol = true;
       s->props.objective = h_inc[k];
       double lb = std::min(h_lb[k], h_inc[k]);
-      if (!unfinished) lb = std::max(lb, std::min(h_inc[k], h_inc[k] - h_gap[k] * std::fabs(h_inc[k])));
+      // nodes within the gap of the incumbent are dropped without being refined: what is proven is the smaller of the open
+      // list's best bound and incumbent - gap*|incumbent| (CPLEX reports the bound of its remaining nodes the same way)
+      lb = std::min(lb, h_inc[k] - h_gap[k] * std::fabs(h_inc[k]));
       s->props.best_bound = lb; s->props.gap = std::fabs(lb - h_inc[k]) / (1e-10 + std::fabs(h_inc[k]));
       s->props.status = unfinished ? MIQP_CPX_STAT_TIME_LIM_FEAS : (s->props.gap <= 1e-9 ? MIQP_CPX_STAT_OPTIMAL : MIQP_CPX_STAT_OPTIMAL_TOL);
       s->Z.assign(h_Z.begin() + (size_t)k * Y.N * Y.nz, h_Z.begin() + (size_t)(k + 1) * Y.N * Y.nz);

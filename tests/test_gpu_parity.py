@@ -346,3 +346,34 @@ def test_full_size_properties(oracle, cfg):
         assert abs(obj - pr.objective) <= 1e-6 * max(1.0, abs(obj))
         oracle.free(h)
     assert nsolved >= 1
+
+
+def test_full_size_bounds_are_mutually_valid(oracle):
+    """2 cars x 20 steps x 32 regions at gap 1e-3, instances both sides finish: every reported lower bound is below the
+    other side's feasible objective (a bound that overstates is caught by the other solver's solution), objectives agree
+    within the two gaps"""
+    from concurrent.futures import ThreadPoolExecutor
+    G = 1e-3
+    ps = [synthetic.generate("cfg3", s, gap=G, max_time=12) for s in range(300, 348)]
+    ws = []
+    for p in ps:
+        w = P.CplexWrapper(); w.resetParameters(p); ws.append(w)
+    sts = P.solve_batch(ws)
+
+    def orc(p):
+        h = oracle.from_params(p, 10)
+        r = oracle.solve(h, oracle.dims(p), gap=G, time_limit=12)
+        oracle.free(h)
+        return r
+    with ThreadPoolExecutor(min(48, os.cpu_count() or 8)) as ex:
+        res = list(ex.map(orc, ps))
+    both = 0
+    for k, (w, st, (ost, r, op)) in enumerate(zip(ws, sts, res)):
+        pr = w.getSolutionProperties()
+        if ost != 0 or op.gap > G + 1e-9 or int(st) != 0 or pr.gap > G + 1e-9:
+            continue
+        both += 1
+        tol = 1e-7 * max(1.0, abs(op.objective))
+        assert pr.objective >= op.best_bound - tol and op.objective >= pr.best_bound - tol, (k, pr.objective, pr.best_bound, op.objective, op.best_bound)
+        assert abs(pr.objective - op.objective) <= 2 * G * max(1.0, abs(op.objective))
+    assert both >= 10
