@@ -66,6 +66,44 @@ def region_tables():
         json.dump(t, open(os.path.join(out_dir, "region_tables_%d.json" % R), "w"))
 
 
+def region_tables_64():
+    """planner_miqp_amd/data/region_tables_64.json for the 4-car config cfg5 (BASELINE.json: 64 regions).  Sources:
+    fraction parameters and acceleration / jerk boxes computed by the planner core (ParameterPreparer restatement, fitting
+    speed 10 m/s, straight-line limits 2 / -4 / 3 / 1.6 / 1.4 as in src/miqp_planner_data.hpp:190-242); front-axle
+    polynomials from the reference's DATA file data/polynoms_from_fitting_64_using_theta.mat (the constant-heading
+    variant, the only 64-region fit shipped as data); the curvature polynomials exist for 64 regions only as C++ literals
+    (common/parameter/fitting_polynomial_parameters.hpp), which are not copied: every 64-sector takes the fitted curvature
+    polynomial of the 32-sector that contains it - an approximation, good enough for a synthetic benchmark instance."""
+    import numpy as np
+    import scipy.io as sio
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    import planner_miqp_amd as P
+    from planner_miqp_amd import planner_core as K
+    P.build_library()
+    R = 64
+    out_dir = os.path.join(HERE, "..", "..", "planner_miqp_amd", "data")
+    pp = K.ParameterPreparer(R, 10, 1, 2, -4, 3, 1.6, 1.4)
+    acc, jerk = pp.CalculateAccLimitsPerCar(), pp.CalculateJerkLimitsPerCar()
+    m = sio.loadmat(os.path.join(REF, "data", "polynoms_from_fitting_64_using_theta.mat"), squeeze_me=True, struct_as_record=False)["lin_result"]
+    t32 = json.load(open(os.path.join(out_dir, "region_tables_32.json")))
+    k32max, k32min = np.array(t32["POLY_KAPPA_AX_MAX"]).reshape(32, 3), np.array(t32["POLY_KAPPA_AX_MIN"]).reshape(32, 3)
+    t = {"fraction_parameters": pp.GetFractionParameters().round(10).tolist(),
+         "POLY_SINT_UB": np.array([m.poly_sin_ub[k] for k in range(R)]).round(10).tolist(),
+         "POLY_SINT_LB": np.array([m.poly_sin_lb[k] for k in range(R)]).round(10).tolist(),
+         "POLY_COSS_UB": np.array([m.poly_cos_ub[k] for k in range(R)]).round(10).tolist(),
+         "POLY_COSS_LB": np.array([m.poly_cos_lb[k] for k in range(R)]).round(10).tolist(),
+         "POLY_KAPPA_AX_MAX": k32max[np.arange(R) // 2].tolist(), "POLY_KAPPA_AX_MIN": k32min[np.arange(R) // 2].tolist()}
+    for nm, d in (("acc", acc), ("jerk", jerk)):
+        for k in ("min_x", "max_x", "min_y", "max_y"):
+            t["%s_%s_%s" % (k[:3], nm, k[-1])] = [np.round(d[k], 4).tolist()]
+    t["total_min_acc"] = float(min(min(t["min_acc_x"][0]), min(t["min_acc_y"][0]))); t["total_max_acc"] = float(max(max(t["max_acc_x"][0]), max(t["max_acc_y"][0])))
+    t["total_min_jerk"] = float(min(min(t["min_jerk_x"][0]), min(t["min_jerk_y"][0]))); t["total_max_jerk"] = float(max(max(t["max_jerk_x"][0]), max(t["max_jerk_y"][0])))
+    t.update(min_vel_x_y=-10, max_vel_x_y=10, minimum_region_change_speed=1, nr_regions=R,
+             source="tests/golden/make_fixtures.py::region_tables_64 (planner core + data/polynoms_from_fitting_64_using_theta.mat + 32-region curvature fit)")
+    json.dump(t, open(os.path.join(out_dir, "region_tables_64.json"), "w"))
+
+
 if __name__ == "__main__":
     main()
     region_tables()
+    region_tables_64()

@@ -377,3 +377,27 @@ def test_full_size_bounds_are_mutually_valid(oracle):
         assert pr.objective >= op.best_bound - tol and op.objective >= pr.best_bound - tol, (k, pr.objective, pr.best_bound, op.objective, op.best_bound)
         assert abs(pr.objective - op.objective) <= 2 * G * max(1.0, abs(op.objective))
     assert both >= 10
+
+
+def test_cfg5_four_cars_64_regions_with_warmstart(oracle):
+    """BASELINE config 5 at its full size (4 cars x 30 steps x 64 regions; raw model 142 720 rows / 13 800 binaries):
+    a time-limited solve returns a vector that is feasible for every raw big-M row; fed back as MIP start
+    (variables_warmstart) the next solve starts from it and is not worse"""
+    p = synthetic.generate("cfg5", 0, gap=0.01, max_time=4.0)
+    h = oracle.from_params(p, 10)
+    assert oracle.sizes(h)["rows"] == 142720 and oracle.sizes(h)["bin"] == 13800
+    w = P.CplexWrapper(); w.resetParameters(p)
+    st = w.callCplex()
+    assert int(st) == 0
+    pr = w.getSolutionProperties(); res = w.getRawResults()
+    assert pr.status in (101, 102, 107) and pr.best_bound <= pr.objective + 1e-9 and pr.nodes > 1000
+    v, obj, worst = oracle.raw_eval(h, res)
+    assert v < 1e-5 and abs(obj - pr.objective) <= 1e-6 * max(1.0, abs(obj)), worst
+    w2 = P.CplexWrapper(); w2.resetParameters(p)
+    w2.addRecedingHorizonWarmstart(res)
+    assert int(w2.callCplex()) == 0
+    pr2 = w2.getSolutionProperties()
+    assert pr2.objective <= pr.objective * (1 + 1e-9) and pr2.NrSolutionPool >= 1
+    v2, obj2, worst2 = oracle.raw_eval(h, w2.getRawResults())
+    assert v2 < 1e-5, worst2
+    oracle.free(h)
