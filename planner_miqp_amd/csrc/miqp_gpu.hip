@@ -16,9 +16,6 @@
 #include <vector>
 
 #include "../../include/miqp_gpu.h"
-#ifndef MIQP_IPM_NT
-#define MIQP_IPM_NT 64
-#endif
 #include "kernels.hip"
 #include "wire_formats.hpp"
 #include "planner_core.hpp"
@@ -182,7 +179,6 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   X.Y = Y; X.n_inst = n_inst; X.open_cap = open_cap; X.npr = npr; X.batch_cap = batch_cap;
   { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); int cus = 256; if (hipGetDeviceProperties(&pr, dv) == hipSuccess) cus = pr.multiProcessorCount;
     size_t l = ipm_lds_bytes(Y); int per = (int)std::max<size_t>(1, std::min<size_t>(4 * (Y.C <= 2 ? MIQP_IPM_WPE : 1), (160 * 1024) / std::max<size_t>(l + 8, 1))); X.ipm_grid_max = cus * per; }
-  // node pool: every processed node emits at most a handful of children; records are not recycled inside one solve
   // node pool: live nodes are bounded by the open lists plus one round of children; processed records are recycled
   size_t want = (size_t)n_inst * ((size_t)open_cap + (size_t)npr * 64 + 64); size_t maxrec = ((size_t)48 << 30) / (size_t)Y.fixlen;   // node records: up to 48 GB of the 288 GB
   X.pool_cap = (int)std::min(want, maxrec);
@@ -244,7 +240,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   return true;
 }
 
-constexpr int IPM_NT = MIQP_IPM_NT;  // threads per node in the interior point kernel
+constexpr int IPM_NT = 64;  // one wavefront per node in the interior point kernel
 size_t ipm_lds_bytes(const Layout& Y) {
   int NZ = Y.nz, N = Y.N;
   size_t d = (size_t)N * NZ + (size_t)ipm_scratch_doubles(N, Y.C) + NZ + 8 + 32 + 2 * ((N + 6) / 2 + 1);
@@ -254,7 +250,6 @@ size_t eval_lds_bytes(const Layout& Y) {
   size_t d = (size_t)Y.N * Y.nz + (size_t)Y.C * Y.N * Y.P + (size_t)Y.C * Y.N;
   return d * 8 + (size_t)(2 * Y.C * Y.N + 64) * 4 + 64 * 8 + 2 * (size_t)Y.fixlen + 64;
 }
-size_t select_lds_bytes(int open_cap) { (void)open_cap; return 0; }
 
 template <int C> void launch_ipm(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { (void)hipMemsetAsync(B.work_counter, 0, 4, st); hipLaunchKernelGGL((ipm_kernel<C, IPM_NT>), dim3(nblocks), dim3(IPM_NT), lds, st, B); }
 template <int C> void launch_eval(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { hipLaunchKernelGGL(eval_kernel<C>, dim3(nblocks), dim3(64), lds, st, B); }
@@ -273,8 +268,7 @@ template <int C> bool set_kernel_lds_c(size_t ipm_lds, size_t eval_lds) {
   HIP_OK(hipFuncSetAttribute((const void*)eval_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eval_lds));
   return true;
 }
-bool set_kernel_lds(const Layout& Y, size_t ipm_lds, size_t eval_lds, size_t sel_lds) {
-  (void)sel_lds;
+bool set_kernel_lds(const Layout& Y, size_t ipm_lds, size_t eval_lds) {
   switch (Y.C) { case 1: return set_kernel_lds_c<1>(ipm_lds, eval_lds); case 2: return set_kernel_lds_c<2>(ipm_lds, eval_lds);
                  case 3: return set_kernel_lds_c<3>(ipm_lds, eval_lds); default: return set_kernel_lds_c<4>(ipm_lds, eval_lds); }
 }
@@ -445,9 +439,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   DevCtx& X = g_ctx;
   if (!ctx_prepare(X, Y, n, open_cap, npr, O0.device)) { for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
   DevBuf& B = X.B;
-  size_t l_ipm = ipm_lds_bytes(Y), l_eval = eval_lds_bytes(Y), l_sel = select_lds_bytes(open_cap);
-  if (l_ipm > 160 * 1024 || l_sel > 160 * 1024) { std::fprintf(stderr, "[miqp_gpu] instance too large for LDS (%zu bytes)\n", l_ipm); for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
-  if (!set_kernel_lds(Y, l_ipm, l_eval, l_sel)) { for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
+  size_t l_ipm = ipm_lds_bytes(Y), l_eval = eval_lds_bytes(Y);
+  if (l_ipm > 160 * 1024 || l_eval > 160 * 1024) { std::fprintf(stderr, "[miqp_gpu] instance too large for LDS (%zu bytes)\n", l_ipm); for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
+  if (!set_kernel_lds(Y, l_ipm, l_eval)) { for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
   // ---- host tables, step-1 presolve
   std::vector<double> hD((size_t)n * Y.dstride); std::vector<int> hT((size_t)n * Y.istride);
   std::vector<double> h_const(n, 0.0), h_gap(n), h_tlim(n);
@@ -505,11 +499,11 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   double tlim = 0; for (int k = 0; k < n; ++k) tlim = std::max(tlim, h_tlim[k]);
   HIP_OK(hipEventRecord(X.ev0, st));
   std::vector<int> h_done_now(n, 0); std::vector<double> h_tdone(n, -1.0);
-  size_t nev = 0; int rounds = 0; long long launched_nodes = 0; bool timed_out = false;
+  size_t nev = 0; int rounds = 0; long long launched_nodes = 0;
   for (;;) {
     HIP_OK(hipMemsetAsync(B.batch_count, 0, 4, st));
     B.open_sel = rounds & 1;
-    hipLaunchKernelGGL(select_kernel, dim3(n), dim3(SEL_THREADS), l_sel, st, B, rounds);
+    hipLaunchKernelGGL(select_kernel, dim3(n), dim3(SEL_THREADS), 0, st, B, rounds);
     hipLaunchKernelGGL(roll_kernel, dim3(1), dim3(1), 0, st, B);
     int bc = 0;
     HIP_OK(hipMemcpyAsync(&bc, B.batch_count, 4, hipMemcpyDeviceToHost, st));
@@ -518,7 +512,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     { const double tn = wall_s() - t0; for (int k = 0; k < n; ++k) if (h_done_now[k] && h_tdone[k] < 0) h_tdone[k] = tn; }   // completion time of every instance
     if (bc <= 0) break;
     if (bc > X.batch_cap) bc = X.batch_cap;
-    if (wall_s() - t0 > tlim) { timed_out = true; break; }
+    if (wall_s() - t0 > tlim) break;   // time limit: instances with open nodes report TIME_LIM_* below
     if (X.ipm_ev.size() < nev + 2) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); X.ipm_ev.push_back(a); X.ipm_ev.push_back(b); }
     HIP_OK(hipEventRecord(X.ipm_ev[nev], st));
     { int gsz = std::min(bc, X.ipm_grid_max); launch_ipm_c(Y.C, B, gsz, l_ipm, st); }
@@ -645,7 +639,6 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     miqp_solver* s = S[k];
     bool have = h_inc[k] < 1e299;
     bool unfinished = (h_flags[k] & 1) || h_oc[k] > 0 || !h_dn[k];
-    (void)timed_out;
     s->props.time = h_tdone[k] >= 0 ? h_tdone[k] : t_solve;   // batch: time from the start of the batch to the instance's proof
     s->props.NrIterations = (int)std::min<long long>(h_iters[k], 2147483647LL); s->props.nodes = h_nodes[k];
     s->props.NrSolutionPool = h_ninc[k];
@@ -896,7 +889,7 @@ int miqp_solver_solve_fixed(miqp_solver_t* s, const miqp_raw_results_c* fixed, m
   const Layout& Y = bs.Y;
   DevCtx& X = g_ctx;
   if (!ctx_prepare(X, Y, 1, 64, 16, s->opts.device)) return -3;
-  if (!set_kernel_lds(Y, ipm_lds_bytes(Y), eval_lds_bytes(Y), select_lds_bytes(64))) return -3;
+  if (!set_kernel_lds(Y, ipm_lds_bytes(Y), eval_lds_bytes(Y))) return -3;
   std::vector<double> D(Y.dstride); std::vector<int> T(Y.istride);
   compile_instance(s->inst, Y, D.data(), T.data());
   std::vector<signed char> fix;
