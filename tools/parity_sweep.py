@@ -8,7 +8,8 @@ import planner_miqp_amd as P, oracle_lib
 from planner_miqp_amd import synthetic
 O = oracle_lib.Oracle(os.path.join(ROOT, "oracle", "_build", "liboracle.so"))
 bad = 0; n = 0; t0 = time.time()
-for cfg, seeds in (("mini", range(6, 70)), ("mini3b", range(4, 24)), ("mini4b", range(4, 14)), ("mini1", range(6, 30))):
+OFF = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+for cfg, seeds in (("mini", range(6 + OFF, 70 + OFF)), ("mini3b", range(4 + OFF, 24 + OFF)), ("mini4b", range(4 + OFF, 14 + OFF)), ("mini1", range(6 + OFF, 30 + OFF)), ("cfg2", range(4 + OFF, 24 + OFF))):
     for s in seeds:
         if time.time() - t0 > float(sys.argv[1]) if len(sys.argv) > 1 else 400:
             break
