@@ -622,9 +622,15 @@ static void sort_alts(int n, int* alts, double* vals) {
   }
 }
 
-static int g_branch_rule = 0; /* 0 earliest step, 1 latest step (experiments: ORC_BRANCH) */
+/* branching order: 3 (default) = car/car disjunctions before obstacle, environment and region ones, the most violated
+   first within a kind, and the earliest violated step until an incumbent exists (the order of the device solver);
+   0 earliest step, 1 latest step, 2 most violated (experiments: ORC_BRANCH) */
+static int g_branch_rule = 3;
+static __thread int g_rule_now = 0;
 static void viol_consider(violation* best, int step, int kind, const int* key, int nalts, const int* alts) {
-  if (g_branch_rule == 0) { if (best->step >= 0 && (best->step < step || (best->step == step && best->kind <= kind))) return; }
+  const int g_branch_rule = g_rule_now;
+  if (g_branch_rule == 3) { if (best->step >= 0 && (best->kind > kind || (best->kind == kind && best->mag >= g_cur_viol))) return; }
+  else if (g_branch_rule == 0) { if (best->step >= 0 && (best->step < step || (best->step == step && best->kind <= kind))) return; }
   else if (g_branch_rule == 1) { if (best->step >= 0 && (best->step > step || (best->step == step && best->kind <= kind))) return; }
   else { if (best->step >= 0 && best->mag >= g_cur_viol) return; }
   best->mag = g_cur_viol;
@@ -970,6 +976,7 @@ int orc_solve(const oinst* I, const orc_opts* o, miqp_raw_results_c* res, miqp_s
       if (verbose > 1) fprintf(stderr, "  node %lld infeasible viol %.2e ok %d it %d\n", props->nodes, q.viol, q.ok, q.it);
     } else if (!(inc < INFINITY) || objlb < inc - 1e-12 * fabs(inc)) {
       violation vb;
+      g_rule_now = (g_branch_rule == 3 && !(inc < INFINITY)) ? 0 : g_branch_rule;
       if (complete(M, nd.fix, q.Z, comp, &vb, FEAS_TOL)) {
         if (!(inc < INFINITY) || obj < inc) { inc = obj; memcpy(inc_fix, comp, M->fixlen); memcpy(incZ, q.Z, sizeof(double) * I->N * M->nz); }
         props->NrSolutionPool++;
