@@ -1436,7 +1436,9 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   // node selection: best bound, interleaved with dives (deepest first) while no incumbent exists, on every 4th
   // round afterwards and whenever the list is more than half full (a depth-first frontier stays small);
   // the order changes how fast incumbents appear, not what is proven
-  const bool dive = !(inc < 1e300) || (round & 3) == 3 || n > cap / 2;
+  const int dive_every = (B.seq_kinds >> 18) & 3;   // experiment switch: 0 every 4th round, 1 never, 2 every 8th, 3 every 2nd
+  const bool periodic = dive_every == 0 ? (round & 3) == 3 : (dive_every == 1 ? false : (dive_every == 2 ? (round & 7) == 7 : (round & 1) == 1));
+  const bool dive = !(inc < 1e300) || periodic || n > cap / 2;
   // ---- pass 1: prune, keys, lower bound
   double lb = 1e300; int mloc = 0;
   for (int k = tid; k < n; k += SEL_THREADS) {
