@@ -1334,6 +1334,10 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       int n = alts_of(j, tmp);
       for (int q = 0; q < n && nalt < 63; ++q) { ck[nalt] = j; ca[nalt] = tmp[q]; nalt++; }
     }
+    // rounding probe (until the instance has an incumbent): one extra child with EVERY undecided disjunction fixed to its
+    // completed value.  It lies inside the first child, so the children stay exhaustive; its relaxation is the exact cost
+    // of the rounding and, when feasible, the first incumbent two rounds after the root instead of one dive level per round
+    if (!(inc_now < 1e300) && nalt < 63 && (B.seq_kinds & 0x400000) == 0) { ck[nalt] = -2; ca[nalt] = 0; nalt++; }
     fam[0] = base; fam[1] = stride; fam[2] = jlo; fam[3] = jhi;
     int ob = atomicAdd(&B.open_count[inst], nalt);
     bool okalloc = ob + nalt <= B.open_cap;
@@ -1362,7 +1366,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       // exclusive children (car/car): the deviating child excludes, at zero slack, the reference alternative of step kk
       // and the alternatives of its earlier siblings at that step
       int negidx = -1, negm = 0;
-      if (chosen.kind == 3 && kk < N && (B.seq_kinds & 0x10000) == 0) {
+      if (chosen.kind == 3 && kk >= 0 && kk < N && (B.seq_kinds & 0x10000) == 0) {
         negidx = Y.f_c2n + (chosen.c * N + kk) * 4 + chosen.o;
         negm = 1 << (int)comp[base + kk * stride];
         for (int a2 = 1; a2 < a; ++a2) if (ck[a2] == kk) negm |= 1 << ca[a2];
@@ -1375,6 +1379,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
           if (j >= jlo && j <= jhi) { if (j < kk) v = comp[k]; else if (j == kk) v = av; }
         }
         if (k == negidx) v = (signed char)negm;
+        if (kk == -2) v = (fix[k] < 0 && k < Y.f_c2n) ? comp[k] : fix[k];   // rounding probe
         dst[k] = v;
       }
 #ifdef MIQP_PROFILE
@@ -1385,7 +1390,8 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + ob + lane;
       // depth word: (tree depth << 6) | preference among siblings (child_inf first) - used by the dive ordering
       int pd = B.batch_depth[node] >> 6;
-      B.open_bound[oi] = objlb - B.inst_const[inst]; B.open_node[oi] = slots[lane]; B.open_depth[oi] = ((pd + 1) << 6) | (63 - lane);
+      B.open_bound[oi] = objlb - B.inst_const[inst]; B.open_node[oi] = slots[lane];
+      B.open_depth[oi] = ck[lane] == -2 ? (((pd + 2) << 6) | 63) : (((pd + 1) << 6) | (63 - lane));   // the probe is dived into first
     }
   }
   FREE_NODE();
