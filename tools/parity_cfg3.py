@@ -9,7 +9,7 @@ import planner_miqp_amd as P, oracle_lib
 from planner_miqp_amd import synthetic
 O = oracle_lib.Oracle(os.path.join(ROOT, "oracle", "_build", "liboracle.so"))
 G = 1e-3
-ps = [synthetic.generate("cfg3", s, gap=G, max_time=15) for s in range(300, 428)]
+ps = [synthetic.generate("cfg3", s, gap=G, max_time=15) for s in range(int(sys.argv[1]) if len(sys.argv) > 1 else 300, (int(sys.argv[1]) if len(sys.argv) > 1 else 300) + 128)]
 ws = []
 for p in ps:
     w = P.CplexWrapper(); w.resetParameters(p); ws.append(w)
@@ -26,5 +26,5 @@ for k, (w, st, (ost, r, op)) in enumerate(zip(ws, sts, res)):
     n += 1
     lo = max(pr.best_bound, op.best_bound); 
     if not (abs(pr.objective - op.objective) <= 2 * G * max(1.0, abs(op.objective)) and pr.objective >= op.best_bound - 1e-6 * abs(op.objective) and op.objective >= pr.best_bound - 1e-6 * abs(pr.objective)):
-        bad += 1; print("MISMATCH seed", 300 + k, pr.objective, pr.best_bound, op.objective, op.best_bound, flush=True)
+        bad += 1; print("MISMATCH seed", (int(sys.argv[1]) if len(sys.argv) > 1 else 300) + k, pr.objective, pr.best_bound, op.objective, op.best_bound, flush=True)
 print("both solved", n, "of", len(ps), "mismatches", bad)
