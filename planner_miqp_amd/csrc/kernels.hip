@@ -1400,7 +1400,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
 
 // ------------------------------------------------------------------------------------------------
 //  select: per instance prune + sort + pick
-constexpr int SEL_THREADS = 256;
+constexpr int SEL_THREADS = 256;   // also the number of radix bins: the histogram is cleared by one thread per bin
 
 // One workgroup per instance.  Reads the open list from buffer `B.open_sel`, prunes it against the incumbent,
 // selects the `take` smallest keys by an MSB-first 8-bit radix select (no full sort, lists live in HBM/L2),
