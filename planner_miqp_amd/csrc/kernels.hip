@@ -1454,7 +1454,10 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     if (inc < 1e300 && (inc - (b + cst)) <= gap * (1e-10 + fabs(inc))) {  // cannot improve the incumbent by more than the gap
       unsigned int q_ = atomicAdd(B.free_tail, 1u); B.free_q[q_ % (unsigned int)B.pool_cap] = nd;
     } else {
-      double kv = dive ? (-(double)dp * 1e9 + fmax(b, -1e8)) : fmax(b, -1e300);
+      // best bound; experiment switch (bits 24..25 of seq_kinds): deeper nodes first among nearly equal bounds
+      const int dbias = (B.seq_kinds >> 24) & 3;
+      const double bb = dbias ? b - (dbias == 1 ? 1e-4 : (dbias == 2 ? 1e-3 : 1e-2)) * fabs(b) * (double)(dp >> 6) : b;
+      double kv = dive ? (-(double)dp * 1e9 + fmax(b, -1e8)) : fmax(bb, -1e300);
       key = d2key(kv); if (key == ~0ull) key = ~0ull - 1;
       mloc++;
     }
