@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   constexpr int RU = NX / 4, GU0 = NX % 4;  // register / first lane group holding the input rows NX..NZ-1  // rows are zero padded to the 16 columns of the MFMA tile
   const Layout& Y = B.Y;
   const int tid = threadIdx.x;
-  const int nbatch = *B.batch_count;
+  const int nbatch = *B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap;   // select may over-count when the batch is full
   const int N = Y.N, NSLOT = Y.NSLOT;
   extern __shared__ double lds[];
   double* Z = lds;                       // [N][NZ]
@@ -1060,7 +1060,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   constexpr int NZ = 8 * C;
   const Layout& Y = B.Y;
   const int node = blockIdx.x, lane = threadIdx.x;
-  if (node >= *B.batch_count) return;
+  if (node >= *B.batch_count || node >= B.batch_cap) return;
 #define FREE_NODE() do { if (lane == 0) { unsigned int q_ = atomicAdd(B.free_tail, 1u); B.free_q[q_ % (unsigned int)B.pool_cap] = B.batch_node[node]; } } while (0)
   const int inst = B.batch_inst[node];
   const double* D = B.inst_d + (size_t)inst * Y.dstride;
@@ -1469,9 +1469,32 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   if (mloc) atomicAdd(&sh_m, mloc);
   __syncthreads();
   const int m = sh_m;
+  // Endgame focus: when only a few instances are still open, the batch is not split evenly but geometrically by gap rank
+  // (1/2 to the instance closest to its proof, 1/4 to the next, ...): finishing one instance after the other brings more
+  // of them below the gap before the time limit than advancing all of them at the same pace.
+  if (tid == 0) sh_pick = 0;   // reused as rank counter until the selection below resets it
+  __syncthreads();
+  const int act_now = *B.active_insts;
+  const bool focus = act_now <= 16 && inc < 1e300 && (B.seq_kinds & 0x8000000) == 0;
+  if (focus) {
+    const double gme = (inc - (lb + cst)) / (1e-10 + fabs(inc));
+    int cntl = 0;
+    for (int j = tid; j < B.n_inst; j += SEL_THREADS) {
+      if (j == inst || B.inst_done[j]) continue;
+      const double ij = B.inc_obj[j];
+      const double gj = ij < 1e299 ? (ij - B.lower_bound[j]) / (1e-10 + fabs(ij)) : 1e300;
+      if (gj < gme || (gj == gme && j < inst)) cntl++;
+    }
+    if (cntl) atomicAdd(&sh_pick, cntl);
+  }
+  __syncthreads();
+  const int rank = sh_pick;
+  __syncthreads();
   if (tid == 0) {
-    int act = *B.active_insts; if (act < 1) act = 1;
-    int w = B.batch_cap / act; if (w < B.nodes_per_round) w = B.nodes_per_round;
+    sh_pick = 0;
+    int act = act_now; if (act < 1) act = 1;
+    int w = (focus && !(B.seq_kinds & 0x10000000)) ? (B.batch_cap >> (rank + 1 < 30 ? rank + 1 : 30)) : B.batch_cap / act;
+    if (w < B.nodes_per_round) w = B.nodes_per_round;
     int take = m < w ? m : w;
     const int maxch = (B.seq_kinds & 15) ? 64 : 16;     // children of one node: first-deviation families up to 63, plain K-way up to 16
     int room = (cap - m) / maxch; if (room < 1) room = 1;

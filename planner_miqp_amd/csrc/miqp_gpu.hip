@@ -433,7 +433,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   const miqp_solver_opts& O0 = S[0]->opts;
   int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(512, 32768 / n));
   if (O0.nodes_per_round <= 0 && std::getenv("MIQP_NPR")) npr = std::max(1, std::atoi(std::getenv("MIQP_NPR")));  // tuning knob
-  int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (std::getenv("MIQP_OPEN_CAP") ? std::atoi(std::getenv("MIQP_OPEN_CAP")) : std::max(32768, std::min(1 << 20, (1 << 24) / n)));
+  int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (std::getenv("MIQP_OPEN_CAP") ? std::atoi(std::getenv("MIQP_OPEN_CAP")) : std::max(32768, std::min(1 << 20, (1 << 27) / n)));   // 524288 per instance at n = 256: 10 GB of list entries, records are shared
   if (open_cap < 64) open_cap = 64;
   if ((size_t)n * npr >= ((size_t)1 << 20)) npr = (int)((((size_t)1 << 20) - 1) / n);
   DevCtx& X = g_ctx;
@@ -504,6 +504,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     HIP_OK(hipMemsetAsync(B.batch_count, 0, 4, st));
     B.open_sel = rounds & 1;
     hipLaunchKernelGGL(select_kernel, dim3(n), dim3(SEL_THREADS), 0, st, B, rounds);
+    if (std::getenv("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d select: %s\n", rounds, hipGetErrorString(e_)); }
     hipLaunchKernelGGL(roll_kernel, dim3(1), dim3(1), 0, st, B);
     int bc = 0;
     HIP_OK(hipMemcpyAsync(&bc, B.batch_count, 4, hipMemcpyDeviceToHost, st));
@@ -540,7 +541,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
       }
     }
 #endif
+    if (std::getenv("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d ipm (%d nodes): %s\n", rounds, bc, hipGetErrorString(e_)); }
     { DevBuf Be = B; Be.open_sel = 1 - (rounds & 1); launch_eval_c(Y.C, Be, bc, l_eval, st); }
+    if (std::getenv("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d eval: %s\n", rounds, hipGetErrorString(e_)); }
     launched_nodes += bc; rounds++;
     if (O0.verbose > 1) std::fprintf(stderr, "[miqp_gpu] round %d: %d nodes\n", rounds, bc);
     if (O0.verbose == 1 && rounds % 25 == 0) {  // progress of the first instance
