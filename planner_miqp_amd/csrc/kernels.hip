@@ -1400,7 +1400,8 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
 
 // ------------------------------------------------------------------------------------------------
 //  select: per instance prune + sort + pick
-constexpr int SEL_THREADS = 256;   // also the number of radix bins: the histogram is cleared by one thread per bin
+constexpr int SEL_THREADS = 1024;  // one workgroup per instance scans its open list (up to 2^20 entries)
+constexpr int SEL_LOWSHIFT = 24;   // the radix select resolves the top 40 key bits (28 mantissa bits); lower bits are ties
 
 // One workgroup per instance.  Reads the open list from buffer `B.open_sel`, prunes it against the incumbent,
 // selects the `take` smallest keys by an MSB-first 8-bit radix select (no full sort, lists live in HBM/L2),
@@ -1513,8 +1514,8 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   // ---- radix select: smallest key value T such that count(key <= T) >= take
   if (take > 0 && take < m) {
     int need = take;
-    for (int shift = 56; shift >= 0; shift -= 8) {
-      hist[tid] = 0u;
+    for (int shift = 56; shift >= SEL_LOWSHIFT; shift -= 8) {
+      if (tid < 256) hist[tid] = 0u;
       __syncthreads();
       const unsigned long long prefix = sh_prefix;
       const unsigned long long himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
@@ -1533,9 +1534,9 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
       __syncthreads();
       need = sh_pick;
     }
-    if (tid == 0) { sh_thr = sh_prefix; sh_ties = need; sh_pick = 0; }
+    if (tid == 0) { sh_thr = sh_prefix; sh_ties = need; sh_pick = 0; }   // threshold on the resolved (high) bits
     __syncthreads();
-  } else if (tid == 0) { sh_thr = take >= m ? (~0ull - 1) : 0ull; sh_ties = 0x7FFFFFFF; sh_pick = 0; }
+  } else if (tid == 0) { sh_thr = take >= m ? ~0ull : 0ull;   /* ~0: above every masked key */ sh_ties = 0x7FFFFFFF; sh_pick = 0; }
   __syncthreads();
   // ---- pass 3: emit the selected nodes, keep the rest
   const unsigned long long thr = sh_thr;
@@ -1545,8 +1546,9 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     double b = B.open_bound[src + k]; int nd = B.open_node[src + k]; int dp = B.open_depth[src + k];
     bool pick = false;
     if (take > 0) {
-      if (key < thr) pick = true;
-      else if (key == thr) { int t = atomicAdd(&sh_ties, -1); pick = t > 0; }
+      const unsigned long long kh = key & (~0ull << SEL_LOWSHIFT);
+      if (kh < thr) pick = true;
+      else if (kh == thr) { int t = atomicAdd(&sh_ties, -1); pick = t > 0; }
     }
     if (pick) {
       int pos = atomicAdd(&sh_pick, 1);
