@@ -6,8 +6,8 @@ import planner_miqp_amd as P
 from planner_miqp_amd import synthetic
 cfg, seed, tl = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
 p = synthetic.generate(cfg, seed, gap=0.01, max_time=tl)
-w = P.CplexWrapper(verbose=1, max_open_nodes=int(os.environ.get("OPEN_CAP", "0"))); w.resetParameters(p); st = w.callCplex(); pr = w.getSolutionProperties()
-print("status", st, "obj", pr.objective, "bound", pr.best_bound, "gap", pr.gap, "nodes", pr.nodes)
+w = P.CplexWrapper(verbose=int(os.environ.get("VERBOSE", "1")), max_open_nodes=int(os.environ.get("OPEN_CAP", "0"))); w.resetParameters(p); st = w.callCplex(); pr = w.getSolutionProperties()
+print("status", st, "obj", pr.objective, "bound", pr.best_bound, "gap", pr.gap, "nodes", pr.nodes, "time", pr.time)
 r = w.getRawResults()
 import numpy as np
 N = p.NumSteps
