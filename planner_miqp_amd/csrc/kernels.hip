@@ -1496,6 +1496,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     int act = act_now; if (act < 1) act = 1;
     int w = (focus && !(B.seq_kinds & 0x10000000)) ? (B.batch_cap >> (rank + 1 < 30 ? rank + 1 : 30)) : B.batch_cap / act;
     if (w < B.nodes_per_round) w = B.nodes_per_round;
+    if (!(inc < 1e300) && w > 512) w = 512;   // no incumbent yet: a narrow dive (a wide one degenerates into breadth first)
     int take = m < w ? m : w;
     const int maxch = (B.seq_kinds & 15) ? 64 : 16;     // children of one node: first-deviation families up to 63, plain K-way up to 16
     int room = (cap - m) / maxch; if (room < 1) room = 1;

@@ -431,7 +431,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   if (!bs.ok) { for (int k = 0; k < n; ++k) { if (S[k]) S[k]->err = bs.err; statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; } std::fprintf(stderr, "[miqp_gpu] %s\n", bs.err.c_str()); return false; }
   const Layout& Y = bs.Y;
   const miqp_solver_opts& O0 = S[0]->opts;
-  int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(512, 32768 / n));
+  int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(16384, 32768 / n));
   if (O0.nodes_per_round <= 0 && std::getenv("MIQP_NPR")) npr = std::max(1, std::atoi(std::getenv("MIQP_NPR")));  // tuning knob
   int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (std::getenv("MIQP_OPEN_CAP") ? std::atoi(std::getenv("MIQP_OPEN_CAP")) : std::max(32768, std::min(1 << 20, (1 << 27) / n)));   // 524288 per instance at n = 256: 10 GB of list entries, records are shared
   if (open_cap < 64) open_cap = 64;
