@@ -1476,7 +1476,8 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   if (tid == 0) sh_pick = 0;   // reused as rank counter until the selection below resets it
   __syncthreads();
   const int act_now = *B.active_insts;
-  const bool focus = act_now <= 16 && inc < 1e300 && (B.seq_kinds & 0x8000000) == 0;
+  const int focus_at = 16 << ((B.seq_kinds >> 29) & 7);   // experiment switch: 16 (default), 32, 64, ...
+  const bool focus = act_now <= focus_at && inc < 1e300 && (B.seq_kinds & 0x8000000) == 0;
   if (focus) {
     const double gme = (inc - (lb + cst)) / (1e-10 + fabs(inc));
     int cntl = 0;
