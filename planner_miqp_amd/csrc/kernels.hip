@@ -1315,10 +1315,10 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     int jlo = 1, jhi = N - 1, total = 1;
     for (int j = 1; j < N; ++j) if (fix[base + j * stride] < 0) total += alts_of(j, tmp);
     if (!((B.seq_kinds >> d.kind) & 1)) { jlo = i; jhi = i; total = 1 + alts_of(i, tmp); }  // plain K-way branching on step i (default)
-    else if (total > 63 || ((B.seq_kinds >> 20) & 31)) {
+    else if (total > 63 || ((B.seq_kinds >> 20) & 15)) {
       // window: from the violated step onwards (steps before it hold in the relaxation and stay undecided), at most
       // `win` steps when that experiment switch is set
-      const int win = (B.seq_kinds >> 20) & 31;
+      const int win = (B.seq_kinds >> 20) & 15;
       jlo = i; total = 1; jhi = i - 1;
       for (int j = i; j < N; ++j) {
         if (win && j >= i + win) break;
@@ -1337,7 +1337,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     // rounding probe (until the instance has an incumbent): one extra child with EVERY undecided disjunction fixed to its
     // completed value.  It lies inside the first child, so the children stay exhaustive; its relaxation is the exact cost
     // of the rounding and, when feasible, the first incumbent two rounds after the root instead of one dive level per round
-    if (!(inc_now < 1e300) && nalt < 63 && (B.seq_kinds & 0x400000) == 0) { ck[nalt] = -2; ca[nalt] = 0; nalt++; }
+    if (!(inc_now < 1e300) && nalt < 63 && (B.seq_kinds & 0x4000000) == 0) { ck[nalt] = -2; ca[nalt] = 0; nalt++; }
     fam[0] = base; fam[1] = stride; fam[2] = jlo; fam[3] = jhi;
     int ob = atomicAdd(&B.open_count[inst], nalt);
     bool okalloc = ob + nalt <= B.open_cap;
@@ -1476,7 +1476,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   if (tid == 0) sh_pick = 0;   // reused as rank counter until the selection below resets it
   __syncthreads();
   const int act_now = *B.active_insts;
-  const int focus_at = 16 << ((B.seq_kinds >> 29) & 7);   // experiment switch: 16 (default), 32, 64, ...
+  const int focus_at = 16 << ((B.seq_kinds >> 29) & 3);   // experiment switch: 16 (default), 32, 64, ...
   const bool focus = act_now <= focus_at && inc < 1e300 && (B.seq_kinds & 0x8000000) == 0;
   if (focus) {
     const double gme = (inc - (lb + cst)) / (1e-10 + fabs(inc));
