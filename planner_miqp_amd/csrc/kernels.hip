@@ -52,7 +52,13 @@ constexpr double QP_TOL = 1.0e-8;      // node relaxations (bounds); the returne
 constexpr double QP_T0 = MIQP_T0;       // initial elastic slack: t*mu (mu ~ rho) starts at the order of s*lambda
 constexpr double QP_TOL_FINAL = 1.0e-13;  // polish of the returned incumbent / solve_fixed
 constexpr double QP_SIGMA = MIQP_SIGMA0;       // centering parameter of the first iteration
-constexpr double QP_SIGMA_LO = 0.02, QP_SIGMA_HI = 0.5;
+#ifndef MIQP_SIGMA_LO
+#define MIQP_SIGMA_LO 0.02
+#endif
+#ifndef MIQP_SIGMA_HI
+#define MIQP_SIGMA_HI 0.5
+#endif
+constexpr double QP_SIGMA_LO = MIQP_SIGMA_LO, QP_SIGMA_HI = MIQP_SIGMA_HI;
 constexpr int QP_MAXIT = 80;
 constexpr int NFIELD = 4;            // per-row state: s, lambda, t, g.dz
 constexpr int NCACHE = 9;            // per-row cache: rhs, aq (-1: inactive), packed columns, 6 coefficients
