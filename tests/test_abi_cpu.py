@@ -150,3 +150,18 @@ def test_lp_export_has_the_reference_model_sizes(lib, tmp_path):
     assert nnz == 29834
     bins = [l for l in txt.split("Binaries")[1].split("End")[0].splitlines() if l.strip()]
     assert len(bins) == 1240
+
+
+def test_all_baseline_configs_generate_and_size(oracle):
+    """every BASELINE config of the generator loads into the oracle with the raw sizes of SURVEY App. B"""
+    for cfg in ("cfg2", "cfg3", "cfg4", "cfg5", "cfg5s", "mini3b"):
+        p = synthetic.generate(cfg, 1)
+        Cn, N, R, E, O = synthetic.CONFIGS[cfg]
+        L = p.max_lines_obstacles
+        h = oracle.from_params(p, 10)
+        s = oracle.sizes(h)
+        K = Cn - 1
+        assert s["bin"] == Cn * N * (5 * E + R + 5 + 5 * O * L) + K * K * N * 16, cfg
+        assert s["cont"] == Cn * N * (12 + 5 * O) + K * K * N * 4, cfg
+        assert int(np.asarray(p.possible_region).sum(1).max()) <= 15 and np.all(np.asarray(p.initial_region) >= 1)
+        oracle.free(h)
