@@ -180,13 +180,17 @@ __device__ inline void pair_cars(int p, int C, int& c1, int& c2) {
 
 struct RowOut { double rhs; double aq; bool active; };
 
-// rows of the relaxation of a node (only alternatives that are fixed); g is this lane's LDS row
-template <int C>
+// rows of the relaxation of a node (only alternatives that are fixed); g is this lane's LDS row.  BUILD = false only
+// decides whether slot (i, slot) carries a row (same tests, nothing written): the kernel first collects the active
+// slots of a node and then builds 64 rows at a time with every lane busy.
+template <int C, bool BUILD = true>
 __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int* T, const signed char* fix, int i, int slot, double* g) {
   constexpr int NZ = 8 * C;
   RowOut r; r.rhs = 0; r.aq = 0; r.active = false;
+  if (BUILD) {
 #pragma unroll
-  for (int q = 0; q < NZ; ++q) g[q] = 0.0;
+    for (int q = 0; q < NZ; ++q) g[q] = 0.0;
+  }
   const int N = Y.N;
   const double* G = D + Y.d_glob;
   if (slot < C * Y.SC) {
@@ -196,6 +200,7 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
     if (rr < 7) {
       if (i < 1 || ((T[Y.i_boxskip + c * N + i] >> rr) & 1)) return r;   // implied by the earlier steps (host box presolve)
       r.active = true;
+      if (!BUILD) return r;
       switch (rr) {
         case 0: g[6 * c + 1] = -1; r.rhs = -G[0]; break;
         case 1: g[6 * c + 4] = -1; r.rhs = -G[0]; break;
@@ -215,6 +220,7 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
       else if (rt) { lo = rt[15 + 2 * s]; hi = rt[16 + 2 * s]; }
       else { lo = G[4]; hi = G[5]; }
       r.active = true;
+      if (!BUILD) return r;
       g[6 * C + 2 * c + s] = up ? 1.0 : -1.0; r.rhs = up ? hi : -lo;
       return r;
     }
@@ -224,10 +230,12 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
       if (h == 3) {
         if (k > 3) return r;
         r.active = true; r.rhs = G[6];
+        if (!BUILD) return r;
         g[6 * c + (k < 2 ? 1 : 4)] = (k & 1) ? -1.0 : 1.0;
         return r;
       }
       r.active = true;
+      if (!BUILD) return r;
       switch (k) {
         case 0: g[6 * c + 1] = rt[0]; g[6 * c + 4] = rt[1]; break;
         case 1: g[6 * c + 1] = rt[2]; g[6 * c + 4] = rt[3]; break;
@@ -256,6 +264,7 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
         }
       }
       r.active = true; r.rhs = ed[2];
+      if (!BUILD) return r;
       add_point(g, r.rhs, c, rt, ENV_PT_D[pt][0], ENV_PT_D[pt][1], ed[0], ed[1]);
       return r;
     }
@@ -273,6 +282,7 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
       }
     }
     r.active = true; r.rhs = ed[2];
+    if (!BUILD) return r;
     add_point(g, r.rhs, c, rt, OBS_PT_D[pt][0], OBS_PT_D[pt][1], ed[0], ed[1]);
     return r;
   }
@@ -310,6 +320,7 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
   else { if (lo) { ca = c2; ta = PT_U; cb = c1; tb = PT_L; } else { ca = c1; ta = PT_U; cb = c2; tb = PT_L; } }
   double al = isx ? 1.0 : 0.0, be = isx ? 0.0 : 1.0;
   r.active = true;
+  if (!BUILD) return r;
   r.rhs = soft ? (which == 0 ? -(Dsep + S) + smax : -(Dsep + S)) : -Dsep;
   r.aq = (!excl && soft && which == 1) ? 2.0 * wsl : 0.0;
   add_point(g, r.rhs, ca, ca == c1 ? rt1 : rt2, ta, ta, al, be);
@@ -477,41 +488,57 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   // ---- decode every row of the node once; active rows are compacted per stage; initial row state
   // Rows with one non-zero and no quadratic slack (the boxes: most rows of a node) are kept apart from the general
   // rows: they touch only the diagonal of the stage Hessian and need one coefficient.
+  // Two passes: (A) every (stage, slot) pair is tested for carrying a row (cheap: the tests of decode_row without
+  // building anything) and the active pairs are compacted, in (stage, slot) order, into a per-block list; (B) the rows
+  // are built 64 at a time with every lane busy (about one slot in five is active).
   double csum = 0.0; int cnt = 0; int base = 0, sbase = 0;
-  for (int i = 0; i < N; ++i) {
-    if (tid == 0) { sstart[i] = base; sst[i] = sbase; }
-    for (int sb = 0; sb < NSLOT; sb += NT) {
-      int slot = sb + tid;
-      double* g = dscr + tid * GS;
-      RowOut r; r.active = false; r.rhs = 0; r.aq = 0;
-      if (slot < NSLOT) r = decode_row<C>(Y, D, T, fix, i, slot, g);
-      unsigned long long cols = 0ull; int nn = 0;
-      double c = r.rhs;
-      if (r.active) {
-        for (int q = 0; q < NZ; ++q) {
-          double v = g[q];
-          if (v != 0.0 && nn < 6) { cols |= (unsigned long long)q << (8 * nn); nn++; c -= v * Z[i * NZ + q]; }
-        }
-      }
-      const bool sgl = r.active && nn == 1 && r.aq == 0.0, mul = r.active && !sgl;
-      const unsigned long long maskM = __ballot(mul), maskS = __ballot(sgl), lt = (1ull << tid) - 1ull;
-      if (r.active) {
-        const int idx = mul ? base + __popcll(maskM & lt) : Y.ROWCAP - 1 - (sbase + __popcll(maskS & lt));
-        for (int k = 0; k < nn; ++k) rc_v[(size_t)k * Y.ROWCAP + idx] = g[(cols >> (8 * k)) & 255];
-        cols |= ((unsigned long long)i << 48) | ((unsigned long long)nn << 56);
-        double s, lam = MIQP_LAM0, t;
-        if (r.aq == 0.0) {
-          if (c > QP_T0) { t = QP_T0; s = c + QP_T0; } else { s = MIQP_S0 * QP_T0; t = s - c; }
-          csum += s * lam + t * (RHO_EL - lam); cnt += 2; tsum += t;
-        } else { lam = fmax(1.0, -2.0 * c * r.aq + 1.0); s = c + lam / r.aq; t = 0.0; csum += s * lam; cnt += 1; }
-        rc_rhs[idx] = r.rhs; rc_col[idx] = __longlong_as_double((long long)cols);
-        if (mul) rc_aq[idx] = r.aq;
-        rs_s[idx] = s; rs_l[idx] = lam; rs_t[idx] = t;
-      }
-      base += __popcll(maskM); sbase += __popcll(maskS);
-    }
+  int* cand = (int*)rs_g;   // the g.dz plane is free until the first step-length loop
+  const unsigned long long lt = (1ull << tid) - 1ull;
+  int ncand = 0;
+  for (int p0 = 0; p0 < N * NSLOT; p0 += NT) {
+    const int pcode = p0 + tid;
+    bool act = false;
+    if (pcode < N * NSLOT) { const int i = pcode / NSLOT; act = decode_row<C, false>(Y, D, T, fix, i, pcode - i * NSLOT, nullptr).active; }
+    const unsigned long long m = __ballot(act);
+    if (act) cand[ncand + __popcll(m & lt)] = pcode;
+    ncand += __popcll(m);
   }
-  if (tid == 0) { sstart[N] = base; sst[N] = sbase; }
+  for (int k = tid; k <= N; k += NT) { sstart[k] = 0; sst[k] = 0; }
+  __syncthreads();
+  for (int c0 = 0; c0 < ncand; c0 += NT) {
+    double* g = dscr + tid * GS;
+    RowOut r; r.active = false; r.rhs = 0; r.aq = 0;
+    int i = 0;
+    if (c0 + tid < ncand) { const int pcode = cand[c0 + tid]; i = pcode / NSLOT; r = decode_row<C, true>(Y, D, T, fix, i, pcode - i * NSLOT, g); }
+    unsigned long long cols = 0ull; int nn = 0;
+    double c = r.rhs;
+    if (r.active) {
+      for (int q = 0; q < NZ; ++q) {
+        double v = g[q];
+        if (v != 0.0 && nn < 6) { cols |= (unsigned long long)q << (8 * nn); nn++; c -= v * Z[i * NZ + q]; }
+      }
+    }
+    const bool sgl = r.active && nn == 1 && r.aq == 0.0, mul = r.active && !sgl;
+    const unsigned long long maskM = __ballot(mul), maskS = __ballot(sgl);
+    if (r.active) {
+      const int idx = mul ? base + __popcll(maskM & lt) : Y.ROWCAP - 1 - (sbase + __popcll(maskS & lt));
+      for (int k = 0; k < nn; ++k) rc_v[(size_t)k * Y.ROWCAP + idx] = g[(cols >> (8 * k)) & 255];
+      cols |= ((unsigned long long)i << 48) | ((unsigned long long)nn << 56);
+      double s, lam = MIQP_LAM0, t;
+      if (r.aq == 0.0) {
+        if (c > QP_T0) { t = QP_T0; s = c + QP_T0; } else { s = MIQP_S0 * QP_T0; t = s - c; }
+        csum += s * lam + t * (RHO_EL - lam); cnt += 2; tsum += t;
+      } else { lam = fmax(1.0, -2.0 * c * r.aq + 1.0); s = c + lam / r.aq; t = 0.0; csum += s * lam; cnt += 1; }
+      rc_rhs[idx] = r.rhs; rc_col[idx] = __longlong_as_double((long long)cols);
+      if (mul) rc_aq[idx] = r.aq;
+      rs_s[idx] = s; rs_l[idx] = lam; rs_t[idx] = t;
+      atomicAdd(mul ? &sstart[i + 1] : &sst[i + 1], 1);   // rows per stage, shifted by one for the prefix sums below
+    }
+    base += __popcll(maskM); sbase += __popcll(maskS);
+  }
+  __syncthreads();
+  if (tid == 0) for (int i = 1; i <= N; ++i) { sstart[i] += sstart[i - 1]; sst[i] += sst[i - 1]; }   // first row of every stage
+  __syncthreads();
   const int NM = base, NS = sbase, NROWS = NM + NS;
   // row r of the node (general rows first): its index in the row arrays
   auto ridx = [&](int r) { return r < NM ? r : Y.ROWCAP - 1 - (r - NM); };
