@@ -180,7 +180,9 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, 
   { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); int cus = 256; if (hipGetDeviceProperties(&pr, dv) == hipSuccess) cus = pr.multiProcessorCount;
     size_t l = ipm_lds_bytes(Y); int per = (int)std::max<size_t>(1, std::min<size_t>(4 * (Y.C <= 2 ? MIQP_IPM_WPE : 1), (160 * 1024) / std::max<size_t>(l + 8, 1))); X.ipm_grid_max = cus * per; }
   // node pool: live nodes are bounded by the open lists plus one round of children; processed records are recycled
-  size_t want = (size_t)n_inst * ((size_t)open_cap + (size_t)npr * 64 + 64); size_t maxrec = ((size_t)48 << 30) / (size_t)Y.fixlen;   // node records: up to 48 GB of the 288 GB
+  size_t want = (size_t)n_inst * ((size_t)open_cap + (size_t)npr * 64 + 64);
+  size_t free_b = 0, total_b = 0; if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
+  size_t maxrec = std::min<size_t>((size_t)48 << 30, free_b / 4) / (size_t)Y.fixlen;   // node records: up to 48 GB of the 288 GB, at most a quarter of what is free
   X.pool_cap = (int)std::min(want, maxrec);
   DevBuf& B = X.B; std::memset(&B, 0, sizeof(B));
   B.qp_tol = QP_TOL; B.use_cutoff = 1;
@@ -435,6 +437,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   if (O0.nodes_per_round <= 0 && std::getenv("MIQP_NPR")) npr = std::max(1, std::atoi(std::getenv("MIQP_NPR")));  // tuning knob
   int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (std::getenv("MIQP_OPEN_CAP") ? std::atoi(std::getenv("MIQP_OPEN_CAP")) : std::max(32768, std::min(1 << 20, (1 << 27) / n)));   // 524288 per instance at n = 256: 10 GB of list entries, records are shared
   if (open_cap < 64) open_cap = 64;
+  { size_t free_b = 0, total_b = 0;   // list entries (40 B per open node) must fit an eighth of the free device memory
+    int ndev_ = 0; if (hipGetDeviceCount(&ndev_) == hipSuccess && ndev_ > 0 && O0.device >= 0) (void)hipSetDevice(O0.device);
+    if (O0.max_open_nodes <= 0 && ndev_ > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) { size_t lim = free_b / 8 / 40 / (size_t)n; if ((size_t)open_cap > lim) open_cap = (int)std::max<size_t>(4096, lim); } }
   if ((size_t)n * npr >= ((size_t)1 << 20)) npr = (int)((((size_t)1 << 20) - 1) / n);
   DevCtx& X = g_ctx;
   if (!ctx_prepare(X, Y, n, open_cap, npr, O0.device)) { for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
