@@ -923,19 +923,16 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
       __syncthreads();
       const int s1 = s0 + SPL < N - 1 ? s0 + SPL : N - 1;
       for (int i = s0; i < s1; ++i) {
-        if (tid < NU) {
-          const double* kv = KL + (i - s0) * KSZ + tid * KSTR;
-          double acc = -kv[NX];
-#pragma unroll
-          for (int q = 0; q < NX; ++q) acc -= kv[q] * dZ[i * NZ + q];
-          dZ[i * NZ + NX + tid] = acc;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // one phase per stage: the three lanes of a chain compute their input redundantly (u = -k - K x) and advance
+        // their own state with it, so the stage needs a single LDS round trip and wave barrier
         if (tid < NX) {
-          const int q0 = 3 * (tid / 3);
-          double acc = ca[0] * dZ[i * NZ + q0] + ca[1] * dZ[i * NZ + q0 + 1] + ca[2] * dZ[i * NZ + q0 + 2] + cb * dZ[i * NZ + NX + tid / 3];
-          dZ[(i + 1) * NZ + tid] = acc;
+          const int ch = tid / 3, q0 = 3 * ch;
+          const double* kv = KL + (i - s0) * KSZ + ch * KSTR;
+          double u = -kv[NX];
+#pragma unroll
+          for (int q = 0; q < NX; ++q) u -= kv[q] * dZ[i * NZ + q];
+          if (tid == q0) dZ[i * NZ + NX + ch] = u;
+          dZ[(i + 1) * NZ + tid] = ca[0] * dZ[i * NZ + q0] + ca[1] * dZ[i * NZ + q0 + 1] + ca[2] * dZ[i * NZ + q0 + 2] + cb * u;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
