@@ -401,3 +401,24 @@ def test_cfg5_four_cars_64_regions_with_warmstart(oracle):
     v2, obj2, worst2 = oracle.raw_eval(h, w2.getRawResults())
     assert v2 < 1e-5, worst2
     oracle.free(h)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 16, 1, 0), (2, 2, 32, 1, 0), (2, 3, 16, 1, 0), (1, 40, 32, 1, 0), (1, 12, 32, 0, 0),
+                                   (2, 6, 32, 0, 0), (2, 6, 16, 2, 1), (3, 4, 16, 1, 1)])
+def test_odd_shapes_match_the_oracle(oracle, shape):
+    """edge shapes: two- and three-step horizons, a 40-step horizon, no environment at all, 16 regions with two cars and an
+    obstacle, three cars with an obstacle - objective equal to 1e-6 relative, states within 1e-4"""
+    for seed in range(2):
+        p = synthetic.generate(shape, seed, gap=1e-7, max_time=30)
+        w = P.CplexWrapper(); w.resetParameters(p)
+        st = w.callCplex()
+        h = oracle.from_params(p, 10)
+        ost, ores, op = oracle.solve(h, oracle.dims(p), gap=1e-7, time_limit=60)
+        assert int(st) == ost, (shape, seed)
+        if ost == 0:
+            pr = w.getSolutionProperties(); res = w.getRawResults()
+            assert abs(pr.objective - op.objective) <= 1e-6 * max(1.0, abs(op.objective)), (shape, seed, pr.objective, op.objective)
+            assert_states_close(res, ores)
+            v, obj, worst = oracle.raw_eval(h, res)
+            assert v < 1e-5, (shape, seed, worst)
+        oracle.free(h)
