@@ -4,10 +4,11 @@
  * The arithmetic of the reference path lives in IBM ILOG CPLEX 12.10 + OPL (util/deps.bzl:69-95),
  * a proprietary dependency that is absent from /root/reference and from this image, so the
  * reference cannot be built here ("unbuildable": there is no oracle/_ref).  This oracle restates
- *   (1) the OPL model cplexmodel/*.mod row by row   (raw_model.c  - sizes + constraint evaluator),
- *   (2) the same model in disjunctive form           (dmodel.c),
- *   (3) the published algorithm class CPLEX applies to it: branch and bound over the binaries with a
- *       convex QP relaxation per node (bnb.c, qp.c: primal-dual interior point on the stage-banded KKT).
+ *   (1) the OPL model (the .mod files of cplexmodel/) row by row   (raw_model.c - sizes + constraint evaluator),
+ *   (2) the same model in disjunctive form and
+ *   (3) the published algorithm class CPLEX applies to it: branch and bound over the binaries with a convex QP
+ *       relaxation per node (solve.c: dense-row Riccati primal-dual interior point, array open list with dives;
+ *       the branching order is the one of the device solver).  inst.c reads ModelParameters records and OPL .dat files.
  * It is pinned against the reference's own known answers (tests/test_oracle_golden.py):
  *   K1 sizes 12361/1240/340/29834, K2 objective 9.57603, K3 solution vector
  *   (test/cplex_wrapper_test.cc:283-456, :857-876), K5 cplexmodel.dat + modelRun.txt feasibility.
