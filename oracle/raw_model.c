@@ -1,6 +1,6 @@
 /* raw_model.c - row-by-row restatement of the OPL model (TEST INFRASTRUCTURE).
  *
- * Every `subject to` statement of cplexmodel/*.mod is emitted as one sparse row over the raw
+ * Every `subject to` statement of the cplexmodel .mod files is emitted as one sparse row over the raw
  * decision variables of cplexmodel/decision_variables.mod:10-53 - duplicates kept, `==` fixings
  * are rows, structural zero coefficients dropped - so that the row/column/non-zero counts can be
  * compared with the reference's own known answer (test/cplex_wrapper_test.cc:866-871:

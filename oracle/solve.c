@@ -1,7 +1,7 @@
 /* solve.c - disjunctive form of the model, stage-banded interior point QP and branch & bound
  * (CPU oracle, TEST INFRASTRUCTURE).
  *
- * Disjunctive reading of cplexmodel/*.mod:
+ * Disjunctive reading of the cplexmodel .mod files:
  *   region   (c,i>=2): exactly one active_region[c,i,j] (model_region_constraints.mod:43-114) combined with
  *                      the low-speed freeze of minimum_speed_constraints.mod:9-49:
  *                      alternative (j, h)   = sector j, outside the slow square through half-plane h,
