@@ -351,7 +351,8 @@ static int qp_solve_tol(const dmodel* M, const orow* rows, int m, qpres* out, do
   for (int k = 0; k < m; ++k) start[rows[k].stage + 1]++;
   for (int i = 0; i < N; ++i) start[i + 1] += start[i];
   { int* pos = (int*)malloc(sizeof(int) * (N + 1)); memcpy(pos, start, sizeof(int) * (N + 1));
-    for (int k = 0; k < m; ++k) order[pos[rows[k].stage]++] = k; free(pos); }
+    for (int k = 0; k < m; ++k) order[pos[rows[k].stage]++] = k;
+    free(pos); }
   double* s = (double*)malloc(sizeof(double) * (m + 1)); double* lam = (double*)malloc(sizeof(double) * (m + 1));
   double* ds = (double*)malloc(sizeof(double) * (m + 1)); double* dlam = (double*)malloc(sizeof(double) * (m + 1));
   double* w = (double*)malloc(sizeof(double) * (m + 1)); double* kap = (double*)malloc(sizeof(double) * (m + 1));
@@ -833,8 +834,10 @@ static void fill_results(const dmodel* M, const signed char* comp, const double*
         if (h == 3) { xp = xn = yp = yn = cb = 1; }
         else {
           int ax = M->hs[j][h][0], sg = M->hs[j][h][1];
-          if (ax == 0 && sg > 0) xp = 0; if (ax == 0 && sg < 0) xn = 0;
-          if (ax == 1 && sg > 0) yp = 0; if (ax == 1 && sg < 0) yn = 0;
+          if (ax == 0 && sg > 0) xp = 0;
+          if (ax == 0 && sg < 0) xn = 0;
+          if (ax == 1 && sg > 0) yp = 0;
+          if (ax == 1 && sg < 0) yn = 0;
           cb = 0;
         }
       }
