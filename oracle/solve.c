@@ -694,7 +694,7 @@ static int complete(const dmodel* M, const signed char* fix, const double* Z, si
           }
           int fx = FIX_ENV(M, fix, c, i, pt);
           if (fx >= 0 && !(pt > 0 && runfixed)) continue;
-          int alts[64]; double vals[64]; int ne = I->E > 64 ? 64 : I->E;
+          int alts[64]; double vals[64] = {0}; int ne = I->E > 64 ? 64 : I->E;
           for (int e = 0; e < ne; ++e) {
             tmp.n = 0; env_rows(M, &tmp, c, i, pt, e, j);
             double v = -1e300; for (int k = 0; k < tmp.n; ++k) v = fmax(v, row_val(M, &tmp.r[k], Z));
