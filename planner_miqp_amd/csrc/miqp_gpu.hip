@@ -46,18 +46,58 @@ static const int OBS_PT_H[5][2] = {{PT_R, PT_R}, {PT_L, PT_L}, {PT_U, PT_L}, {PT
 namespace {
 
 // ---------------------------------------------------------------- raw model sizes
-void raw_sizes(const HostInst& I, int& rows, int& bin, int& cont, int& nnz_unused) {
+// rows / binary / continuous columns / non-zeros of the model OPL generates from cplexmodel/*.mod for this instance
+// (cplex.getNrows / getNbinVars / getNcols - bin / getNNZs, src/cplex_wrapper.cpp:679-690).  Counted per statement of
+// the .mod files: every `==` fixing is a row, duplicated rows stay, structural zero coefficients are dropped.
+void raw_sizes(const HostInst& I, int& rows, int& bin, int& cont, int& nnz_out) {
   long C = I.C, N = I.N, R = I.R, E = I.E, O = I.O, L = I.L, K = I.C - 1;
   bin = (int)(C * N * (5 * E + R + 5 + 5 * O * L) + K * K * N * 16);
   cont = (int)(C * N * (12 + 5 * O) + K * K * N * 4);
-  long a4 = 0;
-  for (int c = 0; c < C; ++c) { long P = 0; for (int j = 0; j < R; ++j) P += I.possible[c * R + j] == 1; a4 += 20 * P + (R - P) + 1; }
+  auto nz = [](double v) { return v != 0.0 ? 1L : 0L; };
+  long a4 = 0, nnz = 0;
+  nnz += C * (17 + 9 * R);                      // A1 initial_conditions.mod:11-61
+  nnz += 24 * (N - 1) * C;                      // A2 model_region_constraints.mod:11-19
+  nnz += 12 * N * C;                            // A3 :22-39
+  for (int c = 0; c < C; ++c) {                 // A4 :43-117
+    long P = 0, per = R;                        // the sum row carries R entries
+    for (int j = 0; j < R; ++j) {
+      if (I.possible[c * R + j] != 1) { per += 1; continue; }
+      P++;
+      const double* F = &I.frac[j * 4];
+      per += nz(F[0]) + nz(F[1]) + 2 + nz(F[2]) + nz(F[3]) + 2;
+      const int pt[4] = {2, 3, 0, 1};
+      for (int k = 0; k < 4; ++k) { const double* p = &I.poly[pt[k]][j * 3]; per += 2 * (3 + nz(I.wb[c] * p[1]) + nz(I.wb[c] * p[2])); }
+      per += 16;                                // jerk and acceleration boxes: 8 rows of 2
+      double rho = (F[1] + F[3]) / (F[0] + F[2]);
+      const double* kx = &I.poly[4][j * 3]; const double* kn = &I.poly[5][j * 3];
+      per += 3 + nz(kx[1]) + nz(kx[2]) + nz(rho) + 3 + nz(kn[1]) + nz(kn[2]) + nz(rho);
+    }
+    a4 += 20 * P + (R - P) + 1;
+    nnz += (N - 1) * per;
+  }
+  nnz += 35 * R * (N - 1) * C;                  // A5 minimum_speed_constraints.mod:9-49
   long env_edges = E > 0 ? I.env_off[E] : 0;
   long r = C * (17 + 5 * R) + 6 * (N - 1) * C + 12 * N * C + (N - 1) * a4 + 15 * R * (N - 1) * C;
-  if (E > 0) r += N * C * (5 * env_edges + 5);
-  if (O > 0) r += N * C * O * (5 * L + 5);
-  if (C > 1) { long tri = 0; for (long c1 = 2; c1 <= K; ++c1) tri += c1 - 1; r += N * 20 * tri + 24 * N * C * (C - 1) / 2; }
-  rows = (int)r; nnz_unused = 0;
+  if (E > 0) {                                  // A6 obstacle_environment_constraints.mod:6-47
+    r += N * C * (5 * env_edges + 5);
+    long per = 5 * E;
+    for (long k = 0; k < env_edges; ++k) { const double* e = &I.env_edges[(size_t)k * 4]; per += 5 * (1 + nz(e[2] - e[0]) + nz(e[3] - e[1])); }
+    nnz += N * C * per;
+  }
+  if (O > 0) {                                  // A7 :52-109
+    r += N * C * O * (5 * L + 5);
+    for (int o = 0; o < O; ++o) for (int i = 0; i < N; ++i) {
+      long per = 5 * (L + (I.obs_soft[o] == 1 ? 1 : 0));
+      for (int k = 0; k < L; ++k) { const double* e = &I.obs_edges[((size_t)(o * N + i) * L + k) * 4]; per += 5 * (1 + nz(e[2] - e[0]) + nz(e[3] - e[1])); }
+      nnz += C * per;
+    }
+  }
+  if (C > 1) {                                  // A8 agent_collision_constraints.mod:10-73
+    long tri = 0; for (long c1 = 2; c1 <= K; ++c1) tri += c1 - 1;
+    r += N * 20 * tri + 24 * N * C * (C - 1) / 2;
+    nnz += N * 20 * tri + 76 * N * C * (C - 1) / 2;
+  }
+  rows = (int)r; nnz_out = (int)nnz;
 }
 
 // ---------------------------------------------------------------- host geometry helpers (results, step-1 presolve)
@@ -467,7 +507,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     }
     int rows, bin, cont, nnz; raw_sizes(s->inst, rows, bin, cont, nnz);
     s->props = miqp_solution_properties_c{}; s->props.NrConstraints = rows; s->props.NrBinaryVariables = bin; s->props.NrFloatVariables = cont;
-    s->props.NonZeroCoefficients = 0;
+    s->props.NonZeroCoefficients = nnz;
   }
   { double gmin = 1.0; for (int k = 0; k < n; ++k) gmin = std::min(gmin, h_gap[k]);
     B.qp_tol = std::min(QP_TOL, std::max(1e-12, 1e-4 * gmin)); }  // node relaxations: accurate to a small fraction of the MIP gap
