@@ -6,6 +6,7 @@
 #ifndef CPLEX_WRAPPER_HEADER
 #define CPLEX_WRAPPER_HEADER
 
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <memory>
@@ -96,10 +97,14 @@ class CplexWrapper {
     try {
       if (!h_) { miqp_solver_opts o{}; o.precision = precision_; o.device = -1; o.gap_override = -1.0; h_ = miqp_solver_create(&o); }
       if (!h_) return FAILED_SEG_FAULT;
-      if (parameterSource_ == DATFILE) { if (miqp_solver_load_dat(h_, datfile_.c_str()) != 0) return FAILED_SEG_FAULT; }
-      else { if (!parameters_ || !pushParameters()) return FAILED_SEG_FAULT; }
-      if (doWarmstart_ == RECEDING_HORIZON_WARMSTART || doWarmstart_ == BOTH_WARMSTART_STRATEGIES) pushWarmstart(*warmstartValues_);
-      else if (doWarmstart_ == LAST_SOLUTION_WARMSTART || doWarmstart_ == BOTH_WARMSTART_STRATEGIES)
+      if (parameterSource_ == DATFILE || (parameterSource_ == MIXED && !parameters_)) {   // MIXED: the C++ inputs when given, else the file
+        if (miqp_solver_load_dat(h_, datfile_.c_str()) != 0) return FAILED_SEG_FAULT;
+      } else { if (!parameters_ || !pushParameters()) return FAILED_SEG_FAULT; }
+      // MIP starts (cplex_wrapper.cpp:121-138): with BOTH_WARMSTART_STRATEGIES the reference applies the receding-horizon
+      // start AND reads the .mst of the last solution
+      miqp_solver_set_warmstart(h_, nullptr, MIQP_WARMSTART_NONE);
+      if ((doWarmstart_ == RECEDING_HORIZON_WARMSTART || doWarmstart_ == BOTH_WARMSTART_STRATEGIES) && warmstartValues_) pushWarmstart(*warmstartValues_);
+      if (doWarmstart_ == LAST_SOLUTION_WARMSTART || doWarmstart_ == BOTH_WARMSTART_STRATEGIES)
         miqp_solver_read_mst(h_, tmpWarmstartFile_.c_str());   // readMIPStarts when the file exists (cplex_wrapper.cpp:128-138)
       const std::string base = debugOutputFilePath_ + "/" + debugOutputFilePrefix_, stamp = stampOf(timestemp);
       if (print_debug_outputs_) {  // cplex_wrapper.cpp:141-155
@@ -244,6 +249,9 @@ class CplexWrapper {
   void pushWarmstart(const RawResults& w) {
     if (w.N <= 0 || w.NrCars <= 0) return;
     Pod p(w.NrCars, w.N, w.NrRegions, w.NrEnvironments, w.NrObstacles, w.MaxLinesObstacles);
+    // every variable of the start travels (initializeWarmstart flattens all 27 arrays, src/cplex_wrapper.cpp:494-639)
+    const Eigen::Tensor<double, 2>* d2[12] = {&w.u_x, &w.u_y, &w.pos_x, &w.vel_x, &w.acc_x, &w.pos_y, &w.vel_y, &w.acc_y, &w.pos_x_front_UB, &w.pos_x_front_LB, &w.pos_y_front_UB, &w.pos_y_front_LB};
+    for (int k = 0; k < 12; ++k) fromTensor<double, 2>(*d2[k], p.d[k].data());
     const Eigen::Tensor<int, 3>* e3[5] = {&w.notWithinEnvironmentRear, &w.notWithinEnvironmentFrontUbUb, &w.notWithinEnvironmentFrontLbUb, &w.notWithinEnvironmentFrontUbLb, &w.notWithinEnvironmentFrontLbLb};
     for (int k = 0; k < 5; ++k) fromTensor<int, 3>(*e3[k], p.i[k].data());
     fromTensor<int, 3>(w.active_region, p.i[5].data());
@@ -253,7 +261,7 @@ class CplexWrapper {
     fromTensor<int, 4>(w.deltacc, p.i[11].data()); fromTensor<int, 5>(w.deltacc_front, p.i[12].data());
     fromTensor<int, 4>(w.car2car_collision, p.i[13].data()); fromTensor<int, 4>(w.slackvars, p.i[14].data());
     fromTensor<int, 3>(w.slackvarsObstacle, p.i[15].data()); fromTensor<int, 4>(w.slackvarsObstacle_front, p.i[16].data());
-    miqp_solver_set_warmstart(h_, &p.c, static_cast<int>(doWarmstart_));
+    miqp_solver_set_warmstart(h_, &p.c, MIQP_WARMSTART_RECEDING_HORIZON);
   }
 
   std::string modfile_, datfile_;

@@ -6,8 +6,10 @@
  * checkout).  The Eigen-typed class with the reference's own name and methods is the header-only
  * adapter include/cplex_wrapper.hpp, which forwards to these functions.
  *
- * Threading: one caller thread per solver handle; handles are independent (src/cplex_wrapper.hpp:61-275
- * has the same contract: one IloEnv per wrapper).  No GPU context is touched before the first solve.
+ * Threading: one caller thread per solver handle (src/cplex_wrapper.hpp:61-275 has the same contract: one IloEnv
+ * per wrapper).  Handles are independent objects; the device buffers behind them are kept per HIP device and a solve
+ * holds that device's lock, so threads with different handles may call concurrently (same device: the solves run one
+ * after the other; different devices: in parallel).  No GPU context is touched before the first solve.
  */
 #ifndef MIQP_GPU_H
 #define MIQP_GPU_H
@@ -23,9 +25,10 @@ typedef struct miqp_solver miqp_solver_t;
 typedef struct miqp_solver_opts {
   int precision;            /* CplexWrapper ctor `precision` (cplex_wrapper.hpp:81-115); inputs are rounded to
                                precision-2 decimals like ModelInputDataSource (hpp:88); <= 0 -> 12 */
-  int device;               /* HIP device ordinal, -1: current */
-  int nodes_per_round;      /* B&B nodes solved per instance and round (0: default 16) */
-  int max_open_nodes;       /* per-instance open-list capacity (0: default 4096) */
+  int device;               /* HIP device ordinal, -1: the calling thread's current device */
+  int nodes_per_round;      /* B&B nodes solved per instance and round (0: default = 32768 / batch size, within 16..16384) */
+  int max_open_nodes;       /* per-instance open-list capacity (0: default = 2^27 / batch size, within 32768..2^20, and at
+                               most an eighth of the free device memory) */
   double gap_override;      /* < 0: use ModelParameters.relative_mip_gap_tolerance */
   int verbose;
 } miqp_solver_opts;
@@ -47,8 +50,13 @@ int miqp_solver_load_dat(miqp_solver_t* s, const char* path);
 int miqp_solver_override_settings(miqp_solver_t* s, double max_solution_time, double relative_mip_gap_tolerance);
 
 /* CplexWrapper::addRecedingHorizonWarmstart / setLastSolutionWarmstart   src/cplex_wrapper.cpp:459-483
- * The vector is tried as an initial incumbent (CPLEX MIPStartSolveMIP: binaries of the start are fixed,
- * the continuous QP is solved on the device; an infeasible start is ignored). */
+ * + initializeWarmstart / addMIPStart / readMIPStarts                    src/cplex_wrapper.cpp:124-138, 494-639
+ * The record is copied.  Two starts can be registered at once, as the reference does with
+ * BOTH_WARMSTART_STRATEGIES: type MIQP_WARMSTART_LAST_SOLUTION fills the last-solution slot, every other type the
+ * receding-horizon slot; MIQP_WARMSTART_NONE (or start == NULL) clears both.  Each start is tried as an initial
+ * incumbent (CPLEX MIPStartSolveMIP: the binaries of the start are fixed, the continuous QP is solved on the device; an
+ * infeasible start, or one whose seven sizes differ from the instance, is ignored).  Starts stay registered across
+ * miqp_solver_set_params.  Returns 0, <0 when the record is refused. */
 int miqp_solver_set_warmstart(miqp_solver_t* s, const miqp_raw_results_c* start, int warmstart_type);
 
 /* CplexWrapper::callCplex(timestamp)                           src/cplex_wrapper.cpp:65-249
@@ -58,8 +66,20 @@ int miqp_solver_solve(miqp_solver_t* s, double timestamp);
 
 /* Batch of independent instances (receding-horizon steps / scenario seeds) solved concurrently on one
  * device; statuses[k] receives the OptimizationStatus of solver k.  All instances must share
- * NumCars, NumSteps, nr_obstacles and max_lines_obstacles.  Returns 0 on success. */
+ * NumCars, NumSteps, nr_regions, nr_environments, nr_obstacles, max_lines_obstacles and opts.device.
+ * Returns 0 on success.  (MiqpPlanner issues one callCplex at a time, src/miqp_planner.cpp:731; the batch entry
+ * is what a scenario-parallel caller binds.) */
 int miqp_solver_solve_batch(miqp_solver_t* const* solvers, int n, int* statuses);
+
+/* The same batch sharded over the first `gpus` HIP devices of this process (<= 0: all visible): instance b runs on
+ * device b mod gpus with one host thread per device and no exchange between the shards;
+ * opts.device of every handle is set to the device it ran on. */
+int miqp_solver_solve_batch_multi(miqp_solver_t* const* solvers, int n, int gpus, int* statuses);
+
+/* cplex.getNrows / getNbinVars / getNcols - getNbinVars / getNNZs of the model OPL would generate for the loaded
+ * instance (collectCplexStatistics, src/cplex_wrapper.cpp:679-690): out[0..3] = rows, binary columns, continuous
+ * columns, non-zeros.  Needs no device. */
+int miqp_solver_raw_sizes(const miqp_solver_t* s, int* out4);
 
 /* CplexWrapper::getRawResults()                                src/cplex_wrapper.hpp:204, cpp:311-448
  * Fills the caller-allocated record (sizes must match the instance). */

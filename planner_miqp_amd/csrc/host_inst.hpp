@@ -42,7 +42,23 @@ inline bool inst_from_params(const miqp_model_params_c* p, int dec, HostInst& I,
   I = HostInst();
   I.N = p->NumSteps; I.C = p->NumCars; I.R = p->nr_regions; I.E = p->nr_environments; I.O = p->nr_obstacles;
   I.L = p->max_lines_obstacles;
-  if (I.C < 1 || I.N < 2 || I.R < 1) { err = "invalid sizes"; return false; }
+  if (I.C < 1 || I.N < 2 || I.R < 1 || I.E < 0 || I.O < 0 || I.L < 0 || (I.O > 0 && I.L < 1)) { err = "invalid sizes"; return false; }
+  {  // every array the sizes announce must be there
+    const void* need[] = {p->agent_safety_distance, p->agent_safety_distance_slack, p->WEIGHTS_POS_X, p->WEIGHTS_VEL_X, p->WEIGHTS_ACC_X, p->WEIGHTS_POS_Y,
+                          p->WEIGHTS_VEL_Y, p->WEIGHTS_ACC_Y, p->WEIGHTS_JERK_X, p->WEIGHTS_JERK_Y, p->WheelBase, p->CollisionRadius, p->IntitialState, p->x_ref,
+                          p->vx_ref, p->y_ref, p->vy_ref, p->min_acc_x, p->max_acc_x, p->min_acc_y, p->max_acc_y, p->min_jerk_x, p->max_jerk_x, p->min_jerk_y,
+                          p->max_jerk_y, p->initial_region, p->possible_region, p->fraction_parameters, p->POLY_SINT_UB, p->POLY_SINT_LB, p->POLY_COSS_UB,
+                          p->POLY_COSS_LB, p->POLY_KAPPA_AX_MAX, p->POLY_KAPPA_AX_MIN};
+    for (const void* q : need) if (!q) { err = "null array in ModelParameters"; return false; }
+    if (I.E > 0 && (!p->env_offsets || !p->env_vertices)) { err = "null environment arrays"; return false; }
+    if (I.O > 0 && (!p->obstacle_vertices || !p->obstacle_is_soft)) { err = "null obstacle arrays"; return false; }
+    for (int e = 0; e < I.E; ++e) if (p->env_offsets[e + 1] - p->env_offsets[e] < 1 || p->env_offsets[e] < 0) { err = "invalid env_offsets"; return false; }
+    for (int c = 0; c < I.C; ++c) {
+      if (p->initial_region[c] < 1 || p->initial_region[c] > I.R) { err = "initial_region outside 1..nr_regions"; return false; }
+      int np = 0; for (int j = 0; j < I.R; ++j) np += p->possible_region[c * I.R + j] == 1;
+      if (np < 1) { err = "car without a possible region"; return false; }
+    }
+  }
   auto r = [&](double v) { return round_dec(v, dec); };
   I.ts = r(p->ts); I.vmin = r(p->min_vel_x_y); I.vmax = r(p->max_vel_x_y); I.amin = r(p->total_min_acc);
   I.amax = r(p->total_max_acc); I.jmin = r(p->total_min_jerk); I.jmax = r(p->total_max_jerk);

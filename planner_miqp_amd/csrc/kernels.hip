@@ -1332,16 +1332,16 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
             if (!((allow_b >> (q * 4 + h)) & 1ull)) continue;
             if (h == 3 && prevj != T[Y.i_regj + c * P + q]) continue;
             if (q * 4 + h == refv) continue;
-            if (n < 16) tmp[n++] = q * 4 + h;
+            if (n < 63) tmp[n++] = q * 4 + h;
           }
         }
-      } else if (d.kind == 1) { for (int e = 0; e < Y.E && n < 16; ++e) if (e != refv) tmp[n++] = e; }
-      else if (d.kind == 2) { int na = Y.L + (T[Y.i_obssoft + d.o] ? 1 : 0); for (int k = 0; k < na && n < 16; ++k) if (k != refv) tmp[n++] = k; }
+      } else if (d.kind == 1) { for (int e = 0; e < Y.E && n < 63; ++e) if (e != refv) tmp[n++] = e; }
+      else if (d.kind == 2) { int na = Y.L + (T[Y.i_obssoft + d.o] ? 1 : 0); for (int k = 0; k < na && n < 63; ++k) if (k != refv) tmp[n++] = k; }
       else { const int am = (T[Y.i_c2callow + d.c * N + j] >> (4 * d.o)) & 15; for (int a2 = 0; a2 < 4; ++a2) if (a2 != refv && ((am >> a2) & 1)) tmp[n++] = a2; }
       return n;
     };
     // window of undecided steps: all of them when the children fit, else the steps from the violated one onwards
-    int tmp[16];
+    int tmp[64];   // alternatives of one disjunction: the host admits at most 62 (batch_layout), region alternatives are <= 15 x 3
     int jlo = 1, jhi = N - 1, total = 1;
     for (int j = 1; j < N; ++j) if (fix[base + j * stride] < 0) total += alts_of(j, tmp);
     if (!((B.seq_kinds >> d.kind) & 1)) { jlo = i; jhi = i; total = 1 + alts_of(i, tmp); }  // plain K-way branching on step i (default)
@@ -1529,7 +1529,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     if (w < B.nodes_per_round) w = B.nodes_per_round;
     if (!(inc < 1e300) && w > 512) w = 512;   // no incumbent yet: a narrow dive (a wide one degenerates into breadth first)
     int take = m < w ? m : w;
-    const int maxch = (B.seq_kinds & 15) ? 64 : 16;     // children of one node: first-deviation families up to 63, plain K-way up to 16
+    const int maxch = 64;     // children of one node: at most 63 (eval_kernel)
     int room = (cap - m) / maxch; if (room < 1) room = 1;
     if (take > room) take = room;
     int base = take > 0 ? atomicAdd(B.batch_count, take) : 0;

@@ -11,8 +11,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/miqp_gpu.h"
@@ -25,6 +28,44 @@ using namespace miqp;
 
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "[miqp_gpu] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return false; } } while (0)
 
+// caller-independent RawResults record (deep copy target; MIP starts are kept in this form until the solve compiles them)
+struct OwnedResults {
+  miqp_raw_results_c r{}; std::vector<std::vector<double>> d; std::vector<std::vector<int>> i;
+  OwnedResults(int C, int N, int R, int E, int O, int L) {
+    const int K = C - 1;
+    r.N = N; r.NrEnvironments = E; r.NrRegions = R; r.NrObstacles = O; r.MaxLinesObstacles = L; r.NrCarToCarCollisions = K; r.NrCars = C;
+    auto D = [&](size_t n) { d.emplace_back(n ? n : 1, 9999999.0); return d.back().data(); };
+    auto J = [&](size_t n) { i.emplace_back(n ? n : 1, 9999999); return i.back().data(); };
+    d.reserve(16); i.reserve(24);
+    const size_t cn = (size_t)C * N;
+    r.u_x = D(cn); r.u_y = D(cn); r.pos_x = D(cn); r.vel_x = D(cn); r.acc_x = D(cn); r.pos_y = D(cn); r.vel_y = D(cn); r.acc_y = D(cn);
+    r.pos_x_front_UB = D(cn); r.pos_x_front_LB = D(cn); r.pos_y_front_UB = D(cn); r.pos_y_front_LB = D(cn);
+    r.notWithinEnvironmentRear = J(cn * E); r.notWithinEnvironmentFrontUbUb = J(cn * E); r.notWithinEnvironmentFrontLbUb = J(cn * E);
+    r.notWithinEnvironmentFrontUbLb = J(cn * E); r.notWithinEnvironmentFrontLbLb = J(cn * E); r.active_region = J(cn * R);
+    r.region_change_not_allowed_x_positive = J(cn); r.region_change_not_allowed_y_positive = J(cn); r.region_change_not_allowed_x_negative = J(cn);
+    r.region_change_not_allowed_y_negative = J(cn); r.region_change_not_allowed_combined = J(cn);
+    r.deltacc = J(cn * O * L); r.deltacc_front = J(cn * O * L * 4); r.car2car_collision = J((size_t)K * K * N * 16); r.slackvars = J((size_t)K * K * N * 4);
+    r.slackvarsObstacle = J(cn * O); r.slackvarsObstacle_front = J(cn * O * 4); r.slackvars_real = D((size_t)K * K * N * 4);
+  }
+  explicit OwnedResults(const HostInst& I) : OwnedResults(I.C, I.N, I.R, I.E, I.O, I.L) {}
+  // deep copy of a caller's record of the same seven sizes (null arrays keep the fill value)
+  void copy_from(const miqp_raw_results_c& f) {
+    const double* const sd[13] = {f.u_x, f.u_y, f.pos_x, f.vel_x, f.acc_x, f.pos_y, f.vel_y, f.acc_y, f.pos_x_front_UB, f.pos_x_front_LB, f.pos_y_front_UB, f.pos_y_front_LB, f.slackvars_real};
+    for (int k = 0; k < 13; ++k) if (sd[k]) std::copy(sd[k], sd[k] + d[k].size(), d[k].begin());
+    const int* const si[17] = {f.notWithinEnvironmentRear, f.notWithinEnvironmentFrontUbUb, f.notWithinEnvironmentFrontLbUb, f.notWithinEnvironmentFrontUbLb, f.notWithinEnvironmentFrontLbLb,
+                               f.active_region, f.region_change_not_allowed_x_positive, f.region_change_not_allowed_y_positive, f.region_change_not_allowed_x_negative,
+                               f.region_change_not_allowed_y_negative, f.region_change_not_allowed_combined, f.deltacc, f.deltacc_front, f.car2car_collision, f.slackvars,
+                               f.slackvarsObstacle, f.slackvarsObstacle_front};
+    for (int k = 0; k < 17; ++k) if (si[k]) std::copy(si[k], si[k] + i[k].size(), i[k].begin());
+  }
+};
+
+// the seven sizes of a RawResults record against the loaded instance (a record of another shape is never indexed)
+static bool dims_match(const miqp_raw_results_c& r, const HostInst& I) {
+  return r.N == I.N && r.NrCars == I.C && r.NrRegions == I.R && r.NrEnvironments == I.E && r.NrObstacles == I.O &&
+         (I.O == 0 || r.MaxLinesObstacles == I.L) && r.NrCarToCarCollisions == I.C - 1;
+}
+
 struct miqp_solver {
   miqp_solver_opts opts{};
   HostInst inst; bool has_inst = false;
@@ -34,8 +75,10 @@ struct miqp_solver {
   std::vector<double> Z; std::vector<signed char> comp; bool has_sol = false;
   Layout lay{};
   double timing[6] = {0, 0, 0, 0, 0, 0};
-  // warm start (tried as first incumbent)
-  bool has_ws = false; std::vector<signed char> ws_fix;
+  // MIP starts (each tried as an additional root: binaries fixed, QP solved, accepted as incumbent when feasible).
+  // Slot 0: receding-horizon start (addRecedingHorizonWarmstart), slot 1: last-solution start (.mst file); with
+  // BOTH_WARMSTART_STRATEGIES the reference applies both (src/cplex_wrapper.cpp:124-138)
+  std::unique_ptr<OwnedResults> ws[2];
   std::string err;
 };
 
@@ -180,6 +223,7 @@ bool step0_check(const HostGeo& G, double& cobj) {
 namespace {
 
 struct DevCtx {
+  std::mutex mu;   // held for the whole solve: one solve at a time per device, different devices run concurrently
   bool ready = false; int device = -1;
   hipStream_t stream = nullptr;
   Layout Y{}; int n_inst = 0, open_cap = 0, batch_cap = 0, pool_cap = 0, npr = 0, ipm_grid_max = 1024;
@@ -201,19 +245,33 @@ struct DevCtx {
   }
 };
 
-DevCtx g_ctx;
+// one context per HIP device (the reference has one IloEnv per wrapper; here the device buffers are shared by the
+// handles that solve on the same device and serialised by the context's mutex)
+std::mutex g_ctx_table_mu;
+std::map<int, std::unique_ptr<DevCtx>> g_ctx_table;
+
+// resolves `device` (-1: the current device) and returns its context; nullptr without a HIP device
+DevCtx* ctx_for_device(int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { std::fprintf(stderr, "[miqp_gpu] no HIP device: the solver has no CPU path\n"); return nullptr; }
+  if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+  if (device >= ndev) { std::fprintf(stderr, "[miqp_gpu] device %d requested, %d visible\n", device, ndev); return nullptr; }
+  std::lock_guard<std::mutex> lk(g_ctx_table_mu);
+  auto& slot = g_ctx_table[device];
+  if (!slot) { slot.reset(new DevCtx()); slot->device = device; }
+  return slot.get();
+}
 
 size_t ipm_lds_bytes(const Layout& Y);
 
 bool same_layout(const Layout& a, const Layout& b) { return std::memcmp(&a, &b, sizeof(Layout)) == 0; }
 
-bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr, int device) {
+// caller holds X.mu; X.device is the resolved device ordinal
+bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr) {
   int batch_cap = n_inst * npr;
+  HIP_OK(hipSetDevice(X.device));   // the calling thread's current device (threads of solve_batch_multi each set their own)
   if (X.ready && same_layout(X.Y, Y) && X.n_inst == n_inst && X.open_cap == open_cap && X.npr == npr) return true;
   if (X.ready || !X.allocs.empty()) X.release();
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { std::fprintf(stderr, "[miqp_gpu] no HIP device: the solver has no CPU path\n"); return false; }
-  if (device >= 0) HIP_OK(hipSetDevice(device));
   if (!X.stream) HIP_OK(hipStreamCreate(&X.stream));
   if (!X.ev0) { HIP_OK(hipEventCreate(&X.ev0)); HIP_OK(hipEventCreate(&X.ev1)); }
   X.Y = Y; X.n_inst = n_inst; X.open_cap = open_cap; X.npr = npr; X.batch_cap = batch_cap;
@@ -460,7 +518,9 @@ BatchShape batch_layout(miqp_solver_t* const* S, int n) {
   }
   if (I0.C > MAXC) { bs.err = "NumCars > 4 is not supported by the device kernels"; return bs; }
   if (P > 15) { bs.err = "more than 15 possible regions per car"; return bs; }
-  if (I0.E > 100 || I0.L > 100) { bs.err = "too many environment pieces / obstacle edges"; return bs; }
+  // one branching creates a child per alternative of the chosen disjunction, at most 63 per node (eval_kernel): a shape
+  // with more alternatives is refused instead of searched incompletely
+  if (I0.E > 62 || I0.L + 1 > 62) { bs.err = "more than 62 environment pieces / 61 obstacle edges"; return bs; }
   bs.Y = make_layout(I0.C, I0.N, I0.R, P, I0.E, EL, I0.O, I0.L); bs.ok = true;
   return bs;
 }
@@ -473,16 +533,21 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   if (!bs.ok) { for (int k = 0; k < n; ++k) { if (S[k]) S[k]->err = bs.err; statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; } std::fprintf(stderr, "[miqp_gpu] %s\n", bs.err.c_str()); return false; }
   const Layout& Y = bs.Y;
   const miqp_solver_opts& O0 = S[0]->opts;
+  auto fail_all = [&](const char* why) { if (why) std::fprintf(stderr, "[miqp_gpu] %s\n", why); for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; };
+  for (int k = 1; k < n; ++k) if (S[k]->opts.device != O0.device) return fail_all("instances of one batch must name the same device (use miqp_solver_solve_batch_multi to span devices)");
+  DevCtx* Xp = ctx_for_device(O0.device);
+  if (!Xp) return fail_all(nullptr);
+  DevCtx& X = *Xp;
+  std::lock_guard<std::mutex> ctx_lock(X.mu);
+  if (hipSetDevice(X.device) != hipSuccess) return fail_all("hipSetDevice failed");
   int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(16384, 32768 / n));
   if (O0.nodes_per_round <= 0 && std::getenv("MIQP_NPR")) npr = std::max(1, std::atoi(std::getenv("MIQP_NPR")));  // tuning knob
   int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (std::getenv("MIQP_OPEN_CAP") ? std::atoi(std::getenv("MIQP_OPEN_CAP")) : std::max(32768, std::min(1 << 20, (1 << 27) / n)));   // 524288 per instance at n = 256: 10 GB of list entries, records are shared
   if (open_cap < 64) open_cap = 64;
   { size_t free_b = 0, total_b = 0;   // list entries (40 B per open node) must fit an eighth of the free device memory
-    int ndev_ = 0; if (hipGetDeviceCount(&ndev_) == hipSuccess && ndev_ > 0 && O0.device >= 0) (void)hipSetDevice(O0.device);
-    if (O0.max_open_nodes <= 0 && ndev_ > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) { size_t lim = free_b / 8 / 40 / (size_t)n; if ((size_t)open_cap > lim) open_cap = (int)std::max<size_t>(4096, lim); } }
+    if (O0.max_open_nodes <= 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) { size_t lim = free_b / 8 / 40 / (size_t)n; if ((size_t)open_cap > lim) open_cap = (int)std::max<size_t>(4096, lim); } }
   if ((size_t)n * npr >= ((size_t)1 << 20)) npr = (int)((((size_t)1 << 20) - 1) / n);
-  DevCtx& X = g_ctx;
-  if (!ctx_prepare(X, Y, n, open_cap, npr, O0.device)) { for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
+  if (!ctx_prepare(X, Y, n, open_cap, npr)) return fail_all(nullptr);
   DevBuf& B = X.B;
   size_t l_ipm = ipm_lds_bytes(Y), l_eval = eval_lds_bytes(Y);
   if (l_ipm > 160 * 1024 || l_eval > 160 * 1024) { std::fprintf(stderr, "[miqp_gpu] instance too large for LDS (%zu bytes)\n", l_ipm); for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
@@ -491,8 +556,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   std::vector<double> hD((size_t)n * Y.dstride); std::vector<int> hT((size_t)n * Y.istride);
   std::vector<double> h_const(n, 0.0), h_gap(n), h_tlim(n);
   std::vector<int> h_done(n, 0);
-  std::vector<signed char> roots((size_t)n * Y.fixlen, (signed char)-1);
-  std::vector<double> ob((size_t)n * 2, 0.0); std::vector<int> on((size_t)n * 2, 0), oc(n, 1);   // the first two open entries of every instance
+  std::vector<signed char> roots((size_t)3 * n * Y.fixlen, (signed char)-1);   // records k: root, n + k / 2n + k: MIP starts of instance k
+  std::vector<double> ob((size_t)n * 3, -1e300); std::vector<int> on((size_t)n * 3, 0), oc(n, 1);   // the first three open entries of every instance
   int active = 0;
   for (int k = 0; k < n; ++k) {
     miqp_solver* s = S[k]; s->lay = Y; s->has_sol = false;
@@ -501,9 +566,16 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     double cobj = 0; bool feas0 = step0_check(G, cobj);
     h_const[k] = cobj; h_gap[k] = s->opts.gap_override >= 0 ? s->opts.gap_override : s->inst.gap; h_tlim[k] = s->inst.tilim;
     if (!feas0) { h_done[k] = 1; oc[k] = 0; } else active++;
-    ob[(size_t)k * 2] = -1e300; on[(size_t)k * 2] = k;
-    if (s->has_ws && (int)s->ws_fix.size() == Y.fixlen && feas0) {  // MIP start: its binaries as a second root candidate
-      oc[k] = 2; ob[(size_t)k * 2 + 1] = -1e300; on[(size_t)k * 2 + 1] = n + k;
+    on[(size_t)k * 3] = k;
+    // MIP starts (initializeWarmstart + addMIPStart / readMIPStarts, src/cplex_wrapper.cpp:124-138, 494-639): the binaries
+    // of each start become an additional root whose QP the first round solves; a feasible one is the first incumbent
+    for (int w = 0; w < 2 && feas0; ++w) {
+      if (!s->ws[w] || !dims_match(s->ws[w]->r, s->inst)) continue;
+      std::vector<signed char> fx;
+      if (!fix_from_results(s->inst, Y, &hT[(size_t)k * Y.istride], &s->ws[w]->r, fx)) continue;
+      const int rec = (1 + w) * n + k;
+      std::copy(fx.begin(), fx.end(), roots.begin() + (size_t)rec * Y.fixlen);
+      on[(size_t)k * 3 + oc[k]] = rec; oc[k]++;
     }
     int rows, bin, cont, nnz; raw_sizes(s->inst, rows, bin, cont, nnz);
     s->props = miqp_solution_properties_c{}; s->props.NrConstraints = rows; s->props.NrBinaryVariables = bin; s->props.NrFloatVariables = cont;
@@ -515,17 +587,16 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   HIP_OK(hipMemcpyAsync((void*)B.inst_d, hD.data(), hD.size() * 8, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync((void*)B.inst_i, hT.data(), hT.size() * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(B.pool_fix, roots.data(), roots.size(), hipMemcpyHostToDevice, st));
-  for (int k = 0; k < n; ++k)
-    if (S[k]->has_ws && (int)S[k]->ws_fix.size() == Y.fixlen) HIP_OK(hipMemcpyAsync(B.pool_fix + (size_t)(n + k) * Y.fixlen, S[k]->ws_fix.data(), Y.fixlen, hipMemcpyHostToDevice, st));
-  int pool0 = 2 * n;
+  int pool0 = 3 * n;
   HIP_OK(hipMemcpyAsync(B.pool_count, &pool0, 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemsetAsync(B.free_head, 0, 4, st)); HIP_OK(hipMemsetAsync(B.free_tail, 0, 4, st)); HIP_OK(hipMemsetAsync(B.free_limit, 0, 4, st));
-  HIP_OK(hipMemcpy2DAsync(B.open_bound, (size_t)open_cap * 8, ob.data(), 16, 16, n, hipMemcpyHostToDevice, st));
-  HIP_OK(hipMemcpy2DAsync(B.open_node, (size_t)open_cap * 4, on.data(), 8, 8, n, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpy2DAsync(B.open_bound, (size_t)open_cap * 8, ob.data(), 24, 24, n, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpy2DAsync(B.open_node, (size_t)open_cap * 4, on.data(), 12, 12, n, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(B.open_count, oc.data(), n * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemsetAsync(B.open_depth, 0, (size_t)2 * n * open_cap * 4, st));
   HIP_OK(hipMemsetAsync(B.inc_key, 0xFF, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inc_seen, 0xFF, (size_t)n * 8, st));
+  HIP_OK(hipMemsetAsync(B.inc_fix, 0xFF, (size_t)n * Y.fixlen, st));   // no incumbent yet: every disjunction undecided
   { std::vector<double> big(n, 1e300); HIP_OK(hipMemcpyAsync(B.inc_obj, big.data(), n * 8, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(B.lower_bound, big.data(), n * 8, hipMemcpyHostToDevice, st)); HIP_OK(hipStreamSynchronize(st)); }
   HIP_OK(hipMemcpyAsync(B.inst_done, h_done.data(), n * 4, hipMemcpyHostToDevice, st));
@@ -734,14 +805,15 @@ void miqp_solver_destroy(miqp_solver_t* s) { delete s; }
 int miqp_solver_set_params(miqp_solver_t* s, const miqp_model_params_c* p) {
   if (!s || !p) return -1;
   s->has_inst = inst_from_params(p, s->opts.precision - 2, s->inst, s->err);
-  s->has_sol = false; s->has_ws = false;
+  s->has_sol = false;   // MIP starts stay registered (the reference keeps them in the wrapper across resetParameters)
+  if (!s->has_inst) std::fprintf(stderr, "[miqp_gpu] %s\n", s->err.c_str());
   return s->has_inst ? 0 : -2;
 }
 
 int miqp_solver_load_dat(miqp_solver_t* s, const char* path) {
   if (!s || !path) return -1;
   s->has_inst = inst_from_dat(path, s->inst, s->err);
-  s->has_sol = false; s->has_ws = false;
+  s->has_sol = false;
   if (!s->has_inst) std::fprintf(stderr, "[miqp_gpu] %s\n", s->err.c_str());
   return s->has_inst ? 0 : -2;
 }
@@ -759,20 +831,50 @@ int miqp_solver_get_dims(const miqp_solver_t* s, int* o) {
 }
 
 int miqp_solver_set_warmstart(miqp_solver_t* s, const miqp_raw_results_c* start, int warmstart_type) {
-  if (!s || !s->has_inst) return -1;
-  if (warmstart_type == MIQP_WARMSTART_NONE || !start) { s->has_ws = false; return 0; }
-  miqp_solver_t* one[1] = {s};
-  BatchShape bs = batch_layout(one, 1);
-  if (!bs.ok) return -2;
-  std::vector<double> D(bs.Y.dstride); std::vector<int> T(bs.Y.istride);
-  compile_instance(s->inst, bs.Y, D.data(), T.data());
-  s->has_ws = fix_from_results(s->inst, bs.Y, T.data(), start, s->ws_fix);
-  return s->has_ws ? 0 : -3;
+  if (!s) return -1;
+  if (warmstart_type == MIQP_WARMSTART_NONE || !start) { s->ws[0].reset(); s->ws[1].reset(); return 0; }
+  // slot 1: the last-solution start (readMIPStarts of the .mst file); slot 0: the receding-horizon start.  With
+  // MIQP_WARMSTART_BOTH the caller registers each of the two with its own call (type RECEDING_HORIZON / LAST_SOLUTION)
+  const int slot = warmstart_type == MIQP_WARMSTART_LAST_SOLUTION ? 1 : 0;
+  if (start->N < 2 || start->NrCars < 1 || start->NrRegions < 1 || start->NrEnvironments < 0 || start->NrObstacles < 0 || start->MaxLinesObstacles < 0 ||
+      start->NrCarToCarCollisions != start->NrCars - 1) return -2;
+  if (s->has_inst && !dims_match(*start, s->inst)) { s->ws[slot].reset(); return -3; }   // a start of another shape is ignored
+  s->ws[slot].reset(new OwnedResults(start->NrCars, start->N, start->NrRegions, start->NrEnvironments, start->NrObstacles, start->MaxLinesObstacles));
+  s->ws[slot]->copy_from(*start);
+  return 0;
 }
 
 int miqp_solver_solve_batch(miqp_solver_t* const* solvers, int n, int* statuses) {
   if (!solvers || n < 1 || !statuses) return -1;
   return solve_batch_impl(solvers, n, statuses) ? 0 : -2;
+}
+
+int miqp_solver_solve_batch_multi(miqp_solver_t* const* solvers, int n, int gpus, int* statuses) {
+  if (!solvers || n < 1 || !statuses) return -1;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { std::fprintf(stderr, "[miqp_gpu] no HIP device: the solver has no CPU path\n"); for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return -2; }
+  if (gpus <= 0 || gpus > ndev) gpus = ndev;
+  if (gpus > n) gpus = n;
+  // instance b -> device b mod G; no data-path exchange between the shards
+  std::vector<std::vector<miqp_solver_t*>> shard(gpus); std::vector<std::vector<int>> st(gpus);
+  for (int b = 0; b < n; ++b) { if (!solvers[b]) return -1; solvers[b]->opts.device = b % gpus; shard[b % gpus].push_back(solvers[b]); }
+  std::vector<char> ok(gpus, 0);
+  std::vector<std::thread> th;
+  for (int g = 0; g < gpus; ++g) {
+    st[g].assign(shard[g].size(), MIQP_STATUS_FAILED_SEG_FAULT);
+    th.emplace_back([&, g] { ok[g] = solve_batch_impl(shard[g].data(), (int)shard[g].size(), st[g].data()) ? 1 : 0; });
+  }
+  for (auto& t : th) t.join();
+  int rc = 0;
+  for (int b = 0; b < n; ++b) statuses[b] = st[b % gpus][b / gpus];
+  for (int g = 0; g < gpus; ++g) if (!ok[g]) rc = -2;
+  return rc;
+}
+
+int miqp_solver_raw_sizes(const miqp_solver_t* s, int* out4) {
+  if (!s || !s->has_inst || !out4) return -1;
+  raw_sizes(s->inst, out4[0], out4[1], out4[2], out4[3]);
+  return 0;
 }
 
 int miqp_solver_solve(miqp_solver_t* s, double timestamp) {
@@ -785,6 +887,7 @@ int miqp_solver_solve(miqp_solver_t* s, double timestamp) {
 
 int miqp_solver_get_results(const miqp_solver_t* s, miqp_raw_results_c* out) {
   if (!s || !out || !s->has_sol) return -1;
+  if (!dims_match(*out, s->inst)) return -2;   // the caller's record must be sized for this instance
   std::vector<double> D(s->lay.dstride); std::vector<int> T(s->lay.istride);
   compile_instance(s->inst, s->lay, D.data(), T.data());
   fill_results(s->inst, s->lay, D.data(), T.data(), s->comp.data(), s->Z.data(), out);
@@ -874,28 +977,6 @@ int miqp_plan(miqp_solver_t* s, miqp_model_params_c* p, int* initial_region, int
   return status == MIQP_STATUS_SUCCESS ? 1 : 0;
 }
 
-namespace {
-// caller-independent RawResults record sized for the instance of `s`
-struct OwnedResults {
-  miqp_raw_results_c r{}; std::vector<std::vector<double>> d; std::vector<std::vector<int>> i;
-  explicit OwnedResults(const HostInst& I) {
-    const int C = I.C, N = I.N, R = I.R, E = I.E, O = I.O, L = I.L, K = I.C - 1;
-    r.N = N; r.NrEnvironments = E; r.NrRegions = R; r.NrObstacles = O; r.MaxLinesObstacles = L; r.NrCarToCarCollisions = K; r.NrCars = C;
-    auto D = [&](size_t n) { d.emplace_back(n ? n : 1, 9999999.0); return d.back().data(); };
-    auto J = [&](size_t n) { i.emplace_back(n ? n : 1, 9999999); return i.back().data(); };
-    d.reserve(16); i.reserve(24);
-    const size_t cn = (size_t)C * N;
-    r.u_x = D(cn); r.u_y = D(cn); r.pos_x = D(cn); r.vel_x = D(cn); r.acc_x = D(cn); r.pos_y = D(cn); r.vel_y = D(cn); r.acc_y = D(cn);
-    r.pos_x_front_UB = D(cn); r.pos_x_front_LB = D(cn); r.pos_y_front_UB = D(cn); r.pos_y_front_LB = D(cn);
-    r.notWithinEnvironmentRear = J(cn * E); r.notWithinEnvironmentFrontUbUb = J(cn * E); r.notWithinEnvironmentFrontLbUb = J(cn * E);
-    r.notWithinEnvironmentFrontUbLb = J(cn * E); r.notWithinEnvironmentFrontLbLb = J(cn * E); r.active_region = J(cn * R);
-    r.region_change_not_allowed_x_positive = J(cn); r.region_change_not_allowed_y_positive = J(cn); r.region_change_not_allowed_x_negative = J(cn);
-    r.region_change_not_allowed_y_negative = J(cn); r.region_change_not_allowed_combined = J(cn);
-    r.deltacc = J(cn * O * L); r.deltacc_front = J(cn * O * L * 4); r.car2car_collision = J((size_t)K * K * N * 16); r.slackvars = J((size_t)K * K * N * 4);
-    r.slackvarsObstacle = J(cn * O); r.slackvarsObstacle_front = J(cn * O * 4); r.slackvars_real = D((size_t)K * K * N * 4);
-  }
-};
-}  // namespace
 
 int miqp_solver_write_dat(const miqp_solver_t* s, const char* path) {
   if (!s || !s->has_inst || !path) return -1;
@@ -935,8 +1016,12 @@ int miqp_solver_solve_fixed(miqp_solver_t* s, const miqp_raw_results_c* fixed, m
   BatchShape bs = batch_layout(one, 1);
   if (!bs.ok) return -2;
   const Layout& Y = bs.Y;
-  DevCtx& X = g_ctx;
-  if (!ctx_prepare(X, Y, 1, 64, 16, s->opts.device)) return -3;
+  if (!dims_match(*fixed, s->inst) || (out && !dims_match(*out, s->inst))) return -2;
+  DevCtx* Xp = ctx_for_device(s->opts.device);
+  if (!Xp) return -3;
+  DevCtx& X = *Xp;
+  std::lock_guard<std::mutex> ctx_lock(X.mu);
+  if (!ctx_prepare(X, Y, 1, 64, 16)) return -3;
   if (!set_kernel_lds(Y, ipm_lds_bytes(Y), eval_lds_bytes(Y))) return -3;
   std::vector<double> D(Y.dstride); std::vector<int> T(Y.istride);
   compile_instance(s->inst, Y, D.data(), T.data());

@@ -45,12 +45,17 @@ def region_of(frac, vx, vy):
 
 
 def generate(config="cfg3", seed=0, gap=0.01, max_time=10.0):
-    C_, N, R, E, O = CONFIGS[config] if isinstance(config, str) else config
+    """config: a name of CONFIGS or a tuple (cars, steps, regions, environment pieces, obstacles[, obstacle edges]);
+    more than two environment pieces split the road into overlapping rectangles, more than four obstacle edges make the
+    obstacles regular polygons around the same rectangle's circumscribed ellipse"""
+    cfg = CONFIGS[config] if isinstance(config, str) else tuple(config)
+    C_, N, R, E, O = cfg[:5]
+    LO = cfg[5] if len(cfg) > 5 else 4
     rng = np.random.Generator(np.random.MT19937(seed))
     T = tables(R)
     p = ModelParameters()
     p.NumSteps, p.nr_regions, p.NumCars, p.nr_obstacles, p.nr_environments = N, R, C_, O, E
-    p.max_lines_obstacles = 4 if O > 0 else 0
+    p.max_lines_obstacles = LO if O > 0 else 0
     p.max_solution_time, p.relative_mip_gap_tolerance = max_time, gap
     p.ts = 0.25
     eps = 1e-6
@@ -97,6 +102,10 @@ def generate(config="cfg3", seed=0, gap=0.01, max_time=10.0):
     elif E == 2:
         p.MultiEnvironmentConvexPolygon = [np.array([[-10, -5.25], [75, -5.25], [75, 5.25], [-10, 5.25]], float),
                                            np.array([[65, -5.25], [150, -5.25], [150, 5.25], [65, 5.25]], float)]
+    elif E > 2:
+        w = 160.0 / E
+        p.MultiEnvironmentConvexPolygon = [np.array([[-10 + e * w - 5, -5.25], [-10 + (e + 1) * w + 5, -5.25], [-10 + (e + 1) * w + 5, 5.25], [-10 + e * w - 5, 5.25]], float)
+                                           for e in range(E)]
     else:
         p.MultiEnvironmentConvexPolygon = []
     obs = []
@@ -106,7 +115,11 @@ def generate(config="cfg3", seed=0, gap=0.01, max_time=10.0):
         per_t = []
         for i in range(N):
             cx = ox + ov * p.ts * i
-            per_t.append(np.array([[cx - hl, oy - hw], [cx + hl, oy - hw], [cx + hl, oy + hw], [cx - hl, oy + hw]], float))
+            if LO == 4:
+                per_t.append(np.array([[cx - hl, oy - hw], [cx + hl, oy - hw], [cx + hl, oy + hw], [cx - hl, oy + hw]], float))
+            else:   # counter-clockwise LO-gon on the ellipse through the rectangle's corners
+                a = 2 * math.pi * (np.arange(LO) + 0.5) / LO
+                per_t.append(np.stack([cx + math.sqrt(2) * hl * np.cos(a), oy + math.sqrt(2) * hw * np.sin(a)], 1))
         obs.append(per_t)
     p.ObstacleConvexPolygon = obs
     p.obstacle_is_soft = [0] * O

@@ -49,6 +49,8 @@ def load_library():
     L.miqp_solver_set_warmstart.restype = C.c_int; L.miqp_solver_set_warmstart.argtypes = [vp, C.POINTER(RawResultsC), C.c_int]
     L.miqp_solver_solve.restype = C.c_int; L.miqp_solver_solve.argtypes = [vp, C.c_double]
     L.miqp_solver_solve_batch.restype = C.c_int; L.miqp_solver_solve_batch.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
+    L.miqp_solver_solve_batch_multi.restype = C.c_int; L.miqp_solver_solve_batch_multi.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.miqp_solver_raw_sizes.restype = C.c_int; L.miqp_solver_raw_sizes.argtypes = [vp, C.POINTER(C.c_int)]
     L.miqp_solver_get_results.restype = C.c_int; L.miqp_solver_get_results.argtypes = [vp, C.POINTER(RawResultsC)]
     L.miqp_solver_get_properties.restype = C.c_int; L.miqp_solver_get_properties.argtypes = [vp, C.POINTER(SolutionPropertiesC)]
     L.miqp_solver_get_dims.restype = C.c_int; L.miqp_solver_get_dims.argtypes = [vp, C.POINTER(C.c_int)]
@@ -70,7 +72,8 @@ EXPORTED_SYMBOLS = ["miqp_solver_create", "miqp_solver_destroy", "miqp_solver_se
                     "miqp_solver_last_timing", "miqp_gpu_version", "miqp_solver_write_dat", "miqp_solver_write_solution",
                     "miqp_solver_write_mst", "miqp_solver_read_mst", "miqp_fraction_parameters", "miqp_mean_angles",
                     "miqp_limits_per_region", "miqp_calculate_region_idx", "miqp_reserve_neighbor_regions",
-                    "miqp_calculate_possible_regions", "miqp_calculate_warmstart", "miqp_plan"]
+                    "miqp_calculate_possible_regions", "miqp_calculate_warmstart", "miqp_plan",
+                    "miqp_solver_solve_batch_multi", "miqp_solver_raw_sizes"]
 
 
 class OptimizationStatus(enum.IntEnum):  # src/cplex_wrapper.hpp:54-59
@@ -191,6 +194,8 @@ class CplexWrapper:
     def _push_inputs(self):
         if self.parameterSource_ == ParameterSource.DATFILE:
             rc = self._L.miqp_solver_load_dat(self._h, self.datfile_.encode())
+        elif self.parameterSource_ == ParameterSource.MIXED and self._params is None:
+            rc = self._L.miqp_solver_load_dat(self._h, self.datfile_.encode())   # MIXED: the C++ inputs when given, else the file
         else:
             if self._params is None:
                 return -1
@@ -198,13 +203,13 @@ class CplexWrapper:
             rc = self._L.miqp_solver_set_params(self._h, C.byref(s))
         if rc != 0:
             return rc
-        ws = None
-        if self.doWarmstart_ in (WarmstartType.RECEDING_HORIZON_WARMSTART, WarmstartType.BOTH_WARMSTART_STRATEGIES):
-            ws = self._warm
-        if ws is not None:
-            wc = ws.to_c()
-            self._L.miqp_solver_set_warmstart(self._h, C.byref(wc), int(self.doWarmstart_))
-        elif self.doWarmstart_ in (WarmstartType.LAST_SOLUTION_WARMSTART, WarmstartType.BOTH_WARMSTART_STRATEGIES):
+        # MIP starts (src/cplex_wrapper.cpp:121-138): the receding-horizon start and, independently of it, the .mst
+        # file of the last solution - with BOTH_WARMSTART_STRATEGIES the reference applies both
+        self._L.miqp_solver_set_warmstart(self._h, None, int(WarmstartType.NO_WARMSTART))
+        if self.doWarmstart_ in (WarmstartType.RECEDING_HORIZON_WARMSTART, WarmstartType.BOTH_WARMSTART_STRATEGIES) and self._warm is not None:
+            wc = self._warm.to_c()
+            self._L.miqp_solver_set_warmstart(self._h, C.byref(wc), int(WarmstartType.RECEDING_HORIZON_WARMSTART))
+        if self.doWarmstart_ in (WarmstartType.LAST_SOLUTION_WARMSTART, WarmstartType.BOTH_WARMSTART_STRATEGIES):
             # cplex.readMIPStarts(tmpWarmstartFile_) when the file exists (src/cplex_wrapper.cpp:128-138)
             if os.path.exists(self.tmpWarmstartFile_):
                 self._L.miqp_solver_read_mst(self._h, self.tmpWarmstartFile_.encode())
@@ -289,14 +294,24 @@ class CplexWrapper:
         rc = self._L.miqp_solver_solve_fixed(self._h, C.byref(fc), C.byref(oc), C.byref(obj), C.byref(it))
         return rc, out, obj.value, it.value
 
+    def rawSizes(self):
+        """rows / binaries / continuous columns / non-zeros of the OPL model of the loaded parameters (no device needed)"""
+        if self._push_inputs() != 0:
+            return None
+        o = (C.c_int * 4)()
+        if self._L.miqp_solver_raw_sizes(self._h, o) != 0:
+            return None
+        return dict(rows=o[0], bin=o[1], cont=o[2], nnz=o[3])
+
     def lastTiming(self):
         t = (C.c_double * 6)()
         self._L.miqp_solver_last_timing(self._h, t)
         return dict(solve_s=t[0], ipm_s=t[1], ipm_launches=int(t[2]), nodes=int(t[3]), ipm_iters=int(t[4]), row_iters=int(t[5]))
 
 
-def solve_batch(wrappers):
-    """Solves independent instances concurrently on one device (miqp_solver_solve_batch)."""
+def solve_batch(wrappers, gpus=None):
+    """Solves independent instances concurrently: on one device (miqp_solver_solve_batch), or with ``gpus`` given
+    sharded b -> device b mod gpus inside the library (miqp_solver_solve_batch_multi; 0 = every visible device)."""
     L = load_library()
     for w in wrappers:
         if w._push_inputs() != 0:
@@ -304,7 +319,7 @@ def solve_batch(wrappers):
     n = len(wrappers)
     hs = (C.c_void_p * n)(*[w._h for w in wrappers])
     st = (C.c_int * n)()
-    rc = L.miqp_solver_solve_batch(hs, n, st)
+    rc = L.miqp_solver_solve_batch(hs, n, st) if gpus is None else L.miqp_solver_solve_batch_multi(hs, n, int(gpus), st)
     if rc != 0:
         return [OptimizationStatus.FAILED_SEG_FAULT] * n
     return [w._collect(st[k]) for k, w in enumerate(wrappers)]

@@ -42,13 +42,3 @@ def k3_results():
     for n in ["slackvarsObstacle", "slackvarsObstacle_front"]:
         getattr(r, n)[...] = 0
     return r, g
-
-
-def canonical_compatible(a: RawResults, b: RawResults, params, tol=1e-5):
-    """Binary parity in canonical form (SURVEY.md section 7 hard part 3): the active region per (car, step) is
-    equal, and every side asserted (binary == 0) by one solution is satisfied by the continuous point of the
-    other.  Returns a list of mismatches."""
-    bad = []
-    if not np.array_equal(a.active_region, b.active_region):
-        bad.append("active_region differs at %s" % (np.argwhere(a.active_region != b.active_region)[:4].tolist(),))
-    return bad

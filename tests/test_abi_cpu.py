@@ -152,6 +152,49 @@ def test_lp_export_has_the_reference_model_sizes(lib, tmp_path):
     assert len(bins) == 1240
 
 
+def test_raw_sizes_match_the_reference_and_the_oracle_enumeration(lib, oracle):
+    """SolutionProperties.NrConstraints / NrBinaryVariables / NrFloatVariables / NonZeroCoefficients
+    (collectCplexStatistics, src/cplex_wrapper.cpp:679-690): the product counts them per .mod statement; the reference
+    asserts 12361 / 1240 / 340 / 29834 for the testcase (test/cplex_wrapper_test.cc:866-871) and the oracle's row-by-row
+    enumeration gives the same four numbers for the other fixtures and for seeded instances of every config"""
+    w = P.CplexWrapper(parameterSource=P.ParameterSource.DATFILE)
+    w.setParameterDatFileAbsolute(dat_path("cplexmodel_testcase.dat"))
+    assert w.rawSizes() == dict(rows=12361, bin=1240, cont=340, nnz=29834)
+    for name in ("cplexmodel.dat", "test_sos.dat"):
+        w = P.CplexWrapper(parameterSource=P.ParameterSource.DATFILE)
+        w.setParameterDatFileAbsolute(dat_path(name))
+        h = oracle.from_dat(dat_path(name))
+        assert w.rawSizes() == oracle.sizes(h), name
+        oracle.free(h)
+    for cfg, seed in (("cfg2", 0), ("cfg3", 1), ("cfg4", 2), ("cfg5", 0), ("mini3", 3), ("mini1", 4), ((2, 6, 16, 2, 1), 0), ((1, 12, 32, 0, 0), 1)):
+        p = synthetic.generate(cfg, seed)
+        if p.nr_obstacles:
+            p.obstacle_is_soft = [1] + [0] * (p.nr_obstacles - 1)
+        w = P.CplexWrapper(); w.resetParameters(p)
+        h = oracle.from_params(p, 10)
+        assert w.rawSizes() == oracle.sizes(h), (cfg, seed)
+        oracle.free(h)
+
+
+def test_invalid_records_are_refused(lib):
+    """sizes and records that do not fit the instance fail with an error code instead of being indexed"""
+    import ctypes as C
+    from planner_miqp_amd.ctypes_types import RawResults
+    p = synthetic.generate("mini", 0)
+    w = P.CplexWrapper(); w.resetParameters(p)
+    assert w._push_inputs() == 0
+    bad = RawResults(2, 9, 32, 1, 0, 0)                       # another horizon
+    assert lib.miqp_solver_set_warmstart(w._h, C.byref(bad.to_c()), 1) < 0
+    good = RawResults(2, 8, 32, 1, 0, 0)
+    assert lib.miqp_solver_set_warmstart(w._h, C.byref(good.to_c()), 1) == 0
+    q = synthetic.generate("mini", 0); q.initial_region = np.array([0, 40])
+    w2 = P.CplexWrapper(); w2.resetParameters(q)
+    assert w2._push_inputs() != 0
+    q = synthetic.generate("mini", 0); q.possible_region = np.zeros_like(q.possible_region)
+    w3 = P.CplexWrapper(); w3.resetParameters(q)
+    assert w3._push_inputs() != 0
+
+
 def test_all_baseline_configs_generate_and_size(oracle):
     """every BASELINE config of the generator loads into the oracle with the raw sizes of SURVEY App. B"""
     for cfg in ("cfg2", "cfg3", "cfg4", "cfg5", "cfg5s", "mini3b"):
