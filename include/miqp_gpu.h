@@ -127,6 +127,10 @@ int miqp_solver_last_timing(const miqp_solver_t* s, double* out6);
 
 /* ParameterPreparer::CalculateFractionParameters             common/parameter/parameter_preparer.cpp:37-52; out[R*4] */
 int miqp_fraction_parameters(int nr_regions, float max_velocity_fitting, double* out);
+/* FittingPolynomialParameters::GetPOLY_*()                    common/parameter/fitting_polynomial_parameters.hpp:28-168
+ * out[6][R*3], row-major [region][3], order SINT_UB, SINT_LB, COSS_UB, COSS_LB, KAPPA_AX_MAX, KAPPA_AX_MIN; returns -2 for a
+ * (nr_regions, max, min velocity) combination outside the seven the reference ships (it throws std::invalid_argument) */
+int miqp_fitting_polynomial_parameters(int nr_regions, float max_velocity_fitting, float min_velocity_fitting, double* out);
 /* ParameterPreparer::CalculateMeanAngleVector                 parameter_preparer.cpp:96-113; out[R] */
 int miqp_mean_angles(const double* fraction_parameters, int nr_regions, double* out);
 /* CalculateAccLimitsPerCar / CalculateJerkLimitsPerCar (RotateLimitVectors)   parameter_preparer.cpp:54-94, 115-143

@@ -916,6 +916,10 @@ int miqp_fraction_parameters(int nr_regions, float max_velocity_fitting, double*
   if (nr_regions < 1 || !out) return -1;
   miqp::fraction_parameters(nr_regions, max_velocity_fitting, out); return 0;
 }
+int miqp_fitting_polynomial_parameters(int nr_regions, float max_velocity_fitting, float min_velocity_fitting, double* out) {
+  if (nr_regions < 1 || !out) return -1;
+  return miqp::fitting_polynomial_parameters(nr_regions, max_velocity_fitting, min_velocity_fitting, out) ? 0 : -2;
+}
 int miqp_mean_angles(const double* fraction_parameters, int nr_regions, double* out) {
   if (!fraction_parameters || nr_regions < 1 || !out) return -1;
   miqp::mean_angles(fraction_parameters, nr_regions, out); return 0;

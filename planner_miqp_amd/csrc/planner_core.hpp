@@ -24,6 +24,21 @@ inline void fraction_parameters(int R, float vmax_fit, double* out) {
   for (int k = 0; k < R; ++k) { int n = (k + 1) % R; out[k * 4 + 2] = out[n * 4 + 0]; out[k * 4 + 3] = out[n * 4 + 1]; }
 }
 
+// FittingPolynomialParameters (common/parameter/fitting_polynomial_parameters.hpp:28-92, 97-168): the six fitted R x 3
+// tables of one (nr_regions, max_velocity_fitting, min_velocity_fitting) variant, row-major [region][3], in the order
+// SINT_UB, SINT_LB, COSS_UB, COSS_LB, KAPPA_AX_MAX, KAPPA_AX_MIN; false for a combination the reference rejects with
+// "Invalid number of regions or velocity!"
+#include "fitting_tables.inc"
+inline bool fitting_polynomial_parameters(int R, float vmax_fit, float vmin_fit, double* out /* [6][R*3] */) {
+  for (const auto& v : FIT_VARIANTS)
+    if (v.R == R && (float)v.vmax == vmax_fit && (float)v.vmin == vmin_fit) {
+      const double* t = &v.t[0][0];
+      for (int k = 0; k < 6 * 3 * R; ++k) out[k] = t[k];
+      return true;
+    }
+  return false;
+}
+
 inline double wrap_2pi(double a) { a = std::fmod(a, 2.0 * M_PI); if (a < 0) a += 2.0 * M_PI; return a; }
 
 // ParameterPreparer::CalculateMeanAngleVector (parameter_preparer.cpp:96-113)

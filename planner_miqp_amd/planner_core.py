@@ -17,6 +17,7 @@ def _lib():
     if not _PROTO:
         dp, ip, f = c_double_p, c_int_p, C.c_float
         L.miqp_fraction_parameters.restype = C.c_int; L.miqp_fraction_parameters.argtypes = [C.c_int, f, dp]
+        L.miqp_fitting_polynomial_parameters.restype = C.c_int; L.miqp_fitting_polynomial_parameters.argtypes = [C.c_int, f, f, dp]
         L.miqp_mean_angles.restype = C.c_int; L.miqp_mean_angles.argtypes = [dp, C.c_int, dp]
         L.miqp_limits_per_region.restype = C.c_int; L.miqp_limits_per_region.argtypes = [dp, C.c_int, f, f, f, f, dp, dp, dp, dp]
         L.miqp_calculate_region_idx.restype = C.c_int; L.miqp_calculate_region_idx.argtypes = [dp, C.c_int, f, f, ip]
@@ -37,6 +38,27 @@ def _d(a):
 
 def _i(a):
     return a.ctypes.data_as(c_int_p)
+
+
+class FittingPolynomialParameters:
+    """common/parameter/fitting_polynomial_parameters.hpp:28-168: the fitted front-axle and curvature polynomials of one
+    (nr_regions, max_velocity_fitting, min_velocity_fitting) variant as R x 3 matrices; an unknown combination raises
+    ValueError("Invalid number of regions or velocity!") like the reference's std::invalid_argument"""
+    _ORDER = ["POLY_SINT_UB", "POLY_SINT_LB", "POLY_COSS_UB", "POLY_COSS_LB", "POLY_KAPPA_AX_MAX", "POLY_KAPPA_AX_MIN"]
+
+    def __init__(self, nr_regions, max_velocity_fitting, min_velocity_fitting):
+        self.nr_regions = int(nr_regions)
+        t = np.zeros((6, self.nr_regions, 3))
+        if _lib().miqp_fitting_polynomial_parameters(self.nr_regions, float(max_velocity_fitting), float(min_velocity_fitting), _d(t)) != 0:
+            raise ValueError("Invalid number of regions or velocity!")
+        self._t = t
+
+    def GetPolynomialDimension(self):
+        return 3
+
+
+for _k, _n in enumerate(FittingPolynomialParameters._ORDER):
+    setattr(FittingPolynomialParameters, "Get" + _n, (lambda k: lambda self: self._t[k].copy())(_k))
 
 
 class ParameterPreparer:

@@ -135,3 +135,43 @@ def test_calculate_warmstart_shift_and_quirks():
     assert np.array_equal(w.active_region[:, :N - 1], a.active_region[:, 1:]) and not w.active_region[:, N - 1].any()  # :982 has no effect
     assert np.array_equal(w.car2car_collision[:, :, :N - 1], a.car2car_collision[:, :, 1:]) and np.array_equal(w.car2car_collision[:, :, N - 1], a.car2car_collision[:, :, N - 1])
     assert np.array_equal(w.deltacc[:, :, :N - 1], a.deltacc[:, :, 1:]) and np.array_equal(w.deltacc_front[:, :, N - 1], a.deltacc_front[:, :, N - 1])
+
+
+def test_fitting_polynomial_parameters_match_the_reference_unit_test():
+    """common/tests/fitting_polynomial_parameters_test.cc:17-167 (EXPECT_EQ: identical doubles; EXPECT_NEAR where the
+    reference uses it): spot values of the (32, 20, 2), (16, 20, 2) and (16, 10, 2) fits, the exact first row block of
+    POLY_SINT_UB_32, valid / invalid parameter pairs"""
+    f = K.FittingPolynomialParameters(32, 20, 2)
+    m = f.GetPOLY_SINT_UB(); assert m.shape == (32, 3) and m[0, 0] == 0.18825 and m[31, 2] == 0.049029
+    should = np.array([0.18825, -0.0091624, 0.05868, 0.38235, -0.019062, 0.050001, 0.55699, -0.023663, 0.036849, 0.71125, -0.023834, 0.024695,
+                       0.83632, -0.019361, 0.013151, 0.93174, -0.019049, 0.0079673, 0.98244, -0.015382, 0.0037045, 1.0047, -0.0055247, 0.00032035]).reshape(8, 3)
+    assert np.allclose(m[:8], should, rtol=1e-12, atol=0)
+    m = f.GetPOLY_SINT_LB(); assert m[0, 0] == -0.005 and m[31, 2] == 0.056807
+    m = f.GetPOLY_COSS_UB(); assert m[0, 0] == 1.005 and m[31, 2] == 0.0055247
+    m = f.GetPOLY_COSS_LB(); assert m[0, 0] == 0.97651 and m[31, 2] == 0.0055499
+    m = f.GetPOLY_KAPPA_AX_MAX(); assert m[0, 0] == -1.0225 and m[31, 2] == -0.1005
+    m = f.GetPOLY_KAPPA_AX_MIN(); assert m[0, 0] == 1.7056 and m[31, 2] == 0.12325
+    m16 = K.FittingPolynomialParameters(16, 20, 2).GetPOLY_SINT_UB()
+    assert m16[0, 0] == 0.348508875688441 and m16[15, 0] == 0.005000000000002289 and m16[0, 1] == -0.017175443784421922 and m16[15, 2] == 0.04559607525876267
+    g = K.FittingPolynomialParameters(16, 10, 2)
+    m = g.GetPOLY_KAPPA_AX_MIN(); assert abs(m[0, 0] - 1.72762) < 1e-4 and abs(m[15, 2] - 0.249466) < 1e-4
+    m = g.GetPOLY_COSS_LB(); assert m[0, 0] == 0.9317320781172977 and m[15, 2] == 0.024320547171933854
+    for bad in ((32, 10, 3), (64, 20, 2), (48, 10, 1)):
+        with pytest.raises(ValueError, match="Invalid number of regions or velocity!"):
+            K.FittingPolynomialParameters(*bad)
+    for ok in ((16, 10, 1), (16, 10, 2), (16, 20, 2), (32, 10, 1), (32, 10, 2), (32, 20, 2), (64, 10, 1)):
+        assert K.FittingPolynomialParameters(*ok).GetPOLY_COSS_UB().shape == (ok[0], 3)
+
+
+def test_fixture_tables_are_the_fitted_variants():
+    """the region tables of the reference's .dat fixtures are the (32, 20, 2) and (16, 20, 2) fits (to the 6 digits OPL
+    prints), and the generator's 64-region table is the (64, 10, 1) fit"""
+    import json, os
+    data = os.path.join(os.path.dirname(K.__file__), "data")
+    names = ["POLY_SINT_UB", "POLY_SINT_LB", "POLY_COSS_UB", "POLY_COSS_LB", "POLY_KAPPA_AX_MAX", "POLY_KAPPA_AX_MIN"]
+    for R, combo, tol in ((32, (32, 20, 2), 1e-5), (16, (16, 20, 2), 1e-3), (64, (64, 10, 1), 0.0)):   # test_sos.dat prints 3-4 digits
+        t = json.load(open(os.path.join(data, "region_tables_%d.json" % R)))
+        f = K.FittingPolynomialParameters(*combo)
+        for n in names:
+            a = np.array(t[n], float).reshape(R, 3); b = getattr(f, "Get" + n)()
+            assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (R, n, np.abs(a - b).max())
