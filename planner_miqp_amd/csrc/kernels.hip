@@ -117,6 +117,9 @@ struct DevBuf {
   int* work_counter;             // next node of the batch to be solved (reset before every ipm launch)
   unsigned long long* prof;      // [40] cycle counters of the phases of ipm_kernel (diagnostic build -DMIQP_PROFILE only)
   unsigned long long* stat_rowiters;
+  int* ovf_count; int* ovf_list;  // nodes the on-chip interior point kernel handed to the memory-backed one (more general rows than its LDS holds)
+  int ovf_mode;                  // 1: ipm_kernel works through ovf_list instead of the whole batch
+  unsigned long long* stats;     // [32] diagnostic counters of the on-chip kernel (MIQP_STATS=1), else null
   signed char* pool_origin;      // diagnostic build: 2*kind + (deviating child) of the branching that created a node record
 };
 
@@ -135,17 +138,41 @@ __device__ inline double inc_from_key(unsigned long long key) {
   return key2d(key & ~0xFFFFFull);
 }
 
+// cross-lane movement without the LDS crossbar: DPP within a row of 16 lanes, v_permlane16_swap / v_permlane32_swap
+// (gfx950) between the rows - a full-rate VALU instruction each instead of a ds_bpermute round trip
+template <int CTRL> __device__ inline double dpp_mov(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// (value of the even row of the pair, value of the odd row) for the row pairs (0,1), (2,3): lane l and lane l ^ 16
+__device__ inline void rows16(double x, double& even, double& odd) {
+  const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  even = __hiloint2double((int)b[0], (int)a[0]); odd = __hiloint2double((int)b[1], (int)a[1]);
+}
+// (value of the lower half, value of the upper half): lane l and lane l ^ 32
+__device__ inline void halves32(double x, double& lower, double& upper) {
+  const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  lower = __hiloint2double((int)b[0], (int)a[0]); upper = __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ inline double sum_xor16(double v) { double a, b; rows16(v, a, b); return a + b; }      // v + v(lane ^ 16), in every lane
+__device__ inline double sum_xor32(double v) { double a, b; halves32(v, a, b); return a + b; }     // v + v(lane ^ 32)
 __device__ inline double wave_min(double v) {
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-  return v;
+  v = fmin(v, dpp_mov<0xB1>(v)); v = fmin(v, dpp_mov<0x4E>(v)); v = fmin(v, dpp_mov<0x141>(v)); v = fmin(v, dpp_mov<0x140>(v));
+  double a, b; rows16(v, a, b); v = fmin(a, b); halves32(v, a, b); return fmin(a, b);
 }
 __device__ inline double wave_max(double v) {
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  return v;
+  v = fmax(v, dpp_mov<0xB1>(v)); v = fmax(v, dpp_mov<0x4E>(v)); v = fmax(v, dpp_mov<0x141>(v)); v = fmax(v, dpp_mov<0x140>(v));
+  double a, b; rows16(v, a, b); v = fmax(a, b); halves32(v, a, b); return fmax(a, b);
 }
-__device__ inline double wave_sum(double v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+__device__ inline double wave_sum(double v) {   // quad, quad pairs, half rows, rows, row pairs, halves
+  v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+  v = sum_xor16(v); return sum_xor32(v);
 }
 
 // alpha*X + beta*Y of car c added to a dense row over the stage vector
@@ -417,7 +444,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   constexpr int RU = NX / 4, GU0 = NX % 4;  // register / first lane group holding the input rows NX..NZ-1  // rows are zero padded to the 16 columns of the MFMA tile
   const Layout& Y = B.Y;
   const int tid = threadIdx.x;
-  const int nbatch = *B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap;   // select may over-count when the batch is full
+  const int nbatch = B.ovf_mode ? *B.ovf_count : (*B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap);   // select may over-count when the batch is full
   const int N = Y.N, NSLOT = Y.NSLOT;
   extern __shared__ double lds[];
   double* Z = lds;                       // [N][NZ]
@@ -444,8 +471,8 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   __syncthreads();
   if (tid == 0) sh_node = atomicAdd(B.work_counter, 1);
   __syncthreads();
-  const int node = sh_node;
-  if (node >= nbatch) break;
+  if (sh_node >= nbatch) break;
+  const int node = B.ovf_mode ? B.ovf_list[sh_node] : sh_node;
   const int inst = B.batch_inst[node];
   const double* D = B.inst_d + (size_t)inst * Y.dstride;
   const int* T = B.inst_i + (size_t)inst * Y.istride;
@@ -1027,6 +1054,10 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   }
   }  // node loop
 }
+
+}  // namespace miqp
+#include "ipm_onchip.hip"
+namespace miqp {
 
 // ------------------------------------------------------------------------------------------------
 //  eval kernel helpers: violation of alternatives evaluated directly from the stage state

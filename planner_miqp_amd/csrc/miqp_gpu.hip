@@ -227,6 +227,7 @@ struct DevCtx {
   bool ready = false; int device = -1;
   hipStream_t stream = nullptr;
   Layout Y{}; int n_inst = 0, open_cap = 0, batch_cap = 0, pool_cap = 0, npr = 0, ipm_grid_max = 1024;
+  int oc_grid = 0;   // resident wavefronts of the on-chip interior point kernel (0: the shape does not qualify)
   DevBuf B{};
   std::vector<void*> allocs;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -276,7 +277,16 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr) 
   if (!X.ev0) { HIP_OK(hipEventCreate(&X.ev0)); HIP_OK(hipEventCreate(&X.ev1)); }
   X.Y = Y; X.n_inst = n_inst; X.open_cap = open_cap; X.npr = npr; X.batch_cap = batch_cap;
   { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); int cus = 256; if (hipGetDeviceProperties(&pr, dv) == hipSuccess) cus = pr.multiProcessorCount;
-    size_t l = ipm_lds_bytes(Y); int per = (int)std::max<size_t>(1, std::min<size_t>(4 * (Y.C <= 2 ? MIQP_IPM_WPE : 1), (160 * 1024) / std::max<size_t>(l + 8, 1))); X.ipm_grid_max = cus * per; }
+    size_t l = ipm_lds_bytes(Y); int per = (int)std::max<size_t>(1, std::min<size_t>(4 * (Y.C <= 2 ? MIQP_IPM_WPE : 1), (160 * 1024) / std::max<size_t>(l + 8, 1))); X.ipm_grid_max = cus * per;
+    // on-chip kernel: up to two cars, horizon within its register slots; 2 wavefronts per SIMD, as many as its LDS admits
+    X.oc_grid = 0;
+    if (Y.C <= 2 && Y.N <= 2 * OC_NSL && !std::getenv("MIQP_IPM_V1")) {
+      size_t lo = (size_t)oc_lds_layout(Y.N, Y.fixlen).total + 16;
+      int perc = (int)std::min<size_t>(8, (160 * 1024) / lo);
+      if (perc >= 1) X.oc_grid = cus * perc;
+    }
+    if (X.oc_grid > X.ipm_grid_max) X.ipm_grid_max = X.oc_grid;   // the per-block buffers are sized for the larger grid
+  }
   // node pool: live nodes are bounded by the open lists plus one round of children; processed records are recycled
   size_t want = (size_t)n_inst * ((size_t)open_cap + (size_t)npr * 64 + 64);
   size_t free_b = 0, total_b = 0; if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
@@ -326,10 +336,14 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr) 
   if (!X.alloc(&B.batch_comp, (size_t)batch_cap * Y.fixlen)) return false;
   if (!X.alloc(&B.rowstate, (size_t)std::min(batch_cap, X.ipm_grid_max) * NFIELD * Y.ROWCAP)) return false;
   if (!X.alloc(&B.rowcache, (size_t)std::min(batch_cap, X.ipm_grid_max) * NCACHE * Y.ROWCAP)) return false;
-  if (!X.alloc(&B.kgain, (size_t)std::min(batch_cap, X.ipm_grid_max) * Y.N * Y.nu * (Y.nx + 2))) return false;
+  if (!X.alloc(&B.kgain, (size_t)std::min(batch_cap, X.ipm_grid_max) * std::max(Y.N * Y.nu * (Y.nx + 2), oc_gain_doubles(Y.N)))) return false;
   if (!X.alloc(&B.work_counter, 1)) return false;
-  if (!X.alloc(&B.prof, 64)) return false;
-  (void)hipMemset(B.prof, 0, 40 * 8);
+  if (!X.alloc(&B.ovf_count, 1)) return false;
+  if (!X.alloc(&B.ovf_list, batch_cap)) return false;
+  HIP_OK(hipMemset(B.ovf_count, 0, 4));
+  if (std::getenv("MIQP_STATS")) { if (!X.alloc(&B.stats, 32)) return false; HIP_OK(hipMemset(B.stats, 0, 32 * 8)); }
+  if (!X.alloc(&B.prof, 128)) return false;
+  (void)hipMemset(B.prof, 0, 128 * 8);
   if (!X.alloc(&B.active_insts, 1)) return false;
   if (!X.alloc(&B.stat_rowiters, 1)) return false;
 #ifdef MIQP_PROFILE
@@ -352,23 +366,51 @@ size_t eval_lds_bytes(const Layout& Y) {
 }
 
 template <int C> void launch_ipm(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { (void)hipMemsetAsync(B.work_counter, 0, 4, st); hipLaunchKernelGGL((ipm_kernel<C, IPM_NT>), dim3(nblocks), dim3(IPM_NT), lds, st, B); }
+template <int C> void launch_ipm_oc(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) {
+  (void)hipMemsetAsync(B.work_counter, 0, 4, st); (void)hipMemsetAsync(B.ovf_count, 0, 4, st);
+  hipLaunchKernelGGL((ipm_onchip_kernel<C, OC_NSL>), dim3(nblocks), dim3(64), lds, st, B);
+}
 template <int C> void launch_eval(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { hipLaunchKernelGGL(eval_kernel<C>, dim3(nblocks), dim3(64), lds, st, B); }
 
 void launch_ipm_c(int C, const DevBuf& B, int nblocks, size_t lds, hipStream_t st) {
   switch (C) { case 1: launch_ipm<1>(B, nblocks, lds, st); break; case 2: launch_ipm<2>(B, nblocks, lds, st); break;
                case 3: launch_ipm<3>(B, nblocks, lds, st); break; default: launch_ipm<4>(B, nblocks, lds, st); }
 }
+// interior point solves of the first `bc` batch entries: the on-chip kernel where the shape qualifies, followed by the
+// memory-backed kernel on the nodes it handed over (their count stays on the device: no host round trip); else the
+// memory-backed kernel on everything
+void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st) {
+  const Layout& Y = X.Y;
+  const size_t l_ipm = ipm_lds_bytes(Y);
+  if (X.oc_grid > 0) {
+    const size_t l_oc = (size_t)oc_lds_layout(Y.N, Y.fixlen).total;
+    if (Y.C == 1) launch_ipm_oc<1>(B, std::min(bc, X.oc_grid), l_oc, st); else launch_ipm_oc<2>(B, std::min(bc, X.oc_grid), l_oc, st);
+    DevBuf Bo = B; Bo.ovf_mode = 1;
+    launch_ipm_c(Y.C, Bo, std::min(bc, X.ipm_grid_max), l_ipm, st);   // blocks without a node read the count and leave
+  } else {
+    launch_ipm_c(Y.C, B, std::min(bc, X.ipm_grid_max), l_ipm, st);
+  }
+}
+
 void launch_eval_c(int C, const DevBuf& B, int nblocks, size_t lds, hipStream_t st) {
   switch (C) { case 1: launch_eval<1>(B, nblocks, lds, st); break; case 2: launch_eval<2>(B, nblocks, lds, st); break;
                case 3: launch_eval<3>(B, nblocks, lds, st); break; default: launch_eval<4>(B, nblocks, lds, st); }
 }
 
+template <int C> bool set_kernel_lds_oc(size_t lds) {
+  HIP_OK(hipFuncSetAttribute((const void*)ipm_onchip_kernel<C, OC_NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return true;
+}
 template <int C> bool set_kernel_lds_c(size_t ipm_lds, size_t eval_lds) {
   HIP_OK(hipFuncSetAttribute((const void*)ipm_kernel<C, IPM_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipm_lds));
   HIP_OK(hipFuncSetAttribute((const void*)eval_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eval_lds));
   return true;
 }
 bool set_kernel_lds(const Layout& Y, size_t ipm_lds, size_t eval_lds) {
+  if (Y.C <= 2 && Y.N <= 2 * OC_NSL) {
+    const size_t l = (size_t)oc_lds_layout(Y.N, Y.fixlen).total;
+    if (l <= 160 * 1024 && !(Y.C == 1 ? set_kernel_lds_oc<1>(l) : set_kernel_lds_oc<2>(l))) return false;
+  }
   switch (Y.C) { case 1: return set_kernel_lds_c<1>(ipm_lds, eval_lds); case 2: return set_kernel_lds_c<2>(ipm_lds, eval_lds);
                  case 3: return set_kernel_lds_c<3>(ipm_lds, eval_lds); default: return set_kernel_lds_c<4>(ipm_lds, eval_lds); }
 }
@@ -632,7 +674,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     if (wall_s() - t0 > tlim) break;   // time limit: instances with open nodes report TIME_LIM_* below
     if (X.ipm_ev.size() < nev + 2) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); X.ipm_ev.push_back(a); X.ipm_ev.push_back(b); }
     HIP_OK(hipEventRecord(X.ipm_ev[nev], st));
-    { int gsz = std::min(bc, X.ipm_grid_max); launch_ipm_c(Y.C, B, gsz, l_ipm, st); }
+    launch_ipm_batch(X, B, bc, st);
     HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
     nev += 2;
 #ifdef MIQP_ABLATE
@@ -700,7 +742,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     HIP_OK(hipStreamSynchronize(st));
     DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL; Bp.use_cutoff = 0;
     int nb = std::min(n, X.batch_cap);
-    { int gsz = std::min(nb, X.ipm_grid_max); launch_ipm_c(Y.C, Bp, gsz, l_ipm, st); }
+    launch_ipm_batch(X, Bp, nb, st);
     HIP_OK(hipMemcpyAsync(h_pobj.data(), B.batch_obj, nb * 8, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(h_pviol.data(), B.batch_viol, nb * 8, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(h_pok.data(), B.batch_ok, nb * 4, hipMemcpyDeviceToHost, st));
@@ -711,17 +753,20 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   HIP_OK(hipGetLastError());
   float ms_all = 0; HIP_OK(hipEventElapsedTime(&ms_all, X.ev0, X.ev1));
 #ifdef MIQP_PROFILE
-  { unsigned long long pf[64]; HIP_OK(hipMemcpy(pf, B.prof, 64 * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemset(B.prof, 0, 64 * 8));
-    { const char* on[8] = {"region.first", "region.other", "env.first", "env.other", "obs.first", "obs.other", "c2c.inf", "c2c.dev"};
-      std::fprintf(stderr, "[miqp_gpu profile] cut-off nodes %llu: unguarded estimate first above the cutoff at iteration %.2f on average, guarded exit at %.2f\n", pf[38], (double)pf[36] / std::max(1ull, pf[38]), (double)pf[37] / std::max(1ull, pf[38]));
-      std::fprintf(stderr, "[miqp_gpu profile] nodes by origin (all / infeasible / cut off):"); for (int q = 0; q < 8; ++q) std::fprintf(stderr, " %s %llu/%llu/%llu", on[q], pf[40 + q], pf[48 + q], pf[56 + q]); std::fprintf(stderr, "\n"); }
-    std::fprintf(stderr, "[miqp_gpu profile] iteration histogram (bins of 10; all / infeasible):"); for (int q = 0; q < 9; ++q) std::fprintf(stderr, " %llu/%llu", pf[16 + q], pf[25 + q]); std::fprintf(stderr, "\n");
-    const char* nm[9] = {"build", "bw.rows", "bw.mfma", "bw.TS", "bw.cholK", "bw.P", "forward", "step", "update"};
-    double tot = 0; for (int q = 0; q < 9; ++q) tot += (double)pf[q];
-    std::fprintf(stderr, "[miqp_gpu profile] nodes %llu iters %llu rows/node %.0f cycles/node-iter %.0f :", pf[10], pf[9], (double)pf[11] / std::max(1ull, pf[10]), tot / std::max(1ull, pf[9]));
-    for (int q = 0; q < 9; ++q) std::fprintf(stderr, " %s %.1f%%", nm[q], 100.0 * pf[q] / tot);
+  { unsigned long long pf[64]; HIP_OK(hipMemcpy(pf, B.prof + 64, 64 * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemset(B.prof, 0, 128 * 8));
+    const char* nm[10] = {"decode", "rowpass", "bw.phi", "bw.TS+p", "bw.readlane+LDL", "bw.Ksolve", "bw.update", "forward", "step", "update"};
+    double tot = 0; for (int q = 0; q < 10; ++q) tot += (double)pf[q];
+    std::fprintf(stderr, "[miqp_gpu profile] on-chip nodes %llu iters %llu cycles/node-iter %.0f :", pf[11], pf[10], tot / std::max(1ull, pf[10]));
+    for (int q = 0; q < 10; ++q) std::fprintf(stderr, " %s %.1f%% (%.0f)", nm[q], 100.0 * pf[q] / tot, (double)pf[q] / std::max(1ull, pf[10]));
     std::fprintf(stderr, "\n"); }
 #endif
+  if (B.stats) {
+    unsigned long long hs[32]; HIP_OK(hipMemcpy(hs, B.stats, sizeof(hs), hipMemcpyDeviceToHost)); HIP_OK(hipMemset(B.stats, 0, sizeof(hs)));
+    const double nn_ = (double)std::max(1ull, hs[0]);
+    std::fprintf(stderr, "[miqp_gpu stats] on-chip nodes %llu (general rows %.1f, coefficients %.1f, box keys %.1f, iterations %.1f per node), handed over %llu; general rows / 32 histogram:", hs[0], hs[1] / nn_, hs[4] / nn_, hs[2] / nn_, hs[5] / nn_, hs[3]);
+    for (int q = 0; q < 16; ++q) std::fprintf(stderr, " %llu", hs[8 + q]);
+    std::fprintf(stderr, "\n");
+  }
   double ms_ipm = 0;
   for (size_t e = 0; e + 1 < nev; e += 2) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, X.ipm_ev[e], X.ipm_ev[e + 1])); ms_ipm += ms; }
   double t_solve = wall_s() - t0;
@@ -1041,7 +1086,7 @@ int miqp_solver_solve_fixed(miqp_solver_t* s, const miqp_raw_results_c* fixed, m
   (void)hipMemcpyAsync(B.batch_inst, &zero, 4, hipMemcpyHostToDevice, st);
   (void)hipMemsetAsync(B.inst_nodes, 0, 8, st); (void)hipMemsetAsync(B.inst_iters, 0, 8, st); (void)hipMemsetAsync(B.stat_rowiters, 0, 8, st);
   { DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL; Bp.use_cutoff = 0;
-    launch_ipm_c(Y.C, Bp, 1, ipm_lds_bytes(Y), st); }
+    launch_ipm_batch(X, Bp, 1, st); }
   std::vector<double> Z((size_t)Y.N * Y.nz); double obj = 0, viol = 0; int ok = 0, it = 0;
   (void)hipMemcpyAsync(Z.data(), B.batch_Z, Z.size() * 8, hipMemcpyDeviceToHost, st);
   (void)hipMemcpyAsync(&obj, B.batch_obj, 8, hipMemcpyDeviceToHost, st);

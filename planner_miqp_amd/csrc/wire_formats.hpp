@@ -18,14 +18,14 @@ namespace miqp {
 // ---------------------------------------------------------------- OPL .dat
 inline void dat_vec(FILE* f, const char* name, const double* v, int n) {
   std::fprintf(f, "%s=[", name);
-  for (int k = 0; k < n; ++k) std::fprintf(f, "%s%.15g", k ? " " : "", v[k]);
+  for (int k = 0; k < n; ++k) std::fprintf(f, "%s%.17g", k ? " " : "", v[k]);
   std::fprintf(f, "];\n");
 }
 inline void dat_mat(FILE* f, const char* name, const std::vector<double>& v, int rows, int cols) {
   std::fprintf(f, "%s=[", name);
   for (int r = 0; r < rows; ++r) {
     std::fprintf(f, "[");
-    for (int k = 0; k < cols; ++k) std::fprintf(f, "%s%.15g", k ? " " : "", v[(size_t)r * cols + k]);
+    for (int k = 0; k < cols; ++k) std::fprintf(f, "%s%.17g", k ? " " : "", v[(size_t)r * cols + k]);
     std::fprintf(f, "]\n");
   }
   std::fprintf(f, "];\n");
@@ -37,16 +37,16 @@ inline bool write_dat(const HostInst& I, FILE* f) {
   const int N = I.N, C = I.C, R = I.R;
   std::fprintf(f, "/* OPL data written by libmiqp_gpu (same names as cplexmodel/parameters.mod) */\n");
   std::fprintf(f, "NumSteps=%d;\nnr_environments=%d;\nnr_regions=%d;\nnr_obstacles=%d;\nmax_lines_obstacles=%d;\nNumCars=%d;\n", N, I.E, R, I.O, I.L, C);
-  std::fprintf(f, "max_solution_time=%.15g;\nrelative_mip_gap_tolerance=%.15g;\n", I.tilim, I.gap);
+  std::fprintf(f, "max_solution_time=%.17g;\nrelative_mip_gap_tolerance=%.17g;\n", I.tilim, I.gap);
   std::fprintf(f, "mipdisplay=2;\nmipemphasis=0;\nrelobjdif=0;\ncutpass=0;\nprobe=0;\nrepairtries=0;\nrinsheur=0;\nvarsel=0;\nmircuts=0;\nparallelmode=0;\n");
-  std::fprintf(f, "ts=%.15g;\ntotal_min_acc=%.15g;\ntotal_max_acc=%.15g;\ntotal_min_jerk=%.15g;\ntotal_max_jerk=%.15g;\nmin_vel_x_y=%.15g;\nmax_vel_x_y=%.15g;\n",
+  std::fprintf(f, "ts=%.17g;\ntotal_min_acc=%.17g;\ntotal_max_acc=%.17g;\ntotal_min_jerk=%.17g;\ntotal_max_jerk=%.17g;\nmin_vel_x_y=%.17g;\nmax_vel_x_y=%.17g;\n",
                I.ts, I.amin, I.amax, I.jmin, I.jmax, I.vmin, I.vmax);
   dat_vec(f, "agent_safety_distance", I.safety.data(), N);
   dat_vec(f, "agent_safety_distance_slack", I.safety_slack.data(), N);
-  std::fprintf(f, "maximum_slack=%.15g;\n", I.max_slack);
+  std::fprintf(f, "maximum_slack=%.17g;\n", I.max_slack);
   const char* wn[8] = {"WEIGHTS_POS_X", "WEIGHTS_VEL_X", "WEIGHTS_ACC_X", "WEIGHTS_POS_Y", "WEIGHTS_VEL_Y", "WEIGHTS_ACC_Y", "WEIGHTS_JERK_X", "WEIGHTS_JERK_Y"};
   for (int k = 0; k < 8; ++k) { std::vector<double> w(C); for (int c = 0; c < C; ++c) w[c] = I.W[c * 8 + k]; dat_vec(f, wn[k], w.data(), C); }
-  std::fprintf(f, "WEIGHTS_SLACK=%.15g;\nWEIGHTS_SLACK_OBSTACLE=%.15g;\n", I.w_slack, I.w_slack_obs);
+  std::fprintf(f, "WEIGHTS_SLACK=%.17g;\nWEIGHTS_SLACK_OBSTACLE=%.17g;\n", I.w_slack, I.w_slack_obs);
   dat_vec(f, "WheelBase", I.wb.data(), C); dat_vec(f, "CollisionRadius", I.rad.data(), C);
   dat_mat(f, "IntitialState", I.x0, C, 6);
   const char* rn[4] = {"x_ref", "vx_ref", "y_ref", "vy_ref"}; const int ri[4] = {0, 1, 3, 4};
@@ -61,7 +61,7 @@ inline bool write_dat(const HostInst& I, FILE* f) {
     for (int q = 0; q < C * R; ++q) { ta[q] = I.acc_lim[(size_t)q * 4 + k]; tj[q] = I.jerk_lim[(size_t)q * 4 + k]; }
     dat_mat(f, an[k], ta, C, R); dat_mat(f, jn[k], tj, C, R);
   }
-  std::fprintf(f, "minimum_region_change_speed=%.15g;\n", I.vm);
+  std::fprintf(f, "minimum_region_change_speed=%.17g;\n", I.vm);
   { std::vector<double> t(C); for (int c = 0; c < C; ++c) t[c] = I.init_region[c]; dat_vec(f, "initial_region", t.data(), C); }
   { std::vector<double> t((size_t)C * R); for (int q = 0; q < C * R; ++q) t[q] = I.possible[q]; dat_mat(f, "possible_region", t, C, R); }
   dat_mat(f, "fraction_parameters", I.frac, R, 4);
@@ -73,7 +73,7 @@ inline bool write_dat(const HostInst& I, FILE* f) {
     std::fprintf(f, "%s[", o ? "," : "");
     for (int i = 0; i < N; ++i) {
       std::fprintf(f, "%s{", i ? "," : "");
-      for (int k = 0; k < I.L; ++k) { const double* e = &I.obs_edges[((size_t)(o * N + i) * I.L + k) * 4]; std::fprintf(f, "<%d,%.15g,%.15g,%.15g,%.15g>\n", k + 1, e[0], e[1], e[2], e[3]); }
+      for (int k = 0; k < I.L; ++k) { const double* e = &I.obs_edges[((size_t)(o * N + i) * I.L + k) * 4]; std::fprintf(f, "<%d,%.17g,%.17g,%.17g,%.17g>\n", k + 1, e[0], e[1], e[2], e[3]); }
       std::fprintf(f, "}");
     }
     std::fprintf(f, "]");
@@ -83,7 +83,7 @@ inline bool write_dat(const HostInst& I, FILE* f) {
   std::fprintf(f, "MultiEnvironmentConvexPolygon=[");
   for (int e = 0; e < I.E; ++e) {
     std::fprintf(f, "%s{", e ? "," : "");
-    for (int k = I.env_off[e]; k < I.env_off[e + 1]; ++k) { const double* ed = &I.env_edges[(size_t)k * 4]; std::fprintf(f, "<%d,%.15g,%.15g,%.15g,%.15g>\n", k - I.env_off[e] + 1, ed[0], ed[1], ed[2], ed[3]); }
+    for (int k = I.env_off[e]; k < I.env_off[e + 1]; ++k) { const double* ed = &I.env_edges[(size_t)k * 4]; std::fprintf(f, "<%d,%.17g,%.17g,%.17g,%.17g>\n", k - I.env_off[e] + 1, ed[0], ed[1], ed[2], ed[3]); }
     std::fprintf(f, "}");
   }
   std::fprintf(f, "];\n");
@@ -120,7 +120,7 @@ inline size_t field_size(const ResultField& f) { size_t n = 1; for (int s : f.sh
 
 // `name = [[..] [..]];` blocks in the layout of OPL's printSolution (cplexmodel/modelRun.txt)
 inline bool write_solution(const miqp_raw_results_c& r, double objective, FILE* f) {
-  std::fprintf(f, "// solution (optimal) with objective %.15g\n", objective);
+  std::fprintf(f, "// solution (optimal) with objective %.17g\n", objective);
   for (auto& fd : result_fields(r)) {
     const size_t n = field_size(fd);
     std::fprintf(f, "%s = ", fd.name);
@@ -129,7 +129,7 @@ inline bool write_solution(const miqp_raw_results_c& r, double objective, FILE* 
     for (int k = (int)fd.shape.size() - 2; k >= 0; --k) stride[k] = stride[k + 1] * (size_t)fd.shape[k + 1];
     for (size_t q = 0; q < n; ++q) {
       for (size_t k = 0; k < fd.shape.size(); ++k) if (q % (stride[k] * (size_t)fd.shape[k]) == 0) std::fprintf(f, "[");
-      if (fd.is_int) std::fprintf(f, "%d", ((const int*)fd.ptr)[q]); else std::fprintf(f, "%.15g", ((const double*)fd.ptr)[q]);
+      if (fd.is_int) std::fprintf(f, "%d", ((const int*)fd.ptr)[q]); else std::fprintf(f, "%.17g", ((const double*)fd.ptr)[q]);
       bool closed = false;
       for (int k = (int)fd.shape.size() - 1; k >= 0; --k) if ((q + 1) % (stride[k] * (size_t)fd.shape[k]) == 0) { std::fprintf(f, "]"); closed = true; }
       std::fprintf(f, closed ? "\n" : " ");
@@ -150,7 +150,7 @@ inline std::string var_name(const ResultField& fd, size_t q) {
 
 inline bool write_mst(const miqp_raw_results_c& r, double objective, FILE* f) {
   std::fprintf(f, "<?xml version = \"1.0\" encoding=\"UTF-8\" standalone=\"yes\"?>\n<CPLEXSolutions version=\"1.2\">\n <CPLEXSolution version=\"1.2\">\n");
-  std::fprintf(f, "  <header\n    problemName=\"planner-miqp\"\n    solutionName=\"m1\"\n    solutionIndex=\"0\"\n    objectiveValue=\"%.15g\"\n    MIPStartEffortLevel=\"4\"\n    writeLevel=\"2\"/>\n  <variables>\n", objective);
+  std::fprintf(f, "  <header\n    problemName=\"planner-miqp\"\n    solutionName=\"m1\"\n    solutionIndex=\"0\"\n    objectiveValue=\"%.17g\"\n    MIPStartEffortLevel=\"4\"\n    writeLevel=\"2\"/>\n  <variables>\n", objective);
   long index = 0;
   for (auto& fd : result_fields(r)) {
     const size_t n = field_size(fd);

@@ -208,3 +208,17 @@ def test_all_baseline_configs_generate_and_size(oracle):
         assert s["cont"] == Cn * N * (12 + 5 * O) + K * K * N * 4, cfg
         assert int(np.asarray(p.possible_region).sum(1).max()) <= 15 and np.all(np.asarray(p.initial_region) >= 1)
         oracle.free(h)
+
+
+def test_written_dat_reproduces_the_rounded_inputs_exactly(lib, tmp_path):
+    """test_hardcoded_data_versus_datfile (test/cplex_wrapper_test.cc:474-505) compares CPPINPUTS and DATFILE runs with
+    EXPECT_DOUBLE_EQ: the external-data file written from the (rounded) C++ inputs must read back to the identical
+    instance - compared through the LP dump, which prints every coefficient with 17 digits"""
+    w = P.CplexWrapper(); w.resetParameters(load_params("cplexmodel_testcase.dat"))
+    out = str(tmp_path / "rt.dat")
+    assert w.writeDat(out) == 0
+    a, b = str(tmp_path / "a.lp"), str(tmp_path / "b.lp")
+    assert lib.miqp_solver_export_lp(w._h, a.encode()) == 0
+    w2 = P.CplexWrapper(parameterSource=P.ParameterSource.DATFILE); w2.setParameterDatFileAbsolute(out)
+    assert w2._push_inputs() == 0 and lib.miqp_solver_export_lp(w2._h, b.encode()) == 0
+    assert open(a).read() == open(b).read()
