@@ -86,12 +86,29 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU) BEFORE anything
+        # touches the GPU, relay rank 0's JSON line and exit with the launcher's code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        # RCCL needs one device per rank; with fewer devices than ranks (a smoke run of the N > 1 path on a small box) the
+        # result counters travel over gloo - the solves themselves never use a collective
+        dist.init_process_group("nccl" if torch.cuda.is_available() and torch.cuda.device_count() >= world else "gloo")
     if torch.cuda.is_available():
+        ndev = torch.cuda.device_count()
+        if world > ndev and rank == 0:
+            print("[bench] %d ranks on %d visible devices: ranks share devices" % (world, ndev), file=sys.stderr)
+        local = local % max(1, ndev)
         torch.cuda.set_device(local)
     import planner_miqp_amd as P
     from planner_miqp_amd import synthetic
@@ -134,7 +151,7 @@ def main():
     sync()
     dt = time.time() - t0
     from planner_miqp_amd.sharding import gather_counts
-    dev = torch.device("cuda", local) if (world > 1 and torch.cuda.is_available()) else None
+    dev = torch.device("cuda", local) if (world > 1 and torch.cuda.is_available() and torch.cuda.device_count() >= world) else None
     g = gather_counts([dt, solved, attempted, ipm_s, launches, iters, rowit, nodes], dev)
     if rank == 0:
         T = max(x[0] for x in g)
@@ -153,6 +170,7 @@ def main():
                    config=dict(workload="%s: %d cars x %d steps x %d regions, %d env pieces, %d obstacles; %d instances per GPU and step, gap %g, time limit %g s"
                                % ((a.config,) + synthetic.CONFIGS[a.config] + (B, a.gap, a.time_limit)),
                                instances_attempted=int(tot_att), instances_solved_to_gap=int(tot_solved),
+                               per_rank=[dict(rank=k, seconds=round(x[0], 3), solved=int(x[1]), attempted=int(x[2]), bnb_nodes=int(x[7])) for k, x in enumerate(g)],
                                bnb_nodes=int(sum(x[7] for x in g)), ipm_iterations=int(sum(x[5] for x in g)),
                                solve_latency_s_rank0=dict(p50=float(np.percentile(lat, 50)), p95=float(np.percentile(lat, 95)), max=float(max(lat))) if lat else None),
                    roofline=dict(bound="mfma", achieved=ach / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s", frac=ach / FP64_PEAK, traffic=traffic,

@@ -76,6 +76,34 @@ int miqp_solver_solve_batch(miqp_solver_t* const* solvers, int n, int* statuses)
  * opts.device of every handle is set to the device it ran on. */
 int miqp_solver_solve_batch_multi(miqp_solver_t* const* solvers, int n, int gpus, int* statuses);
 
+/* ---- one hard instance split over the ranks of a job (the reference walks its alternative
+ * start configurations one after the other on one CPU, src/miqp_planner.cpp:694-749) ----
+ * Every rank loads the SAME instance into its own handle and calls miqp_solver_solve_split with its rank.  The alternatives
+ * of one or two car/car disjunctions partition the branch-and-bound tree over the ranks; once per round the ranks run
+ * `exchange(user, 0, words, 4, 0)` = in-place all-reduce(min) over `count` unsigned 64-bit words (incumbent | owner rank,
+ * lower bound, done, time-up: the best incumbent prunes everywhere, every rank takes the same stop decision), and at the
+ * end `exchange(user, 1, buf, nbytes, root)` = broadcast of the owner's solution.  The callback returns 0 on success.
+ * Returns the OptimizationStatus, identical on every rank, and every rank holds the full result. */
+typedef int (*miqp_exchange_fn)(void* user, int op, void* buf, int count, int root);
+int miqp_solver_solve_split(miqp_solver_t* s, double timestamp, int world, int rank, miqp_exchange_fn exchange, void* user);
+
+/* Built-in transport of that exchange: RCCL (librccl is loaded at run time) over xGMI, one communicator per process.
+ * Rank 0 creates the 128-byte id (miqp_comm_unique_id) and hands it to the others by any means (e.g. the launcher's
+ * store); every rank then calls miqp_comm_init with the device it solves on.  miqp_solver_solve_split_rccl = solve_split
+ * with ncclAllReduce(ncclUint64, ncclMin) / ncclBroadcast on the solver's stream. */
+int miqp_comm_unique_id(char* out128);
+int miqp_comm_init(int world, int rank, const char* id128, int device);
+int miqp_comm_finalize(void);
+int miqp_solver_solve_split_rccl(miqp_solver_t* s, double timestamp);
+/* checks a transport against the contract above (min over unsigned words incl. values with the top bit set, broadcast from
+ * every root); exchange == NULL: the RCCL communicator of miqp_comm_init.  0 when it conforms. */
+int miqp_comm_selftest(miqp_exchange_fn exchange, void* user, int world, int rank);
+
+/* the roots rank `rank` of `world` starts from in a tree split of the loaded instance (no device needed): writes up to `cap`
+ * entries of (record index, alternative) pairs flattened as root_of_pair[k], index[k], value[k]; returns the number of pairs,
+ * *nroots_out = the number of roots of this rank, *ncombos_out = the size of the partition */
+int miqp_solver_split_roots(const miqp_solver_t* s, int world, int rank, int* root_of_pair, int* index, int* value, int cap, int* nroots_out, int* ncombos_out);
+
 /* cplex.getNrows / getNbinVars / getNcols - getNbinVars / getNNZs of the model OPL would generate for the loaded
  * instance (collectCplexStatistics, src/cplex_wrapper.cpp:679-690): out[0..3] = rows, binary columns, continuous
  * columns, non-zeros.  Needs no device. */

@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
     const double* Rf = D + Y.d_ref;
     double cutoff = 1e300;
     {
-      const double inc0 = inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]);
+      const double inc0 = fmin(inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]), B.inc_ext[inst]);
       if (B.use_cutoff && inc0 < 1e300) cutoff = inc0 - B.inst_gap[inst] * (1e-10 + fabs(inc0)) - B.inst_const[inst];
     }
 #ifdef MIQP_PROFILE

@@ -98,6 +98,7 @@ struct DevBuf {
   unsigned long long* inc_key;   // orderable(objective) with the batch slot in the low 20 bits
   unsigned long long* inc_seen;  // key whose solution has been copied to inc_fix / inc_Z
   double* inc_obj;               // objective of the stored incumbent
+  double* inc_ext;               // upper bound from outside (tree split over ranks: the best incumbent of the other ranks), 1e300 otherwise
   signed char* inc_fix; double* inc_Z;
   double* lower_bound; int* inst_done; int* inst_flags; double* inst_gap; double* inst_const;
   long long* inst_nodes; long long* inst_iters; int* inst_ninc;
@@ -499,7 +500,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   // abandoned (weak duality on the penalised QP; also catches infeasible nodes, whose penalty term is huge)
   double cutoff = 1e300;
   {
-    const double inc0 = inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]);
+    const double inc0 = fmin(inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]), B.inc_ext[inst]);
     if (B.use_cutoff && inc0 < 1e300) cutoff = inc0 - B.inst_gap[inst] * (1e-10 + fabs(inc0)) - B.inst_const[inst];
   }
   double tsum = 0.0;   // sum of the elastic slacks of the current iterate
@@ -1158,7 +1159,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   // what the node proves: the dual value of its relaxation (the primal value of an interior point iterate lies above the
   // optimum of the relaxation by the remaining complementarity)
   const double objlb = obj - fmax(0.0, B.batch_bound[node]);
-  const double inc_now = inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]);
+  const double inc_now = fmin(inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]), B.inc_ext[inst]);   // own incumbent or the one another rank of a tree split found
   if (inc_now < 1e300 && !(objlb < inc_now - 1e-12 * fabs(inc_now))) { FREE_NODE(); return; }  // bound not better than the incumbent
   const double tol = FEAS_TOL;
   const int NCI = C * (N - 1);
@@ -1497,7 +1498,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     if (tid == 0) B.inc_obj[inst] = B.batch_obj[slot];
   }
   __syncthreads();
-  const double inc = sh_inc < 1e300 ? B.inc_obj[inst] : 1e300;
+  const double inc = fmin(sh_inc < 1e300 ? B.inc_obj[inst] : 1e300, B.inc_ext[inst]);   // what prunes: the best incumbent known (own or, in a tree split, another rank's)
   const double cst = B.inst_const[inst];
   const double gap = B.inst_gap[inst];
   int n = B.open_count[inst]; if (n > cap) n = cap;

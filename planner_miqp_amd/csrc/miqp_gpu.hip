@@ -4,6 +4,7 @@
 // There is no CPU solve path in this library: without a HIP device the solve entry points return
 // MIQP_STATUS_FAILED_SEG_FAULT (the reference's code for "the solver could not run", cplex_wrapper.cpp:97-109).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -313,6 +314,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr) 
   if (!X.alloc(&B.inc_key, n_inst)) return false;
   if (!X.alloc(&B.inc_seen, n_inst)) return false;
   if (!X.alloc(&B.inc_obj, n_inst)) return false;
+  if (!X.alloc(&B.inc_ext, n_inst)) return false;
   if (!X.alloc(&B.inc_fix, (size_t)n_inst * Y.fixlen)) return false;
   if (!X.alloc(&B.inc_Z, (size_t)n_inst * Y.N * Y.nz)) return false;
   if (!X.alloc(&B.lower_bound, n_inst)) return false;
@@ -567,10 +569,42 @@ BatchShape batch_layout(miqp_solver_t* const* S, int n) {
   return bs;
 }
 
+unsigned long long host_d2key(double v) { unsigned long long u; std::memcpy(&u, &v, 8); return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull); }
+double host_key2d(unsigned long long k) { unsigned long long u = (k & 0x8000000000000000ull) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k; double v; std::memcpy(&v, &u, 8); return v; }
+
 double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // ---------------------------------------------------------------- the batch solve
-bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
+// Tree split of ONE instance over the ranks of a job.  The alternatives of one or two car/car
+// disjunctions partition the tree (every rank starts from the roots it owns); once per round the ranks exchange
+// {incumbent | owner rank, lower bound, done, time-up} by an all-reduce(min) of four 64-bit words - the best incumbent prunes
+// on every rank - and at the end the owner broadcasts the solution.
+struct SplitCtx { int world, rank; miqp_exchange_fn fn; void* user; };
+constexpr int SPLIT_MAXROOTS = 64;
+
+// root records of the split: the cartesian product of the allowed alternatives of the rear/rear group of every car pair at
+// the last step, then at the middle step, until there are at least 4 combinations per rank (at most SPLIT_MAXROOTS)
+void split_roots(const Layout& Y, const int* T, std::vector<std::vector<std::pair<int, int>>>& combos, int world) {
+  combos.assign(1, {});
+  if (Y.C < 2) return;   // a single car has no car/car disjunction: rank 0 keeps the whole tree
+  const int steps[2] = {Y.N - 1, (Y.N - 1) / 2};
+  for (int si = 0; si < 2; ++si) {
+    const int i = steps[si];
+    if (i < 1 || (si == 1 && i == steps[0])) continue;
+    for (int p = 0; p < Y.NP; ++p) {
+      if ((int)combos.size() >= 4 * world) return;
+      const int am0 = T[Y.i_c2callow + p * Y.N + i] & 15, am = am0 ? am0 : 15;
+      int na = 0; for (int a = 0; a < 4; ++a) na += (am >> a) & 1;
+      if (na < 2 || (int)combos.size() * na > SPLIT_MAXROOTS) continue;
+      std::vector<std::vector<std::pair<int, int>>> next;
+      for (auto& c : combos) for (int a = 0; a < 4; ++a) if ((am >> a) & 1) { auto d = c; d.emplace_back(Y.f_c2c + (p * Y.N + i) * 4 + 0, a); next.push_back(std::move(d)); }
+      combos.swap(next);
+    }
+  }
+}
+
+bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const SplitCtx* split = nullptr) {
+  if (split && n != 1) { for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
   BatchShape bs = batch_layout(S, n);
   if (!bs.ok) { for (int k = 0; k < n; ++k) { if (S[k]) S[k]->err = bs.err; statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; } std::fprintf(stderr, "[miqp_gpu] %s\n", bs.err.c_str()); return false; }
   const Layout& Y = bs.Y;
@@ -598,8 +632,11 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   std::vector<double> hD((size_t)n * Y.dstride); std::vector<int> hT((size_t)n * Y.istride);
   std::vector<double> h_const(n, 0.0), h_gap(n), h_tlim(n);
   std::vector<int> h_done(n, 0);
-  std::vector<signed char> roots((size_t)3 * n * Y.fixlen, (signed char)-1);   // records k: root, n + k / 2n + k: MIP starts of instance k
-  std::vector<double> ob((size_t)n * 3, -1e300); std::vector<int> on((size_t)n * 3, 0), oc(n, 1);   // the first three open entries of every instance
+  const int MAXR = split ? SPLIT_MAXROOTS + 2 : 3;   // root records per instance: the root (or this rank's roots of a tree split) and the MIP starts
+  std::vector<signed char> roots; roots.reserve((size_t)MAXR * n * Y.fixlen);
+  std::vector<double> ob((size_t)n * MAXR, -1e300); std::vector<int> on((size_t)n * MAXR, 0), oc(n, 0);   // the first open entries of every instance
+  int nrec = 0;
+  auto add_root = [&](int k, const std::vector<signed char>& fx) { roots.insert(roots.end(), fx.begin(), fx.end()); on[(size_t)k * MAXR + oc[k]] = nrec++; oc[k]++; };
   int active = 0;
   for (int k = 0; k < n; ++k) {
     miqp_solver* s = S[k]; s->lay = Y; s->has_sol = false;
@@ -607,18 +644,26 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     HostGeo G{s->inst, Y, &hD[(size_t)k * Y.dstride], &hT[(size_t)k * Y.istride]};
     double cobj = 0; bool feas0 = step0_check(G, cobj);
     h_const[k] = cobj; h_gap[k] = s->opts.gap_override >= 0 ? s->opts.gap_override : s->inst.gap; h_tlim[k] = s->inst.tilim;
-    if (!feas0) { h_done[k] = 1; oc[k] = 0; } else active++;
-    on[(size_t)k * 3] = k;
+    if (!feas0) h_done[k] = 1;
+    else if (!split) add_root(k, std::vector<signed char>(Y.fixlen, (signed char)-1));
+    else {
+      std::vector<std::vector<std::pair<int, int>>> combos; split_roots(Y, &hT[(size_t)k * Y.istride], combos, split->world);
+      for (size_t q = 0; q < combos.size(); ++q) {
+        if ((int)(q % (size_t)split->world) != split->rank) continue;
+        std::vector<signed char> fx(Y.fixlen, (signed char)-1);
+        for (auto& d : combos[q]) fx[d.first] = (signed char)d.second;
+        add_root(k, fx);
+      }
+    }
     // MIP starts (initializeWarmstart + addMIPStart / readMIPStarts, src/cplex_wrapper.cpp:124-138, 494-639): the binaries
     // of each start become an additional root whose QP the first round solves; a feasible one is the first incumbent
     for (int w = 0; w < 2 && feas0; ++w) {
       if (!s->ws[w] || !dims_match(s->ws[w]->r, s->inst)) continue;
       std::vector<signed char> fx;
       if (!fix_from_results(s->inst, Y, &hT[(size_t)k * Y.istride], &s->ws[w]->r, fx)) continue;
-      const int rec = (1 + w) * n + k;
-      std::copy(fx.begin(), fx.end(), roots.begin() + (size_t)rec * Y.fixlen);
-      on[(size_t)k * 3 + oc[k]] = rec; oc[k]++;
+      if (oc[k] < MAXR) add_root(k, fx);
     }
+    if (oc[k] > 0) active++; else h_done[k] = 1;   // (a rank of a tree split may own no root)
     int rows, bin, cont, nnz; raw_sizes(s->inst, rows, bin, cont, nnz);
     s->props = miqp_solution_properties_c{}; s->props.NrConstraints = rows; s->props.NrBinaryVariables = bin; s->props.NrFloatVariables = cont;
     s->props.NonZeroCoefficients = nnz;
@@ -629,17 +674,18 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   HIP_OK(hipMemcpyAsync((void*)B.inst_d, hD.data(), hD.size() * 8, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync((void*)B.inst_i, hT.data(), hT.size() * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(B.pool_fix, roots.data(), roots.size(), hipMemcpyHostToDevice, st));
-  int pool0 = 3 * n;
+  int pool0 = nrec;
   HIP_OK(hipMemcpyAsync(B.pool_count, &pool0, 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemsetAsync(B.free_head, 0, 4, st)); HIP_OK(hipMemsetAsync(B.free_tail, 0, 4, st)); HIP_OK(hipMemsetAsync(B.free_limit, 0, 4, st));
-  HIP_OK(hipMemcpy2DAsync(B.open_bound, (size_t)open_cap * 8, ob.data(), 24, 24, n, hipMemcpyHostToDevice, st));
-  HIP_OK(hipMemcpy2DAsync(B.open_node, (size_t)open_cap * 4, on.data(), 12, 12, n, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpy2DAsync(B.open_bound, (size_t)open_cap * 8, ob.data(), (size_t)MAXR * 8, (size_t)MAXR * 8, n, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpy2DAsync(B.open_node, (size_t)open_cap * 4, on.data(), (size_t)MAXR * 4, (size_t)MAXR * 4, n, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(B.open_count, oc.data(), n * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemsetAsync(B.open_depth, 0, (size_t)2 * n * open_cap * 4, st));
   HIP_OK(hipMemsetAsync(B.inc_key, 0xFF, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inc_seen, 0xFF, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inc_fix, 0xFF, (size_t)n * Y.fixlen, st));   // no incumbent yet: every disjunction undecided
   { std::vector<double> big(n, 1e300); HIP_OK(hipMemcpyAsync(B.inc_obj, big.data(), n * 8, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(B.inc_ext, big.data(), n * 8, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(B.lower_bound, big.data(), n * 8, hipMemcpyHostToDevice, st)); HIP_OK(hipStreamSynchronize(st)); }
   HIP_OK(hipMemcpyAsync(B.inst_done, h_done.data(), n * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemsetAsync(B.inst_flags, 0, (size_t)n * 4, st));
@@ -658,6 +704,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
   HIP_OK(hipEventRecord(X.ev0, st));
   std::vector<int> h_done_now(n, 0); std::vector<double> h_tdone(n, -1.0);
   size_t nev = 0; int rounds = 0; long long launched_nodes = 0;
+  double sp_inc = 1e300, sp_lb = -1e300; int sp_owner = 0; bool sp_timeup = false, sp_finished = false;   // state of a tree split
   for (;;) {
     HIP_OK(hipMemsetAsync(B.batch_count, 0, 4, st));
     B.open_sel = rounds & 1;
@@ -669,9 +716,28 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
     HIP_OK(hipMemcpyAsync(h_done_now.data(), B.inst_done, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     { const double tn = wall_s() - t0; for (int k = 0; k < n; ++k) if (h_done_now[k] && h_tdone[k] < 0) h_tdone[k] = tn; }   // completion time of every instance
-    if (bc <= 0) break;
+    if (split) {   // once per round: the ranks agree on incumbent, bound and whether to go on (identical decisions everywhere)
+      unsigned long long kinc = ~0ull; double lbl = 1e300;
+      HIP_OK(hipMemcpy(&kinc, B.inc_key, 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(&lbl, B.lower_bound, 8, hipMemcpyDeviceToHost));
+      const bool local_done = bc <= 0;
+      unsigned long long w[4];
+      w[0] = kinc >= 0xFFF0000000000000ull ? ~0ull : ((kinc & ~0xFFFFFull) | (unsigned long long)split->rank);
+      w[1] = host_d2key(local_done && kinc >= 0xFFF0000000000000ull ? 1e300 : (local_done ? std::min(lbl, 1e300) : lbl));
+      w[2] = local_done ? ~0ull : 0ull;
+      w[3] = (wall_s() - t0 > tlim) ? 0ull : ~0ull;
+      if (split->fn(split->user, 0, w, 4, 0) != 0) return fail_all("incumbent exchange failed");
+      sp_inc = w[0] >= 0xFFF0000000000000ull ? 1e300 : host_key2d(w[0] & ~0xFFFFFull); sp_owner = (int)(w[0] & 0xFFFFFull);
+      sp_lb = host_key2d(w[1]); sp_timeup = w[3] == 0ull;
+      HIP_OK(hipMemcpyAsync(B.inc_ext, &sp_inc, 8, hipMemcpyHostToDevice, st));
+      const bool all_done = w[2] == ~0ull;
+      const bool gap_ok = sp_inc < 1e299 && (sp_inc - sp_lb) <= h_gap[0] * (1e-10 + std::fabs(sp_inc));
+      if (all_done || sp_timeup || gap_ok) { sp_finished = all_done || gap_ok; break; }
+      if (local_done) { rounds++; continue; }   // nothing left here: keep taking part in the exchange
+    } else {
+      if (bc <= 0) break;
+      if (wall_s() - t0 > tlim) break;   // time limit: instances with open nodes report TIME_LIM_* below
+    }
     if (bc > X.batch_cap) bc = X.batch_cap;
-    if (wall_s() - t0 > tlim) break;   // time limit: instances with open nodes report TIME_LIM_* below
     if (X.ipm_ev.size() < nev + 2) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); X.ipm_ev.push_back(a); X.ipm_ev.push_back(b); }
     HIP_OK(hipEventRecord(X.ipm_ev[nev], st));
     launch_ipm_batch(X, B, bc, st);
@@ -798,6 +864,20 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses) {
       std::copy(h_pZ.begin() + (size_t)k * Y.N * Y.nz, h_pZ.begin() + (size_t)(k + 1) * Y.N * Y.nz, h_Z.begin() + (size_t)k * Y.N * Y.nz);
     }
   }
+  if (split) {
+    // the owner of the best incumbent hands its polished solution to every rank: {objective, states, completed record}
+    std::vector<unsigned char> buf(8 + h_Z.size() * 8 + h_fix.size());
+    unsigned long long w[2] = {h_inc[0] < 1e299 ? ((host_d2key(h_inc[0]) & ~0xFFFFFull) | (unsigned long long)split->rank) : ~0ull, ~0ull};
+    if (split->fn(split->user, 0, w, 2, 0) != 0) return fail_all("incumbent exchange failed");
+    if (w[0] < 0xFFF0000000000000ull) {
+      const int owner = (int)(w[0] & 0xFFFFFull);
+      if (owner == split->rank) { std::memcpy(buf.data(), &h_inc[0], 8); std::memcpy(buf.data() + 8, h_Z.data(), h_Z.size() * 8); std::memcpy(buf.data() + 8 + h_Z.size() * 8, h_fix.data(), h_fix.size()); }
+      if (split->fn(split->user, 1, buf.data(), (int)buf.size(), owner) != 0) return fail_all("solution broadcast failed");
+      std::memcpy(&h_inc[0], buf.data(), 8); std::memcpy(h_Z.data(), buf.data() + 8, h_Z.size() * 8); std::memcpy(h_fix.data(), buf.data() + 8 + h_Z.size() * 8, h_fix.size());
+      h_lb[0] = std::min(sp_lb, h_inc[0]);
+    }
+    h_flags[0] = sp_finished ? 0 : 1; h_oc[0] = 0; h_dn[0] = 1;   // the verdict of the whole job, the same on every rank
+  }
   long long tot_iters = 0; for (int k = 0; k < n; ++k) tot_iters += h_iters[k];
   for (int k = 0; k < n; ++k) {
     miqp_solver* s = S[k];
@@ -914,6 +994,117 @@ int miqp_solver_solve_batch_multi(miqp_solver_t* const* solvers, int n, int gpus
   for (int b = 0; b < n; ++b) statuses[b] = st[b % gpus][b / gpus];
   for (int g = 0; g < gpus; ++g) if (!ok[g]) rc = -2;
   return rc;
+}
+
+int miqp_solver_solve_split(miqp_solver_t* s, double timestamp, int world, int rank, miqp_exchange_fn exchange, void* user) {
+  (void)timestamp;
+  if (!s || !s->has_inst || world < 1 || rank < 0 || rank >= world || !exchange) return MIQP_STATUS_FAILED_SEG_FAULT;
+  SplitCtx sc{world, rank, exchange, user};
+  miqp_solver_t* one[1] = {s}; int st = MIQP_STATUS_FAILED_SEG_FAULT;
+  if (!solve_batch_impl(one, 1, &st, &sc)) return MIQP_STATUS_FAILED_SEG_FAULT;
+  return st;
+}
+
+int miqp_solver_split_roots(const miqp_solver_t* s, int world, int rank, int* root_of_pair, int* index, int* value, int cap, int* nroots_out, int* ncombos_out) {
+  if (!s || !s->has_inst || world < 1 || rank < 0 || rank >= world) return -1;
+  miqp_solver_t* one[1] = {const_cast<miqp_solver_t*>(s)};
+  BatchShape bs = batch_layout(one, 1);
+  if (!bs.ok) return -2;
+  std::vector<double> D(bs.Y.dstride); std::vector<int> T(bs.Y.istride);
+  compile_instance(s->inst, bs.Y, D.data(), T.data());
+  std::vector<std::vector<std::pair<int, int>>> combos; split_roots(bs.Y, T.data(), combos, world);
+  int np = 0, nr = 0;
+  for (size_t q = 0; q < combos.size(); ++q) {
+    if ((int)(q % (size_t)world) != rank) continue;
+    for (auto& d : combos[q]) { if (np < cap) { if (root_of_pair) root_of_pair[np] = nr; if (index) index[np] = d.first; if (value) value[np] = d.second; } np++; }
+    nr++;
+  }
+  if (nroots_out) *nroots_out = nr;
+  if (ncombos_out) *ncombos_out = (int)combos.size();
+  return np;
+}
+
+// ---------------------------------------------------------------- RCCL transport of the exchange (librccl loaded at run time)
+struct Id128 { char b[128]; };   // ncclUniqueId is passed by value
+namespace {
+struct Rccl {
+  void* lib = nullptr; void* comm = nullptr; int world = 0, rank = 0, device = -1; void* dbuf = nullptr; size_t dcap = 0; hipStream_t stream = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+};
+Rccl g_rccl; std::mutex g_rccl_mu;
+bool rccl_load() {
+  if (g_rccl.lib) return true;
+  for (const char* nm : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (g_rccl.lib) break; }
+  if (!g_rccl.lib) { std::fprintf(stderr, "[miqp_gpu] librccl not found: %s\n", dlerror()); return false; }
+  g_rccl.GetUniqueId = (int (*)(void*))dlsym(g_rccl.lib, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(void**, int, Id128, int))dlsym(g_rccl.lib, "ncclCommInitRank");
+  g_rccl.CommDestroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
+  g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
+  g_rccl.Broadcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(g_rccl.lib, "ncclBroadcast");
+  return g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllReduce && g_rccl.Broadcast;
+}
+// miqp_exchange_fn over the communicator: tiny host buffers staged through one device buffer
+int rccl_exchange(void*, int op, void* buf, int count, int root) {
+  Rccl& R = g_rccl;
+  if (!R.comm) return -1;
+  const size_t bytes = op == 0 ? (size_t)count * 8 : (size_t)count;
+  if (hipSetDevice(R.device) != hipSuccess) return -2;
+  if (bytes > R.dcap) { if (R.dbuf) (void)hipFree(R.dbuf); R.dcap = std::max<size_t>(bytes, 1 << 16); if (hipMalloc(&R.dbuf, R.dcap) != hipSuccess) { R.dbuf = nullptr; R.dcap = 0; return -2; } }
+  if (hipMemcpyAsync(R.dbuf, buf, bytes, hipMemcpyHostToDevice, R.stream) != hipSuccess) return -2;
+  const int rc = op == 0 ? R.AllReduce(R.dbuf, R.dbuf, (size_t)count, /*ncclUint64*/ 5, /*ncclMin*/ 3, R.comm, R.stream)
+                         : R.Broadcast(R.dbuf, R.dbuf, bytes, /*ncclUint8*/ 1, root, R.comm, R.stream);
+  if (rc != 0) return -3;
+  if (hipMemcpyAsync(buf, R.dbuf, bytes, hipMemcpyDeviceToHost, R.stream) != hipSuccess) return -2;
+  return hipStreamSynchronize(R.stream) == hipSuccess ? 0 : -2;
+}
+}  // namespace
+
+int miqp_comm_unique_id(char* out128) {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (!out128 || !rccl_load()) return -1;
+  return g_rccl.GetUniqueId(out128) == 0 ? 0 : -2;
+}
+int miqp_comm_init(int world, int rank, const char* id128, int device) {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (!id128 || world < 1 || rank < 0 || rank >= world || !rccl_load()) return -1;
+  if (g_rccl.comm) return -4;   // one communicator per process
+  int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { std::fprintf(stderr, "[miqp_gpu] no HIP device\n"); return -2; }
+  if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+  if (hipSetDevice(device) != hipSuccess) return -2;
+  Id128 id; std::memcpy(id.b, id128, 128);
+  if (g_rccl.CommInitRank(&g_rccl.comm, world, id, rank) != 0) { g_rccl.comm = nullptr; return -3; }
+  if (hipStreamCreate(&g_rccl.stream) != hipSuccess) return -2;
+  g_rccl.world = world; g_rccl.rank = rank; g_rccl.device = device;
+  return 0;
+}
+int miqp_comm_finalize(void) {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (g_rccl.comm) { g_rccl.CommDestroy(g_rccl.comm); g_rccl.comm = nullptr; }
+  if (g_rccl.dbuf) { (void)hipFree(g_rccl.dbuf); g_rccl.dbuf = nullptr; g_rccl.dcap = 0; }
+  if (g_rccl.stream) { (void)hipStreamDestroy(g_rccl.stream); g_rccl.stream = nullptr; }
+  return 0;
+}
+int miqp_comm_selftest(miqp_exchange_fn exchange, void* user, int world, int rank) {
+  if (!exchange) { if (!g_rccl.comm) return -1; exchange = rccl_exchange; world = g_rccl.world; rank = g_rccl.rank; }
+  // all-reduce(min) of unsigned words: one word that is smallest on the last rank, one on rank 0, one with the top bit set
+  unsigned long long w[3] = {1000ull - (unsigned long long)rank, 5ull + (unsigned long long)rank, 0x8000000000000000ull + (unsigned long long)(world - rank)};
+  if (exchange(user, 0, w, 3, 0) != 0) return -2;
+  if (w[0] != 1000ull - (unsigned long long)(world - 1) || w[1] != 5ull || w[2] != 0x8000000000000001ull) return -3;
+  for (int root = 0; root < world; ++root) {
+    unsigned char b[37]; for (int k = 0; k < 37; ++k) b[k] = (unsigned char)(rank == root ? (7 * k + root) & 255 : 0xEE);
+    if (exchange(user, 1, b, 37, root) != 0) return -4;
+    for (int k = 0; k < 37; ++k) if (b[k] != (unsigned char)((7 * k + root) & 255)) return -5;
+  }
+  return 0;
+}
+int miqp_solver_solve_split_rccl(miqp_solver_t* s, double timestamp) {
+  if (!g_rccl.comm || !s) return MIQP_STATUS_FAILED_SEG_FAULT;
+  s->opts.device = g_rccl.device;
+  return miqp_solver_solve_split(s, timestamp, g_rccl.world, g_rccl.rank, rccl_exchange, nullptr);
 }
 
 int miqp_solver_raw_sizes(const miqp_solver_t* s, int* out4) {

@@ -11,6 +11,8 @@ from .ctypes_types import (ModelParameters, ModelParamsC, RawResults, RawResults
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+# miqp_exchange_fn (include/miqp_gpu.h): int (*)(void* user, int op, void* buf, int count, int root)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int)
 
 
 def library_path():
@@ -51,6 +53,14 @@ def load_library():
     L.miqp_solver_solve_batch.restype = C.c_int; L.miqp_solver_solve_batch.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
     L.miqp_solver_solve_batch_multi.restype = C.c_int; L.miqp_solver_solve_batch_multi.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.miqp_solver_raw_sizes.restype = C.c_int; L.miqp_solver_raw_sizes.argtypes = [vp, C.POINTER(C.c_int)]
+    L.miqp_solver_solve_split.restype = C.c_int; L.miqp_solver_solve_split.argtypes = [vp, C.c_double, C.c_int, C.c_int, EXCHANGE_FN, vp]
+    L.miqp_solver_solve_split_rccl.restype = C.c_int; L.miqp_solver_solve_split_rccl.argtypes = [vp, C.c_double]
+    L.miqp_solver_split_roots.restype = C.c_int
+    L.miqp_solver_split_roots.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.miqp_comm_unique_id.restype = C.c_int; L.miqp_comm_unique_id.argtypes = [C.c_char_p]
+    L.miqp_comm_init.restype = C.c_int; L.miqp_comm_init.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+    L.miqp_comm_finalize.restype = C.c_int; L.miqp_comm_finalize.argtypes = []
+    L.miqp_comm_selftest.restype = C.c_int; L.miqp_comm_selftest.argtypes = [EXCHANGE_FN, vp, C.c_int, C.c_int]
     L.miqp_solver_get_results.restype = C.c_int; L.miqp_solver_get_results.argtypes = [vp, C.POINTER(RawResultsC)]
     L.miqp_solver_get_properties.restype = C.c_int; L.miqp_solver_get_properties.argtypes = [vp, C.POINTER(SolutionPropertiesC)]
     L.miqp_solver_get_dims.restype = C.c_int; L.miqp_solver_get_dims.argtypes = [vp, C.POINTER(C.c_int)]
@@ -73,7 +83,9 @@ EXPORTED_SYMBOLS = ["miqp_solver_create", "miqp_solver_destroy", "miqp_solver_se
                     "miqp_solver_write_mst", "miqp_solver_read_mst", "miqp_fraction_parameters", "miqp_mean_angles",
                     "miqp_limits_per_region", "miqp_calculate_region_idx", "miqp_reserve_neighbor_regions",
                     "miqp_calculate_possible_regions", "miqp_calculate_warmstart", "miqp_plan",
-                    "miqp_solver_solve_batch_multi", "miqp_solver_raw_sizes", "miqp_fitting_polynomial_parameters"]
+                    "miqp_solver_solve_batch_multi", "miqp_solver_raw_sizes", "miqp_fitting_polynomial_parameters",
+                    "miqp_solver_solve_split", "miqp_solver_solve_split_rccl", "miqp_solver_split_roots", "miqp_comm_unique_id",
+                    "miqp_comm_init", "miqp_comm_finalize", "miqp_comm_selftest"]
 
 
 class OptimizationStatus(enum.IntEnum):  # src/cplex_wrapper.hpp:54-59
@@ -258,6 +270,34 @@ class CplexWrapper:
         st = self._collect(self._L.miqp_solver_solve(self._h, float(timestamp)))
         self._debug_after(timestamp, st)
         return st
+
+    def callCplexSplit(self, world, rank, exchange=None, timestamp=0.0):
+        """one instance whose branch-and-bound tree is split over the ranks of a job (miqp_solver_solve_split): every rank
+        calls this with the same parameters; ``exchange`` is an EXCHANGE_FN (e.g. sharding.torch_exchange()), None = the RCCL
+        communicator of sharding.init_rccl_comm().  Every rank returns the same status and holds the full result."""
+        if self._push_inputs() != 0:
+            return OptimizationStatus.FAILED_SEG_FAULT
+        if exchange is None:
+            st = self._L.miqp_solver_solve_split_rccl(self._h, float(timestamp))
+        else:
+            st = self._L.miqp_solver_solve_split(self._h, float(timestamp), int(world), int(rank), exchange, None)
+        return self._collect(st)
+
+    def splitRoots(self, world, rank):
+        """the roots of rank ``rank`` in a tree split over ``world`` ranks: (list of roots, each a list of (record index,
+        alternative) fixings; size of the partition).  No device needed."""
+        if self._push_inputs() != 0:
+            return None
+        cap = 4096
+        ro, ix, va = (C.c_int * cap)(), (C.c_int * cap)(), (C.c_int * cap)()
+        nr, nc = C.c_int(0), C.c_int(0)
+        n = self._L.miqp_solver_split_roots(self._h, int(world), int(rank), ro, ix, va, cap, C.byref(nr), C.byref(nc))
+        if n < 0:
+            return None
+        roots = [[] for _ in range(nr.value)]
+        for k in range(min(n, cap)):
+            roots[ro[k]].append((ix[k], va[k]))
+        return roots, nc.value
 
     def getRawResults(self):
         return self._results

@@ -107,31 +107,63 @@ def test_shard_indices_partition():
     assert sorted(seen) == list(range(n))
 
 
-def test_gloo_two_ranks_gather():
-    """the N>1 path of bench.py: independent shards, one gather of result counters (gloo, world_size 2)"""
-    code = r'''
-import os, sys
-sys.path.insert(0, %r)
-import torch, torch.distributed as dist
-from planner_miqp_amd.sharding import shard_indices, gather_counts
-dist.init_process_group("gloo")
-r, w = dist.get_rank(), dist.get_world_size()
-mine = shard_indices(10, r, w)
-g = gather_counts([float(len(mine)), float(sum(mine))])
-if r == 0:
-    assert sum(x[0] for x in g) == 10 and sum(x[1] for x in g) == 45, g
-    print("GATHER_OK")
-dist.destroy_process_group()
-''' % ROOT
+def _run_ranks(code, nproc=2, port=29533, timeout=600):
     import tempfile
     with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
         f.write(code)
         script = f.name
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29533", script], capture_output=True, text=True, env=env, timeout=300)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc, "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), script], capture_output=True, text=True, env=env, timeout=timeout)
     os.unlink(script)
-    assert "GATHER_OK" in out.stdout, out.stdout + out.stderr
+    return out
+
+
+def test_gloo_two_ranks_shard_solve_and_exchange():
+    """the N > 1 paths on two gloo ranks (no GPU here, so every solve ends in the loud no-device failure - the sharding, the
+    gather and the incumbent-exchange transport are the real code): (1) solve_sharded: instance b -> rank b mod 2, every
+    instance reported exactly once and in order on both ranks; (2) the exchange callback the tree split uses, checked by the
+    library's own contract test (all-reduce(min) over unsigned words incl. the top bit, broadcast from every root);
+    (3) the roots of the two ranks partition the tree; (4) a split solve reaches the transport-independent failure path on
+    both ranks without hanging"""
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+import planner_miqp_amd as P
+from planner_miqp_amd import synthetic, sharding
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+ws = []
+for s in range(7):
+    x = P.CplexWrapper(); x.resetParameters(synthetic.generate("mini", s)); ws.append(x)
+rec = sharding.solve_sharded(ws)
+assert len(rec) == 7 and all(q is not None for q in rec), rec
+assert all(q["status"] == int(P.OptimizationStatus.FAILED_SEG_FAULT) for q in rec) or torch.cuda.is_available()
+g = sharding.gather_counts([float(len(sharding.shard_indices(7, r, w))), float(sum(sharding.shard_indices(7, r, w)))])
+assert sum(x[0] for x in g) == 7 and sum(x[1] for x in g) == 21, g
+ex = sharding.torch_exchange()
+L = P.load_library()
+assert L.miqp_comm_selftest(ex, None, w, r) == 0
+x = P.CplexWrapper(); x.resetParameters(synthetic.generate("cfg5s", 0))
+mine, ncomb = x.splitRoots(w, r)
+allr = [None] * w
+dist.all_gather_object(allr, mine)
+flat = [tuple(q) for part in allr for q in part]
+assert len(flat) == ncomb == len(set(flat)) and ncomb >= 4 * w, (ncomb, len(flat))
+keys = sorted({k for q in flat for k, _ in q})
+import itertools
+alts = {k: sorted({v for q in flat for kk, v in q if kk == k}) for k in keys}
+assert sorted(flat) == sorted(tuple(zip(keys, c)) for c in itertools.product(*[alts[k] for k in keys])), "not a partition"
+if not torch.cuda.is_available():
+    st = sharding.split_solve(x, ex)
+    assert st == P.OptimizationStatus.FAILED_SEG_FAULT
+if r == 0:
+    print("SHARD_OK")
+dist.destroy_process_group()
+""" % ROOT
+    out = _run_ranks(code)
+    assert "SHARD_OK" in out.stdout, out.stdout + out.stderr
 
 
 def test_lp_export_has_the_reference_model_sizes(lib, tmp_path):

@@ -281,6 +281,81 @@ def test_two_threads_with_their_own_handles():
         assert b is not None and abs(a - b) <= 1e-9 * max(1.0, abs(a))
 
 
+SPLIT_SCRIPT = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+import planner_miqp_amd as P
+from planner_miqp_amd import synthetic, sharding
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(r %% torch.cuda.device_count())
+mode = sys.argv[1]
+out = []
+if mode == "rccl":
+    sharding.init_rccl_comm(torch.cuda.current_device())
+    assert P.load_library().miqp_comm_selftest(P.wrapper.EXCHANGE_FN(), None, 0, 0) == 0
+ex = None if mode == "rccl" else sharding.torch_exchange()
+for cfg, seed in (("mini", 1), ("mini3b", 2), ("cfg3", 3)):
+    x = P.CplexWrapper(device=torch.cuda.current_device()); x.resetParameters(synthetic.generate(cfg, seed, gap=1e-6, max_time=60))
+    st = sharding.split_solve(x, ex)
+    pr = x.getSolutionProperties(); res = x.getRawResults()
+    out.append(dict(cfg=cfg, seed=seed, status=int(st), objective=pr.objective, bound=pr.best_bound, nodes=int(pr.nodes), px=res.pos_x.tolist() if res is not None else None))
+allo = [None] * w
+dist.all_gather_object(allo, out)
+if r == 0:
+    print("SPLIT_JSON " + json.dumps(allo))
+if mode == "rccl":
+    P.load_library().miqp_comm_finalize()
+dist.destroy_process_group()
+"""
+
+
+def _run_split(tmp_path, mode, nproc):
+    import json, subprocess, sys, socket
+    script = tmp_path / "split.py"
+    script.write_text(SPLIT_SCRIPT % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc, "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(script), mode], capture_output=True, text=True, env=env, timeout=900)
+    line = [l for l in out.stdout.splitlines() if l.startswith("SPLIT_JSON ")]
+    return (json.loads(line[0][len("SPLIT_JSON "):]) if line else None), out
+
+
+def test_tree_split_over_two_ranks_matches_the_plain_solve(tmp_path):
+    """C1: one instance, its tree split over two ranks (two processes; on a one-GPU box they share the device),
+    incumbent / bound / stop exchanged once per round by all-reduce(min) over the torch.distributed group, solution broadcast
+    by the owner: both ranks return the same status, objective and trajectory, and they are those of the unsplit solve"""
+    res, out = _run_split(tmp_path, "torch", 2)
+    assert res is not None, out.stdout[-2000:] + out.stderr[-2000:]
+    for a, b in zip(res[0], res[1]):
+        assert a["status"] == b["status"] == 0 and a["objective"] == b["objective"] and a["px"] == b["px"], (a["cfg"], a["objective"], b["objective"])
+        w = P.CplexWrapper(); w.resetParameters(synthetic.generate(a["cfg"], a["seed"], gap=1e-6, max_time=60))
+        assert int(w.callCplex()) == 0
+        o = w.getSolutionProperties().objective
+        assert abs(a["objective"] - o) <= 2e-6 * max(1.0, abs(o)), (a["cfg"], a["objective"], o)
+        assert a["bound"] <= a["objective"] + 1e-9
+
+
+def test_tree_split_over_rccl(tmp_path):
+    """the same exchange over the library's RCCL communicator (ncclAllReduce(min, uint64) / ncclBroadcast): one rank per
+    visible device (a one-GPU box runs the degenerate one-rank communicator - RCCL does not place two ranks on one device)"""
+    import torch
+    n = max(1, min(2, torch.cuda.device_count()))
+    res, out = _run_split(tmp_path, "rccl", n)
+    assert res is not None, out.stdout[-2000:] + out.stderr[-2000:]
+    for rk in res:
+        for a in rk:
+            assert a["status"] == 0 and a["bound"] <= a["objective"] + 1e-9
+    for a in res[0]:
+        w = P.CplexWrapper(); w.resetParameters(synthetic.generate(a["cfg"], a["seed"], gap=1e-6, max_time=60))
+        assert int(w.callCplex()) == 0
+        o = w.getSolutionProperties().objective
+        assert abs(a["objective"] - o) <= 2e-6 * max(1.0, abs(o))
+
+
 def test_infeasible_instance_reports_no_solution():
     """initial pose outside the environment: CPLEX status 'infeasible' -> FAILED_NO_SOLUT, NaN objective (cpp:231-240)"""
     p = synthetic.generate("mini1", 0)
