@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_PEAK = 78.6e12  # MI355X FP64 matrix == FP64 vector peak (AMD public spec; half the f32 rate of MI355X_MICROARCH.md)
+FP64_PEAK_MEASURED = 71.4e12  # back-to-back v_mfma_f64_16x16x4_f64, 2 waves per SIMD on every CU (profiles/r02_fp64_peak.json)
 
 
 def f_iter(C, N):
@@ -74,6 +75,53 @@ def cpu_baseline(params_list, gap, time_limit, budget_s=20.0):
                 value_1core=s1 / d1 if d1 > 0 else 0.0)
 
 
+def find_cplex():
+    """the CPLEX 12.10 the reference links (util/deps.bzl:69-95), if this host has it: interactive optimizer binary or python API"""
+    import shutil
+    for c in ("/opt/ibm/ILOG/CPLEX_Studio1210/cplex/bin/x86-64_linux/cplex", "/opt/ibm/ILOG/CPLEX_Studio128/cplex/bin/x86-64_linux/cplex"):
+        if os.path.exists(c):
+            return ("binary", c)
+    c = shutil.which("cplex")
+    if c:
+        return ("binary", c)
+    try:
+        import cplex  # noqa: F401
+        return ("python", "cplex")
+    except Exception:
+        return None
+
+
+def cplex_baseline(lp_files, gap, time_limit, budget_s=30.0):
+    """CPLEX column of the comparison: each exported LP solved with mipgap / tilim / all threads, solve
+    time only; None when CPLEX is not installed (never estimated)"""
+    import re
+    import subprocess
+    found = find_cplex()
+    if not found or not lp_files:
+        return None
+    t0 = time.time(); solved = 0; tried = 0; tsolve = 0.0
+    for lp in lp_files:
+        if time.time() - t0 > budget_s:
+            break
+        tried += 1
+        if found[0] == "binary":
+            r = subprocess.run([found[1], "-c", "read %s" % lp, "set mip tolerances mipgap %g" % gap, "set timelimit %g" % time_limit, "optimize"],
+                               capture_output=True, text=True)
+            m = re.search(r"Solution time =\s*([0-9.]+) sec", r.stdout)
+            ok = "Objective =" in r.stdout and "time limit exceeded" not in r.stdout.lower()
+            tsolve += float(m.group(1)) if m else time_limit
+        else:
+            import cplex
+            c = cplex.Cplex(lp); c.set_results_stream(None); c.set_log_stream(None)
+            c.parameters.mip.tolerances.mipgap.set(gap); c.parameters.timelimit.set(time_limit)
+            a = c.get_time(); c.solve(); tsolve += c.get_time() - a
+            ok = c.solution.get_status() in (101, 102)
+        solved += int(ok)
+    return dict(value=solved / tsolve if tsolve > 0 else 0.0, unit="MIQP solves/s", cores=os.cpu_count(), kind="reference",
+                sample="CPLEX (%s) on the first %d exported .lp files, mipgap %g, tilim %g s, default threads: %d to the gap, %.1f s of solve time"
+                       % (found[1], tried, gap, time_limit, solved, tsolve))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +132,7 @@ def main():
     ap.add_argument("--gap", type=float, default=0.01)
     ap.add_argument("--time-limit", type=float, default=10.0, help="max_solution_time per instance (reference default 10 s)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dump-lp", default=None, metavar="DIR", help="write the raw big-M model of every instance of the first timed step as CPLEX .lp (miqp_solver_export_lp) so that a licence holder can fill in the CPLEX column")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -131,6 +180,15 @@ def main():
         return ps, ws
 
     batches = [make_batch(s) for s in range(a.warmup + a.steps)]
+    lp_files = []
+    if a.dump_lp and rank == 0:
+        os.makedirs(a.dump_lp, exist_ok=True)
+        L = P.load_library()
+        for k, w in enumerate(batches[a.warmup][1]):
+            if w._push_inputs() == 0:
+                f = os.path.join(a.dump_lp, "%s_seed%d.lp" % (a.config, (a.warmup * world + rank) * B + k))
+                if L.miqp_solver_export_lp(w._h, f.encode()) == 0:
+                    lp_files.append(f)
     for s in range(a.warmup):
         P.solve_batch(batches[s][1])
     sync()
@@ -160,10 +218,12 @@ def main():
         # roofline of the dominant kernel (ipm_kernel), rank 0: algorithmic flops / HIP-event time of its launches
         flops = iters * f_iter(Cc, N) + rowit * F_ROW
         ach = flops / ipm_s if ipm_s > 0 else 0.0
-        traffic = None  # HBM bytes per launch come from the committed rocprofv3 PMC passes (cannot be collected live)
-        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        # L2<->fabric bytes per launch of the interior point kernels: not measurable inside this process; the figure of the
+        # committed rocprofv3 --pmc passes of the same configuration (profiles/r02_traffic.json says how it was taken)
+        traffic = None; traffic_note = None
+        tj = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tj) and a.config == "cfg3":
-            traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+            tjd = json.load(open(tj)); traffic = tjd.get("bytes_per_round_corrected"); traffic_note = tjd.get("note")
         out = dict(metric="MIQP solves/sec to 1% gap, 2-agent x 20-step x 32-region", value=tot_solved / T, unit="MIQP solves/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * T / a.steps, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f64", data="synthetic",
@@ -174,10 +234,13 @@ def main():
                                bnb_nodes=int(sum(x[7] for x in g)), ipm_iterations=int(sum(x[5] for x in g)),
                                solve_latency_s_rank0=dict(p50=float(np.percentile(lat, 50)), p95=float(np.percentile(lat, 95)), max=float(max(lat))) if lat else None),
                    roofline=dict(bound="mfma", achieved=ach / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s", frac=ach / FP64_PEAK, traffic=traffic,
-                                 kernel="ipm_kernel", launches=int(launches), avg_launch_ms=1e3 * ipm_s / max(1, launches),
-                                 flops_per_launch=flops / max(1, launches)))
+                                 traffic_note=traffic_note, peak_measured=FP64_PEAK_MEASURED / 1e12, frac_of_measured_peak=ach / FP64_PEAK_MEASURED,
+                                 kernel="ipm_onchip_kernel<2,10> followed by ipm_kernel<2,64> on the nodes it hands over (one pair per B&B round)",
+                                 launches=int(launches), avg_launch_ms=1e3 * ipm_s / max(1, launches), flops_per_launch=flops / max(1, launches)))
         if not a.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(batches[a.warmup][0], a.gap, a.time_limit)
+            cpx = cplex_baseline(lp_files, a.gap, a.time_limit) if lp_files else None
+            out["cplex_baseline"] = cpx if cpx else ("CPLEX not available on this host" + ("" if lp_files else " (run with --dump-lp DIR to export the instances)"))
         elif not a.no_cpu:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -116,6 +116,7 @@ class CplexWrapper {
       miqp_solution_properties_c p{}; miqp_solver_get_properties(h_, &p);
       solutionProperties_ = {p.status, p.gap, p.objective, p.time, p.NrConstraints, p.NrBinaryVariables, p.NrFloatVariables,
                              p.NonZeroCoefficients, p.NrIterations, p.NrSolutionPool};
+      if (st != SUCCESS) { solutionProperties_.objective = std::nan(""); solutionProperties_.gap = std::nan(""); }   // cplex_wrapper.cpp:231-248
       if (st == SUCCESS) {
         pullResults(); lastSolution_ = std::make_shared<RawResults>(*rawResults_);
         const bool last = doWarmstart_ == LAST_SOLUTION_WARMSTART || doWarmstart_ == BOTH_WARMSTART_STRATEGIES;

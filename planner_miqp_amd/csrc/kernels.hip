@@ -815,7 +815,16 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     double* pv = svv + NZ;           // [NX]
     double* Km = pv + NX;            // [NU][NX+1]
     const double h1 = ts, h2 = 0.5 * ts * ts, h3 = ts * ts * ts / 6.0;
+    constexpr int KBW = (NX + 3) / 4;
+    const int wg = tid >> 4, wc = tid & 15;
+    const bool c1ok = 16 + wc < NZ;   // column of the second tile column inside the stage vector (3 cars: 24 of 32)
+    double abw[KBW][2];   // [A B] as MFMA operand: lane (g, c) holds AB[4 kb + g][16 t + c]
+#pragma unroll
+    for (int kb = 0; kb < KBW; ++kb)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) abw[kb][t] = (4 * kb + wg < NX && 16 * t + wc < NZ) ? ab_entry<C>(4 * kb + wg, 16 * t + wc, ts) : 0.0;
     for (int j = N - 1; j >= 0; --j) {
+      PROF_T(tw0);
       for (int k = tid; k < NZ * NZ; k += NT) Sm[k] = 0.0;
       __syncthreads();
       if (tid < NZ) { Sm[tid * NZ + tid] = 2.0 * Wd[tid]; svv[tid] = 2.0 * Wd[tid] * (Z[j * NZ + tid] - Rf[j * NZ + tid]); }
@@ -845,6 +854,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
         }
       }
       __syncthreads();
+      PROF_T(tw1); PROF_ACC(1, tw0, tw1);
       if (it == 1 && tid < NZ) rmax = fmax(rmax, fabs(svv[tid]));
       if (j == N - 1) {   // u_{N-1} = 0 (initial_conditions.mod:25-26): P = Phi_xx, p = rr_x
         for (int k = tid; k < NX * NX; k += NT) Pm[k] = Sm[(k / NX) * NZ + k % NX];
@@ -852,23 +862,51 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
         __syncthreads();
         continue;
       }
-      // T = P [A B]
-      for (int k = tid; k < NX * NZ; k += NT) {
-        const int i = k / NZ, b = k - i * NZ;
-        const double* Pi = Pm + i * NX;
-        double v;
-        if (b < NX) { const int ch = b / 3, kb = b - 3 * ch; v = Pi[b]; if (kb >= 1) v += h1 * Pi[b - 1]; if (kb >= 2) v += h2 * Pi[b - 2]; }
-        else { const int ch = b - NX; v = h3 * Pi[3 * ch] + h2 * Pi[3 * ch + 1] + h1 * Pi[3 * ch + 2]; }
-        Tm[k] = v;
+      // T = P [A B] and S = Phi + [A B]' T as 2 x 2 tilings of v_mfma_f64_16x16x4_f64 over the LDS-resident matrices: tile
+      // (ti, tj) = rows 16 ti .., columns 16 tj ..; lane (g, c) feeds A[i = c][k = g] / B[k = g][j = c] of a k block and
+      // owns D[g + 4 r][c].  [A B] comes from registers (abw), P / T operands and the S accumulators from LDS.
+      {
+        d4_t t00 = {0, 0, 0, 0}, t01 = {0, 0, 0, 0}, t10 = {0, 0, 0, 0}, t11 = {0, 0, 0, 0};
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb) {
+          const int kr = 4 * kb + wg;   // k index = row of P (P is symmetric: P[i][k] = Pm[k][i])
+          const double a0 = (kr < NX) ? Pm[kr * NX + wc] : 0.0;
+          const double a1 = (kr < NX && 16 + wc < NX) ? Pm[kr * NX + 16 + wc] : 0.0;
+          t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, abw[kb][0], t00, 0, 0, 0);
+          t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, abw[kb][1], t01, 0, 0, 0);
+          t10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, abw[kb][0], t10, 0, 0, 0);
+          t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, abw[kb][1], t11, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i0 = wg + 4 * r, i1 = 16 + wg + 4 * r;
+          Tm[i0 * NZ + wc] = t00[r]; if (c1ok) Tm[i0 * NZ + 16 + wc] = t01[r];
+          if (i1 < NX) { Tm[i1 * NZ + wc] = t10[r]; if (c1ok) Tm[i1 * NZ + 16 + wc] = t11[r]; }
+        }
       }
       __syncthreads();
-      // S = Phi + [A B]' T,  sv = rr + [A B]' p
-      for (int k = tid; k < NZ * NZ; k += NT) {
-        const int a = k / NZ, b = k - a * NZ;
-        double v;
-        if (a < NX) { const int ch = a / 3, ka = a - 3 * ch; v = Tm[a * NZ + b]; if (ka >= 1) v += h1 * Tm[(a - 1) * NZ + b]; if (ka >= 2) v += h2 * Tm[(a - 2) * NZ + b]; }
-        else { const int ch = a - NX; v = h3 * Tm[(3 * ch) * NZ + b] + h2 * Tm[(3 * ch + 1) * NZ + b] + h1 * Tm[(3 * ch + 2) * NZ + b]; }
-        Sm[k] += v;
+      {
+        d4_t s00, s01, s10, s11;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i0 = wg + 4 * r, i1 = 16 + wg + 4 * r;
+          s00[r] = Sm[i0 * NZ + wc]; s01[r] = c1ok ? Sm[i0 * NZ + 16 + wc] : 0.0; s10[r] = i1 < NZ ? Sm[i1 * NZ + wc] : 0.0; s11[r] = (i1 < NZ && c1ok) ? Sm[i1 * NZ + 16 + wc] : 0.0;
+        }
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb) {
+          const int kr = 4 * kb + wg;   // k index = row of T
+          const double b0 = (kr < NX) ? Tm[kr * NZ + wc] : 0.0, b1 = (kr < NX && c1ok) ? Tm[kr * NZ + 16 + wc] : 0.0;
+          s00 = __builtin_amdgcn_mfma_f64_16x16x4f64(abw[kb][0], b0, s00, 0, 0, 0);
+          s01 = __builtin_amdgcn_mfma_f64_16x16x4f64(abw[kb][0], b1, s01, 0, 0, 0);
+          s10 = __builtin_amdgcn_mfma_f64_16x16x4f64(abw[kb][1], b0, s10, 0, 0, 0);
+          s11 = __builtin_amdgcn_mfma_f64_16x16x4f64(abw[kb][1], b1, s11, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i0 = wg + 4 * r, i1 = 16 + wg + 4 * r;
+          Sm[i0 * NZ + wc] = s00[r]; if (c1ok) Sm[i0 * NZ + 16 + wc] = s01[r];
+          if (i1 < NZ) { Sm[i1 * NZ + wc] = s10[r]; if (c1ok) Sm[i1 * NZ + 16 + wc] = s11[r]; }
+        }
       }
       if (tid < NZ) {
         const int a = tid; double v;
@@ -877,6 +915,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
         svv[a] += v;
       }
       __syncthreads();
+      PROF_T(tw2); PROF_ACC(3, tw1, tw2);
       // Suu = L D L' in the registers of every lane
       double Lm[NU][NU], dinv[NU], dvec[NU];
 #pragma unroll
@@ -912,13 +951,33 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
         for (int a = 0; a < NU; ++a) { Km[a * (NX + 1) + tid] = xk[a]; KG[(j * NU + a) * KSTR + tid] = xk[a]; }
       }
       __syncthreads();
-      // P = Sxx - Sxu' K,  p = sv_x - Sxu' k
-      for (int k = tid; k < NX * NX; k += NT) {
-        const int a = k / NX, b = k - a * NX;
-        double v = Sm[a * NZ + b];
+      PROF_T(tw3); PROF_ACC(4, tw2, tw3);
+      // P = Sxx - Sxu' K as an MFMA rank-NU update of the tiles of S:  A[i][k = q] = -S[NX + q][i],  B[k = q][j] = K[q][j]
+      {
+        d4_t p00, p01, p10, p11;
 #pragma unroll
-        for (int q = 0; q < NU; ++q) v -= Sm[(NX + q) * NZ + a] * Km[q * (NX + 1) + b];
-        Pm[k] = v;
+        for (int r = 0; r < 4; ++r) {
+          const int i0 = wg + 4 * r, i1 = 16 + wg + 4 * r;
+          p00[r] = Sm[i0 * NZ + wc]; p01[r] = c1ok ? Sm[i0 * NZ + 16 + wc] : 0.0; p10[r] = i1 < NZ ? Sm[i1 * NZ + wc] : 0.0; p11[r] = (i1 < NZ && c1ok) ? Sm[i1 * NZ + 16 + wc] : 0.0;
+        }
+#pragma unroll
+        for (int qb = 0; qb < (NU + 3) / 4; ++qb) {
+          const int q = 4 * qb + wg;
+          const bool qv = q < NU;
+          const double a0 = qv ? -Sm[(NX + q) * NZ + wc] : 0.0, a1 = (qv && c1ok) ? -Sm[(NX + q) * NZ + 16 + wc] : 0.0;
+          const double b0 = qv ? Km[q * (NX + 1) + wc] : 0.0, b1 = (qv && 16 + wc < NX) ? Km[q * (NX + 1) + 16 + wc] : 0.0;
+          p00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, p00, 0, 0, 0);
+          p01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, p01, 0, 0, 0);
+          p10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, p10, 0, 0, 0);
+          p11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, p11, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i0 = wg + 4 * r, i1 = 16 + wg + 4 * r;
+          Pm[i0 * NX + wc] = p00[r];
+          if (16 + wc < NX) Pm[i0 * NX + 16 + wc] = p01[r];
+          if (i1 < NX) { Pm[i1 * NX + wc] = p10[r]; if (16 + wc < NX) Pm[i1 * NX + 16 + wc] = p11[r]; }
+        }
       }
       if (tid < NX) {
         double v = svv[tid];
@@ -927,6 +986,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
         pv[tid] = v;
       }
       __syncthreads();
+      PROF_T(tw4); PROF_ACC(5, tw3, tw4);
     }
     }
     if (it == 1) R0 = block_max<NT>(rmax, red);

@@ -819,12 +819,17 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipGetLastError());
   float ms_all = 0; HIP_OK(hipEventElapsedTime(&ms_all, X.ev0, X.ev1));
 #ifdef MIQP_PROFILE
-  { unsigned long long pf[64]; HIP_OK(hipMemcpy(pf, B.prof + 64, 64 * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemset(B.prof, 0, 128 * 8));
+  { unsigned long long pf[64]; HIP_OK(hipMemcpy(pf, B.prof + 64, 64 * 8, hipMemcpyDeviceToHost));
     const char* nm[10] = {"decode", "rowpass", "bw.phi", "bw.TS+p", "bw.readlane+LDL", "bw.Ksolve", "bw.update", "forward", "step", "update"};
     double tot = 0; for (int q = 0; q < 10; ++q) tot += (double)pf[q];
+    { unsigned long long po[16]; HIP_OK(hipMemcpy(po, B.prof, 16 * 8, hipMemcpyDeviceToHost));
+      const char* no[9] = {"build", "bw.rows/assemble", "bw.mfma", "bw.TS", "bw.cholK", "bw.P", "forward", "step", "update"};
+      double to = 0; for (int q = 0; q < 9; ++q) to += (double)po[q];
+      if (po[10]) { std::fprintf(stderr, "[miqp_gpu profile] memory-backed kernel nodes %llu iters %llu cycles/node-iter %.0f :", po[10], po[9], to / std::max(1ull, po[9]));
+        for (int q = 0; q < 9; ++q) std::fprintf(stderr, " %s %.1f%% (%.0f)", no[q], 100.0 * po[q] / to, (double)po[q] / std::max(1ull, po[9])); std::fprintf(stderr, "\n"); } }
     std::fprintf(stderr, "[miqp_gpu profile] on-chip nodes %llu iters %llu cycles/node-iter %.0f :", pf[11], pf[10], tot / std::max(1ull, pf[10]));
     for (int q = 0; q < 10; ++q) std::fprintf(stderr, " %s %.1f%% (%.0f)", nm[q], 100.0 * pf[q] / tot, (double)pf[q] / std::max(1ull, pf[10]));
-    std::fprintf(stderr, "\n"); }
+    std::fprintf(stderr, "\n"); HIP_OK(hipMemset(B.prof, 0, 128 * 8)); }
 #endif
   if (B.stats) {
     unsigned long long hs[32]; HIP_OK(hipMemcpy(hs, B.stats, sizeof(hs), hipMemcpyDeviceToHost)); HIP_OK(hipMemset(B.stats, 0, sizeof(hs)));
