@@ -114,6 +114,15 @@ __device__ inline bool box_of_slot(const Layout& Y, const double* D, const int* 
   return false;
 }
 
+// lane index recomputed from the execution mask (64-thread workgroups: lane = thread).  The passes of the iteration loop take
+// their lane-dependent addresses from this instead of from values defined before the loop: those would have to stay in
+// registers across the Riccati sweep, where none are spare, and come back from scratch memory at every use.
+__device__ inline int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 // lambda + kappa and w of one row for the Newton system of the next iteration (see row_step)
 __device__ inline void row_weight(double s, double lam, double t, bool soft, double aq, double tau, double& w, double& lk) {
   const double il = frcp(lam);
@@ -124,8 +133,11 @@ __device__ inline void row_weight(double s, double lam, double t, bool soft, dou
   lk = lam + ((tau - s * lam) * il - r2mu) * w;
 }
 
-template <int C, int NSL>
+// ABL != 0 (diagnostic build -DMIQP_ABLATE, replayed on a batch the real kernel has solved): 15 iterations per node without
+// convergence tests and with the parts named by the mask switched off - only the run time of such an instance is read
+template <int C, int NSL, int ABL = 0>
 __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
+  constexpr int OC_ABL = ABL;
   static_assert(C <= 2, "one 16 x 16 tile per stage");
   constexpr int NX = 6 * C, NU = 2 * C, NZ = 8 * C;
   constexpr int KB = (NX + 3) / 4;
@@ -166,9 +178,9 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
     __syncthreads();
     if (tid == 0) sh_node = atomicAdd(B.work_counter, 1);
     __syncthreads();
-    const int node = sh_node;
-    if (node >= nbatch) break;
-    const int inst = B.batch_inst[node];
+    const int node = __builtin_amdgcn_readfirstlane(sh_node);   // wave-uniform by construction: said so, everything derived from it
+    if (node >= nbatch) break;                                    // (instance tables, references) is then addressed from SGPRs
+    const int inst = __builtin_amdgcn_readfirstlane(B.batch_inst[node]);
     const double* D = B.inst_d + (size_t)inst * Y.dstride;
     const int* T = B.inst_i + (size_t)inst * Y.istride;
     const double ts = D[Y.d_glob + 7];
@@ -206,24 +218,48 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) abr[kb] = (4 * kb + lg < NX && lc < NZ) ? ab_entry<C>(4 * kb + lg, lc, ts) : 0.0;
 
-    // ---- decode, pass A: which (stage, slot) pairs carry a row; box rows go straight to their key, general rows are listed
+    // ---- decode, pass A: which (stage, slot) pairs carry a row; box rows go straight to their key, general rows are marked in a
+    // bitmap over (stage, slot).  The pairs are walked class by class (velocity / acceleration bounds, jerk bounds, region
+    // rows, rear-point edges, front-point edges, obstacles, car/car, car/car exclusions), so that the lanes of one pass take
+    // the same branch of the decoder and their table loads go out together; the bitmap restores the (stage, slot) order.
     int ngen = 0;
-    for (int p0 = 0; p0 < N * NSLOT; p0 += 64) {
-      const int pcode = p0 + tid;
-      bool gen = false;
-      if (pcode < N * NSLOT) {
-        const int i = pcode / NSLOT, slot = pcode - i * NSLOT;
-        if (decode_row<C, false>(Y, D, T, fix, i, slot, nullptr).active) {
-          int col; double sg, rh;
-          if (box_of_slot<C>(Y, D, T, fix, i, slot, col, sg, rh)) atomicMin(&bkey[(i * 2 + (sg < 0.0 ? 1 : 0)) * 16 + col], d2key(rh));
-          else gen = true;
+    {
+      unsigned long long* const bmp = (unsigned long long*)scr;          // [nw] one bit per (stage, slot)
+      const int nw = (N * NSLOT + 63) >> 6;
+      unsigned short* const pre = (unsigned short*)(bmp + nw);           // [nw] general rows before every word
+      for (int k = tid; k < nw; k += 64) bmp[k] = 0ull;
+      OC_WAVE_SYNC();
+      const int cls_off[8] = {0, 7, 11, 16, 16 + Y.EL, 16 + 5 * Y.EL, C * Y.SC, C * Y.SC + 8 * Y.NP};
+      const int cls_cnt[8] = {7, 4, 5, Y.EL, 4 * Y.EL, 5 * Y.O, 8 * Y.NP, 16 * Y.NP};
+#pragma unroll 1
+      for (int cl = 0; cl < 8; ++cl) {
+        const int cnt = cls_cnt[cl], off = cls_off[cl];
+        const bool percar = cl < 6;
+        const int per = percar ? C * cnt : cnt, total = N * per;
+        for (int e0 = 0; e0 < total; e0 += 64) {
+          const int e = e0 + tid;
+          if (e < total) {
+            const int i = e / per, rem = e - i * per;
+            const int slot = percar ? (rem / cnt) * Y.SC + off + rem % cnt : off + rem;
+            if (decode_row<C, false>(Y, D, T, fix, i, slot, nullptr).active) {
+              int col; double sg, rh;
+              if (box_of_slot<C>(Y, D, T, fix, i, slot, col, sg, rh)) atomicMin(&bkey[(i * 2 + (sg < 0.0 ? 1 : 0)) * 16 + col], d2key(rh));
+              else { const int pcode = i * NSLOT + slot; atomicOr(&bmp[pcode >> 6], 1ull << (pcode & 63)); }
+            }
+          }
         }
       }
-      const unsigned long long m = __ballot(gen);
-      if (gen) { const int pos = ngen + __popcll(m & lt); if (pos < OC_GCAP + 64) cand[pos] = (unsigned short)pcode; }
-      ngen += __popcll(m);
+      OC_WAVE_SYNC();
+      if (tid == 0) { int a = 0; for (int k = 0; k < nw; ++k) { pre[k] = (unsigned short)(a < 65535 ? a : 65535); a += __popcll(bmp[k]); } pre[nw] = (unsigned short)(a < 65535 ? a : 65535); }
+      OC_WAVE_SYNC();
+      ngen = pre[nw];
+      if (ngen <= OC_GCAP)
+        for (int k = tid; k < nw; k += 64) {
+          unsigned long long bits = bmp[k]; int pos = pre[k];
+          while (bits) { const int b = __ffsll((long long)bits) - 1; cand[pos++] = (unsigned short)(k * 64 + b); bits &= bits - 1ull; }
+        }
+      OC_WAVE_SYNC();
     }
-    OC_WAVE_SYNC();
     // ---- pass B: the general rows, OC_SCR at a time through dense scratch rows; packed into LDS in (stage, slot) order
     bool overflow = ngen > OC_GCAP;
     int ncoef = 0;
@@ -340,30 +376,36 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
         for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) { const double d = Z[k] - Rf[(k >> 4) * NZ + q]; o += Wd[q] * d * d; } }
         obj = wave_sum(o);
       }
+      if (OC_ABL) { if (it > 15) { ok = 1; break; } }
+      else {
       if (comp < B.qp_tol * fmax(1.0, fabs(obj)) && resid_fac * R0 < 1e-7) { ok = 1; break; }
       if (it > 1 && resid_fac * R0 < 1e-9 * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }
+      }
       const double tau = sigma * comp;
       OCP_T(tp_r0);
       // ================= row pass 1: weights of every row for this iteration
       // box rows -> diagonal and gradient contribution per (stage, column): the two sides of a column sit in lanes l, l ^ 16
       // (no branches around the slots: the ten independent chains interleave; unused slots carry a benign state and are masked)
+      const int l1 = fresh_lane();
+      double* const dgp = Dg + (l1 >> 5) * 16 + (l1 & 15); double* const gdp = dgp + N * 16;
+      const bool side0 = ((l1 >> 4) & 1) == 0; const double sg1 = side0 ? 1.0 : -1.0; const int par1 = l1 >> 5;
 #pragma unroll
-      for (int k0 = 0; k0 < NSL; k0 += OC_GRP) {
+      for (int k0 = 0; k0 < (((OC_ABL) & 2) ? 0 : NSL); k0 += OC_GRP) {
         if (2 * k0 < N) {   // wave-uniform; a basic block per group keeps the live ranges short
 #pragma unroll
           for (int k = k0; k < k0 + OC_GRP && k < NSL; ++k) {
-            const int i = 2 * k + par;
+            const int i = 2 * k + par1;
             const bool act = (bact >> k) & 1u;
             double w, lk; row_weight(bs[k], bl[k], bt[k], false, 0.0, tau, w, lk);
-            w = act ? w : 0.0; lk = act ? lk * bsgn : 0.0;
+            w = act ? w : 0.0; lk = act ? lk * sg1 : 0.0;
             w = sum_xor16(w); lk = sum_xor16(lk);
-            if (side == 0 && i < N) { Dg[i * 16 + lc] = w; Gd[i * 16 + lc] = lk; }
+            if (side0 && i < N) { dgp[k * 32] = w; gdp[k * 32] = lk; }   // row 2 k + par, column lc: one base, the slot as immediate offset
           }
         }
       }
 #pragma unroll
-      for (int q = 0; q < OC_GSLOTS; ++q) {
-        const int r = q * 64 + tid;
+      for (int q = 0; q < (((OC_ABL) & 4) ? 0 : OC_GSLOTS); ++q) {
+        const int r = q * 64 + l1;
         const bool soft = ((gflag >> q) & 1u) != 0u;
         double w, lk; row_weight(gs_[q], gl_[q], gt_[q], soft, aqs, tau, w, lk);
         const double isw = frsq(w);
@@ -396,16 +438,17 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
           };
           // the first eight rows (most stages have fewer) as straight-line code that the scheduler can spread over the
           // elimination of the previous stage; the rest in a loop
-          kblock(rb); kblock(rb + 4);
-          for (int r0 = rb + 8; r0 < re; r0 += 4) kblock(r0);
+          if (!((OC_ABL) & 8)) { kblock(rb); kblock(rb + 4);
+          for (int r0 = rb + 8; r0 < re; r0 += 4) kblock(r0); }
           racc = sum_xor16(racc); racc = sum_xor32(racc);
+          const int lp = fresh_lane(), lcp = lp & 15, lgp = lp >> 4;
           {
-            const double dd = lc < NZ ? 2.0 * Wd[lc] + Dg[j * 16 + lc] : 0.0;
+            const double dd = lcp < NZ ? 2.0 * Wd[lcp] + Dg[j * 16 + lcp] : 0.0;
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) if (lg + 4 * rg == lc) acc[rg] += dd;
+            for (int rg = 0; rg < 4; ++rg) if (lgp + 4 * rg == lcp) acc[rg] += dd;
           }
-          rrc = lc < NZ ? racc + Gd[j * 16 + lc] + 2.0 * Wd[lc] * (Z[j * 16 + lc] - rfn) : 0.0;
-          if (j > 0 && lc < NZ) rfn = Rf[(j - 1) * NZ + lc];
+          rrc = lcp < NZ ? racc + Gd[j * 16 + lcp] + 2.0 * Wd[lcp] * (Z[j * 16 + lcp] - rfn) : 0.0;
+          if (j > 0 && lcp < NZ) rfn = Rf[(j - 1) * NZ + lcp];
           if (it == 1) rmax = fmax(rmax, fabs(rrc));
         };
         d4_t accA; double rrA;
@@ -421,13 +464,13 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
           OCP_T(tp_s1); OCP_ACC(2, tp_s0, tp_s1);
           d4_t accT = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int kb = 0; kb < KB; ++kb) accT = __builtin_amdgcn_mfma_f64_16x16x4f64(Pd[kb], abr[kb], accT, 0, 0, 0);
+          for (int kb = 0; kb < (((OC_ABL) & 16) ? 0 : KB); ++kb) accT = __builtin_amdgcn_mfma_f64_16x16x4f64(Pd[kb], abr[kb], accT, 0, 0, 0);
 #pragma unroll
-          for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(abr[kb], accT[kb], acc, 0, 0, 0);
+          for (int kb = 0; kb < (((OC_ABL) & 16) ? 0 : KB); ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(abr[kb], accT[kb], acc, 0, 0, 0);
           double part = 0.0;
 #pragma unroll
-          for (int kb = 0; kb < KB; ++kb) part += abr[kb] * __shfl(pcol, 4 * kb + lg);
-          part = sum_xor16(part); part = sum_xor32(part);
+          for (int kb = 0; kb < (((OC_ABL) & 32) ? 0 : KB); ++kb) part += abr[kb] * __shfl(pcol, 4 * kb + lg);
+          if (!((OC_ABL) & 32)) { part = sum_xor16(part); part = sum_xor32(part); }
           const double svc = rrc + part;
           const double own = acc[RU];
           OCP_T(tp_s2); OCP_ACC(3, tp_s1, tp_s2);
@@ -438,6 +481,10 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
 #pragma unroll
             for (int q2 = 0; q2 <= q; ++q2) Lm[q][q2] = readlane_d(own, (GU0 + q) * 16 + NX + q2);
           }
+          if ((OC_ABL) & 64) {
+#pragma unroll
+            for (int a = 0; a < NU; ++a) { dvec[a] = 1.0; dinv[a] = 1.0; }
+          } else
 #pragma unroll
           for (int a = 0; a < NU; ++a) {
 #pragma unroll
@@ -459,7 +506,7 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
           for (int a = 0; a < NU; ++a) {
             double v = col[a], w2 = su[a];
 #pragma unroll
-            for (int q = 0; q < a; ++q) { v -= Lm[a][q] * xk[q]; w2 -= Lm[a][q] * kk[q]; }
+            for (int q = 0; q < (((OC_ABL) & 64) ? 0 : a); ++q) { v -= Lm[a][q] * xk[q]; w2 -= Lm[a][q] * kk[q]; }
             xk[a] = v; kk[a] = w2;
           }
 #pragma unroll
@@ -468,7 +515,7 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
           for (int a = NU - 1; a >= 0; --a) {
             double v = xk[a], w2 = kk[a];
 #pragma unroll
-            for (int q = a + 1; q < NU; ++q) { v -= Lm[q][a] * xk[q]; w2 -= Lm[q][a] * kk[q]; }
+            for (int q = (((OC_ABL) & 64) ? NU : a + 1); q < NU; ++q) { v -= Lm[q][a] * xk[q]; w2 -= Lm[q][a] * kk[q]; }
             xk[a] = v; kk[a] = w2;
           }
           OCP_T(tp_s4); OCP_ACC(5, tp_s3, tp_s4);
@@ -498,34 +545,36 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
       {
         // no branch inside the stage loop (the memory counters stay exact): the 2 NSL - 1 stages always run, the ones behind
         // the horizon on clamped addresses, and write rows of the step buffer that nobody reads
-        auto kload = [&](int i) { const int ic = i < N - 2 ? i : N - 2; return KGs[ic * 64 + tid]; };
+        const int lf = fresh_lane(), lcf = lf & 15, lgf = lf >> 4;
+        const bool gownf = lgf < NU && lcf <= NX;
+        auto kload = [&](int i) { const int ic = i < N - 2 ? i : N - 2; return KGs[ic * 64 + lf]; };
         double kring[OC_PF];
 #pragma unroll
         for (int i = 0; i < OC_PF; ++i) kring[i] = kload(OC_KL0 + i);
-        if (tid < 16) dZ[tid] = 0.0;
+        if (lf < 16) dZ[lf] = 0.0;
         // [A B] row of this lane, rebuilt from a value of this iteration so that it is not kept in registers across the backward sweep
         const double tsl = fma(0.0, tau, ts);
         double ca[3], cb;
-        { const int k3 = tid % 3;
+        { const int k3 = lf % 3;
 #pragma unroll
           for (int m = 0; m < 3; ++m) { int d = m - k3; ca[m] = d < 0 ? 0.0 : (d == 0 ? 1.0 : (d == 1 ? tsl : 0.5 * tsl * tsl)); }
           cb = k3 == 0 ? tsl * tsl * tsl / 6.0 : (k3 == 1 ? 0.5 * tsl * tsl : tsl); }
-        const int chs = tid < NX ? tid / 3 : 0, q0 = 3 * chs;
+        const int chs = lf < NX ? lf / 3 : 0, q0 = 3 * chs;
         OC_WAVE_SYNC();
 #pragma unroll
-        for (int i = 0; i < 2 * NSL - 1; ++i) {
+        for (int i = 0; i < (((OC_ABL) & 128) ? 0 : 2 * NSL - 1); ++i) {
           double kq;
-          if (i < OC_KL0) kq = KL0[i * 64 + tid];
+          if (i < OC_KL0) kq = KL0[i * 64 + lf];
           else { kq = kring[(i - OC_KL0) % OC_PF]; kring[(i - OC_KL0) % OC_PF] = kload(i + OC_PF); }
-          const double xq = lc < NX ? dZ[i * 16 + lc] : 1.0;
-          double pu = gown ? -kq * xq : 0.0;   // (a select: the entries nobody owns were never written)
+          const double xq = lcf < NX ? dZ[i * 16 + lcf] : 1.0;
+          double pu = gownf ? -kq * xq : 0.0;   // (a select: the entries nobody owns were never written)
           pu += dpp_mov<0xB1>(pu); pu += dpp_mov<0x4E>(pu); pu += dpp_mov<0x141>(pu); pu += dpp_mov<0x140>(pu);   // sum over the row
-          if (lc == 0 && lg < NU) dZ[i * 16 + NX + lg] = pu;
+          if (lcf == 0 && lgf < NU) dZ[i * 16 + NX + lgf] = pu;
           OC_WAVE_SYNC();
           {
             const double* x = dZ + i * 16;
             const double xn = ca[0] * x[q0] + ca[1] * x[q0 + 1] + ca[2] * x[q0 + 2] + cb * x[NX + chs];
-            if (tid < NX) dZ[(i + 1) * 16 + tid] = xn;
+            if (lf < NX) dZ[(i + 1) * 16 + lf] = xn;
           }
           OC_WAVE_SYNC();
           __builtin_amdgcn_sched_barrier(0);
@@ -536,14 +585,16 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
       OCP_T(tp_f1); OCP_ACC(7, tp_f0, tp_f1);
       // ================= step length: ratio test over all rows
       double rinv = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      const int l2 = fresh_lane();
+      const double* const dzp = dZ + (l2 >> 5) * 16 + (l2 & 15);   // step of the box rows of this lane: row 2 k + par at offset 32 k
+      const double sg2 = ((l2 >> 4) & 1) ? -1.0 : 1.0;
 #pragma unroll
-      for (int k0 = 0; k0 < NSL; k0 += OC_GRP) {
+      for (int k0 = 0; k0 < (((OC_ABL) & 256) ? 0 : NSL); k0 += OC_GRP) {
         if (2 * k0 < N) {
 #pragma unroll
           for (int k = k0; k < k0 + OC_GRP && k < NSL; ++k) {
-            const int i = 2 * k + par;
             const bool act = (bact >> k) & 1u;
-            const double s = bs[k], lam = bl[k], t = bt[k], gd = act ? bsgn * dZ[i * 16 + lc] : 0.0;
+            const double s = bs[k], lam = bl[k], t = bt[k], gd = act ? sg2 * dzp[k * 32] : 0.0;
             double ds, dl, dt; row_step(s, lam, t, 0.0, gd, tau, ds, dl, dt);
             const double mu = RHO_EL - lam;
             const double rr_ = fmax(fmax(-ds * __builtin_amdgcn_rcp(s), -dl * __builtin_amdgcn_rcp(lam)), fmax(-dt * __builtin_amdgcn_rcp(t), dl * __builtin_amdgcn_rcp(mu)));
@@ -555,7 +606,7 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
       }
 #pragma unroll
       for (int q = 0; q < OC_GSLOTS; ++q) {
-        const int r = q * 64 + tid;
+        const int r = q * 64 + l2;
         const bool used = ((gflag >> (8 + q)) & 1u) != 0u, soft = ((gflag >> q) & 1u) != 0u;
         double gd = 0.0;
         if (used) {
@@ -584,15 +635,17 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
       OCP_T(tp_f2); OCP_ACC(8, tp_f1, tp_f2);
       // ================= update
       double tnew = 0.0;
-      for (int k = tid; k < N * 16; k += 64) Z[k] += alpha * dZ[k];
+      const int l3 = fresh_lane();
+      for (int k = l3; k < N * 16; k += 64) Z[k] += alpha * dZ[k];
+      const double* const dzq = dZ + (l3 >> 5) * 16 + (l3 & 15);
+      const double sg3 = ((l3 >> 4) & 1) ? -1.0 : 1.0;
 #pragma unroll
-      for (int k0 = 0; k0 < NSL; k0 += OC_GRP) {
+      for (int k0 = 0; k0 < (((OC_ABL) & 512) ? 0 : NSL); k0 += OC_GRP) {
         if (2 * k0 < N) {
 #pragma unroll
           for (int k = k0; k < k0 + OC_GRP && k < NSL; ++k) {
-            const int i = 2 * k + par;
             const bool act = (bact >> k) & 1u;
-            const double s = bs[k], lam = bl[k], t = bt[k], gd = act ? bsgn * dZ[i * 16 + lc] : 0.0;
+            const double s = bs[k], lam = bl[k], t = bt[k], gd = act ? sg3 * dzq[k * 32] : 0.0;
             double ds, dl, dt; row_step(s, lam, t, 0.0, gd, tau, ds, dl, dt);
             const double al = act ? alpha : 0.0;
             bs[k] = s + al * ds; bl[k] = lam + al * dl; bt[k] = t + al * dt;
@@ -614,7 +667,7 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
       sigma = fmin(QP_SIGMA_HI, fmax(QP_SIGMA_LO, 1.0 - alpha));
       OC_WAVE_SYNC();
       OCP_T(tp_f3); OCP_ACC(9, tp_f2, tp_f3);
-      if (alpha < 1e-12) break;
+      if (!(OC_ABL) && alpha < 1e-12) break;
     }
     // ---- final measures: worst elastic violation, slack cost.  Every elastic row keeps g.z + s - t = rhs along the whole
     // iteration (feasible start, ds - dt = -g.dz), so its residual rhs - g.z is s - t

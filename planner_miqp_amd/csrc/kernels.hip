@@ -473,8 +473,8 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   if (tid == 0) sh_node = atomicAdd(B.work_counter, 1);
   __syncthreads();
   if (sh_node >= nbatch) break;
-  const int node = B.ovf_mode ? B.ovf_list[sh_node] : sh_node;
-  const int inst = B.batch_inst[node];
+  const int node = __builtin_amdgcn_readfirstlane(B.ovf_mode ? B.ovf_list[sh_node] : sh_node);   // wave-uniform: addressed from SGPRs
+  const int inst = __builtin_amdgcn_readfirstlane(B.batch_inst[node]);
   const double* D = B.inst_d + (size_t)inst * Y.dstride;
   const int* T = B.inst_i + (size_t)inst * Y.istride;
   const double ts = D[Y.d_glob + 7];

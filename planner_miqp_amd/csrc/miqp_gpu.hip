@@ -281,8 +281,10 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr) 
     size_t l = ipm_lds_bytes(Y); int per = (int)std::max<size_t>(1, std::min<size_t>(4 * (Y.C <= 2 ? MIQP_IPM_WPE : 1), (160 * 1024) / std::max<size_t>(l + 8, 1))); X.ipm_grid_max = cus * per;
     // on-chip kernel: up to two cars, horizon within its register slots; 2 wavefronts per SIMD, as many as its LDS admits
     X.oc_grid = 0;
-    if (Y.C <= 2 && Y.N <= 2 * OC_NSL && !std::getenv("MIQP_IPM_V1")) {
-      size_t lo = (size_t)oc_lds_layout(Y.N, Y.fixlen).total + 16;
+    const OcLds ol = oc_lds_layout(Y.N, Y.fixlen);
+    const size_t bitmap_b = (size_t)((Y.N * Y.NSLOT + 63) / 64) * 10 + 16;   // decode bitmap + prefix inside the scratch region
+    if (Y.C <= 2 && Y.N <= 2 * OC_NSL && bitmap_b <= (size_t)(ol.r - ol.u) && !std::getenv("MIQP_IPM_V1")) {
+      size_t lo = (size_t)ol.total + 16;
       int perc = (int)std::min<size_t>(8, (160 * 1024) / lo);
       if (perc >= 1) X.oc_grid = cus * perc;
     }
@@ -743,28 +745,37 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     launch_ipm_batch(X, B, bc, st);
     HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
     nev += 2;
+    if (bc == X.batch_cap) {   // MIQP_REPLAY=k (diagnostic): the first full batch is solved k more times under a timer - the kernels
+      static int replay = std::getenv("MIQP_REPLAY") ? std::atoi(std::getenv("MIQP_REPLAY")) : 0;   // only read and write batch slots
+      if (replay > 0) {
+        hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+        HIP_OK(hipEventRecord(e0, st));
+        for (int r = 0; r < replay; ++r) launch_ipm_batch(X, B, bc, st);
+        HIP_OK(hipEventRecord(e1, st)); HIP_OK(hipStreamSynchronize(st));
+        float ms = 0; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<int> its(bc); HIP_OK(hipMemcpy(its.data(), B.batch_it, (size_t)bc * 4, hipMemcpyDeviceToHost));
+        long long tot = 0; for (int v : its) tot += v;
+        std::fprintf(stderr, "[miqp_gpu replay] %d nodes, %lld node-iterations: %.3f ms per pass, %.1f ns per node-iteration\n", bc, tot, ms / replay, 1e6 * ms / replay / (double)tot);
 #ifdef MIQP_ABLATE
-    if (bc == X.batch_cap) {   // cost map: the same full batch replayed with parts of the kernel switched off
-      static bool done_abl = false;
-      if (!done_abl) {
-        done_abl = true;
-        const int masks[] = {256, 257, 258, 260, 264, 272, 288, 320, 384, 256 + 255, 256 + 255 + 1024, 256 + 255 + 2048, 256 + 255 + 1024 + 2048, 512};
-        for (int mk : masks) {
-          DevBuf Ba = B; Ba.abl = mk; Ba.use_cutoff = 0;
-          hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
-          int gsz = std::min(bc, X.ipm_grid_max);
-          launch_ipm<2>(Ba, gsz, l_ipm, st);
-          HIP_OK(hipEventRecord(e0, st));
-          for (int r = 0; r < 3; ++r) launch_ipm<2>(Ba, gsz, l_ipm, st);
-          HIP_OK(hipEventRecord(e1, st)); HIP_OK(hipStreamSynchronize(st));
-          float ms = 0; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
-          std::fprintf(stderr, "[miqp_gpu ablate] mask %3d: %.3f ms per launch of %d nodes x 20 iterations = %.2f us per 1000 node-iterations\n", mk, ms / 3, bc, 1e3 * ms / 3 / (bc * 20.0) * 1e3);
+        if (X.oc_grid > 0 && Y.C == 2) {   // cost map of the on-chip kernel: the same batch, 15 iterations per node, parts switched off
+          const size_t l_oc = (size_t)oc_lds_layout(Y.N, Y.fixlen).total;
+          auto run = [&](auto kern, int mask) {
+            HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_oc));
+            auto once = [&] { (void)hipMemsetAsync(B.work_counter, 0, 4, st); (void)hipMemsetAsync(B.ovf_count, 0, 4, st); hipLaunchKernelGGL(kern, dim3(std::min(bc, X.oc_grid)), dim3(64), l_oc, st, B); };
+            once(); HIP_OK(hipEventRecord(e0, st)); for (int r = 0; r < 3; ++r) once(); HIP_OK(hipEventRecord(e1, st)); HIP_OK(hipStreamSynchronize(st));
+            float m2 = 0; HIP_OK(hipEventElapsedTime(&m2, e0, e1));
+            std::fprintf(stderr, "[miqp_gpu ablate] mask %4d: %.3f ms per pass of %d nodes x 15 iterations = %.1f ns per node-iteration\n", mask, m2 / 3, bc, 1e6 * m2 / 3 / (bc * 15.0));
+            return true;
+          };
+          run(ipm_onchip_kernel<2, OC_NSL, 1>, 1); run(ipm_onchip_kernel<2, OC_NSL, 3>, 3); run(ipm_onchip_kernel<2, OC_NSL, 5>, 5); run(ipm_onchip_kernel<2, OC_NSL, 9>, 9);
+          run(ipm_onchip_kernel<2, OC_NSL, 17>, 17); run(ipm_onchip_kernel<2, OC_NSL, 33>, 33); run(ipm_onchip_kernel<2, OC_NSL, 65>, 65); run(ipm_onchip_kernel<2, OC_NSL, 129>, 129);
+          run(ipm_onchip_kernel<2, OC_NSL, 257>, 257); run(ipm_onchip_kernel<2, OC_NSL, 513>, 513); run(ipm_onchip_kernel<2, OC_NSL, 1023>, 1023);
+          launch_ipm_batch(X, B, bc, st);   // the replays clobbered the batch results: solve the real batch again
         }
-        // the replay clobbered the batch results: solve the real batch again below
-        launch_ipm<2>(B, std::min(bc, X.ipm_grid_max), l_ipm, st);
+#endif
+        replay = 0;
       }
     }
-#endif
     if (std::getenv("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d ipm (%d nodes): %s\n", rounds, bc, hipGetErrorString(e_)); }
     { DevBuf Be = B; Be.open_sel = 1 - (rounds & 1); launch_eval_c(Y.C, Be, bc, l_eval, st); }
     if (std::getenv("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d eval: %s\n", rounds, hipGetErrorString(e_)); }
