@@ -47,6 +47,9 @@ __host__ __device__ inline OcLds oc_lds_layout(int N, int fixlen) {
 #ifdef MIQP_PROFILE
 #define OCP_T(var) const long long var = clock64()
 #define OCP_ACC(k, t0, t1) ocp_[k] += (unsigned long long)((t1) - (t0))
+#elif defined(MIQP_ISA_MARKS)   // tools/isa_report.py: phase boundaries as comments in the assembly
+#define OCP_T(var) asm volatile("; OCMARK " #var)
+#define OCP_ACC(k, t0, t1)
 #else
 #define OCP_T(var)
 #define OCP_ACC(k, t0, t1)
