@@ -94,6 +94,14 @@ struct DevBuf {
   // eval appends children to that other one); unsorted, selection by radix select on the 64-bit key
   double* open_bound; int* open_node; int* open_depth; int* open_count; int open_cap; int open_sel;
   unsigned long long* open_key;
+  // second tier of the open list ("far"): single-buffered, append-only between refills.  The two-buffer list above holds the
+  // nodes with the lowest bounds (everything <= near_thr), which is all that best-bound selection has to scan and copy every
+  // round; children with a bound above near_thr are appended here and come back, lowest bounds first, when the near list
+  // runs low (select_kernel).  Sized from the 288 GB of HBM: best-bound order survives frontiers of millions of nodes.
+  double* far_bound; int* far_node; int* far_depth; int* far_count; int far_cap;
+  unsigned long long* far_minkey;   // orderable(min bound) over the far entries (atomicMin on insert, recomputed by a refill)
+  double* near_thr;                 // children with bound > near_thr go to the far tier (1e300: tier unused so far)
+  int* inst_mode;                   // 1: the round dives (depth first): children stay in the near list whatever their bound
   // per instance state
   unsigned long long* inc_key;   // orderable(objective) with the batch slot in the low 20 bits
   unsigned long long* inc_seen;  // key whose solution has been copied to inc_fix / inc_Z
@@ -1210,6 +1218,10 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   __syncthreads();
   const double viol = B.batch_viol[node];
   const int okq = B.batch_ok[node];
+  if (B.stats && lane == 0) {   // diagnostic (MIQP_STATS): outcome of the node and the iterations it took
+    const int oc_ = okq == 2 ? 1 : (viol > FEAS_TOL ? 0 : (okq != 1 ? 2 : 3));   // infeasible, cut off, not converged, solved
+    atomicAdd(&B.stats[32 + oc_], 1ull); atomicAdd(&B.stats[36 + oc_], (unsigned long long)B.batch_it[node]);
+  }
   if (viol > FEAS_TOL || okq != 1) { FREE_NODE(); return; }  // infeasible relaxation, or abandoned at the incumbent cutoff
   // soft obstacles that this node ignores cost WEIGHTS_SLACK_OBSTACLE each (obstacle_environment_constraints.mod:85-91)
   int nign = 0;
@@ -1220,7 +1232,8 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   // optimum of the relaxation by the remaining complementarity)
   const double objlb = obj - fmax(0.0, B.batch_bound[node]);
   const double inc_now = fmin(inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]), B.inc_ext[inst]);   // own incumbent or the one another rank of a tree split found
-  if (inc_now < 1e300 && !(objlb < inc_now - 1e-12 * fabs(inc_now))) { FREE_NODE(); return; }  // bound not better than the incumbent
+  if (inc_now < 1e300 && !(objlb < inc_now - 1e-12 * fabs(inc_now))) { if (B.stats && lane == 0) atomicAdd(&B.stats[40], 1ull); FREE_NODE(); return; }  // bound not better than the incumbent
+  if (B.stats && lane == 0 && inc_now < 1e300 && (inc_now - objlb) <= B.inst_gap[inst] * (1e-10 + fabs(inc_now))) atomicAdd(&B.stats[41], 1ull);   // (children will be pruned by the gap)
   const double tol = FEAS_TOL;
   const int NCI = C * (N - 1);
   // ---------------- phase R: region alternatives per (c, i)
@@ -1375,6 +1388,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
   __syncthreads();
   if (best == 0x7FFFFFFF) {
+    if (B.stats && lane == 0) atomicAdd(&B.stats[42], 1ull);
     // integer feasible: candidate incumbent.  The winner of the 64-bit atomicMin owns the low 20 bits (batch slot).
     signed char* dst = B.batch_comp + (size_t)node * Y.fixlen;
     for (int k = lane; k < Y.fixlen; k += 64) dst[k] = comp[k];
@@ -1461,8 +1475,17 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     // of the rounding and, when feasible, the first incumbent two rounds after the root instead of one dive level per round
     if (!(inc_now < 1e300) && nalt < 63 && (B.seq_kinds & 0x4000000) == 0) { ck[nalt] = -2; ca[nalt] = 0; nalt++; }
     fam[0] = base; fam[1] = stride; fam[2] = jlo; fam[3] = jhi;
-    int ob = atomicAdd(&B.open_count[inst], nalt);
-    bool okalloc = ob + nalt <= B.open_cap;
+    // tier of the children (they share the parent's bound): above the near threshold they wait in the far tier
+    const double cb_ = objlb - B.inst_const[inst];
+    int tofar = 0, ob = 0;
+    if (B.far_cap > 0 && !B.inst_mode[inst] && cb_ > B.near_thr[inst]) {
+      ob = atomicAdd(&B.far_count[inst], nalt);
+      if (ob + nalt <= B.far_cap) { tofar = 1; atomicMin(&B.far_minkey[inst], d2key(cb_)); }
+      else   // tier full: the reserved slots below the capacity become dead entries (the count stays clamped until the next refill)
+        for (int q = ob; q < ob + nalt && q < B.far_cap; ++q) { B.far_bound[(size_t)inst * B.far_cap + q] = 1e300; B.far_node[(size_t)inst * B.far_cap + q] = -1; }
+    }
+    if (!tofar) ob = atomicAdd(&B.open_count[inst], nalt);
+    bool okalloc = tofar || ob + nalt <= B.open_cap;
     if (okalloc) {
       unsigned int h = atomicAdd(B.free_head, (unsigned int)nalt);
       if ((int)(*B.free_limit - h) >= nalt) {          // recycled records
@@ -1473,8 +1496,14 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         for (int a = 0; a < nalt; ++a) slots[a] = nb + a;
       }
     }
-    if (!okalloc) { atomicOr(&B.inst_flags[inst], 1); nalt = 0; }
-    sh_base[1] = ob; sh_base[2] = nalt;
+    if (!okalloc) {   // list or record pool exhausted: the instance is flagged incomplete; the reserved list slots become dead entries
+      atomicOr(&B.inst_flags[inst], 1);
+      if (tofar) for (int q = ob; q < ob + nalt; ++q) { B.far_bound[(size_t)inst * B.far_cap + q] = 1e300; B.far_node[(size_t)inst * B.far_cap + q] = -1; }
+      else for (int q = ob; q < ob + nalt && q < B.open_cap; ++q) { size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + q; B.open_bound[oi] = 1e300; B.open_node[oi] = -1; B.open_depth[oi] = 0; }
+      nalt = 0;
+    }
+    if (B.stats && nalt > 0) { atomicAdd(&B.stats[43], 1ull); atomicAdd(&B.stats[44], (unsigned long long)nalt); atomicAdd(&B.stats[48 + chosen.kind], 1ull); atomicAdd(&B.stats[52 + chosen.kind], (unsigned long long)nalt); }
+    sh_base[0] = tofar; sh_base[1] = ob; sh_base[2] = nalt;
   }
   __syncthreads();
   nalt = sh_base[2];
@@ -1509,11 +1538,16 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
 #endif
     }
     if (lane < nalt) {
-      size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + ob + lane;
       // depth word: (tree depth << 6) | preference among siblings (child_inf first) - used by the dive ordering
       int pd = B.batch_depth[node] >> 6;
-      B.open_bound[oi] = objlb - B.inst_const[inst]; B.open_node[oi] = slots[lane];
-      B.open_depth[oi] = ck[lane] == -2 ? (((pd + 2) << 6) | 63) : (((pd + 1) << 6) | (63 - lane));   // the probe is dived into first
+      const int dw = ck[lane] == -2 ? (((pd + 2) << 6) | 63) : (((pd + 1) << 6) | (63 - lane));   // the probe is dived into first
+      if (sh_base[0]) {
+        size_t oi = (size_t)inst * B.far_cap + ob + lane;
+        B.far_bound[oi] = objlb - B.inst_const[inst]; B.far_node[oi] = slots[lane]; B.far_depth[oi] = dw;
+      } else {
+        size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + ob + lane;
+        B.open_bound[oi] = objlb - B.inst_const[inst]; B.open_node[oi] = slots[lane]; B.open_depth[oi] = dw;
+      }
     }
   }
   FREE_NODE();
@@ -1528,14 +1562,25 @@ constexpr int SEL_LOWSHIFT = 24;   // the radix select resolves the top 40 key b
 // One workgroup per instance.  Reads the open list from buffer `B.open_sel`, prunes it against the incumbent,
 // selects the `take` smallest keys by an MSB-first 8-bit radix select (no full sort, lists live in HBM/L2),
 // emits them into the round's batch and writes the survivors to the other buffer.
+// position of a lane's item in a list that the whole workgroup appends to: one atomic per wavefront
+__device__ inline int wave_append(int* counter, bool pred) {
+  const unsigned long long mk = __ballot(pred);
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == (int)(__ffsll((long long)mk) - 1)) base = atomicAdd(counter, __popcll(mk));
+  base = __shfl(base, mk ? (int)(__ffsll((long long)mk) - 1) : 0);
+  return base + __popcll(mk & ((1ull << lane) - 1ull));
+}
+
 __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round) {
   const Layout& Y = B.Y;
   const int inst = blockIdx.x, tid = threadIdx.x;
   const int cap = B.open_cap;
-  __shared__ int sh_take, sh_base, sh_m, sh_keep, sh_pick, sh_ties;
+  __shared__ int sh_take, sh_base, sh_m, sh_keep, sh_pick, sh_ties, sh_w, sh_mv, sh_all;
   __shared__ double sh_inc;
-  __shared__ unsigned int hist[256];
-  __shared__ unsigned long long sh_prefix, sh_thr;
+  __shared__ unsigned int hist[256], dhist[256];
+  __shared__ int sh_dkeep;
+  __shared__ unsigned long long sh_prefix, sh_thr, sh_fmin;
   __shared__ double red[SEL_THREADS];
   if (B.inst_done[inst]) return;
   const size_t src = ((size_t)B.open_sel * B.n_inst + inst) * cap, dst = ((size_t)(1 - B.open_sel) * B.n_inst + inst) * cap;
@@ -1562,36 +1607,146 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   const double cst = B.inst_const[inst];
   const double gap = B.inst_gap[inst];
   int n = B.open_count[inst]; if (n > cap) n = cap;
+  auto prunable = [&](double b) { return inc < 1e300 && (inc - (b + cst)) <= gap * (1e-10 + fabs(inc)); };   // cannot improve the incumbent by more than the gap
+  // MSB-first 8-bit radix select on the resolved key bits: leaves in sh_prefix the smallest T with count(key <= T) >= need
+  // (sh_all = 1 instead when fewer than `need` keys exist) and returns how many keys equal to T are still needed
+  auto radix = [&](auto keyf, int cnt, int need) -> int {
+    if (tid == 0) { sh_prefix = 0ull; sh_all = 0; }
+    __syncthreads();
+    for (int shift = 56; shift >= SEL_LOWSHIFT; shift -= 8) {
+      if (tid < 256) hist[tid] = 0u;
+      __syncthreads();
+      const unsigned long long prefix = sh_prefix;
+      const unsigned long long himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+      for (int k = tid; k < cnt; k += SEL_THREADS) {
+        unsigned long long key = keyf(k);
+        if (key != ~0ull && (key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255ull], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned int cum = 0; int bin = 0;
+        for (bin = 0; bin < 256; ++bin) { if (cum + hist[bin] >= (unsigned int)need) break; cum += hist[bin]; }
+        if (bin > 255) { bin = 255; if (shift == 56) sh_all = 1; }
+        sh_prefix = prefix | ((unsigned long long)bin << shift);
+        sh_pick = need - (int)cum;   // how many of the keys with this prefix are still needed
+      }
+      __syncthreads();
+      need = sh_pick;
+      if (sh_all) break;
+    }
+    __syncthreads();
+    return need;
+  };
+  const unsigned long long lowmask = (1ull << SEL_LOWSHIFT) - 1ull;
+  const int keep = cap / 8, spill_at = cap / 4;
+  const size_t fb = (size_t)inst * (size_t)B.far_cap;
+  int fc = B.far_cap > 0 ? B.far_count[inst] : 0; if (fc > B.far_cap) fc = B.far_cap;
   // node selection: best bound, interleaved with dives (deepest first) while no incumbent exists, on every 4th
-  // round afterwards and whenever the list is more than half full (a depth-first frontier stays small);
-  // the order changes how fast incumbents appear, not what is proven
+  // round afterwards and whenever the list is more than half full or the record pool is nearly exhausted (a depth-first
+  // frontier stays small); the order changes how fast incumbents appear, not what is proven
   const int dive_every = (B.seq_kinds >> 18) & 3;   // experiment switch: 0 every 4th round, 1 never, 2 every 8th, 3 every 2nd
   const bool periodic = dive_every == 0 ? (round & 3) == 3 : (dive_every == 1 ? false : (dive_every == 2 ? (round & 7) == 7 : (round & 1) == 1));
-  const bool dive = !(inc < 1e300) || periodic || n > cap / 2;
-  // ---- pass 1: prune, keys, lower bound
+  bool pool_tight;
+  { const int pc = *B.pool_count; const long long live = (long long)(pc < B.pool_cap ? pc : B.pool_cap) - (long long)(int)(*B.free_tail - *B.free_head);
+    pool_tight = live > (long long)B.pool_cap / 10 * 9; }
+  const bool dive = !(inc < 1e300) || periodic || n > cap / 2 || pool_tight;
+  auto order_key = [&](double b, int dp) -> unsigned long long {
+    // best bound; experiment switch (bits 24..25 of seq_kinds): deeper nodes first among nearly equal bounds
+    const int dbias = (B.seq_kinds >> 24) & 3;
+    const double bb = dbias ? b - (dbias == 1 ? 1e-4 : (dbias == 2 ? 1e-3 : 1e-2)) * fabs(b) * (double)(dp >> 6) : b;
+    const double kv = dive ? (-(double)dp * 1e9 + fmax(b, -1e8)) : fmax(bb, -1e300);
+    const unsigned long long key = d2key(kv); return key == ~0ull ? ~0ull - 1 : key;
+  };
+  // ---- pass 1: prune, keys, lower bound, population per tree depth
+  for (int k = tid; k < 256; k += SEL_THREADS) dhist[k] = 0u;
+  __syncthreads();
   double lb = 1e300; int mloc = 0;
   for (int k = tid; k < n; k += SEL_THREADS) {
     double b = B.open_bound[src + k]; int nd = B.open_node[src + k]; int dp = B.open_depth[src + k];
-    lb = fmin(lb, b);
     unsigned long long key = ~0ull;
-    if (inc < 1e300 && (inc - (b + cst)) <= gap * (1e-10 + fabs(inc))) {  // cannot improve the incumbent by more than the gap
+    if (nd < 0) { keys[k] = key; continue; }   // dead entry (a reservation that could not be filled)
+    if (prunable(b)) {
       unsigned int q_ = atomicAdd(B.free_tail, 1u); B.free_q[q_ % (unsigned int)B.pool_cap] = nd;
     } else {
-      // best bound; experiment switch (bits 24..25 of seq_kinds): deeper nodes first among nearly equal bounds
-      const int dbias = (B.seq_kinds >> 24) & 3;
-      const double bb = dbias ? b - (dbias == 1 ? 1e-4 : (dbias == 2 ? 1e-3 : 1e-2)) * fabs(b) * (double)(dp >> 6) : b;
-      double kv = dive ? (-(double)dp * 1e9 + fmax(b, -1e8)) : fmax(bb, -1e300);
-      key = d2key(kv); if (key == ~0ull) key = ~0ull - 1;
+      lb = fmin(lb, b);
+      key = order_key(b, dp);
+      atomicAdd(&dhist[(dp >> 6) > 255 ? 255 : (dp >> 6)], 1u);
       mloc++;
     }
     keys[k] = key;
   }
+  if (mloc) atomicAdd(&sh_m, mloc);
+  __syncthreads();
+  int m = sh_m;
+  // ---- far tier: when the near list cannot fill a batch any more, the far entries with the lowest bounds come back
+  // (threshold by radix select on their bounds), the ones the incumbent prunes are dropped and the rest is compacted in
+  // place, chunk by chunk (a chunk is read completely before anything is written at or below it)
+  if (fc > 0 && m < (B.batch_cap < keep ? B.batch_cap : keep)) {
+    auto fkey = [&](int k) -> unsigned long long {
+      const double b = B.far_bound[fb + k];
+      if (B.far_node[fb + k] < 0 || prunable(b)) return ~0ull;
+      const unsigned long long key = d2key(b); return key == ~0ull ? ~0ull - 1 : key;
+    };
+    radix(fkey, fc, keep - m);
+    const unsigned long long thr = sh_all ? ~0ull : sh_prefix;
+    if (tid == 0) { sh_w = 0; sh_mv = 0; sh_fmin = ~0ull; }
+    __syncthreads();
+    int room = cap - n; if (room > cap / 2 - m) room = cap / 2 - m; if (room < 0) room = 0;
+    constexpr int PER = 4;
+    for (int c0 = 0; c0 < fc; c0 += SEL_THREADS * PER) {
+      double eb[PER]; int en[PER], ed[PER], act[PER];   // -1 nothing, 0 drop, 1 stay, 2 move to the near list
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int k = c0 + j * SEL_THREADS + tid;
+        act[j] = -1;
+        if (k < fc) {
+          eb[j] = B.far_bound[fb + k]; en[j] = B.far_node[fb + k]; ed[j] = B.far_depth[fb + k];
+          if (en[j] < 0) act[j] = -1;
+          else if (prunable(eb[j])) act[j] = 0;
+          else { unsigned long long key = d2key(eb[j]); if (key == ~0ull) key = ~0ull - 1; act[j] = ((key & ~lowmask) <= thr) ? 2 : 1; }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        if (act[j] == 0) { unsigned int q_ = atomicAdd(B.free_tail, 1u); B.free_q[q_ % (unsigned int)B.pool_cap] = en[j]; }
+        int t = wave_append(&sh_mv, act[j] == 2);
+        if (act[j] == 2) {
+          if (t < room) {
+            B.open_bound[src + n + t] = eb[j]; B.open_node[src + n + t] = en[j]; B.open_depth[src + n + t] = ed[j]; keys[n + t] = order_key(eb[j], ed[j]);
+            lb = fmin(lb, eb[j]); atomicAdd(&dhist[(ed[j] >> 6) > 255 ? 255 : (ed[j] >> 6)], 1u);
+          } else act[j] = 1;
+        }
+        int pos = wave_append(&sh_w, act[j] == 1);
+        if (act[j] == 1) { B.far_bound[fb + pos] = eb[j]; B.far_node[fb + pos] = en[j]; B.far_depth[fb + pos] = ed[j]; atomicMin(&sh_fmin, d2key(eb[j])); }
+      }
+      __syncthreads();
+    }
+    const int moved = sh_mv < room ? sh_mv : room;
+    n += moved; m += moved;
+    fc = sh_w;
+    __syncthreads();
+    if (tid == 0) {
+      B.far_count[inst] = fc; B.far_minkey[inst] = sh_fmin;
+      B.near_thr[inst] = (fc > 0 && thr != ~0ull) ? key2d(thr | lowmask) : 1e300;   // what stays behind lies above the threshold
+    }
+  }
   red[tid] = lb; __syncthreads();
   for (int s = SEL_THREADS / 2; s > 0; s >>= 1) { if (tid < s) red[tid] = fmin(red[tid], red[tid + s]); __syncthreads(); }
   lb = red[0];
-  if (mloc) atomicAdd(&sh_m, mloc);
-  __syncthreads();
-  const int m = sh_m;
+  if (fc > 0) lb = fmin(lb, key2d(B.far_minkey[inst]));   // the instance's bound covers both tiers
+  // ---- spill: a best-bound round that finds the near list long keeps the `keep` lowest keys there and moves the rest to the
+  // far tier (pass 3); from then on children above the threshold are appended to the far tier directly (eval_kernel).
+  // The deepest levels (up to keep / 2 nodes) stay whatever their bound: they are the stack of the periodic dives.
+  const bool spill = B.far_cap > 0 && !dive && m > spill_at && fc < B.far_cap;
+  unsigned long long thr_spill = ~0ull;
+  if (spill) {
+    radix([&](int k) { return keys[k]; }, n, keep);
+    thr_spill = sh_all ? ~0ull : sh_prefix;
+    if (tid == 0) { unsigned int cum = 0; int d = 255; for (; d >= 0; --d) { if (cum + dhist[d] > (unsigned int)(keep / 2)) break; cum += dhist[d]; } sh_dkeep = d + 1; }
+    __syncthreads();
+  }
+  const int dkeep = sh_dkeep;
   // Endgame focus: when only a few instances are still open, the batch is not split evenly but geometrically by gap rank
   // (1/2 to the instance closest to its proof, 1/4 to the next, ...): finishing one instance after the other brings more
   // of them below the gap before the time limit than advancing all of them at the same pace.
@@ -1627,65 +1782,62 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     int base = take > 0 ? atomicAdd(B.batch_count, take) : 0;
     if (base + take > B.batch_cap) take = B.batch_cap > base ? B.batch_cap - base : 0;
     sh_take = take; sh_base = base;
-    double lbt = (n > 0 ? lb + cst : inc);
+    double lbt = ((n > 0 || fc > 0) && lb < 1e300 ? lb + cst : inc);
     if (inc < 1e300 && lbt > inc) lbt = inc;
     B.lower_bound[inst] = lbt;
-    if (m == 0) { B.inst_done[inst] = 1; atomicSub(B.active_insts, 1); }
-    sh_prefix = 0ull; sh_thr = ~0ull;
+    if (m == 0 && fc == 0) { B.inst_done[inst] = 1; atomicSub(B.active_insts, 1); }
+    B.inst_mode[inst] = dive ? 1 : 0;
+    sh_thr = ~0ull; sh_w = fc; sh_fmin = ~0ull;
   }
   __syncthreads();
   const int take = sh_take, base = sh_base;
   // ---- radix select: smallest key value T such that count(key <= T) >= take
   if (take > 0 && take < m) {
-    int need = take;
-    for (int shift = 56; shift >= SEL_LOWSHIFT; shift -= 8) {
-      if (tid < 256) hist[tid] = 0u;
-      __syncthreads();
-      const unsigned long long prefix = sh_prefix;
-      const unsigned long long himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
-      for (int k = tid; k < n; k += SEL_THREADS) {
-        unsigned long long key = keys[k];
-        if (key != ~0ull && (key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255ull], 1u);
-      }
-      __syncthreads();
-      if (tid == 0) {
-        unsigned int cum = 0; int bin = 0;
-        for (bin = 0; bin < 256; ++bin) { if (cum + hist[bin] >= (unsigned int)need) break; cum += hist[bin]; }
-        if (bin > 255) bin = 255;
-        sh_prefix = prefix | ((unsigned long long)bin << shift);
-        sh_pick = need - (int)cum;   // how many of the keys with this prefix are still needed
-      }
-      __syncthreads();
-      need = sh_pick;
-    }
+    const int need = radix([&](int k) { return keys[k]; }, n, take);
     if (tid == 0) { sh_thr = sh_prefix; sh_ties = need; sh_pick = 0; }   // threshold on the resolved (high) bits
     __syncthreads();
   } else if (tid == 0) { sh_thr = take >= m ? ~0ull : 0ull;   /* ~0: above every masked key */ sh_ties = 0x7FFFFFFF; sh_pick = 0; }
   __syncthreads();
-  // ---- pass 3: emit the selected nodes, keep the rest
+  // ---- pass 3: emit the selected nodes, keep the rest (near list, or far tier when the round spills)
   const unsigned long long thr = sh_thr;
-  for (int k = tid; k < n; k += SEL_THREADS) {
-    unsigned long long key = keys[k];
-    if (key == ~0ull) continue;
-    double b = B.open_bound[src + k]; int nd = B.open_node[src + k]; int dp = B.open_depth[src + k];
+  for (int k0 = 0; k0 < n; k0 += SEL_THREADS) {
+    const int k = k0 + tid;
+    unsigned long long key = k < n ? keys[k] : ~0ull;
+    const bool live = key != ~0ull;
+    double b = 0.0; int nd = 0, dp = 0;
     bool pick = false;
-    if (take > 0) {
-      const unsigned long long kh = key & (~0ull << SEL_LOWSHIFT);
-      if (kh < thr) pick = true;
-      else if (kh == thr) { int t = atomicAdd(&sh_ties, -1); pick = t > 0; }
+    if (live) {
+      b = B.open_bound[src + k]; nd = B.open_node[src + k]; dp = B.open_depth[src + k];
+      if (take > 0) {
+        const unsigned long long kh = key & (~0ull << SEL_LOWSHIFT);
+        if (kh < thr) pick = true;
+        else if (kh == thr) { int t = atomicAdd(&sh_ties, -1); pick = t > 0; }
+      }
+      if (pick) {
+        int pos = atomicAdd(&sh_pick, 1);
+        if (pos < take) { B.batch_node[base + pos] = nd; B.batch_inst[base + pos] = inst; B.batch_bound[base + pos] = b; B.batch_depth[base + pos] = dp; }
+        else pick = false;
+      }
     }
-    if (pick) {
-      int pos = atomicAdd(&sh_pick, 1);
-      if (pos < take) { B.batch_node[base + pos] = nd; B.batch_inst[base + pos] = inst; B.batch_bound[base + pos] = b; B.batch_depth[base + pos] = dp; }
-      else pick = false;
+    bool tofar = live && !pick && spill && (key & ~lowmask) > thr_spill && (dp >> 6) < dkeep;
+    int fpos = wave_append(&sh_w, tofar);
+    if (tofar) {
+      if (fpos < B.far_cap) { B.far_bound[fb + fpos] = b; B.far_node[fb + fpos] = nd; B.far_depth[fb + fpos] = dp; atomicMin(&sh_fmin, d2key(b)); }
+      else tofar = false;
     }
-    if (!pick) {
-      int pos = atomicAdd(&sh_keep, 1);
-      B.open_bound[dst + pos] = b; B.open_node[dst + pos] = nd; B.open_depth[dst + pos] = dp;
-    }
+    const bool stay = live && !pick && !tofar;
+    int pos = wave_append(&sh_keep, stay);
+    if (stay) { B.open_bound[dst + pos] = b; B.open_node[dst + pos] = nd; B.open_depth[dst + pos] = dp; }
   }
   __syncthreads();
-  if (tid == 0) B.open_count[inst] = sh_keep;
+  if (tid == 0) {
+    B.open_count[inst] = sh_keep;
+    if (spill) {
+      B.far_count[inst] = sh_w < B.far_cap ? sh_w : B.far_cap;
+      if (sh_fmin != ~0ull) atomicMin(&B.far_minkey[inst], sh_fmin);
+      B.near_thr[inst] = thr_spill != ~0ull ? key2d(thr_spill | lowmask) : 1e300;
+    }
+  }
 }
 
 // makes the records freed so far available to the next eval launch

@@ -227,7 +227,7 @@ struct DevCtx {
   std::mutex mu;   // held for the whole solve: one solve at a time per device, different devices run concurrently
   bool ready = false; int device = -1;
   hipStream_t stream = nullptr;
-  Layout Y{}; int n_inst = 0, open_cap = 0, batch_cap = 0, pool_cap = 0, npr = 0, ipm_grid_max = 1024;
+  Layout Y{}; int n_inst = 0, open_cap = 0, far_cap = 0, batch_cap = 0, pool_cap = 0, npr = 0, ipm_grid_max = 1024;
   int oc_grid = 0;   // resident wavefronts of the on-chip interior point kernel (0: the shape does not qualify)
   DevBuf B{};
   std::vector<void*> allocs;
@@ -291,10 +291,15 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr) 
     if (X.oc_grid > X.ipm_grid_max) X.ipm_grid_max = X.oc_grid;   // the per-block buffers are sized for the larger grid
   }
   // node pool: live nodes are bounded by the open lists plus one round of children; processed records are recycled
-  size_t want = (size_t)n_inst * ((size_t)open_cap + (size_t)npr * 64 + 64);
   size_t free_b = 0, total_b = 0; if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
-  size_t maxrec = std::min<size_t>((size_t)48 << 30, free_b / 4) / (size_t)Y.fixlen;   // node records: up to 48 GB of the 288 GB, at most a quarter of what is free
-  X.pool_cap = (int)std::min(want, maxrec);
+  // far tier of the open lists (16 B per entry): up to 2^24 entries per instance within a tenth of the free memory
+  // (256 instances: 4 M entries each, 16 GB); MIQP_FAR_CAP overrides, 0 switches the tier off
+  { size_t fc = std::min<size_t>((size_t)1 << 24, free_b / 10 / 16 / (size_t)n_inst);
+    if (const char* e = std::getenv("MIQP_FAR_CAP")) fc = (size_t)std::max(0LL, std::atoll(e));
+    X.far_cap = fc < 4096 ? 0 : (int)fc; }
+  size_t want = (size_t)n_inst * ((size_t)open_cap + (size_t)X.far_cap + (size_t)npr * 64 + 64);
+  size_t maxrec = std::min<size_t>((size_t)64 << 30, free_b / 4) / (size_t)Y.fixlen;   // node records: up to 64 GB of the 288 GB, at most a quarter of what is free
+  X.pool_cap = (int)std::min<size_t>(std::min(want, maxrec), (size_t)0x7FFFFFF0);
   DevBuf& B = X.B; std::memset(&B, 0, sizeof(B));
   B.qp_tol = QP_TOL; B.use_cutoff = 1;
   B.seq_kinds = std::getenv("MIQP_SEQ_KINDS") ? std::atoi(std::getenv("MIQP_SEQ_KINDS")) : (5 << 8);   // plain K-way children, branching order 5 (see eval_kernel)
@@ -313,6 +318,16 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr) 
   if (!X.alloc(&B.open_depth, (size_t)2 * n_inst * open_cap)) return false;
   if (!X.alloc(&B.open_key, (size_t)n_inst * open_cap)) return false;
   if (!X.alloc(&B.open_count, n_inst)) return false;
+  B.far_cap = X.far_cap;
+  if (X.far_cap > 0) {
+    if (!X.alloc(&B.far_bound, (size_t)n_inst * X.far_cap)) return false;
+    if (!X.alloc(&B.far_node, (size_t)n_inst * X.far_cap)) return false;
+    if (!X.alloc(&B.far_depth, (size_t)n_inst * X.far_cap)) return false;
+  }
+  if (!X.alloc(&B.far_count, n_inst)) return false;
+  if (!X.alloc(&B.far_minkey, n_inst)) return false;
+  if (!X.alloc(&B.near_thr, n_inst)) return false;
+  if (!X.alloc(&B.inst_mode, n_inst)) return false;
   if (!X.alloc(&B.inc_key, n_inst)) return false;
   if (!X.alloc(&B.inc_seen, n_inst)) return false;
   if (!X.alloc(&B.inc_obj, n_inst)) return false;
@@ -345,7 +360,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr) 
   if (!X.alloc(&B.ovf_count, 1)) return false;
   if (!X.alloc(&B.ovf_list, batch_cap)) return false;
   HIP_OK(hipMemset(B.ovf_count, 0, 4));
-  if (std::getenv("MIQP_STATS")) { if (!X.alloc(&B.stats, 32)) return false; HIP_OK(hipMemset(B.stats, 0, 32 * 8)); }
+  if (std::getenv("MIQP_STATS")) { if (!X.alloc(&B.stats, 64)) return false; HIP_OK(hipMemset(B.stats, 0, 64 * 8)); }
   if (!X.alloc(&B.prof, 128)) return false;
   (void)hipMemset(B.prof, 0, 128 * 8);
   if (!X.alloc(&B.active_insts, 1)) return false;
@@ -682,12 +697,14 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemcpy2DAsync(B.open_bound, (size_t)open_cap * 8, ob.data(), (size_t)MAXR * 8, (size_t)MAXR * 8, n, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpy2DAsync(B.open_node, (size_t)open_cap * 4, on.data(), (size_t)MAXR * 4, (size_t)MAXR * 4, n, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(B.open_count, oc.data(), n * 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemsetAsync(B.far_count, 0, (size_t)n * 4, st)); HIP_OK(hipMemsetAsync(B.far_minkey, 0xFF, (size_t)n * 8, st));
+  HIP_OK(hipMemsetAsync(B.inst_mode, 0, (size_t)n * 4, st));
   HIP_OK(hipMemsetAsync(B.open_depth, 0, (size_t)2 * n * open_cap * 4, st));
   HIP_OK(hipMemsetAsync(B.inc_key, 0xFF, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inc_seen, 0xFF, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inc_fix, 0xFF, (size_t)n * Y.fixlen, st));   // no incumbent yet: every disjunction undecided
   { std::vector<double> big(n, 1e300); HIP_OK(hipMemcpyAsync(B.inc_obj, big.data(), n * 8, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(B.inc_ext, big.data(), n * 8, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(B.inc_ext, big.data(), n * 8, hipMemcpyHostToDevice, st)); HIP_OK(hipMemcpyAsync(B.near_thr, big.data(), n * 8, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(B.lower_bound, big.data(), n * 8, hipMemcpyHostToDevice, st)); HIP_OK(hipStreamSynchronize(st)); }
   HIP_OK(hipMemcpyAsync(B.inst_done, h_done.data(), n * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemsetAsync(B.inst_flags, 0, (size_t)n * 4, st));
@@ -705,7 +722,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   double tlim = 0; for (int k = 0; k < n; ++k) tlim = std::max(tlim, h_tlim[k]);
   HIP_OK(hipEventRecord(X.ev0, st));
   std::vector<int> h_done_now(n, 0); std::vector<double> h_tdone(n, -1.0);
-  size_t nev = 0; int rounds = 0; long long launched_nodes = 0;
+  size_t nev = 0; int rounds = 0, empty_rounds = 0; long long launched_nodes = 0;
   double sp_inc = 1e300, sp_lb = -1e300; int sp_owner = 0; bool sp_timeup = false, sp_finished = false;   // state of a tree split
   for (;;) {
     HIP_OK(hipMemsetAsync(B.batch_count, 0, 4, st));
@@ -736,8 +753,13 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       if (all_done || sp_timeup || gap_ok) { sp_finished = all_done || gap_ok; break; }
       if (local_done) { rounds++; continue; }   // nothing left here: keep taking part in the exchange
     } else {
-      if (bc <= 0) break;
       if (wall_s() - t0 > tlim) break;   // time limit: instances with open nodes report TIME_LIM_* below
+      if (bc <= 0) {   // an empty batch ends the search once every instance is done (a round may come up empty while a list tier is being reorganised)
+        bool all_done = true; for (int k = 0; k < n; ++k) all_done = all_done && h_done_now[k];
+        if (all_done || ++empty_rounds > 8) break;
+        rounds++; continue;
+      }
+      empty_rounds = 0;
     }
     if (bc > X.batch_cap) bc = X.batch_cap;
     if (X.ipm_ev.size() < nev + 2) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); X.ipm_ev.push_back(a); X.ipm_ev.push_back(b); }
@@ -785,8 +807,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       double lb0 = 0, io0 = 0; int oc0 = 0; unsigned long long k0 = 0;
       HIP_OK(hipMemcpyAsync(&lb0, B.lower_bound, 8, hipMemcpyDeviceToHost, st)); HIP_OK(hipMemcpyAsync(&io0, B.inc_obj, 8, hipMemcpyDeviceToHost, st));
       HIP_OK(hipMemcpyAsync(&oc0, B.open_count, 4, hipMemcpyDeviceToHost, st)); HIP_OK(hipMemcpyAsync(&k0, B.inc_key, 8, hipMemcpyDeviceToHost, st));
+      int fc0 = 0; HIP_OK(hipMemcpyAsync(&fc0, B.far_count, 4, hipMemcpyDeviceToHost, st));
       HIP_OK(hipStreamSynchronize(st));
-      std::fprintf(stderr, "[miqp_gpu] t %.2f s round %d nodes %lld: instance 0 bound %.4f incumbent %.4f open %d\n", wall_s() - t0, rounds, launched_nodes, lb0, k0 >= 0xFFF0000000000000ull ? INFINITY : io0 + h_const[0], oc0);
+      std::fprintf(stderr, "[miqp_gpu] t %.2f s round %d nodes %lld: instance 0 bound %.4f incumbent %.4f open %d + %d\n", wall_s() - t0, rounds, launched_nodes, lb0, k0 >= 0xFFF0000000000000ull ? INFINITY : io0 + h_const[0], oc0, fc0);
     }
   }
   if (const char* dp = std::getenv("MIQP_DUMP_OPEN")) {   // diagnostic: open list of instance 0 (bound, depth, fix record of the 400 lowest)
@@ -843,11 +866,15 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     std::fprintf(stderr, "\n"); HIP_OK(hipMemset(B.prof, 0, 128 * 8)); }
 #endif
   if (B.stats) {
-    unsigned long long hs[32]; HIP_OK(hipMemcpy(hs, B.stats, sizeof(hs), hipMemcpyDeviceToHost)); HIP_OK(hipMemset(B.stats, 0, sizeof(hs)));
+    unsigned long long hs[64]; HIP_OK(hipMemcpy(hs, B.stats, sizeof(hs), hipMemcpyDeviceToHost)); HIP_OK(hipMemset(B.stats, 0, sizeof(hs)));
     const double nn_ = (double)std::max(1ull, hs[0]);
     std::fprintf(stderr, "[miqp_gpu stats] on-chip nodes %llu (general rows %.1f, coefficients %.1f, box keys %.1f, iterations %.1f per node), handed over %llu; general rows / 32 histogram:", hs[0], hs[1] / nn_, hs[4] / nn_, hs[2] / nn_, hs[5] / nn_, hs[3]);
     for (int q = 0; q < 16; ++q) std::fprintf(stderr, " %llu", hs[8 + q]);
     std::fprintf(stderr, "\n");
+    std::fprintf(stderr, "[miqp_gpu stats] node outcomes: infeasible %llu (%.1f it), cut off %llu (%.1f it), not converged %llu (%.1f it), solved %llu (%.1f it) of which: bound >= incumbent %llu, within gap %llu, integer feasible %llu, branched %llu (%.2f children; by kind region/env/obstacle/car-car: %llu x %.1f, %llu x %.1f, %llu x %.1f, %llu x %.1f)\n",
+                 hs[32], hs[36] / (double)std::max(1ull, hs[32]), hs[33], hs[37] / (double)std::max(1ull, hs[33]), hs[34], hs[38] / (double)std::max(1ull, hs[34]), hs[35], hs[39] / (double)std::max(1ull, hs[35]),
+                 hs[40], hs[41], hs[42], hs[43], hs[44] / (double)std::max(1ull, hs[43]), hs[48], hs[52] / (double)std::max(1ull, hs[48]), hs[49], hs[53] / (double)std::max(1ull, hs[49]),
+                 hs[50], hs[54] / (double)std::max(1ull, hs[50]), hs[51], hs[55] / (double)std::max(1ull, hs[51]));
   }
   double ms_ipm = 0;
   for (size_t e = 0; e + 1 < nev; e += 2) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, X.ipm_ev[e], X.ipm_ev[e + 1])); ms_ipm += ms; }

@@ -19,9 +19,9 @@ for k, (w, st) in enumerate(zip(ws, sts)):
     rows.append((int(pr.nodes), round(pr.time, 3), step * B + k, int(st), pr.status, round(pr.gap, 5)))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
-print("batch %.2f s, %d nodes; timing %s" % (dt, tot, json.dumps(ws[0].lastTiming())))
+print("batch %.2f s, %d nodes, solved %d / %d; timing %s" % (dt, tot, sum(1 for r in rows if r[4] in (101, 102)), len(rows), json.dumps(ws[0].lastTiming())))
 cum = 0
-for r in rows[:24]:
+for r in rows[:int(os.environ.get('BP_TOP', '24'))]:
     cum += r[0]
     print("seed %4d nodes %9d (cum %.3f) time %7.3f st %d cplex-status %d gap %.5f" % (r[2], r[0], cum / tot, r[1], r[3], r[4], r[5]))
 ts = np.array(sorted(r[1] for r in rows))
