@@ -14,6 +14,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -628,6 +629,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   const miqp_solver_opts& O0 = S[0]->opts;
   auto fail_all = [&](const char* why) { if (why) std::fprintf(stderr, "[miqp_gpu] %s\n", why); for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; };
   for (int k = 1; k < n; ++k) if (S[k]->opts.device != O0.device) return fail_all("instances of one batch must name the same device (use miqp_solver_solve_batch_multi to span devices)");
+  const double t_enter = wall_s();
   DevCtx* Xp = ctx_for_device(O0.device);
   if (!Xp) return fail_all(nullptr);
   DevCtx& X = *Xp;
@@ -641,6 +643,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     if (O0.max_open_nodes <= 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) { size_t lim = free_b / 8 / 40 / (size_t)n; if ((size_t)open_cap > lim) open_cap = (int)std::max<size_t>(4096, lim); } }
   if ((size_t)n * npr >= ((size_t)1 << 20)) npr = (int)((((size_t)1 << 20) - 1) / n);
   if (!ctx_prepare(X, Y, n, open_cap, npr)) return fail_all(nullptr);
+  const double t_ctx = wall_s() - t_enter;
   DevBuf& B = X.B;
   size_t l_ipm = ipm_lds_bytes(Y), l_eval = eval_lds_bytes(Y);
   if (l_ipm > 160 * 1024 || l_eval > 160 * 1024) { std::fprintf(stderr, "[miqp_gpu] instance too large for LDS (%zu bytes)\n", l_ipm); for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
@@ -655,21 +658,25 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   int nrec = 0;
   auto add_root = [&](int k, const std::vector<signed char>& fx) { roots.insert(roots.end(), fx.begin(), fx.end()); on[(size_t)k * MAXR + oc[k]] = nrec++; oc[k]++; };
   int active = 0;
-  for (int k = 0; k < n; ++k) {
+  // per instance (independent, spread over host threads): tables, step-0 check, the fix records of its roots
+  std::vector<std::vector<std::vector<signed char>>> inst_roots(n);
+  std::vector<char> h_feas0(n, 0);
+  auto prepare_one = [&](int k) {
     miqp_solver* s = S[k]; s->lay = Y; s->has_sol = false;
     compile_instance(s->inst, Y, &hD[(size_t)k * Y.dstride], &hT[(size_t)k * Y.istride]);
     HostGeo G{s->inst, Y, &hD[(size_t)k * Y.dstride], &hT[(size_t)k * Y.istride]};
     double cobj = 0; bool feas0 = step0_check(G, cobj);
     h_const[k] = cobj; h_gap[k] = s->opts.gap_override >= 0 ? s->opts.gap_override : s->inst.gap; h_tlim[k] = s->inst.tilim;
-    if (!feas0) h_done[k] = 1;
-    else if (!split) add_root(k, std::vector<signed char>(Y.fixlen, (signed char)-1));
-    else {
+    h_feas0[k] = feas0 ? 1 : 0;
+    auto& R = inst_roots[k];
+    if (feas0 && !split) R.emplace_back(Y.fixlen, (signed char)-1);
+    else if (feas0) {
       std::vector<std::vector<std::pair<int, int>>> combos; split_roots(Y, &hT[(size_t)k * Y.istride], combos, split->world);
       for (size_t q = 0; q < combos.size(); ++q) {
         if ((int)(q % (size_t)split->world) != split->rank) continue;
         std::vector<signed char> fx(Y.fixlen, (signed char)-1);
         for (auto& d : combos[q]) fx[d.first] = (signed char)d.second;
-        add_root(k, fx);
+        R.push_back(std::move(fx));
       }
     }
     // MIP starts (initializeWarmstart + addMIPStart / readMIPStarts, src/cplex_wrapper.cpp:124-138, 494-639): the binaries
@@ -678,13 +685,25 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       if (!s->ws[w] || !dims_match(s->ws[w]->r, s->inst)) continue;
       std::vector<signed char> fx;
       if (!fix_from_results(s->inst, Y, &hT[(size_t)k * Y.istride], &s->ws[w]->r, fx)) continue;
-      if (oc[k] < MAXR) add_root(k, fx);
+      if ((int)R.size() < MAXR) R.push_back(std::move(fx));
     }
-    if (oc[k] > 0) active++; else h_done[k] = 1;   // (a rank of a tree split may own no root)
     int rows, bin, cont, nnz; raw_sizes(s->inst, rows, bin, cont, nnz);
     s->props = miqp_solution_properties_c{}; s->props.NrConstraints = rows; s->props.NrBinaryVariables = bin; s->props.NrFloatVariables = cont;
     s->props.NonZeroCoefficients = nnz;
+  };
+  { const int nth = std::max(1, std::min<int>({n / 8, (int)std::thread::hardware_concurrency(), 32}));
+    if (nth <= 1) for (int k = 0; k < n; ++k) prepare_one(k);
+    else {
+      std::atomic<int> next{0}; std::vector<std::thread> th;
+      for (int t = 0; t < nth; ++t) th.emplace_back([&] { for (int k = next.fetch_add(1); k < n; k = next.fetch_add(1)) prepare_one(k); });
+      for (auto& t : th) t.join();
+    } }
+  for (int k = 0; k < n; ++k) {
+    if (!h_feas0[k]) h_done[k] = 1;
+    for (auto& fx : inst_roots[k]) add_root(k, fx);
+    if (oc[k] > 0) active++; else h_done[k] = 1;   // (a rank of a tree split may own no root)
   }
+  const double t_tables = wall_s() - t_enter - t_ctx;
   { double gmin = 1.0; for (int k = 0; k < n; ++k) gmin = std::min(gmin, h_gap[k]);
     B.qp_tol = std::min(QP_TOL, std::max(1e-12, 1e-4 * gmin)); }  // node relaxations: accurate to a small fraction of the MIP gap
   hipStream_t st = X.stream;
@@ -719,6 +738,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
 
   // ---- rounds
   double t0 = wall_s();
+  const double t_setup = t0 - t_enter;
   double tlim = 0; for (int k = 0; k < n; ++k) tlim = std::max(tlim, h_tlim[k]);
   HIP_OK(hipEventRecord(X.ev0, st));
   std::vector<int> h_done_now(n, 0); std::vector<double> h_tdone(n, -1.0);
@@ -949,6 +969,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     }
     statuses[k] = s->status;
   }
+  if (std::getenv("MIQP_STATS")) std::fprintf(stderr, "[miqp_gpu stats] host: setup %.3f s (device context %.3f, instance tables and presolve %.3f, upload %.3f), rounds %.3f s (%d), results %.3f s\n", t_setup, t_ctx, t_tables, t_setup - t_ctx - t_tables, t_solve, rounds, wall_s() - t0 - t_solve);
   return true;
 }
 
