@@ -247,7 +247,7 @@ struct Layout {
   int C, N, R, P, E, EL, O, L, NP;   // P = max possible regions per car, EL = max edges per environment piece
   int nx, nu, nz, SC, NSLOT, ROWCAP;
   // double offsets
-  int d_x0, d_wd, d_ref, d_glob, d_u0box, d_misc, d_dsep, d_ssl, d_smax, d_reg, d_env, d_obs, d_theta, dstride;
+  int d_x0, d_wd, d_ref, d_glob, d_u0box, d_misc, d_dsep, d_ssl, d_smax, d_reg, d_env, d_obs, d_theta, d_lift, dstride;
   // int offsets
   int i_nposs, i_regj, i_nhs, i_hs, i_envn, i_obssoft, i_initj, i_dom, i_allow, i_boxskip, i_c2callow, istride;
   // fix record (bytes)
@@ -262,7 +262,7 @@ inline Layout make_layout(int C, int N, int R, int P, int E, int EL, int O, int 
   int o = 0;
   Y.d_x0 = o; o += C * 6; Y.d_wd = o; o += Y.nz; Y.d_ref = o; o += N * Y.nz; Y.d_glob = o; o += 8; Y.d_u0box = o; o += C * 4;
   Y.d_misc = o; o += 4; Y.d_dsep = o; o += Y.NP * N; Y.d_ssl = o; o += N; Y.d_smax = o; o += N; Y.d_reg = o; o += C * P * REGSZ;
-  Y.d_env = o; o += E * EL * 3; Y.d_obs = o; o += O * N * L * 3; Y.d_theta = o; o += C * 4; Y.dstride = (o + 7) & ~7;
+  Y.d_env = o; o += E * EL * 3; Y.d_obs = o; o += O * N * L * 3; Y.d_theta = o; o += C * 4; Y.d_lift = o; o += C * 2 * N * 16; Y.dstride = (o + 7) & ~7;
   o = 0;
   Y.i_nposs = o; o += C; Y.i_regj = o; o += C * P; Y.i_nhs = o; o += C * P; Y.i_hs = o; o += C * P * 4; Y.i_envn = o; o += E;
   Y.i_obssoft = o; o += O; Y.i_initj = o; o += C; Y.i_dom = o; o += C * P * 4; Y.i_allow = o; o += C * N * 2; Y.i_boxskip = o; o += C * N; Y.i_c2callow = o; o += Y.NP * N; Y.istride = (o + 3) & ~3;
@@ -331,6 +331,49 @@ inline double min_affine_over_polygon(const std::vector<std::array<double, 3>>& 
   return best;
 }
 
+// Response tables of the objective for the bound lifting of eval_kernel.  With the multipliers of a solved node fixed, its
+// Lagrangian is D + 1/2 (z - z*)' H (z - z*) on the trajectories of the dynamics (H: the objective's Hessian 2 W per
+// stage, nothing else); a child that adds the row g.z <= r, violated by v at z*, therefore costs at least
+// D + v^2 / (2 g Sigma g'), Sigma = Zu H_u^-1 Zu' the response of the stage's (p, v, a, u) to the inputs under H.
+// The chains (car, axis) are independent triple integrators with their own weights: one 4 x 4 block per (car, axis, stage).
+inline void lift_tables(const HostInst& I, const Layout& Y, double* D) {
+  const int N = Y.N, M = N - 1;   // inputs u_0 .. u_{N-2} (the last stage has no input)
+  const double ts = I.ts;
+  std::vector<double> R((size_t)N * 3), H((size_t)M * M), Zu((size_t)4 * M), Yv((size_t)4 * M);
+  { double r[3] = {ts * ts * ts / 6.0, 0.5 * ts * ts, ts};   // A^k B
+    for (int k = 0; k < N; ++k) { R[k * 3] = r[0]; R[k * 3 + 1] = r[1]; R[k * 3 + 2] = r[2]; r[0] += ts * r[1] + 0.5 * ts * ts * r[2]; r[1] += ts * r[2]; } }
+  for (int c = 0; c < Y.C; ++c)
+    for (int ax = 0; ax < 2; ++ax) {
+      double* out = D + Y.d_lift + (size_t)((c * 2 + ax) * N) * 16;
+      const double w[4] = {I.W[c * 8 + 3 * ax], I.W[c * 8 + 3 * ax + 1], I.W[c * 8 + 3 * ax + 2], I.W[c * 8 + 6 + ax]};
+      std::fill(H.begin(), H.end(), 0.0);
+      for (int i = 1; i < N; ++i)
+        for (int j = 0; j < i && j < M; ++j)
+          for (int k = 0; k <= j; ++k) {
+            const double* a = &R[(i - 1 - j) * 3]; const double* b = &R[(i - 1 - k) * 3];
+            H[(size_t)j * M + k] += 2.0 * (w[0] * a[0] * b[0] + w[1] * a[1] * b[1] + w[2] * a[2] * b[2]);
+          }
+      for (int j = 0; j < M; ++j) H[(size_t)j * M + j] += 2.0 * w[3];
+      bool ok = true;   // Cholesky, lower triangle in place
+      for (int j = 0; j < M && ok; ++j) {
+        double d = H[(size_t)j * M + j];
+        for (int k = 0; k < j; ++k) d -= H[(size_t)j * M + k] * H[(size_t)j * M + k];
+        if (!(d > 1e-12)) { ok = false; break; }
+        d = std::sqrt(d); H[(size_t)j * M + j] = d;
+        for (int i = j + 1; i < M; ++i) { double v = H[(size_t)i * M + j]; for (int k = 0; k < j; ++k) v -= H[(size_t)i * M + k] * H[(size_t)j * M + k]; H[(size_t)i * M + j] = v / d; }
+      }
+      for (int i = 0; i < N; ++i) {
+        if (!ok) { for (int q = 0; q < 16; ++q) out[i * 16 + q] = (q % 5 == 0) ? 1e300 : 0.0; continue; }   // no curvature: no lifting
+        std::fill(Zu.begin(), Zu.end(), 0.0);
+        for (int j = 0; j < i && j < M; ++j) for (int q = 0; q < 3; ++q) Zu[(size_t)q * M + j] = R[(i - 1 - j) * 3 + q];
+        if (i < M) Zu[(size_t)3 * M + i] = 1.0;
+        for (int q = 0; q < 4; ++q)   // Yv = L^-1 Zu'
+          for (int j = 0; j < M; ++j) { double v = Zu[(size_t)q * M + j]; for (int k = 0; k < j; ++k) v -= H[(size_t)j * M + k] * Yv[(size_t)q * M + k]; Yv[(size_t)q * M + j] = v / H[(size_t)j * M + j]; }
+        for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) { double v = 0; for (int j = 0; j < M; ++j) v += Yv[(size_t)a * M + j] * Yv[(size_t)b * M + j]; out[i * 16 + a * 4 + b] = v; }
+      }
+    }
+}
+
 // fills one instance's block of the device tables
 inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int* T) {
   std::fill(D, D + Y.dstride, 0.0); std::fill(T, T + Y.istride, 0);
@@ -343,6 +386,7 @@ inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int*
     double th = std::atan2(I.x0[c * 6 + 4], I.x0[c * 6 + 1]);
     D[Y.d_theta + c * 4 + 0] = I.x0[c * 6 + 0] + std::cos(th) * I.wb[c]; D[Y.d_theta + c * 4 + 1] = I.x0[c * 6 + 3] + std::sin(th) * I.wb[c];
   }
+  lift_tables(I, Y, D);
   double* G = D + Y.d_glob; G[0] = I.vmin; G[1] = I.vmax; G[2] = I.amin; G[3] = I.amax; G[4] = I.jmin; G[5] = I.jmax; G[6] = I.vm; G[7] = I.ts;
   for (int c = 0; c < C; ++c) {  // initial_conditions.mod:30-48
     int j0 = I.init_region[c] - 1;

@@ -1206,10 +1206,14 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   double* altval = (double*)(altbuf + 64);           // [64]
   signed char* fix = (signed char*)(altval + 64);    // [fixlen]
   signed char* comp = fix + Y.fixlen;                // [fixlen]
+  signed char* cfix = comp + Y.fixlen;               // [fixlen] fix record of the child whose rows are being lifted
+  double* gsc = (double*)(cfix + Y.fixlen);          // [64][NZ + 1] one dense row per lane
   __shared__ BranchDesc chosen;
   __shared__ int sh_base[3];
   __shared__ int slots[64];
   __shared__ int ck[64], ca[64], fam[4];
+  __shared__ int k_ck[64], k_ca[64], k_neg[64], k_ord[64], k_pos[64];
+  __shared__ double clift[64], k_bnd[64];
 
   const double* Zi = B.batch_Z + (size_t)node * N * NZ;
   const signed char* src = B.pool_fix + (size_t)B.batch_node[node] * Y.fixlen;
@@ -1475,53 +1479,122 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     // of the rounding and, when feasible, the first incumbent two rounds after the root instead of one dive level per round
     if (!(inc_now < 1e300) && nalt < 63 && (B.seq_kinds & 0x4000000) == 0) { ck[nalt] = -2; ca[nalt] = 0; nalt++; }
     fam[0] = base; fam[1] = stride; fam[2] = jlo; fam[3] = jhi;
-    // tier of the children (they share the parent's bound): above the near threshold they wait in the far tier
-    const double cb_ = objlb - B.inst_const[inst];
-    int tofar = 0, ob = 0;
-    if (B.far_cap > 0 && !B.inst_mode[inst] && cb_ > B.near_thr[inst]) {
-      ob = atomicAdd(&B.far_count[inst], nalt);
-      if (ob + nalt <= B.far_cap) { tofar = 1; atomicMin(&B.far_minkey[inst], d2key(cb_)); }
-      else   // tier full: the reserved slots below the capacity become dead entries (the count stays clamped until the next refill)
-        for (int q = ob; q < ob + nalt && q < B.far_cap; ++q) { B.far_bound[(size_t)inst * B.far_cap + q] = 1e300; B.far_node[(size_t)inst * B.far_cap + q] = -1; }
-    }
-    if (!tofar) ob = atomicAdd(&B.open_count[inst], nalt);
-    bool okalloc = tofar || ob + nalt <= B.open_cap;
-    if (okalloc) {
-      unsigned int h = atomicAdd(B.free_head, (unsigned int)nalt);
-      if ((int)(*B.free_limit - h) >= nalt) {          // recycled records
-        for (int a = 0; a < nalt; ++a) slots[a] = B.free_q[(h + a) % (unsigned int)B.pool_cap];
-      } else {                                          // fresh records
-        int nb = atomicAdd(B.pool_count, nalt);
-        if (nb + nalt > B.pool_cap) okalloc = false;
-        for (int a = 0; a < nalt; ++a) slots[a] = nb + a;
-      }
-    }
-    if (!okalloc) {   // list or record pool exhausted: the instance is flagged incomplete; the reserved list slots become dead entries
-      atomicOr(&B.inst_flags[inst], 1);
-      if (tofar) for (int q = ob; q < ob + nalt; ++q) { B.far_bound[(size_t)inst * B.far_cap + q] = 1e300; B.far_node[(size_t)inst * B.far_cap + q] = -1; }
-      else for (int q = ob; q < ob + nalt && q < B.open_cap; ++q) { size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + q; B.open_bound[oi] = 1e300; B.open_node[oi] = -1; B.open_depth[oi] = 0; }
-      nalt = 0;
-    }
-    if (B.stats && nalt > 0) { atomicAdd(&B.stats[43], 1ull); atomicAdd(&B.stats[44], (unsigned long long)nalt); atomicAdd(&B.stats[48 + chosen.kind], 1ull); atomicAdd(&B.stats[52 + chosen.kind], (unsigned long long)nalt); }
-    sh_base[0] = tofar; sh_base[1] = ob; sh_base[2] = nalt;
+    sh_base[2] = nalt;
   }
   __syncthreads();
   nalt = sh_base[2];
-  if (nalt <= 0) { FREE_NODE(); return; }
-  {
-    const int base = fam[0], stride = fam[1], jlo = fam[2], jhi = fam[3];
-    const int ob = sh_base[1];
+  const int base = fam[0], stride = fam[1], jlo = fam[2], jhi = fam[3];
+  // ---------------- bound lifting.  With the node's multipliers fixed its Lagrangian grows like 1/2 (z - z*)' H (z - z*)
+  // around the solution z* (H: the objective's Hessian on the trajectories of the dynamics - host tables d_lift); a child
+  // whose fix record activates the hard row g.z <= r, violated by v at z*, therefore costs at least
+  //     (dual value of the node) + v^2 / (2 g Sigma g').
+  // Every row the child's record activates at the branching step is decoded exactly as the interior point kernels will see
+  // it; the largest single-row lift is the child's bound.  Children that cannot beat the incumbent any more are not created.
+  const bool plain = jlo == jhi && !(B.seq_kinds & 0x20000);   // (experiment switch: lifting off)
+  if (plain) {
+    const int i = chosen.i;
+    for (int k = lane; k < Y.fixlen; k += 64) cfix[k] = fix[k];
+    __syncthreads();
+    const double* LT = D + Y.d_lift;
+    double* gl = gsc + lane * (NZ + 1);
     for (int a = 0; a < nalt; ++a) {
-      signed char* dst = B.pool_fix + (size_t)slots[a] * Y.fixlen;
-      const int kk = ck[a]; const signed char av = (signed char)ca[a];
-      // exclusive children (car/car): the deviating child excludes, at zero slack, the reference alternative of step kk
-      // and the alternatives of its earlier siblings at that step
+      const int kk = ck[a];
+      if (kk == -2) { if (lane == 0) clift[a] = 0.0; continue; }
       int negidx = -1, negm = 0;
       if (chosen.kind == 3 && kk >= 0 && kk < N && (B.seq_kinds & 0x10000) == 0) {
         negidx = Y.f_c2n + (chosen.c * N + kk) * 4 + chosen.o;
         negm = 1 << (int)comp[base + kk * stride];
         for (int a2 = 1; a2 < a; ++a2) if (ck[a2] == kk) negm |= 1 << ca[a2];
       }
+      if (lane == 0) { cfix[base + i * stride] = kk == i ? (signed char)ca[a] : comp[base + i * stride]; if (negidx >= 0) cfix[negidx] = (signed char)negm; }
+      __syncthreads();
+      double lift = 0.0;
+      for (int sl = lane; sl < Y.NSLOT; sl += 64) {
+        const RowOut r = decode_row<C, true>(Y, D, T, cfix, i, sl, gl);
+        if (!r.active || r.aq != 0.0) continue;
+        double v = -r.rhs;
+#pragma unroll
+        for (int q = 0; q < NZ; ++q) v += gl[q] * Z[i * NZ + q];
+        if (!(v > 1e-7)) continue;
+        double gam = 0.0;
+        for (int c = 0; c < C; ++c)
+          for (int ax = 0; ax < 2; ++ax) {
+            const double g4[4] = {gl[6 * c + 3 * ax], gl[6 * c + 3 * ax + 1], gl[6 * c + 3 * ax + 2], gl[6 * C + 2 * c + ax]};
+            if (g4[0] == 0.0 && g4[1] == 0.0 && g4[2] == 0.0 && g4[3] == 0.0) continue;
+            const double* S4 = LT + ((c * 2 + ax) * N + i) * 16;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) gam += g4[p] * S4[p * 4 + q] * g4[q];
+          }
+        if (gam > 1e-300) lift = fmax(lift, 0.5 * v * v / gam);
+      }
+      lift = wave_max(lift);
+      if (lane == 0) { clift[a] = lift * (1.0 - 1e-6); cfix[base + i * stride] = fix[base + i * stride]; if (negidx >= 0) cfix[negidx] = fix[negidx]; }
+      __syncthreads();
+    }
+  } else if (lane < 64) clift[lane] = 0.0;
+  __syncthreads();
+  if (lane == 0) {
+    // children that survive, each with its own bound and list tier
+    const double cst = B.inst_const[inst], gapi = B.inst_gap[inst];
+    const double thr = B.far_cap > 0 && !B.inst_mode[inst] ? B.near_thr[inst] : 1e300;
+    int nk = 0, nfar = 0, nnear = 0; double fmin_ = 1e300;
+    for (int a = 0; a < nalt; ++a) {
+      const double cb = objlb + clift[a];
+      if (inc_now < 1e300 && (inc_now - cb) <= gapi * (1e-10 + fabs(inc_now))) { if (B.stats) atomicAdd(&B.stats[56], 1ull); continue; }
+      int negm = 0;
+      if (chosen.kind == 3 && ck[a] >= 0 && ck[a] < N && (B.seq_kinds & 0x10000) == 0) {
+        negm = 1 << (int)comp[base + ck[a] * stride];
+        for (int a2 = 1; a2 < a; ++a2) if (ck[a2] == ck[a]) negm |= 1 << ca[a2];
+      }
+      const bool tf = (cb - cst) > thr;
+      k_ck[nk] = ck[a]; k_ca[nk] = ca[a]; k_neg[nk] = negm; k_ord[nk] = a; k_bnd[nk] = cb - cst;
+      k_pos[nk] = tf ? (0x40000000 | nfar++) : nnear++;
+      if (tf) fmin_ = fmin(fmin_, cb - cst);
+      nk++;
+    }
+    int fbase = 0, obase = 0; bool okalloc = true;
+    if (nfar > 0) {
+      fbase = atomicAdd(&B.far_count[inst], nfar);
+      if (fbase + nfar <= B.far_cap) atomicMin(&B.far_minkey[inst], d2key(fmin_));
+      else {   // tier full: the reserved slots below the capacity become dead entries, the children go to the near list
+        for (int q = fbase; q < fbase + nfar && q < B.far_cap; ++q) { B.far_bound[(size_t)inst * B.far_cap + q] = 1e300; B.far_node[(size_t)inst * B.far_cap + q] = -1; }
+        for (int q = 0; q < nk; ++q) if (k_pos[q] & 0x40000000) k_pos[q] = nnear++;
+        nfar = 0;
+      }
+    }
+    if (nnear > 0) { obase = atomicAdd(&B.open_count[inst], nnear); okalloc = obase + nnear <= B.open_cap; }
+    if (okalloc && nk > 0) {
+      unsigned int h = atomicAdd(B.free_head, (unsigned int)nk);
+      if ((int)(*B.free_limit - h) >= nk) {          // recycled records
+        for (int q = 0; q < nk; ++q) slots[q] = B.free_q[(h + q) % (unsigned int)B.pool_cap];
+      } else {                                          // fresh records
+        int nb = atomicAdd(B.pool_count, nk);
+        if (nb + nk > B.pool_cap) okalloc = false;
+        for (int q = 0; q < nk; ++q) slots[q] = nb + q;
+      }
+    }
+    if (!okalloc) {   // list or record pool exhausted: the instance is flagged incomplete; the reserved list slots become dead entries
+      atomicOr(&B.inst_flags[inst], 1);
+      for (int q = fbase; q < fbase + nfar; ++q) { B.far_bound[(size_t)inst * B.far_cap + q] = 1e300; B.far_node[(size_t)inst * B.far_cap + q] = -1; }
+      for (int q = obase; q < obase + nnear && q < B.open_cap; ++q) { size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + q; B.open_bound[oi] = 1e300; B.open_node[oi] = -1; B.open_depth[oi] = 0; }
+      nk = 0;
+    }
+    if (B.stats && nk > 0) { atomicAdd(&B.stats[43], 1ull); atomicAdd(&B.stats[44], (unsigned long long)nk); atomicAdd(&B.stats[48 + chosen.kind], 1ull); atomicAdd(&B.stats[52 + chosen.kind], (unsigned long long)nk); }
+    sh_base[0] = fbase; sh_base[1] = obase; sh_base[2] = nk;
+  }
+  __syncthreads();
+  const int nk = sh_base[2];
+  if (nk <= 0) { FREE_NODE(); return; }
+  {
+    for (int q = 0; q < nk; ++q) {
+      signed char* dst = B.pool_fix + (size_t)slots[q] * Y.fixlen;
+      const int kk = k_ck[q]; const signed char av = (signed char)k_ca[q];
+      // exclusive children (car/car): the deviating child excludes, at zero slack, the reference alternative of step kk
+      // and the alternatives of its earlier siblings at that step
+      int negidx = -1; const int negm = k_neg[q];
+      if (chosen.kind == 3 && kk >= 0 && kk < N && (B.seq_kinds & 0x10000) == 0) negidx = Y.f_c2n + (chosen.c * N + kk) * 4 + chosen.o;
       for (int k = lane; k < Y.fixlen; k += 64) {
         signed char v = fix[k];
         int rel = k - base;
@@ -1534,19 +1607,19 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         dst[k] = v;
       }
 #ifdef MIQP_PROFILE
-      if (lane == 0) B.pool_origin[slots[a]] = (signed char)(2 * chosen.kind + (a > 0 ? 1 : 0));
+      if (lane == 0) B.pool_origin[slots[q]] = (signed char)(2 * chosen.kind + (k_ord[q] > 0 ? 1 : 0));
 #endif
     }
-    if (lane < nalt) {
+    if (lane < nk) {
       // depth word: (tree depth << 6) | preference among siblings (child_inf first) - used by the dive ordering
       int pd = B.batch_depth[node] >> 6;
-      const int dw = ck[lane] == -2 ? (((pd + 2) << 6) | 63) : (((pd + 1) << 6) | (63 - lane));   // the probe is dived into first
-      if (sh_base[0]) {
-        size_t oi = (size_t)inst * B.far_cap + ob + lane;
-        B.far_bound[oi] = objlb - B.inst_const[inst]; B.far_node[oi] = slots[lane]; B.far_depth[oi] = dw;
+      const int dw = k_ck[lane] == -2 ? (((pd + 2) << 6) | 63) : (((pd + 1) << 6) | (63 - k_ord[lane]));   // the probe is dived into first
+      if (k_pos[lane] & 0x40000000) {
+        size_t oi = (size_t)inst * B.far_cap + sh_base[0] + (k_pos[lane] & 0x3FFFFFFF);
+        B.far_bound[oi] = k_bnd[lane]; B.far_node[oi] = slots[lane]; B.far_depth[oi] = dw;
       } else {
-        size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + ob + lane;
-        B.open_bound[oi] = objlb - B.inst_const[inst]; B.open_node[oi] = slots[lane]; B.open_depth[oi] = dw;
+        size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + sh_base[1] + k_pos[lane];
+        B.open_bound[oi] = k_bnd[lane]; B.open_node[oi] = slots[lane]; B.open_depth[oi] = dw;
       }
     }
   }
