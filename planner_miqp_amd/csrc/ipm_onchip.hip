@@ -117,6 +117,22 @@ __device__ inline bool box_of_slot(const Layout& Y, const double* D, const int* 
   return false;
 }
 
+// Column order of the stage vector inside the on-chip kernel.  Two cars: CHAIN-MAJOR - the four triple integrator chains
+// (car, axis) side by side per derivative, column 4 k + chain for (position, velocity, acceleration) = k = 0, 1, 2 and
+// 12 + chain for the jerk input - so that [A B] becomes "identity blocks h^m / m! on the m-th block diagonal":
+//   P [A B]      is a sum of the tile shifted right by 4 m columns  (DPP row_shr within the 16 lanes of a row),
+//   [A B]' T     is a sum over the registers of one lane             (row 4 k + chain <-> lane group chain, register k),
+// i.e. the two products of the Riccati step need no MFMA and no LDS.  One car keeps the model's order and the MFMA form.
+template <int C, bool CM> __device__ inline int oc_pcol(int l) { return (CM && l < 6 * C) ? 2 * C * (l % 3) + l / 3 : l; }   // model column -> kernel column
+template <int C, bool CM> __device__ inline int oc_lcol(int p) { return (CM && p < 6 * C) ? 3 * (p % (2 * C)) + p / (2 * C) : p; }   // and back
+// value of the lane CTRL columns to the left / right inside the row of 16 lanes (row_shr : 0x110 + n, row_shl : 0x100 + n), 0 outside
+template <int CTRL> __device__ inline double dpp_shift0(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
 // lane index recomputed from the execution mask (64-thread workgroups: lane = thread).  The passes of the iteration loop take
 // their lane-dependent addresses from this instead of from values defined before the loop: those would have to stay in
 // registers across the Riccati sweep, where none are spare, and come back from scratch memory at every use.
@@ -141,6 +157,7 @@ __device__ inline void row_weight(double s, double lam, double t, bool soft, dou
 template <int C, int NSL, int ABL = 0>
 __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
   constexpr int OC_ABL = ABL;
+  constexpr bool CM = C == 2 && !(ABL & 1024);   // chain-major columns, shift form of the Riccati products (mask 1024 of the diagnostic build: the MFMA form)
   static_assert(C <= 2, "one 16 x 16 tile per stage");
   constexpr int NX = 6 * C, NU = 2 * C, NZ = 8 * C;
   constexpr int KB = (NX + 3) / 4;
@@ -191,18 +208,19 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
     {
       const signed char* src = B.pool_fix + (size_t)B.batch_node[node] * Y.fixlen;
       for (int k = tid; k < Y.fixlen; k += 64) fix[k] = src[k];
-      if (tid < 16) Wd[tid] = tid < NZ ? D[Y.d_wd + tid] : 0.0;
+      if (tid < 16) Wd[tid] = tid < NZ ? D[Y.d_wd + oc_lcol<C, CM>(tid)] : 0.0;
       for (int k = tid; k < N * 16; k += 64) Z[k] = 0.0;
       for (int k = tid; k < N * 32; k += 64) bkey[k] = ~0ull;
       for (int k = tid; k <= N + 1; k += 64) sstart[k] = 0;
     }
     __syncthreads();
-    if (tid < NX) Z[tid] = D[Y.d_x0 + tid];
+    if (tid < NX) Z[tid] = D[Y.d_x0 + oc_lcol<C, CM>(tid)];
     OC_WAVE_SYNC();
     for (int i = 0; i + 1 < N; ++i) {  // free rollout (u = 0)
       if (tid < NX) {
         double acc = 0;
-        for (int q = 3 * (tid / 3); q < 3 * (tid / 3) + 3; ++q) acc += ab_entry<C>(tid, q, ts) * Z[i * 16 + q];
+        if (CM) { const int k = tid / (2 * C); acc = Z[i * 16 + tid]; if (k < 2) acc += ts * Z[i * 16 + tid + 2 * C]; if (k < 1) acc += 0.5 * ts * ts * Z[i * 16 + tid + 4 * C]; }
+        else for (int q = 3 * (tid / 3); q < 3 * (tid / 3) + 3; ++q) acc += ab_entry<C>(tid, q, ts) * Z[i * 16 + q];
         Z[(i + 1) * 16 + tid] = acc;
       }
       OC_WAVE_SYNC();
@@ -217,9 +235,9 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
     unsigned long long ocp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     OCP_T(tp_d0);
-    double abr[KB];
+    double abr[KB];   // [A B] as MFMA operand (one car; two cars use the shift form, see oc_pcol)
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) abr[kb] = (4 * kb + lg < NX && lc < NZ) ? ab_entry<C>(4 * kb + lg, lc, ts) : 0.0;
+    for (int kb = 0; kb < KB; ++kb) abr[kb] = (!CM && 4 * kb + lg < NX && lc < NZ) ? ab_entry<C>(4 * kb + lg, lc, ts) : 0.0;
 
     // ---- decode, pass A: which (stage, slot) pairs carry a row; box rows go straight to their key, general rows are marked in a
     // bitmap over (stage, slot).  The pairs are walked class by class (velocity / acceleration bounds, jerk bounds, region
@@ -246,7 +264,7 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
             const int slot = percar ? (rem / cnt) * Y.SC + off + rem % cnt : off + rem;
             if (decode_row<C, false>(Y, D, T, fix, i, slot, nullptr).active) {
               int col; double sg, rh;
-              if (box_of_slot<C>(Y, D, T, fix, i, slot, col, sg, rh)) atomicMin(&bkey[(i * 2 + (sg < 0.0 ? 1 : 0)) * 16 + col], d2key(rh));
+              if (box_of_slot<C>(Y, D, T, fix, i, slot, col, sg, rh)) atomicMin(&bkey[(i * 2 + (sg < 0.0 ? 1 : 0)) * 16 + oc_pcol<C, CM>(col)], d2key(rh));
               else { const int pcode = i * NSLOT + slot; atomicOr(&bmp[pcode >> 6], 1ull << (pcode & 63)); }
             }
           }
@@ -282,7 +300,8 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
           if (v != 0.0 && nn < 6) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) if (k == nn) v6[k] = v;
-            map |= (unsigned long long)(nn + 1) << (4 * q); cols |= (unsigned int)q << (4 * nn); nn++;
+            const int pq = oc_pcol<C, CM>(q);
+            map |= (unsigned long long)(nn + 1) << (4 * pq); cols |= (unsigned int)pq << (4 * nn); nn++;
           }
         }
       }
@@ -376,7 +395,7 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
     for (it = 1; it <= QP_MAXIT; ++it) {
       {
         double o = 0.0;
-        for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) { const double d = Z[k] - Rf[(k >> 4) * NZ + q]; o += Wd[q] * d * d; } }
+        for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) { const double d = Z[k] - Rf[(k >> 4) * NZ + oc_lcol<C, CM>(q)]; o += Wd[q] * d * d; } }
         obj = wave_sum(o);
       }
       if (OC_ABL) { if (it > 15) { ok = 1; break; } }
@@ -421,7 +440,7 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
       {
         d4_t Pd = {0.0, 0.0, 0.0, 0.0};
         double pcol = 0.0;
-        double rfn = lc < NZ ? Rf[(N - 1) * NZ + lc] : 0.0;
+        double rfn = lc < NZ ? Rf[(N - 1) * NZ + oc_lcol<C, CM>(lc)] : 0.0;
         // Phi_j = 2W + diag(box rows) + Gh' Gh, rr_j = 2W(z - ref) + (box rows) + Gh' f : the general rows of stage j enter four
         // at a time, lane (g, c) picks the coefficient of column c of row 4 kb + g through the row's column map
         auto phi = [&](int j, d4_t& acc, double& rrc) {
@@ -451,7 +470,7 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
             for (int rg = 0; rg < 4; ++rg) if (lgp + 4 * rg == lcp) acc[rg] += dd;
           }
           rrc = lcp < NZ ? racc + Gd[j * 16 + lcp] + 2.0 * Wd[lcp] * (Z[j * 16 + lcp] - rfn) : 0.0;
-          if (j > 0 && lcp < NZ) rfn = Rf[(j - 1) * NZ + lcp];
+          if (j > 0 && lcp < NZ) rfn = Rf[(j - 1) * NZ + oc_lcol<C, CM>(lcp)];
           if (it == 1) rmax = fmax(rmax, fabs(rrc));
         };
         d4_t accA; double rrA;
@@ -465,15 +484,30 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
           OCP_T(tp_s0);
           if (i > 0) phi(i - 1, accA, rrA);   // independent of this stage's elimination: its LDS round trips hide behind the MFMA chains below
           OCP_T(tp_s1); OCP_ACC(2, tp_s0, tp_s1);
-          d4_t accT = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int kb = 0; kb < (((OC_ABL) & 16) ? 0 : KB); ++kb) accT = __builtin_amdgcn_mfma_f64_16x16x4f64(Pd[kb], abr[kb], accT, 0, 0, 0);
-#pragma unroll
-          for (int kb = 0; kb < (((OC_ABL) & 16) ? 0 : KB); ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(abr[kb], accT[kb], acc, 0, 0, 0);
           double part = 0.0;
+          if constexpr (CM) {
+            // T = P [A B] (columns shifted by 4 m, weight h^m / m!), S += [A B]' T (registers of the lane), part = [A B]' p
+            const double h1 = ts, h2 = 0.5 * ts * ts, h3 = ts * ts * ts / 6.0;
+            if (!((OC_ABL) & 16)) {
+              d4_t Tt;
 #pragma unroll
-          for (int kb = 0; kb < (((OC_ABL) & 32) ? 0 : KB); ++kb) part += abr[kb] * __shfl(pcol, 4 * kb + lg);
-          if (!((OC_ABL) & 32)) { part = sum_xor16(part); part = sum_xor32(part); }
+              for (int r = 0; r < 3; ++r) Tt[r] = Pd[r] + h1 * dpp_shift0<0x114>(Pd[r]) + h2 * dpp_shift0<0x118>(Pd[r]) + h3 * dpp_shift0<0x11C>(Pd[r]);
+              acc[0] += Tt[0];
+              acc[1] += Tt[1] + h1 * Tt[0];
+              acc[2] += Tt[2] + h1 * Tt[1] + h2 * Tt[0];
+              acc[3] += h1 * Tt[2] + h2 * Tt[1] + h3 * Tt[0];
+            }
+            if (!((OC_ABL) & 32)) part = pcol + h1 * dpp_shift0<0x114>(pcol) + h2 * dpp_shift0<0x118>(pcol) + h3 * dpp_shift0<0x11C>(pcol);
+          } else {
+            d4_t accT = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < (((OC_ABL) & 16) ? 0 : KB); ++kb) accT = __builtin_amdgcn_mfma_f64_16x16x4f64(Pd[kb], abr[kb], accT, 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < (((OC_ABL) & 16) ? 0 : KB); ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(abr[kb], accT[kb], acc, 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < (((OC_ABL) & 32) ? 0 : KB); ++kb) part += abr[kb] * __shfl(pcol, 4 * kb + lg);
+            if (!((OC_ABL) & 32)) { part = sum_xor16(part); part = sum_xor32(part); }
+          }
           const double svc = rrc + part;
           const double own = acc[RU];
           OCP_T(tp_s2); OCP_ACC(3, tp_s1, tp_s2);
@@ -558,11 +592,11 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
         // [A B] row of this lane, rebuilt from a value of this iteration so that it is not kept in registers across the backward sweep
         const double tsl = fma(0.0, tau, ts);
         double ca[3], cb;
-        { const int k3 = lf % 3;
+        { const int k3 = CM ? (lf / (2 * C)) % 3 : lf % 3;   // derivative this lane's state column carries
 #pragma unroll
           for (int m = 0; m < 3; ++m) { int d = m - k3; ca[m] = d < 0 ? 0.0 : (d == 0 ? 1.0 : (d == 1 ? tsl : 0.5 * tsl * tsl)); }
           cb = k3 == 0 ? tsl * tsl * tsl / 6.0 : (k3 == 1 ? 0.5 * tsl * tsl : tsl); }
-        const int chs = lf < NX ? lf / 3 : 0, q0 = 3 * chs;
+        const int chs = lf < NX ? (CM ? lf % (2 * C) : lf / 3) : 0, q0 = CM ? chs : 3 * chs, qs = CM ? 2 * C : 1;   // the chain's (p, v, a) sit at q0 + m qs
         OC_WAVE_SYNC();
 #pragma unroll
         for (int i = 0; i < (((OC_ABL) & 128) ? 0 : 2 * NSL - 1); ++i) {
@@ -576,7 +610,7 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
           OC_WAVE_SYNC();
           {
             const double* x = dZ + i * 16;
-            const double xn = ca[0] * x[q0] + ca[1] * x[q0 + 1] + ca[2] * x[q0 + 2] + cb * x[NX + chs];
+            const double xn = ca[0] * x[q0] + ca[1] * x[q0 + qs] + ca[2] * x[q0 + 2 * qs] + cb * x[NX + chs];
             if (lf < NX) dZ[(i + 1) * 16 + lf] = xn;
           }
           OC_WAVE_SYNC();
@@ -689,11 +723,11 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
     viol = wave_max(viol); scost = wave_sum(scost);
     {
       double o = 0.0;
-      for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) { const double d = Z[k] - Rf[(k >> 4) * NZ + q]; o += Wd[q] * d * d; } }
+      for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) { const double d = Z[k] - Rf[(k >> 4) * NZ + oc_lcol<C, CM>(q)]; o += Wd[q] * d * d; } }
       obj = wave_sum(o) + scost;
     }
     double* Zo = B.batch_Z + (size_t)node * N * NZ;
-    for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) Zo[(k >> 4) * NZ + q] = Z[k]; }
+    for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) Zo[(k >> 4) * NZ + oc_lcol<C, CM>(q)] = Z[k]; }
     if (tid == 0) {
       const int itc = it > QP_MAXIT ? QP_MAXIT : it;
       B.batch_obj[node] = obj; B.batch_viol[node] = viol; B.batch_ok[node] = ok;

@@ -1209,7 +1209,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   signed char* cfix = comp + Y.fixlen;               // [fixlen] fix record of the child whose rows are being lifted
   double* gsc = (double*)(cfix + Y.fixlen);          // [64][NZ + 1] one dense row per lane
   __shared__ BranchDesc chosen;
-  __shared__ int sh_base[3];
+  __shared__ int sh_base[4];
   __shared__ int slots[64];
   __shared__ int ck[64], ca[64], fam[4];
   __shared__ int k_ck[64], k_ca[64], k_neg[64], k_ord[64], k_pos[64];
@@ -1555,16 +1555,32 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       nk++;
     }
     int fbase = 0, obase = 0; bool okalloc = true;
+    if (nnear > 0) {
+      obase = atomicAdd(&B.open_count[inst], nnear);
+      if (obase + nnear > B.open_cap) {   // near list full: its reserved slots below the capacity become dead entries, the children wait in the far tier
+        for (int q = obase; q < obase + nnear && q < B.open_cap; ++q) { size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + q; B.open_bound[oi] = 1e300; B.open_node[oi] = -1; B.open_depth[oi] = 0; }
+        if (B.far_cap > 0) { for (int q = 0; q < nk; ++q) if (!(k_pos[q] & 0x40000000)) { k_pos[q] = 0x40000000 | nfar++; fmin_ = fmin(fmin_, k_bnd[q]); } }
+        else okalloc = false;
+        nnear = 0; obase = 0;
+      }
+    }
+    const int nnear_kept = nnear;
     if (nfar > 0) {
       fbase = atomicAdd(&B.far_count[inst], nfar);
       if (fbase + nfar <= B.far_cap) atomicMin(&B.far_minkey[inst], d2key(fmin_));
       else {   // tier full: the reserved slots below the capacity become dead entries, the children go to the near list
         for (int q = fbase; q < fbase + nfar && q < B.far_cap; ++q) { B.far_bound[(size_t)inst * B.far_cap + q] = 1e300; B.far_node[(size_t)inst * B.far_cap + q] = -1; }
-        for (int q = 0; q < nk; ++q) if (k_pos[q] & 0x40000000) k_pos[q] = nnear++;
+        int extra = 0;
+        for (int q = 0; q < nk; ++q) if (k_pos[q] & 0x40000000) k_pos[q] = 0x20000000 | extra++;   // second near reservation behind the first
         nfar = 0;
+        const int ob2 = atomicAdd(&B.open_count[inst], extra);
+        if (ob2 + extra > B.open_cap) {
+          okalloc = false;
+          for (int q = ob2; q < ob2 + extra && q < B.open_cap; ++q) { size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + q; B.open_bound[oi] = 1e300; B.open_node[oi] = -1; B.open_depth[oi] = 0; }
+        }
+        sh_base[3] = ob2;
       }
     }
-    if (nnear > 0) { obase = atomicAdd(&B.open_count[inst], nnear); okalloc = obase + nnear <= B.open_cap; }
     if (okalloc && nk > 0) {
       unsigned int h = atomicAdd(B.free_head, (unsigned int)nk);
       if ((int)(*B.free_limit - h) >= nk) {          // recycled records
@@ -1578,7 +1594,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     if (!okalloc) {   // list or record pool exhausted: the instance is flagged incomplete; the reserved list slots become dead entries
       atomicOr(&B.inst_flags[inst], 1);
       for (int q = fbase; q < fbase + nfar; ++q) { B.far_bound[(size_t)inst * B.far_cap + q] = 1e300; B.far_node[(size_t)inst * B.far_cap + q] = -1; }
-      for (int q = obase; q < obase + nnear && q < B.open_cap; ++q) { size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + q; B.open_bound[oi] = 1e300; B.open_node[oi] = -1; B.open_depth[oi] = 0; }
+      for (int q = obase; q < obase + nnear_kept && q < B.open_cap; ++q) { size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + q; B.open_bound[oi] = 1e300; B.open_node[oi] = -1; B.open_depth[oi] = 0; }
       nk = 0;
     }
     if (B.stats && nk > 0) { atomicAdd(&B.stats[43], 1ull); atomicAdd(&B.stats[44], (unsigned long long)nk); atomicAdd(&B.stats[48 + chosen.kind], 1ull); atomicAdd(&B.stats[52 + chosen.kind], (unsigned long long)nk); }
@@ -1618,7 +1634,8 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         size_t oi = (size_t)inst * B.far_cap + sh_base[0] + (k_pos[lane] & 0x3FFFFFFF);
         B.far_bound[oi] = k_bnd[lane]; B.far_node[oi] = slots[lane]; B.far_depth[oi] = dw;
       } else {
-        size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + sh_base[1] + k_pos[lane];
+        const int np_ = (k_pos[lane] & 0x20000000) ? sh_base[3] + (k_pos[lane] & 0x1FFFFFFF) : sh_base[1] + k_pos[lane];
+        size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + np_;
         B.open_bound[oi] = k_bnd[lane]; B.open_node[oi] = slots[lane]; B.open_depth[oi] = dw;
       }
     }
@@ -1711,18 +1728,18 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     return need;
   };
   const unsigned long long lowmask = (1ull << SEL_LOWSHIFT) - 1ull;
-  const int keep = cap / 8, spill_at = cap / 4;
+  const int keep = cap / 4, spill_at = cap / 2;   // near list after a spill / refill, and the length that triggers a spill
   const size_t fb = (size_t)inst * (size_t)B.far_cap;
   int fc = B.far_cap > 0 ? B.far_count[inst] : 0; if (fc > B.far_cap) fc = B.far_cap;
   // node selection: best bound, interleaved with dives (deepest first) while no incumbent exists, on every 4th
-  // round afterwards and whenever the list is more than half full or the record pool is nearly exhausted (a depth-first
+  // round afterwards and whenever the list is three quarters full or the record pool is nearly exhausted (a depth-first
   // frontier stays small); the order changes how fast incumbents appear, not what is proven
   const int dive_every = (B.seq_kinds >> 18) & 3;   // experiment switch: 0 every 4th round, 1 never, 2 every 8th, 3 every 2nd
   const bool periodic = dive_every == 0 ? (round & 3) == 3 : (dive_every == 1 ? false : (dive_every == 2 ? (round & 7) == 7 : (round & 1) == 1));
   bool pool_tight;
   { const int pc = *B.pool_count; const long long live = (long long)(pc < B.pool_cap ? pc : B.pool_cap) - (long long)(int)(*B.free_tail - *B.free_head);
     pool_tight = live > (long long)B.pool_cap / 10 * 9; }
-  const bool dive = !(inc < 1e300) || periodic || n > cap / 2 || pool_tight;
+  const bool dive = !(inc < 1e300) || periodic || n > cap / 4 * 3 || pool_tight;
   auto order_key = [&](double b, int dp) -> unsigned long long {
     // best bound; experiment switch (bits 24..25 of seq_kinds): deeper nodes first among nearly equal bounds
     const int dbias = (B.seq_kinds >> 24) & 3;
@@ -1754,7 +1771,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   // ---- far tier: when the near list cannot fill a batch any more, the far entries with the lowest bounds come back
   // (threshold by radix select on their bounds), the ones the incumbent prunes are dropped and the rest is compacted in
   // place, chunk by chunk (a chunk is read completely before anything is written at or below it)
-  if (fc > 0 && m < (B.batch_cap < keep ? B.batch_cap : keep)) {
+  if (fc > 0 && m < keep / 4) {   // (keep / 4 still fills the widest share of a batch: open_cap >= 8 x batch_cap, miqp_gpu.hip)
     auto fkey = [&](int k) -> unsigned long long {
       const double b = B.far_bound[fb + k];
       if (B.far_node[fb + k] < 0 || prunable(b)) return ~0ull;
@@ -1764,7 +1781,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     const unsigned long long thr = sh_all ? ~0ull : sh_prefix;
     if (tid == 0) { sh_w = 0; sh_mv = 0; sh_fmin = ~0ull; }
     __syncthreads();
-    int room = cap - n; if (room > cap / 2 - m) room = cap / 2 - m; if (room < 0) room = 0;
+    int room = cap - n; if (room > keep - m) room = keep - m; if (room < 0) room = 0;
     constexpr int PER = 4;
     for (int c0 = 0; c0 < fc; c0 += SEL_THREADS * PER) {
       double eb[PER]; int en[PER], ed[PER], act[PER];   // -1 nothing, 0 drop, 1 stay, 2 move to the near list
@@ -1849,7 +1866,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     if (w < B.nodes_per_round) w = B.nodes_per_round;
     if (!(inc < 1e300) && w > 512) w = 512;   // no incumbent yet: a narrow dive (a wide one degenerates into breadth first)
     int take = m < w ? m : w;
-    const int maxch = 64;     // children of one node: at most 63 (eval_kernel)
+    const int maxch = B.far_cap > 0 ? 8 : 64;     // children of one node: at most 63 (eval_kernel); with a far tier behind the list an overflow is absorbed there
     int room = (cap - m) / maxch; if (room < 1) room = 1;
     if (take > room) take = room;
     int base = take > 0 ? atomicAdd(B.batch_count, take) : 0;

@@ -637,7 +637,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   if (hipSetDevice(X.device) != hipSuccess) return fail_all("hipSetDevice failed");
   int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(16384, 32768 / n));
   if (O0.nodes_per_round <= 0 && std::getenv("MIQP_NPR")) npr = std::max(1, std::atoi(std::getenv("MIQP_NPR")));  // tuning knob
-  int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (std::getenv("MIQP_OPEN_CAP") ? std::atoi(std::getenv("MIQP_OPEN_CAP")) : std::max(32768, std::min(1 << 20, (1 << 27) / n)));   // 524288 per instance at n = 256: 10 GB of list entries, records are shared
+  int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (std::getenv("MIQP_OPEN_CAP") ? std::atoi(std::getenv("MIQP_OPEN_CAP")) : std::max(1 << 17, std::min(1 << 20, (1 << 28) / n)));   // near lists: 1 M entries per instance up to n = 256 (10 GB of list entries), 262144 at n = 1024; records are shared
   if (open_cap < 64) open_cap = 64;
   { size_t free_b = 0, total_b = 0;   // list entries (40 B per open node) must fit an eighth of the free device memory
     if (O0.max_open_nodes <= 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) { size_t lim = free_b / 8 / 40 / (size_t)n; if ((size_t)open_cap > lim) open_cap = (int)std::max<size_t>(4096, lim); } }
@@ -812,6 +812,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
           run(ipm_onchip_kernel<2, OC_NSL, 1>, 1); run(ipm_onchip_kernel<2, OC_NSL, 3>, 3); run(ipm_onchip_kernel<2, OC_NSL, 5>, 5); run(ipm_onchip_kernel<2, OC_NSL, 9>, 9);
           run(ipm_onchip_kernel<2, OC_NSL, 17>, 17); run(ipm_onchip_kernel<2, OC_NSL, 33>, 33); run(ipm_onchip_kernel<2, OC_NSL, 65>, 65); run(ipm_onchip_kernel<2, OC_NSL, 129>, 129);
           run(ipm_onchip_kernel<2, OC_NSL, 257>, 257); run(ipm_onchip_kernel<2, OC_NSL, 513>, 513); run(ipm_onchip_kernel<2, OC_NSL, 1023>, 1023);
+          run(ipm_onchip_kernel<2, OC_NSL, 1025>, 1025);   // the MFMA form of P [A B], [A B]' T on the model's column order
           launch_ipm_batch(X, B, bc, st);   // the replays clobbered the batch results: solve the real batch again
         }
 #endif
