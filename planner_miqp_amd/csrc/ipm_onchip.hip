@@ -142,6 +142,37 @@ __device__ inline int fresh_lane() {
   return l;
 }
 
+// cheap necessary condition for slot (i, slot) to carry a row, from the fix record alone (the first tests of decode_row; no
+// table loads): the decode walks all N x NSLOT slots with this and runs the full test only on the few hundred survivors
+template <int C>
+__device__ inline bool slot_maybe(const Layout& Y, const signed char* fix, int i, int slot) {
+  const int N = Y.N;
+  if (slot < C * Y.SC) {
+    const int c = slot / Y.SC, rr = slot - c * Y.SC;
+    if (rr < 11) return true;
+    if (i < 1) return false;
+    const int code = (int)fix[Y.f_reg + c * N + i];
+    if (rr < 16) return code >= 0 && ((code & 3) != 3 || rr - 11 <= 3);
+    int q = rr - 16;
+    if (q < 5 * Y.EL) {
+      if (Y.E < 1) return false;
+      const int pt = q / Y.EL;
+      const int e = Y.E == 1 ? 0 : (int)fix[Y.f_env + (c * N + i) * 5 + pt];
+      return e >= 0 && (pt == 0 || code >= 0);
+    }
+    q -= 5 * Y.EL;
+    const int o = q / 5, pt = q - o * 5;
+    const int kk = (int)fix[Y.f_obs + ((c * Y.O + o) * N + i) * 5 + pt];
+    return kk >= 0 && kk < Y.L && (pt == 0 || code >= 0);
+  }
+  if (C < 2 || i < 1) return false;
+  const int q = slot - C * Y.SC;
+  if (q < Y.NP * 8) { const int p = q >> 3, grp = (q & 7) >> 1; return (int)fix[Y.f_c2c + (p * N + i) * 4 + grp] >= 0; }
+  const int q2 = q - Y.NP * 8, p = q2 >> 4, grp = (q2 >> 2) & 3, alt = q2 & 3;
+  const int m = (int)fix[Y.f_c2n + (p * N + i) * 4 + grp];
+  return m > 0 && ((m >> alt) & 1);
+}
+
 // lambda + kappa and w of one row for the Newton system of the next iteration (see row_step)
 __device__ inline void row_weight(double s, double lam, double t, bool soft, double aq, double tau, double& w, double& lk) {
   const double il = frcp(lam);
@@ -252,6 +283,23 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
       OC_WAVE_SYNC();
       const int cls_off[8] = {0, 7, 11, 16, 16 + Y.EL, 16 + 5 * Y.EL, C * Y.SC, C * Y.SC + 8 * Y.NP};
       const int cls_cnt[8] = {7, 4, 5, Y.EL, 4 * Y.EL, 5 * Y.O, 8 * Y.NP, 16 * Y.NP};
+      auto take = [&](int i, int slot) {   // full test of one (stage, slot); box rows to their key, general rows to the bitmap
+        if (decode_row<C, false>(Y, D, T, fix, i, slot, nullptr).active) {
+          int col; double sg, rh;
+          if (box_of_slot<C>(Y, D, T, fix, i, slot, col, sg, rh)) atomicMin(&bkey[(i * 2 + (sg < 0.0 ? 1 : 0)) * 16 + oc_pcol<C, CM>(col)], d2key(rh));
+          else { const int pcode = i * NSLOT + slot; atomicOr(&bmp[pcode >> 6], 1ull << (pcode & 63)); }
+        }
+      };
+      // the candidates of the sparse classes (everything but the state / input bounds) are collected first with the cheap test
+      unsigned short* const plist = pre + ((nw + 1 + 3) & ~3);
+      const int LCAP = (int)(((char*)(L0 + LL.r) - (char*)plist) / 2) - 64;
+      int nlist = 0;
+      auto flush = [&]() {
+        OC_WAVE_SYNC();
+        for (int j0 = 0; j0 < nlist; j0 += 64) if (j0 + tid < nlist) { const int pc = plist[j0 + tid]; const int i = pc / NSLOT; take(i, pc - i * NSLOT); }
+        OC_WAVE_SYNC();
+        nlist = 0;
+      };
 #pragma unroll 1
       for (int cl = 0; cl < 8; ++cl) {
         const int cnt = cls_cnt[cl], off = cls_off[cl];
@@ -259,18 +307,17 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
         const int per = percar ? C * cnt : cnt, total = N * per;
         for (int e0 = 0; e0 < total; e0 += 64) {
           const int e = e0 + tid;
-          if (e < total) {
-            const int i = e / per, rem = e - i * per;
-            const int slot = percar ? (rem / cnt) * Y.SC + off + rem % cnt : off + rem;
-            if (decode_row<C, false>(Y, D, T, fix, i, slot, nullptr).active) {
-              int col; double sg, rh;
-              if (box_of_slot<C>(Y, D, T, fix, i, slot, col, sg, rh)) atomicMin(&bkey[(i * 2 + (sg < 0.0 ? 1 : 0)) * 16 + oc_pcol<C, CM>(col)], d2key(rh));
-              else { const int pcode = i * NSLOT + slot; atomicOr(&bmp[pcode >> 6], 1ull << (pcode & 63)); }
-            }
-          }
+          int i = 0, slot = 0; bool in = e < total;
+          if (in) { i = e / per; const int rem = e - i * per; slot = percar ? (rem / cnt) * Y.SC + off + rem % cnt : off + rem; }
+          if (cl < 2) { if (in) take(i, slot); continue; }
+          const bool cnd = in && slot_maybe<C>(Y, fix, i, slot);
+          const unsigned long long mk = __ballot(cnd);
+          if (cnd) plist[nlist + __popcll(mk & lt)] = (unsigned short)(i * NSLOT + slot);
+          nlist += __popcll(mk);
+          if (nlist > LCAP) flush();
         }
       }
-      OC_WAVE_SYNC();
+      flush();
       if (tid == 0) { int a = 0; for (int k = 0; k < nw; ++k) { pre[k] = (unsigned short)(a < 65535 ? a : 65535); a += __popcll(bmp[k]); } pre[nw] = (unsigned short)(a < 65535 ? a : 65535); }
       OC_WAVE_SYNC();
       ngen = pre[nw];
@@ -392,12 +439,12 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
     double resid_fac = 1.0, R0 = 0.0, obj = 0.0;
     double sigma = QP_SIGMA;
     unsigned long long rowiters = 0;
+    {
+      double o = 0.0;
+      for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) { const double d = Z[k] - Rf[(k >> 4) * NZ + oc_lcol<C, CM>(q)]; o += Wd[q] * d * d; } }
+      obj = wave_sum(o);
+    }
     for (it = 1; it <= QP_MAXIT; ++it) {
-      {
-        double o = 0.0;
-        for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) { const double d = Z[k] - Rf[(k >> 4) * NZ + oc_lcol<C, CM>(q)]; o += Wd[q] * d * d; } }
-        obj = wave_sum(o);
-      }
       if (OC_ABL) { if (it > 15) { ok = 1; break; } }
       else {
       if (comp < B.qp_tol * fmax(1.0, fabs(obj)) && resid_fac * R0 < 1e-7) { ok = 1; break; }
@@ -673,7 +720,13 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
       // ================= update
       double tnew = 0.0;
       const int l3 = fresh_lane();
-      for (int k = l3; k < N * 16; k += 64) Z[k] += alpha * dZ[k];
+      // objective of the next iterate: its reference values are requested here and meet the updated Z at the end of the pass
+      constexpr int NZW = (2 * NSL * 16 + 63) / 64;
+      double rfv[NZW];
+#pragma unroll
+      for (int j = 0; j < NZW; ++j) { const int k = l3 + 64 * j, q = k & 15; rfv[j] = (k < N * 16 && q < NZ) ? Rf[(k >> 4) * NZ + oc_lcol<C, CM>(q)] : 0.0; }
+#pragma unroll
+      for (int j = 0; j < NZW; ++j) { const int k = l3 + 64 * j; if (k < N * 16) Z[k] += alpha * dZ[k]; }
       const double* const dzq = dZ + (l3 >> 5) * 16 + (l3 & 15);
       const double sg3 = ((l3 >> 4) & 1) ? -1.0 : 1.0;
 #pragma unroll
@@ -700,6 +753,13 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
         tnew += (used && !soft) ? gt_[q] : 0.0;
       }
       tsum = wave_sum(tnew);
+      {
+        const int l4 = fresh_lane();
+        double o = 0.0;
+#pragma unroll
+        for (int j = 0; j < NZW; ++j) { const int k = l4 + 64 * j, q = k & 15; if (k < N * 16 && q < NZ) { const double d = Z[k] - rfv[j]; o += Wd[q] * d * d; } }
+        obj = wave_sum(o);
+      }
       resid_fac *= (1.0 - alpha);
       sigma = fmin(QP_SIGMA_HI, fmax(QP_SIGMA_LO, 1.0 - alpha));
       OC_WAVE_SYNC();
@@ -721,11 +781,7 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
       }
     }
     viol = wave_max(viol); scost = wave_sum(scost);
-    {
-      double o = 0.0;
-      for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) { const double d = Z[k] - Rf[(k >> 4) * NZ + oc_lcol<C, CM>(q)]; o += Wd[q] * d * d; } }
-      obj = wave_sum(o) + scost;
-    }
+    obj += scost;   // (obj is the quadratic objective of the final Z: recomputed by every update, and a node leaves the loop right after one or at its top)
     double* Zo = B.batch_Z + (size_t)node * N * NZ;
     for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) Zo[(k >> 4) * NZ + oc_lcol<C, CM>(q)] = Z[k]; }
     if (tid == 0) {

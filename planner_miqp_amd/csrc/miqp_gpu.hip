@@ -284,7 +284,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr) 
     X.oc_grid = 0;
     const OcLds ol = oc_lds_layout(Y.N, Y.fixlen);
     const size_t bitmap_b = (size_t)((Y.N * Y.NSLOT + 63) / 64) * 10 + 16;   // decode bitmap + prefix inside the scratch region
-    if (Y.C <= 2 && Y.N <= 2 * OC_NSL && bitmap_b <= (size_t)(ol.r - ol.u) && !std::getenv("MIQP_IPM_V1")) {
+    if (Y.C <= 2 && Y.N <= 2 * OC_NSL && bitmap_b + 1024 <= (size_t)(ol.r - ol.u) && !std::getenv("MIQP_IPM_V1")) {
       size_t lo = (size_t)ol.total + 16;
       int perc = (int)std::min<size_t>(8, (160 * 1024) / lo);
       if (perc >= 1) X.oc_grid = cus * perc;
