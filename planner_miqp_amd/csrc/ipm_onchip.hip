@@ -456,6 +456,12 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
       // box rows -> diagonal and gradient contribution per (stage, column): the two sides of a column sit in lanes l, l ^ 16
       // (no branches around the slots: the ten independent chains interleave; unused slots carry a benign state and are masked)
       const int l1 = fresh_lane();
+      constexpr int NZW1 = (2 * NSL * 16 + 63) / 64;
+      double rf1[CM ? NZW1 : 1];   // chain-major form: the objective's share of the gradient joins Gd at the end of the pass
+      if constexpr (CM) {
+#pragma unroll
+        for (int j = 0; j < NZW1; ++j) { const int k = l1 + 64 * j, q = k & 15; rf1[j] = (k < N * 16 && q < NZ) ? Rf[(k >> 4) * NZ + oc_lcol<C, CM>(q)] : 0.0; }
+      }
       double* const dgp = Dg + (l1 >> 5) * 16 + (l1 & 15); double* const gdp = dgp + N * 16;
       const bool side0 = ((l1 >> 4) & 1) == 0; const double sg1 = side0 ? 1.0 : -1.0; const int par1 = l1 >> 5;
 #pragma unroll
@@ -472,19 +478,132 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
           }
         }
       }
+      if constexpr (CM) OC_WAVE_SYNC();   // the box rows' gradient entries are in place before the general rows add theirs
 #pragma unroll
       for (int q = 0; q < (((OC_ABL) & 4) ? 0 : OC_GSLOTS); ++q) {
         const int r = q * 64 + l1;
         const bool soft = ((gflag >> q) & 1u) != 0u;
         double w, lk; row_weight(gs_[q], gl_[q], gt_[q], soft, aqs, tau, w, lk);
         const double isw = frsq(w);
-        if (r < NM) { gswfs[2 * r] = w * isw; gswfs[2 * r + 1] = lk * isw; }
+        if (r < NM) {
+          gswfs[2 * r] = w * isw;
+          if constexpr (CM) {   // gradient of the row straight into the stage's gradient vector (LDS atomics; the sweep then reads one array)
+            const uint4 m4 = gmeta[r];
+            const int off = (int)(m4.z & 0xFFFFu), nn = (int)((m4.z >> 16) & 7u), i = (int)((m4.z >> 20) & 0x7FFu);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (k < nn) atomicAdd(&Gd[i * 16 + ((m4.w >> (4 * k)) & 15u)], gcoef[off + k] * lk);
+          } else gswfs[2 * r + 1] = lk * isw;
+        }
       }
       OC_WAVE_SYNC();
+      double rmax = 0.0;
+      if constexpr (CM) {
+#pragma unroll
+        for (int j = 0; j < NZW1; ++j) {
+          const int k = l1 + 64 * j, q = k & 15;
+          if (k < N * 16 && q < NZ) { const double v = Gd[k] + 2.0 * Wd[q] * (Z[k] - rf1[j]); Gd[k] = v; rmax = fmax(rmax, fabs(v)); }
+        }
+        OC_WAVE_SYNC();
+      }
       OCP_T(tp_r1); OCP_ACC(1, tp_r0, tp_r1);
       // ================= backward sweep (Riccati recursion in MFMA registers, see ipm_kernel)
-      double rmax = 0.0;
-      {
+      if constexpr (CM) {
+        // Chain-major form.  Gd holds the complete gradient rr of every stage; the vector p of the recursion lives in ROW layout
+        // (lane group = chain, register = derivative: the layout of the tile's rows), so that [A B]' p is a sum over the lane's
+        // registers.  The input block is eliminated by Gauss-Jordan on the four input rows of the tile (one register): row q is
+        // broadcast over the lane groups, normalised by its pivot (row_newbcast picks the pivot / multiplier column inside the
+        // rows), and subtracted from the others; after pivot 0 its column is spent (a unit vector) and carries the vector s_u,
+        // so the rows end as [K | k] in the layout the forward sweep reads, and ONE MFMA forms the Schur complement of the
+        // tile and, in column 12, the next p.
+        const double h1 = ts, h2 = 0.5 * ts * ts, h3 = ts * ts * ts / 6.0;
+        d4_t Pd = {0.0, 0.0, 0.0, 0.0};
+        double pr[3];
+        auto phiM = [&](int j, d4_t& acc) {
+          const int rb = sstart[j], re = sstart[j + 1];
+          acc = d4_t{0.0, 0.0, 0.0, 0.0};
+          auto kblock = [&](int r0) {
+            const int r = r0 + lg;
+            double a = 0.0;
+            if (r < re) {
+              const uint4 m4 = gmeta[r];
+              const unsigned int nib = lc < 8 ? (m4.x >> (4 * lc)) & 15u : (m4.y >> (4 * (lc - 8))) & 15u;
+              if (nib) a = gcoef[(m4.z & 0xFFFFu) + nib - 1u] * gswfs[2 * r];
+            }
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+          };
+          if (!((OC_ABL) & 8)) { kblock(rb); kblock(rb + 4);
+          for (int r0 = rb + 8; r0 < re; r0 += 4) kblock(r0); }
+          const int lp = fresh_lane(), lcp = lp & 15, lgp = lp >> 4;
+          const double dd = lcp < NZ ? 2.0 * Wd[lcp] + Dg[j * 16 + lcp] : 0.0;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) if (lgp + 4 * rg == lcp) acc[rg] += dd;
+        };
+        auto bcast_group = [&](double v, int q) {   // the value of lane group q in every group
+          double t = lg == q ? v : 0.0;
+          t = sum_xor16(t); return sum_xor32(t);
+        };
+        d4_t accA;
+        phiM(N - 1, accA);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) Pd[rg] = (rg < 3 && lc < NX) ? accA[rg] : 0.0;   // u_{N-1} = 0: P = Phi_xx, p = rr_x
+        { const int lq = fresh_lane();
+#pragma unroll
+          for (int k = 0; k < 3; ++k) pr[k] = Gd[(N - 1) * 16 + (lq >> 4) + 4 * k]; }
+        if (N >= 2) phiM(N - 2, accA);
+        for (int i = N - 2; i >= 0; --i) {
+          d4_t acc = accA;
+          OCP_T(tp_s0);
+          if (i > 0) phiM(i - 1, accA);
+          OCP_T(tp_s1); OCP_ACC(2, tp_s0, tp_s1);
+          double sv[4];
+          { const int lq = fresh_lane(); const double* gr = Gd + i * 16 + (lq >> 4);
+            sv[0] = gr[0]; sv[1] = gr[4]; sv[2] = gr[8]; sv[3] = gr[12]; }
+          if (!((OC_ABL) & 16)) {
+            d4_t Tt;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) Tt[r] = Pd[r] + h1 * dpp_shift0<0x114>(Pd[r]) + h2 * dpp_shift0<0x118>(Pd[r]) + h3 * dpp_shift0<0x11C>(Pd[r]);
+            acc[0] += Tt[0];
+            acc[1] += Tt[1] + h1 * Tt[0];
+            acc[2] += Tt[2] + h1 * Tt[1] + h2 * Tt[0];
+            acc[3] += h1 * Tt[2] + h2 * Tt[1] + h3 * Tt[0];
+          }
+          if (!((OC_ABL) & 32)) {
+            sv[0] += pr[0];
+            sv[1] += pr[1] + h1 * pr[0];
+            sv[2] += pr[2] + h1 * pr[1] + h2 * pr[0];
+            sv[3] += h1 * pr[2] + h2 * pr[1] + h3 * pr[0];
+          }
+          const double own = acc[3];
+          OCP_T(tp_s2); OCP_ACC(3, tp_s1, tp_s2);
+          double W3 = own;
+          if (!((OC_ABL) & 64)) {
+            {   // pivot 0, the vector still beside the rows
+              const double d = dpp_mov<0x15C>(W3);
+              const double rowq = bcast_group(W3, 0), s0 = bcast_group(sv[3], 0);
+              const double inv = frcp(fmax(dpp_mov<0x15C>(rowq), 1e-300));
+              const double rown = rowq * inv, s0n = s0 * inv;
+              W3 = lg == 0 ? rown : fma(-d, rown, W3);
+              sv[3] = lg == 0 ? s0n : fma(-d, s0n, sv[3]);
+              W3 = lc == 12 ? sv[3] : W3;
+            }
+#define OC_PIVOT(Q, CTRL) { const double d = dpp_mov<CTRL>(W3); const double rowq = bcast_group(W3, Q); \
+              const double inv = frcp(fmax(dpp_mov<CTRL>(rowq), 1e-300)); const double rown = rowq * inv; \
+              W3 = lg == Q ? rown : fma(-d, rown, W3); }
+            OC_PIVOT(1, 0x15D) OC_PIVOT(2, 0x15E) OC_PIVOT(3, 0x15F)
+#undef OC_PIVOT
+          }
+          OCP_T(tp_s4); OCP_ACC(5, tp_s2, tp_s4);
+          if (lc <= NX) { if (i < OC_KL0) KL0[i * 64 + lg * 16 + lc] = W3; else KG[i * 64 + lg * 16 + lc] = W3; }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) acc[k] = lc == 12 ? sv[k] : acc[k];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-own, lc <= NX ? W3 : 0.0, acc, 0, 0, 0);
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) Pd[rg] = (rg < 3 && lc < NX) ? acc[rg] : 0.0;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) pr[k] = dpp_mov<0x15C>(acc[k]);
+          OCP_T(tp_s5); OCP_ACC(6, tp_s4, tp_s5);
+        }
+      } else {
         d4_t Pd = {0.0, 0.0, 0.0, 0.0};
         double pcol = 0.0;
         double rfn = lc < NZ ? Rf[(N - 1) * NZ + oc_lcol<C, CM>(lc)] : 0.0;
