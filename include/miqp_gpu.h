@@ -108,6 +108,11 @@ int miqp_solver_split_roots(const miqp_solver_t* s, int world, int rank, int* ro
  * instance (collectCplexStatistics, src/cplex_wrapper.cpp:679-690): out[0..3] = rows, binary columns, continuous
  * columns, non-zeros.  Needs no device. */
 int miqp_solver_raw_sizes(const miqp_solver_t* s, int* out4);
+/* Diagnostic (no reference counterpart, no device needed): the response tables behind the bound lifting of the branch and
+   bound - for every (car, axis, step) the 4 x 4 matrix Zu H^-1 Zu' of the chain's (position, velocity,
+   acceleration, jerk) at that step under the objective's Hessian; out[((car * 2 + axis) * N + step) * 16 + 4 a + b].
+   Returns the number of doubles written, < 0 on error (-3: cap too small). */
+int miqp_solver_lift_tables(const miqp_solver_t* s, double* out, int cap);
 
 /* CplexWrapper::getRawResults()                                src/cplex_wrapper.hpp:204, cpp:311-448
  * Fills the caller-allocated record (sizes must match the instance). */

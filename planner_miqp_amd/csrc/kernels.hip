@@ -1509,7 +1509,16 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       if (lane == 0) { cfix[base + i * stride] = kk == i ? (signed char)ca[a] : comp[base + i * stride]; if (negidx >= 0) cfix[negidx] = (signed char)negm; }
       __syncthreads();
       double lift = 0.0;
-      for (int sl = lane; sl < Y.NSLOT; sl += 64) {
+      // slots whose row can depend on the changed byte: a region code touches every slot of its car and the car/car slots,
+      // the other kinds only their own rows
+      int s0 = 0, s1 = Y.NSLOT, s2 = 0, s3 = 0;   // [s0, s1) and [s2, s3)
+      if (chosen.kind == 0) { s0 = chosen.c * Y.SC; s1 = s0 + Y.SC; s2 = C * Y.SC; s3 = Y.NSLOT; }
+      else if (chosen.kind == 1) { s0 = chosen.c * Y.SC + 16 + chosen.pt * Y.EL; s1 = s0 + Y.EL; }
+      else if (chosen.kind == 2) { s0 = chosen.c * Y.SC + 16 + 5 * Y.EL + chosen.o * 5 + chosen.pt; s1 = s0 + 1; }
+      else { s0 = C * Y.SC + chosen.c * 8 + chosen.o * 2; s1 = s0 + 2; s2 = C * Y.SC + 8 * Y.NP + chosen.c * 16 + chosen.o * 4; s3 = s2 + 4; }
+      const int n01 = s1 - s0, ntot = n01 + (s3 - s2);
+      for (int e = lane; e < ntot; e += 64) {
+        const int sl = e < n01 ? s0 + e : s2 + (e - n01);
         const RowOut r = decode_row<C, true>(Y, D, T, cfix, i, sl, gl);
         if (!r.active || r.aq != 0.0) continue;
         double v = -r.rhs;
@@ -1732,14 +1741,16 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   const size_t fb = (size_t)inst * (size_t)B.far_cap;
   int fc = B.far_cap > 0 ? B.far_count[inst] : 0; if (fc > B.far_cap) fc = B.far_cap;
   // node selection: best bound, interleaved with dives (deepest first) while no incumbent exists, on every 4th
-  // round afterwards and whenever the list is three quarters full or the record pool is nearly exhausted (a depth-first
+  // round afterwards and whenever the list is full (without a far tier: half full) or the record pool is nearly exhausted (a depth-first
   // frontier stays small); the order changes how fast incumbents appear, not what is proven
   const int dive_every = (B.seq_kinds >> 18) & 3;   // experiment switch: 0 every 4th round, 1 never, 2 every 8th, 3 every 2nd
   const bool periodic = dive_every == 0 ? (round & 3) == 3 : (dive_every == 1 ? false : (dive_every == 2 ? (round & 7) == 7 : (round & 1) == 1));
   bool pool_tight;
   { const int pc = *B.pool_count; const long long live = (long long)(pc < B.pool_cap ? pc : B.pool_cap) - (long long)(int)(*B.free_tail - *B.free_head);
     pool_tight = live > (long long)B.pool_cap / 10 * 9; }
-  const bool dive = !(inc < 1e300) || periodic || n > cap / 4 * 3 || pool_tight;
+  // (with a far tier a long near list is spilled, not dived; only when that tier fills up too does the search go depth first)
+  const bool lists_full = B.far_cap > 0 ? fc > B.far_cap / 4 * 3 : n > cap / 2;
+  const bool dive = !(inc < 1e300) || periodic || lists_full || pool_tight;
   auto order_key = [&](double b, int dp) -> unsigned long long {
     // best bound; experiment switch (bits 24..25 of seq_kinds): deeper nodes first among nearly equal bounds
     const int dbias = (B.seq_kinds >> 24) & 3;
@@ -1828,7 +1839,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   // ---- spill: a best-bound round that finds the near list long keeps the `keep` lowest keys there and moves the rest to the
   // far tier (pass 3); from then on children above the threshold are appended to the far tier directly (eval_kernel).
   // The deepest levels (up to keep / 2 nodes) stay whatever their bound: they are the stack of the periodic dives.
-  const bool spill = B.far_cap > 0 && !dive && m > spill_at && fc < B.far_cap;
+  const bool spill = B.far_cap > 0 && m > spill_at && fc < B.far_cap;   // (in a dive round the keys are depths: the deepest nodes stay)
   unsigned long long thr_spill = ~0ull;
   if (spill) {
     radix([&](int k) { return keys[k]; }, n, keep);
@@ -1868,6 +1879,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     int take = m < w ? m : w;
     const int maxch = B.far_cap > 0 ? 8 : 64;     // children of one node: at most 63 (eval_kernel); with a far tier behind the list an overflow is absorbed there
     int room = (cap - m) / maxch; if (room < 1) room = 1;
+    if (B.far_cap > 0 && room < 1024) room = 1024;   // (children that find the near list full go to the far tier)
     if (take > room) take = room;
     int base = take > 0 ? atomicAdd(B.batch_count, take) : 0;
     if (base + take > B.batch_cap) take = B.batch_cap > base ? B.batch_cap - base : 0;
@@ -1925,7 +1937,8 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     if (spill) {
       B.far_count[inst] = sh_w < B.far_cap ? sh_w : B.far_cap;
       if (sh_fmin != ~0ull) atomicMin(&B.far_minkey[inst], sh_fmin);
-      B.near_thr[inst] = thr_spill != ~0ull ? key2d(thr_spill | lowmask) : 1e300;
+      // after a spill by depth the near list is no longer "everything below a bound": children go to the far tier until the next refill sets the threshold again
+      B.near_thr[inst] = dive ? -1e300 : (thr_spill != ~0ull ? key2d(thr_spill | lowmask) : 1e300);
     }
   }
 }

@@ -1178,6 +1178,19 @@ int miqp_solver_raw_sizes(const miqp_solver_t* s, int* out4) {
   return 0;
 }
 
+int miqp_solver_lift_tables(const miqp_solver_t* s, double* out, int cap) {
+  if (!s || !s->has_inst || !out) return -1;
+  miqp_solver_t* one[1] = {const_cast<miqp_solver_t*>(s)};
+  BatchShape bs = batch_layout(one, 1);
+  if (!bs.ok) return -2;
+  const int n = bs.Y.C * 2 * bs.Y.N * 16;
+  if (cap < n) return -3;
+  std::vector<double> D(bs.Y.dstride, 0.0);
+  lift_tables(s->inst, bs.Y, D.data());
+  std::copy(D.begin() + bs.Y.d_lift, D.begin() + bs.Y.d_lift + n, out);
+  return n;
+}
+
 int miqp_solver_solve(miqp_solver_t* s, double timestamp) {
   (void)timestamp;
   if (!s || !s->has_inst) return MIQP_STATUS_FAILED_SEG_FAULT;

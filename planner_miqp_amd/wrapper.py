@@ -7,7 +7,9 @@ import enum
 import os
 import subprocess
 
-from .ctypes_types import (ModelParameters, ModelParamsC, RawResults, RawResultsC, SolutionPropertiesC, SolverOptsC)
+import numpy as np
+
+from .ctypes_types import (ModelParameters, ModelParamsC, RawResults, RawResultsC, SolutionPropertiesC, SolverOptsC, c_double_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -53,6 +55,7 @@ def load_library():
     L.miqp_solver_solve_batch.restype = C.c_int; L.miqp_solver_solve_batch.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
     L.miqp_solver_solve_batch_multi.restype = C.c_int; L.miqp_solver_solve_batch_multi.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.miqp_solver_raw_sizes.restype = C.c_int; L.miqp_solver_raw_sizes.argtypes = [vp, C.POINTER(C.c_int)]
+    L.miqp_solver_lift_tables.restype = C.c_int; L.miqp_solver_lift_tables.argtypes = [vp, c_double_p, C.c_int]
     L.miqp_solver_solve_split.restype = C.c_int; L.miqp_solver_solve_split.argtypes = [vp, C.c_double, C.c_int, C.c_int, EXCHANGE_FN, vp]
     L.miqp_solver_solve_split_rccl.restype = C.c_int; L.miqp_solver_solve_split_rccl.argtypes = [vp, C.c_double]
     L.miqp_solver_split_roots.restype = C.c_int
@@ -83,7 +86,7 @@ EXPORTED_SYMBOLS = ["miqp_solver_create", "miqp_solver_destroy", "miqp_solver_se
                     "miqp_solver_write_mst", "miqp_solver_read_mst", "miqp_fraction_parameters", "miqp_mean_angles",
                     "miqp_limits_per_region", "miqp_calculate_region_idx", "miqp_reserve_neighbor_regions",
                     "miqp_calculate_possible_regions", "miqp_calculate_warmstart", "miqp_plan",
-                    "miqp_solver_solve_batch_multi", "miqp_solver_raw_sizes", "miqp_fitting_polynomial_parameters",
+                    "miqp_solver_solve_batch_multi", "miqp_solver_raw_sizes", "miqp_solver_lift_tables", "miqp_fitting_polynomial_parameters",
                     "miqp_solver_solve_split", "miqp_solver_solve_split_rccl", "miqp_solver_split_roots", "miqp_comm_unique_id",
                     "miqp_comm_init", "miqp_comm_finalize", "miqp_comm_selftest"]
 
@@ -333,6 +336,17 @@ class CplexWrapper:
         it = C.c_int(0)
         rc = self._L.miqp_solver_solve_fixed(self._h, C.byref(fc), C.byref(oc), C.byref(obj), C.byref(it))
         return rc, out, obj.value, it.value
+
+    def liftTables(self):
+        """response tables of the bound lifting, array [car][axis][step][4][4] (diagnostic, no device needed)"""
+        if self._push_inputs() != 0:
+            raise RuntimeError("invalid parameters")
+        p = self._params
+        out = np.zeros((p.NumCars, 2, p.NumSteps, 4, 4))
+        n = self._L.miqp_solver_lift_tables(self._h, out.ctypes.data_as(c_double_p), out.size)
+        if n != out.size:
+            raise RuntimeError("miqp_solver_lift_tables failed (%d)" % n)
+        return out
 
     def rawSizes(self):
         """rows / binaries / continuous columns / non-zeros of the OPL model of the loaded parameters (no device needed)"""

@@ -254,3 +254,32 @@ def test_written_dat_reproduces_the_rounded_inputs_exactly(lib, tmp_path):
     w2 = P.CplexWrapper(parameterSource=P.ParameterSource.DATFILE); w2.setParameterDatFileAbsolute(out)
     assert w2._push_inputs() == 0 and lib.miqp_solver_export_lp(w2._h, b.encode()) == 0
     assert open(a).read() == open(b).read()
+
+
+def test_lift_tables_match_a_dense_computation():
+    """the response tables behind the bound lifting (host_inst.hpp::lift_tables): Sigma_i = Zu_i H^-1 Zu_i' of every
+    triple-integrator chain, rebuilt here from first principles with dense numpy algebra"""
+    import planner_miqp_amd as P
+    from planner_miqp_amd import synthetic
+    p = synthetic.generate("cfg3", 5, gap=0.01, max_time=1.0)
+    w = P.CplexWrapper(); w.resetParameters(p)
+    T = w.liftTables()
+    N, ts = p.NumSteps, p.ts
+    A = np.array([[1, ts, ts * ts / 2], [0, 1, ts], [0, 0, 1.0]]); Bv = np.array([ts ** 3 / 6, ts * ts / 2, ts])
+    M = N - 1
+    for c in range(p.NumCars):
+        for ax, names in enumerate((("WEIGHTS_POS_X", "WEIGHTS_VEL_X", "WEIGHTS_ACC_X", "WEIGHTS_JERK_X"), ("WEIGHTS_POS_Y", "WEIGHTS_VEL_Y", "WEIGHTS_ACC_Y", "WEIGHTS_JERK_Y"))):
+            wts = np.array([np.asarray(getattr(p, n)).reshape(-1)[c] for n in names])
+            Zu = np.zeros((N, 4, M))
+            for i in range(N):
+                for j in range(min(i, M)):
+                    Zu[i, :3, j] = np.linalg.matrix_power(A, i - 1 - j) @ Bv
+                if i < M:
+                    Zu[i, 3, i] = 1.0
+            H = sum(Zu[i].T @ np.diag(2 * wts) @ Zu[i] for i in range(N))
+            Hi = np.linalg.inv(H)
+            for i in range(N):
+                S = Zu[i] @ Hi @ Zu[i].T
+                assert np.allclose(T[c, ax, i], S, rtol=1e-8, atol=1e-12), (c, ax, i)
+                assert np.allclose(S, S.T) and np.all(np.linalg.eigvalsh(T[c, ax, i]) > -1e-12)
+    assert np.all(T[:, :, 0, :3, :] == 0)   # the first state is fixed: only its input responds

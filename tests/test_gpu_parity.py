@@ -635,3 +635,49 @@ def test_odd_shapes_match_the_oracle(oracle, shape):
             v, obj, worst = oracle.raw_eval(h, res)
             assert v < 1e-5, (shape, seed, worst)
         oracle.free(h)
+
+
+SEARCH_SCRIPT = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+import planner_miqp_amd as P
+from planner_miqp_amd import synthetic
+cap = int(sys.argv[1])
+out = []
+for cfg, seed, gap in (("cfg3", 0, 1e-6), ("cfg3", 2, 1e-6), ("cfg3", 5, 1e-6), ("cfg3", 33, 1e-4), ("cfg3", 118, 0.01), ("cfg4", 1, 1e-4)):
+    w = P.CplexWrapper(max_open_nodes=cap); w.resetParameters(synthetic.generate(cfg, seed, gap=gap, max_time=60))
+    st = w.callCplex(); pr = w.getSolutionProperties()
+    out.append(dict(cfg=cfg, seed=seed, gap=gap, st=int(st), status=pr.status, objective=pr.objective, bound=pr.best_bound, nodes=int(pr.nodes)))
+print("SEARCH_JSON " + json.dumps(out))
+"""
+
+
+def _run_search(tmp_path, cap, env_extra):
+    import json, subprocess, sys
+    script = tmp_path / "search.py"
+    script.write_text(SEARCH_SCRIPT % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, str(script), str(cap)], capture_output=True, text=True, env=dict(os.environ, **env_extra), timeout=900)
+    line = [l for l in out.stdout.splitlines() if l.startswith("SEARCH_JSON ")]
+    assert line, out.stdout[-2000:] + out.stderr[-2000:]
+    return json.loads(line[0][len("SEARCH_JSON "):])
+
+
+def test_search_devices_change_the_order_not_the_answer(tmp_path):
+    """The two-tier open list and the bound lifting only reorder / prune the search: with the lifting switched off
+    (MIQP_SEQ_KINDS bit 17), with the far tier switched off (MIQP_FAR_CAP=0) and with a near list of 65536 entries (a sixteenth of
+    the default: the tiers spill and refill all the time), every instance is proven to its gap with the same optimum (own processes: the
+    switches are read when the device context is built)."""
+    ref = _run_search(tmp_path, 0, {})
+    variants = {"no lifting": (0, {"MIQP_SEQ_KINDS": str((5 << 8) | 0x20000)}), "no far tier": (0, {"MIQP_FAR_CAP": "0"}),
+                "short near list": (65536, {})}
+    assert all(r["st"] == 0 and r["status"] in (101, 102) for r in ref), ref
+    for name, (cap, env) in variants.items():
+        got = _run_search(tmp_path, cap, env)
+        for a, b in zip(ref, got):
+            tol = max(2e-6, 2.0 * a["gap"]) * max(1.0, abs(a["objective"]))
+            assert b["st"] == 0 and b["status"] in (101, 102), (name, b)
+            assert abs(a["objective"] - b["objective"]) <= tol, (name, a, b)
+            assert b["bound"] <= a["objective"] + tol and a["bound"] <= b["objective"] + tol, (name, a, b)
+    # what the lifting buys on a hard instance (seed 118): at least a third fewer nodes
+    nl = _run_search(tmp_path, 0, variants["no lifting"][1])
+    assert ref[4]["nodes"] < 0.67 * nl[4]["nodes"], (ref[4]["nodes"], nl[4]["nodes"])
