@@ -1183,6 +1183,33 @@ __device__ inline double c2c_alt_viol(const Layout& Y, const double* D, int p, i
   return lhs + (soft ? Dsep + S : Dsep);
 }
 
+// --- scores for the choice of the branching disjunction: lower bound on what an alternative costs, from the diagonal of the
+// response tables (the exact lift with the cross terms is computed for the children of the chosen disjunction only)
+struct LiftDiag { double p, v, a, u; };
+__device__ inline void lift_diag(const Layout& Y, const double* D, int c, int i, LiftDiag& X, LiftDiag& Yd) {
+  const double* S = D + Y.d_lift + ((c * 2) * Y.N + i) * 16;
+  X.p = S[0]; X.v = S[5]; X.a = S[10]; X.u = S[15];
+  S += Y.N * 16;
+  Yd.p = S[0]; Yd.v = S[5]; Yd.a = S[10]; Yd.u = S[15];
+}
+__device__ inline double lift1(double v, double gam) { return (v > 0.0 && gam > 1e-300 && gam < 1e200) ? 0.5 * v * v / gam : 0.0; }
+
+__device__ inline double region_alt_lift(const Layout& Y, const double* D, const int* T, int c, int q, int h, const CarState& s, bool with_jerk,
+                                         const LiftDiag& X, const LiftDiag& Yd) {
+  const double* rt = D + Y.d_reg + (c * Y.P + q) * REGSZ;
+  const double vm = D[Y.d_glob + 6];
+  double l = fmax(lift1(fmax(s.ax - rt[12], rt[11] - s.ax), X.a), lift1(fmax(s.ay - rt[14], rt[13] - s.ay), Yd.a));
+  if (with_jerk) l = fmax(l, fmax(lift1(fmax(s.ux - rt[16], rt[15] - s.ux), X.u), lift1(fmax(s.uy - rt[18], rt[17] - s.uy), Yd.u)));
+  if (h == 3) return fmax(l, fmax(lift1(fabs(s.vx) - vm, X.v), lift1(fabs(s.vy) - vm, Yd.v)));
+  l = fmax(l, lift1(rt[0] * s.vx + rt[1] * s.vy, rt[0] * rt[0] * X.v + rt[1] * rt[1] * Yd.v));
+  l = fmax(l, lift1(rt[2] * s.vx + rt[3] * s.vy, rt[2] * rt[2] * X.v + rt[3] * rt[3] * Yd.v));
+  const int* hs = T + Y.i_hs + ((c * Y.P + q) * 2 + h) * 2;
+  l = fmax(l, lift1(vm - hs[1] * (hs[0] == 0 ? s.vx : s.vy), hs[0] == 0 ? X.v : Yd.v));
+  l = fmax(l, lift1(s.ay - rt[4] * s.ax - rt[6] * s.vx - rt[7] * s.vy - rt[5], Yd.a + rt[4] * rt[4] * X.a + rt[6] * rt[6] * X.v + rt[7] * rt[7] * Yd.v));
+  l = fmax(l, lift1(-s.ay + rt[4] * s.ax + rt[9] * s.vx + rt[10] * s.vy + rt[8], Yd.a + rt[4] * rt[4] * X.a + rt[9] * rt[9] * X.v + rt[10] * rt[10] * Yd.v));
+  return l;
+}
+
 struct BranchDesc { int prio; int kind; int c; int o; int i; int pt; };  // kind: 0 region 1 env 2 obs 3 c2c
 
 template <int C>
@@ -1200,7 +1227,8 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   double* Z = lds;                                   // [N][NZ]
   double* slowv = Z + N * NZ;                        // [C*N][P] slow-alternative violation per possible region
   double* fastv = slowv + C * N * P;                 // [C*N] best fast alternative violation
-  int* fastc = (int*)(fastv + C * N);                // [C*N] its code
+  double* rlift = fastv + C * N;                     // [C*N] smallest lift over the region alternatives (branching score)
+  int* fastc = (int*)(rlift + C * N);                // [C*N] its code
   int* vflag = fastc + C * N;                        // [C*N] region violated
   int* altbuf = vflag + C * N;                       // [64]
   double* altval = (double*)(altbuf + 64);           // [64]
@@ -1254,6 +1282,9 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       // canonical choice (ties at sector borders are common): the first non-slow alternative, in (region, half-plane)
       // order, whose rows hold within tol; else the slow alternative if it holds; else the least violated one
       double bv = 1e300; int bc = -1; bool found = false;
+      LiftDiag LX, LYd; lift_diag(Y, D, c, i, LX, LYd);
+      double ml = 1e300;
+      const bool want_score = ((B.seq_kinds >> 8) & 15) >= 10;
       const unsigned long long allow = ((unsigned long long)(unsigned int)T[Y.i_allow + (c * N + i) * 2 + 1] << 32) | (unsigned int)T[Y.i_allow + (c * N + i) * 2];
       for (int q = 0; q < np; ++q) {
         slowv[(c * N + i) * P + q] = ((nxtq >= 0 && nxtq != q) || !((allow >> (q * 4 + 3)) & 1ull)) ? 1e300 : region_alt_viol(Y, D, T, c, q, 3, s, wj);
@@ -1262,11 +1293,12 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         for (int h = 0; h < nh; ++h) {
           if (!((allow >> (q * 4 + h)) & 1ull)) continue;  // unreachable velocity set (host presolve)
           double v = region_alt_viol(Y, D, T, c, q, h, s, wj);
+          if (want_score) ml = fmin(ml, region_alt_lift(Y, D, T, c, q, h, s, wj, LX, LYd));
           if (!found && v <= tol) { found = true; bv = 0.0; bc = q * 4 + h; }
           if (!found && v < bv) { bv = v; bc = q * 4 + h; }
         }
       }
-      fastv[c * N + i] = bv; fastc[c * N + i] = bc; vflag[c * N + i] = 0;
+      fastv[c * N + i] = bv; fastc[c * N + i] = bc; vflag[c * N + i] = 0; rlift[c * N + i] = ml < 1e300 ? ml : 0.0;
     }
   }
   __syncthreads();
@@ -1298,8 +1330,14 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   // 250 instead of 184 of 256 headline instances reach 1 % in 10 s; car/car decisions fix the homotopy class, and the
   // many region alternatives are only enumerated inside a class).
   const int prio_mode = inc_now < 1e300 ? ((B.seq_kinds >> 8) & 15) : 0;
-  auto consider = [&](int step, int kind, int c, int o, int pt, double vv) {
+  auto consider = [&](int step, int kind, int c, int o, int pt, double vv, double sc = 0.0) {
     int major = step * 4 + kind;
+    // score modes: sc = the smallest lift over the alternatives of the disjunction, i.e. what the bound gains at least on
+    // every child (a surrogate of strong branching); 10: largest score first, 11: the same inside the kind order of mode 5
+    const int sci = 65535 - (int)fmin(65535.0, sc * 16.0);
+    if (prio_mode == 10) major = sci;
+    else if (prio_mode == 11) major = (3 - kind) * 65536 + sci;
+    else
     if (prio_mode == 1) major = (3 - kind) * 32 + step;
     else if (prio_mode == 2) major = kind * 32 + step;
     else if (prio_mode == 3) major = 100000 - (int)(fmin(vv, 99.0) * 1000.0);
@@ -1318,7 +1356,9 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       int c = L / (N - 1), i = 1 + L % (N - 1);
       const double* z = Z + i * NZ;
       CarState s = {z[6 * c], z[6 * c + 1], z[6 * c + 2], z[6 * c + 3], z[6 * c + 4], z[6 * c + 5], z[6 * C + 2 * c], z[6 * C + 2 * c + 1]};
-      if (vflag[c * N + i]) consider(i, 0, c, 0, 0, fastv[c * N + i]);
+      if (vflag[c * N + i]) consider(i, 0, c, 0, 0, fastv[c * N + i], rlift[c * N + i]);
+      LiftDiag LX, LYd; lift_diag(Y, D, c, i, LX, LYd);
+      const double rsc = rlift[c * N + i];
       int code = (int)comp[Y.f_reg + c * N + i];
       const double* rt = D + Y.d_reg + (c * P + (code >> 2)) * REGSZ;
       bool runfixed = fix[Y.f_reg + c * N + i] < 0;
@@ -1326,34 +1366,44 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         for (int pt = 0; pt < 5; ++pt) {
           double X, Yc; point_xy(s, rt, ENV_PT_D[pt][0], ENV_PT_D[pt][1], X, Yc);
           if (Y.E == 1) {
-            if (pt > 0 && runfixed) { double v = env_alt_viol(Y, D, T, 0, X, Yc); if (v > tol) consider(i, 0, c, 0, 0, v); }
+            if (pt > 0 && runfixed) { double v = env_alt_viol(Y, D, T, 0, X, Yc); if (v > tol) consider(i, 0, c, 0, 0, v, rsc); }
             comp[Y.f_env + (c * N + i) * 5 + pt] = 0;
             continue;
           }
           int fx = (int)fix[Y.f_env + (c * N + i) * 5 + pt];
           if (fx >= 0 && !(pt > 0 && runfixed)) continue;
-          bool okk; double bv = 1e300;
+          bool okk; double bv = 1e300, sc = 1e300;
           if (fx >= 0) { bv = env_alt_viol(Y, D, T, fx, X, Yc); okk = bv <= tol; }
           else {
             int be = 0;
-            for (int e = 0; e < Y.E; ++e) { double v = env_alt_viol(Y, D, T, e, X, Yc); if (v < bv) { bv = v; be = e; } }
+            for (int e = 0; e < Y.E; ++e) {
+              double v = env_alt_viol(Y, D, T, e, X, Yc); if (v < bv) { bv = v; be = e; }
+              if (prio_mode >= 10) {   // lift of piece e: its most expensive edge
+                double le = 0.0; const int ne = T[Y.i_envn + e];
+                for (int k = 0; k < ne; ++k) { const double* ed = D + Y.d_env + (e * Y.EL + k) * 3; le = fmax(le, lift1(ed[0] * X + ed[1] * Yc - ed[2], ed[0] * ed[0] * LX.p + ed[1] * ed[1] * LYd.p)); }
+                sc = fmin(sc, le);
+              }
+            }
             okk = bv <= tol; comp[Y.f_env + (c * N + i) * 5 + pt] = (signed char)be;
           }
-          if (!okk) { if (pt > 0 && runfixed) consider(i, 0, c, 0, 0, bv); else consider(i, 1, c, 0, pt, bv); }
+          if (!okk) { if (pt > 0 && runfixed) consider(i, 0, c, 0, 0, bv, rsc); else consider(i, 1, c, 0, pt, bv, sc < 1e300 ? sc : 0.0); }
         }
       for (int o = 0; o < Y.O; ++o)
         for (int pt = 0; pt < 5; ++pt) {
           int fx = (int)fix[Y.f_obs + ((c * Y.O + o) * N + i) * 5 + pt];
           if (fx >= 0 && (fx >= Y.L || !(pt > 0 && runfixed))) continue;
           double X, Yc; point_xy(s, rt, OBS_PT_D[pt][0], OBS_PT_D[pt][1], X, Yc);
-          bool okk; double bv = 1e300;
+          bool okk; double bv = 1e300, sc = T[Y.i_obssoft + o] ? D[Y.d_misc + 1] : 1e300;   // (a soft obstacle can be ignored at its price)
           if (fx >= 0) { const double* ed = D + Y.d_obs + ((o * N + i) * Y.L + fx) * 3; bv = ed[0] * X + ed[1] * Yc - ed[2]; okk = bv <= tol; }
           else {
             int bk = 0;
-            for (int k = 0; k < Y.L; ++k) { const double* ed = D + Y.d_obs + ((o * N + i) * Y.L + k) * 3; double v = ed[0] * X + ed[1] * Yc - ed[2]; if (v < bv) { bv = v; bk = k; } }
+            for (int k = 0; k < Y.L; ++k) {
+              const double* ed = D + Y.d_obs + ((o * N + i) * Y.L + k) * 3; double v = ed[0] * X + ed[1] * Yc - ed[2]; if (v < bv) { bv = v; bk = k; }
+              sc = fmin(sc, lift1(v, ed[0] * ed[0] * LX.p + ed[1] * ed[1] * LYd.p));
+            }
             okk = bv <= tol; comp[Y.f_obs + ((c * Y.O + o) * N + i) * 5 + pt] = (signed char)bk;
           }
-          if (!okk) { if (pt > 0 && runfixed) consider(i, 0, c, 0, 0, bv); else consider(i, 2, c, o, pt, bv); }
+          if (!okk) { if (pt > 0 && runfixed) consider(i, 0, c, 0, 0, bv, rsc); else consider(i, 2, c, o, pt, bv, sc < 1e300 ? sc : 0.0); }
         }
     }
   }
@@ -1368,21 +1418,27 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         CarState s2 = {z[6 * c2], z[6 * c2 + 1], z[6 * c2 + 2], z[6 * c2 + 3], z[6 * c2 + 4], z[6 * c2 + 5], z[6 * C + 2 * c2], z[6 * C + 2 * c2 + 1]};
         int code1 = (int)comp[Y.f_reg + c1 * N + i], code2 = (int)comp[Y.f_reg + c2 * N + i];
         const double* rt1 = D + Y.d_reg + (c1 * P + (code1 >> 2)) * REGSZ; const double* rt2 = D + Y.d_reg + (c2 * P + (code2 >> 2)) * REGSZ;
+        double gx12, gy12;
+        { LiftDiag A1, B1, A2, B2; lift_diag(Y, D, c1, i, A1, B1); lift_diag(Y, D, c2, i, A2, B2); gx12 = A1.p + A2.p; gy12 = B1.p + B2.p; }
         for (int g = 0; g < 4; ++g) {
           bool need1 = g >= 2, need2 = (g == 1 || g == 3);
           int unf = -1;
           if (need1 && fix[Y.f_reg + c1 * N + i] < 0) unf = c1; else if (need2 && fix[Y.f_reg + c2 * N + i] < 0) unf = c2;
           int fx = (int)fix[Y.f_c2c + (p * N + i) * 4 + g];
           if (fx >= 0 && unf < 0) continue;
-          bool okk; double bv = 1e300;
+          bool okk; double bv = 1e300, sc = 1e300;
           if (fx >= 0) { bv = c2c_alt_viol(Y, D, p, i, g, fx, s1, rt1, s2, rt2); okk = bv <= tol; }
           else {
             int ba = 0;
             const int am = (T[Y.i_c2callow + p * N + i] >> (4 * g)) & 15;   // alternatives some reachable positions can satisfy (host presolve)
-            for (int a = 0; a < 4; ++a) { if (am && !((am >> a) & 1)) continue; double v = c2c_alt_viol(Y, D, p, i, g, a, s1, rt1, s2, rt2); if (v < bv) { bv = v; ba = a; } }
+            for (int a = 0; a < 4; ++a) {
+              if (am && !((am >> a) & 1)) continue;
+              double v = c2c_alt_viol(Y, D, p, i, g, a, s1, rt1, s2, rt2); if (v < bv) { bv = v; ba = a; }
+              sc = fmin(sc, lift1(v, a < 2 ? gx12 : gy12));
+            }
             okk = bv <= tol; comp[Y.f_c2c + (p * N + i) * 4 + g] = (signed char)ba;
           }
-          if (!okk) { if (unf >= 0) consider(i, 0, unf, 0, 0, bv); else consider(i, 3, p, g, 0, bv); }
+          if (!okk) { if (unf >= 0) consider(i, 0, unf, 0, 0, bv, rlift[unf * N + i]); else consider(i, 3, p, g, 0, bv, sc < 1e300 ? sc : 0.0); }
         }
       }
     }

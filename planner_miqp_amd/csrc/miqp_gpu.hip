@@ -381,7 +381,7 @@ size_t ipm_lds_bytes(const Layout& Y) {
   return d * 8 + (size_t)Y.fixlen + 16;
 }
 size_t eval_lds_bytes(const Layout& Y) {
-  size_t d = (size_t)Y.N * Y.nz + (size_t)Y.C * Y.N * Y.P + (size_t)Y.C * Y.N;
+  size_t d = (size_t)Y.N * Y.nz + (size_t)Y.C * Y.N * Y.P + 2 * (size_t)Y.C * Y.N;
   return d * 8 + (size_t)(2 * Y.C * Y.N + 64) * 4 + 64 * 8 + 3 * (size_t)Y.fixlen + (size_t)64 * (Y.nz + 1) * 8 + 64;
 }
 
