@@ -123,6 +123,7 @@ struct DevBuf {
   int use_cutoff;                // 0: solve every node to convergence (polish of the incumbent, solve_fixed)
   int seq_kinds;                 // bit k set: first-deviation (time family) branching for disjunction kind k, else single step
   int abl;                       // ablation mask of the diagnostic build (0 otherwise)
+  int opt2;                      // MIQP_OPT2: bit 0 rounding probe at every branched node; bits 4.. = K: probe at nodes where at most K lanes of the completion saw a violated disjunction (default 8; 0 = only until the first incumbent)
   int* work_counter;             // next node of the batch to be solved (reset before every ipm launch)
   unsigned long long* prof;      // [40] cycle counters of the phases of ipm_kernel (diagnostic build -DMIQP_PROFILE only)
   unsigned long long* stat_rowiters;
@@ -1461,6 +1462,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     FREE_NODE();
     return;
   }
+  const unsigned long long bal_viol = __ballot(mine.prio != 0x7FFFFFFF);   // lanes that saw a violated disjunction
   unsigned long long bal = __ballot(mine.prio == best);
   int winner = __ffsll((long long)bal) - 1;
   if (lane == winner) chosen = mine;
@@ -1530,10 +1532,12 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       int n = alts_of(j, tmp);
       for (int q = 0; q < n && nalt < 63; ++q) { ck[nalt] = j; ca[nalt] = tmp[q]; nalt++; }
     }
-    // rounding probe (until the instance has an incumbent): one extra child with EVERY undecided disjunction fixed to its
+    // rounding probe (until the instance has an incumbent, and afterwards at nearly integral nodes - at most K (car | pair, step)
+    // sites with a violated disjunction, K = 8: 256 instances 9.1 -> 6.5 s, 90 % quantile of the finish time 1.5 -> 0.75 s):
+    // one extra child with EVERY undecided disjunction fixed to its
     // completed value.  It lies inside the first child, so the children stay exhaustive; its relaxation is the exact cost
     // of the rounding and, when feasible, the first incumbent two rounds after the root instead of one dive level per round
-    if (!(inc_now < 1e300) && nalt < 63 && (B.seq_kinds & 0x4000000) == 0) { ck[nalt] = -2; ca[nalt] = 0; nalt++; }
+    if ((!(inc_now < 1e300) || (B.opt2 & 1) || ((B.opt2 >> 4) && __popcll(bal_viol) <= (B.opt2 >> 4))) && nalt < 63 && (B.seq_kinds & 0x4000000) == 0) { ck[nalt] = -2; ca[nalt] = 0; nalt++; }
     fam[0] = base; fam[1] = stride; fam[2] = jlo; fam[3] = jhi;
     sh_base[2] = nalt;
   }

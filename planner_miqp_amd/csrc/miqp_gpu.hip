@@ -303,6 +303,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr) 
   X.pool_cap = (int)std::min<size_t>(std::min(want, maxrec), (size_t)0x7FFFFFF0);
   DevBuf& B = X.B; std::memset(&B, 0, sizeof(B));
   B.qp_tol = QP_TOL; B.use_cutoff = 1;
+  B.opt2 = std::getenv("MIQP_OPT2") ? std::atoi(std::getenv("MIQP_OPT2")) : (8 << 4);   // rounding probe at nodes with at most 8 violated sites (eval_kernel)
   B.seq_kinds = std::getenv("MIQP_SEQ_KINDS") ? std::atoi(std::getenv("MIQP_SEQ_KINDS")) : (5 << 8);   // plain K-way children, branching order 5 (see eval_kernel)
   B.Y = Y; B.pool_cap = X.pool_cap; B.open_cap = open_cap; B.batch_cap = batch_cap; B.nodes_per_round = npr; B.n_inst = n_inst;
   double* dd; int* ii;
