@@ -1331,7 +1331,9 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   // 250 instead of 184 of 256 headline instances reach 1 % in 10 s; car/car decisions fix the homotopy class, and the
   // many region alternatives are only enumerated inside a class).
   const int prio_mode = inc_now < 1e300 ? ((B.seq_kinds >> 8) & 15) : 0;
+  double myvmax = 0.0;   // largest violation this lane saw (the rounding probe is only worth its QP at nearly integral nodes)
   auto consider = [&](int step, int kind, int c, int o, int pt, double vv, double sc = 0.0) {
+    myvmax = fmax(myvmax, vv);
     int major = step * 4 + kind;
     // score modes: sc = the smallest lift over the alternatives of the disjunction, i.e. what the bound gains at least on
     // every child (a surrogate of strong branching); 10: largest score first, 11: the same inside the kind order of mode 5
@@ -1463,6 +1465,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     return;
   }
   const unsigned long long bal_viol = __ballot(mine.prio != 0x7FFFFFFF);   // lanes that saw a violated disjunction
+  const double vmax_all = wave_max(myvmax);
   unsigned long long bal = __ballot(mine.prio == best);
   int winner = __ffsll((long long)bal) - 1;
   if (lane == winner) chosen = mine;
@@ -1537,7 +1540,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     // one extra child with EVERY undecided disjunction fixed to its
     // completed value.  It lies inside the first child, so the children stay exhaustive; its relaxation is the exact cost
     // of the rounding and, when feasible, the first incumbent two rounds after the root instead of one dive level per round
-    if ((!(inc_now < 1e300) || (B.opt2 & 1) || ((B.opt2 >> 4) && __popcll(bal_viol) <= (B.opt2 >> 4))) && nalt < 63 && (B.seq_kinds & 0x4000000) == 0) { ck[nalt] = -2; ca[nalt] = 0; nalt++; }
+    if ((!(inc_now < 1e300) || (B.opt2 & 1) || (((B.opt2 >> 4) & 15) && __popcll(bal_viol) <= ((B.opt2 >> 4) & 15) && (!(B.opt2 >> 8) || vmax_all <= 0.05 * (double)(B.opt2 >> 8)))) && nalt < 63 && (B.seq_kinds & 0x4000000) == 0) { ck[nalt] = -2; ca[nalt] = 0; nalt++; }
     fam[0] = base; fam[1] = stride; fam[2] = jlo; fam[3] = jhi;
     sh_base[2] = nalt;
   }
@@ -1698,7 +1701,12 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     if (lane < nk) {
       // depth word: (tree depth << 6) | preference among siblings (child_inf first) - used by the dive ordering
       int pd = B.batch_depth[node] >> 6;
-      const int dw = k_ck[lane] == -2 ? (((pd + 2) << 6) | 63) : (((pd + 1) << 6) | (63 - k_ord[lane]));   // the probe is dived into first
+      int pref = k_ord[lane];
+      if (B.opt2 & 2) {   // experiment: dives prefer the sibling with the smallest lifted bound instead of the sibling order
+        pref = 0;
+        for (int q = 0; q < nk; ++q) if (k_bnd[q] < k_bnd[lane] || (k_bnd[q] == k_bnd[lane] && q < lane)) pref++;
+      }
+      const int dw = k_ck[lane] == -2 ? (((pd + 2) << 6) | 63) : (((pd + 1) << 6) | (63 - pref));   // the probe is dived into first
       if (k_pos[lane] & 0x40000000) {
         size_t oi = (size_t)inst * B.far_cap + sh_base[0] + (k_pos[lane] & 0x3FFFFFFF);
         B.far_bound[oi] = k_bnd[lane]; B.far_node[oi] = slots[lane]; B.far_depth[oi] = dw;
