@@ -1805,7 +1805,10 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     return need;
   };
   const unsigned long long lowmask = (1ull << SEL_LOWSHIFT) - 1ull;
-  const int keep = cap / 4, spill_at = cap / 2;   // near list after a spill / refill, and the length that triggers a spill
+  // near list after a spill / refill, and the length that triggers a spill: a few batches' worth is enough (every pass of this
+  // kernel is linear in it), refills are cheap
+  int keep = cap / 4; { const int k2 = 2 * B.batch_cap > 65536 ? 2 * B.batch_cap : 65536; if (keep > k2) keep = k2; }
+  const int spill_at = 2 * keep;
   const size_t fb = (size_t)inst * (size_t)B.far_cap;
   int fc = B.far_cap > 0 ? B.far_count[inst] : 0; if (fc > B.far_cap) fc = B.far_cap;
   // node selection: best bound, interleaved with dives (deepest first) while no incumbent exists, on every 4th
@@ -1856,7 +1859,16 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
       if (B.far_node[fb + k] < 0 || prunable(b)) return ~0ull;
       const unsigned long long key = d2key(b); return key == ~0ull ? ~0ull - 1 : key;
     };
-    radix(fkey, fc, keep - m);
+    // a long tier is not radix-selected itself (five passes of one workgroup over millions of entries) but through a strided
+    // sample of at most `keep` entries parked behind the near list's keys: the threshold only has to be about right
+    const int stride = fc > 4 * keep ? (fc + keep - 1) / keep : 1;
+    if (stride > 1) {
+      const int ns = (fc + stride - 1) / stride;
+      for (int j = tid; j < ns; j += SEL_THREADS) keys[n + j] = fkey(j * stride);
+      __syncthreads();
+      int need_s = (keep - m) / stride; if (need_s < 1) need_s = 1;
+      radix([&](int k) { return keys[n + k]; }, ns, need_s);
+    } else radix(fkey, fc, keep - m);
     const unsigned long long thr = sh_all ? ~0ull : sh_prefix;
     if (tid == 0) { sh_w = 0; sh_mv = 0; sh_fmin = ~0ull; }
     __syncthreads();
