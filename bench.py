@@ -128,8 +128,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU and step, all in flight at once (independent planning instances; "
-                    "throughput grows with the batch because the hard tail of a batch runs into the time limit either way: 256 -> 25/s, 1024 -> 70/s, "
-                    "4096 -> 337/s on one MI355X with 98 / 97 / 90 %% of the instances proven in time - profiles/r02_batch_sweep.json)")
+                    "throughput grows with the batch because the hard tail of a batch runs into the time limit either way: 256 -> 25/s, 1024 -> 99/s, "
+                    "4096 -> 350/s on one MI355X with 99.6 / 99.3 / 95 %% of the instances proven in time; the default is the largest batch that proves >= 98 %% - profiles/r02_batch_sweep.json)")
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--gap", type=float, default=0.01)
     ap.add_argument("--time-limit", type=float, default=10.0, help="max_solution_time per instance (reference default 10 s)")
