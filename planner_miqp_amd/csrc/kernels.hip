@@ -123,7 +123,7 @@ struct DevBuf {
   int use_cutoff;                // 0: solve every node to convergence (polish of the incumbent, solve_fixed)
   int seq_kinds;                 // bit k set: first-deviation (time family) branching for disjunction kind k, else single step
   int abl;                       // ablation mask of the diagnostic build (0 otherwise)
-  int opt2;                      // MIQP_OPT2: bit 0 rounding probe at every branched node; bits 4.. = K: probe at nodes where at most K lanes of the completion saw a violated disjunction (default 8; 0 = only until the first incumbent)
+  int opt2;                      // MIQP_OPT2: bit 0 rounding probe at every branched node; bits 4.. = K: probe at nodes where at most K lanes of the completion saw a violated disjunction (default 8; 0 = only until the first incumbent); bits 2..3 = s: only every 4^s-th such node (by a hash of its record number); bits 8.. = largest violation, in units of 0.05, a probed node may show; bit 1: dives prefer the sibling with the smallest lifted bound
   int* work_counter;             // next node of the batch to be solved (reset before every ipm launch)
   unsigned long long* prof;      // [40] cycle counters of the phases of ipm_kernel (diagnostic build -DMIQP_PROFILE only)
   unsigned long long* stat_rowiters;
@@ -1540,7 +1540,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     // one extra child with EVERY undecided disjunction fixed to its
     // completed value.  It lies inside the first child, so the children stay exhaustive; its relaxation is the exact cost
     // of the rounding and, when feasible, the first incumbent two rounds after the root instead of one dive level per round
-    if ((!(inc_now < 1e300) || (B.opt2 & 1) || (((B.opt2 >> 4) & 15) && __popcll(bal_viol) <= ((B.opt2 >> 4) & 15) && (!(B.opt2 >> 8) || vmax_all <= 0.05 * (double)(B.opt2 >> 8)))) && nalt < 63 && (B.seq_kinds & 0x4000000) == 0) { ck[nalt] = -2; ca[nalt] = 0; nalt++; }
+    if ((!(inc_now < 1e300) || (B.opt2 & 1) || (((B.opt2 >> 4) & 15) && __popcll(bal_viol) <= ((B.opt2 >> 4) & 15) && ((B.batch_node[node] * 2654435761u >> 16) & ((1u << (2 * ((B.opt2 >> 2) & 3))) - 1u)) == 0u && (!(B.opt2 >> 8) || vmax_all <= 0.05 * (double)(B.opt2 >> 8)))) && nalt < 63 && (B.seq_kinds & 0x4000000) == 0) { ck[nalt] = -2; ca[nalt] = 0; nalt++; }
     fam[0] = base; fam[1] = stride; fam[2] = jlo; fam[3] = jhi;
     sh_base[2] = nalt;
   }
