@@ -14,6 +14,9 @@
 //   * the contributions of the box rows to the stage Hessians / gradients are computed for all stages in one pass and
 //     parked in LDS (the region later reused for the step), so the Riccati loop has no row loop at all.
 //   * only the Riccati gains leave the CU (10 KB per node, L2 resident) for the forward sweep.
+//   * two cars: the columns of the stage vector are ordered chain-major (oc_pcol), which turns P [A B] into DPP column
+//     shifts and [A B]' T into sums over a lane's registers; the input block is eliminated by Gauss-Jordan on the four
+//     input rows of the tile (row_newbcast / permlane swaps), one MFMA forms the Schur complement and the next vector.
 // Nodes with more general rows than the on-chip capacity are queued for ipm_kernel (the general, memory-backed kernel).
 namespace miqp {
 

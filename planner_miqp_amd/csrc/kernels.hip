@@ -1,12 +1,16 @@
 // kernels.hip - CDNA4 (gfx950) device code of the MIQP solver.
 //
-//   select_kernel     one workgroup per instance: prune the open list against the incumbent, pick the `take` best
-//                     bounds by an 8-bit radix select over the HBM-resident list (dives: deepest first), termination.
-//   ipm_kernel<C>     one 64-lane wavefront per B&B node (nodes handed out dynamically): the rows of the node are
-//                     decoded once from the per-instance tables; stage-banded primal-dual interior point with a Riccati
-//                     recursion whose stage algebra stays in MFMA registers (C <= 2) or in dense LDS matrices (C = 3, 4).
+//   select_kernel     one workgroup per instance: prune the near list against the incumbent, pick the `take` best
+//                     bounds by an 8-bit radix select (dives: deepest first), spill to / refill from the far tier of
+//                     the open list in HBM, lower bound over both tiers, termination.
+//   ipm_onchip_kernel<C>  (ipm_onchip.hip, C <= 2, N <= 20) one 64-lane wavefront per B&B node, the whole working set in
+//                     registers and LDS: box rows keyed by (stage, column, side) in registers, general rows compacted in
+//                     LDS, Riccati recursion in the MFMA tile layout with shift-form products and Gauss-Jordan elimination.
+//   ipm_kernel<C>     the general, memory-backed interior point kernel: nodes the on-chip kernel hands over (more general
+//                     rows than its LDS holds), and everything for C = 3, 4 (dense LDS stage matrices, 2x2-tiled MFMA).
 //   eval_kernel<C>    one wavefront per node: canonical completion of the undecided disjunctions, incumbent update
-//                     (64-bit atomicMin), choice of the branching disjunction (wave reduction), child emission.
+//                     (64-bit atomicMin), choice of the branching disjunction (wave reduction), bound lifting of the
+//                     children from the node's dual solution, child emission into the two list tiers.
 //   roll_kernel       publishes the node records freed in this round to the next one.
 //
 // The model being solved is the disjunctive form of cplexmodel/*.mod described in host_inst.hpp / DESIGN.md.
