@@ -706,7 +706,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   }
   const double t_tables = wall_s() - t_enter - t_ctx;
   { double gmin = 1.0; for (int k = 0; k < n; ++k) gmin = std::min(gmin, h_gap[k]);
-    B.qp_tol = std::min(QP_TOL, std::max(1e-12, 1e-4 * gmin)); }  // node relaxations: accurate to a small fraction of the MIP gap
+    const double ftol = std::getenv("MIQP_QPTOL_F") ? std::atof(std::getenv("MIQP_QPTOL_F")) : 1e-4;   // (tuning knob)
+    const double tolcap = std::getenv("MIQP_QPTOL") ? std::atof(std::getenv("MIQP_QPTOL")) : QP_TOL;
+    B.qp_tol = std::min(tolcap, std::max(1e-12, ftol * gmin)); }  // node relaxations: accurate to a small fraction of the MIP gap
   hipStream_t st = X.stream;
   HIP_OK(hipMemcpyAsync((void*)B.inst_d, hD.data(), hD.size() * 8, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync((void*)B.inst_i, hT.data(), hT.size() * 4, hipMemcpyHostToDevice, st));
