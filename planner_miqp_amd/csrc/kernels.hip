@@ -127,7 +127,7 @@ struct DevBuf {
   int use_cutoff;                // 0: solve every node to convergence (polish of the incumbent, solve_fixed)
   int seq_kinds;                 // bit k set: first-deviation (time family) branching for disjunction kind k, else single step
   int abl;                       // ablation mask of the diagnostic build (0 otherwise)
-  int opt2;                      // MIQP_OPT2: bit 0 rounding probe at every branched node; bits 4.. = K: probe at nodes where at most K lanes of the completion saw a violated disjunction (default 8; 0 = only until the first incumbent); bits 2..3 = s: only every 4^s-th such node (by a hash of its record number); bits 8.. = largest violation, in units of 0.05, a probed node may show; bit 1: dives prefer the sibling with the smallest lifted bound
+  int opt2;                      // MIQP_OPT2: bit 0 rounding probe at every branched node; bits 4.. = K: probe at nodes where at most K lanes of the completion saw a violated disjunction (default 8; 0 = only until the first incumbent); bits 2..3 = s: only every 4^s-th such node (by a hash of its record number); bits 8.. = largest violation, in units of 0.05, a probed node may show; bit 1: dives prefer the sibling with the smallest lifted bound; bit 16: probes leave the front-point environment / obstacle disjunctions undecided (all measured: no gain)
   int* work_counter;             // next node of the batch to be solved (reset before every ipm launch)
   unsigned long long* prof;      // [40] cycle counters of the phases of ipm_kernel (diagnostic build -DMIQP_PROFILE only)
   unsigned long long* stat_rowiters;
@@ -1695,7 +1695,12 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
           if (j >= jlo && j <= jhi) { if (j < kk) v = comp[k]; else if (j == kk) v = av; }
         }
         if (k == negidx) v = (signed char)negm;
-        if (kk == -2) v = (fix[k] < 0 && k < Y.f_c2n) ? comp[k] : fix[k];   // rounding probe
+        if (kk == -2) {   // rounding probe
+          v = (fix[k] < 0 && k < Y.f_c2n) ? comp[k] : fix[k];
+          // (experiment, MIQP_OPT2 bit 16: the probe leaves the front-point environment / obstacle disjunctions undecided - a
+          // smaller relaxation; it is then an ordinary node that the completion may still find integer feasible)
+          if ((B.opt2 & 0x10000) && fix[k] < 0 && k >= Y.f_env && k < Y.f_c2c && (k - Y.f_env) % 5 != 0) v = fix[k];
+        }
         dst[k] = v;
       }
 #ifdef MIQP_PROFILE
