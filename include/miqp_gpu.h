@@ -177,6 +177,18 @@ int miqp_reserve_neighbor_regions(int* row, int nr_regions, int expansions);
 /* CalculatePossibleRegions                                    regions.cpp:114-127; flags[R] */
 int miqp_calculate_possible_regions(const double* fraction_parameters, int nr_regions, const double* theta_ref, int n, int* flags);
 /* MiqpPlanner::CalculateWarmstart: last solution shifted by one step (with its quirks)   src/miqp_planner.cpp:787-1051 */
+/* ReferenceTrajectoryGenerator::GenerateTrajectory on a polyline (common/reference/reference_trajectory_generator.cpp:51-148;
+   bark's spline smoothing of the centre line replaced by the polyline itself: identical on straight reference lines).
+   ref_xy: n_ref points (x, y); state5 = (time, x, y, theta, v); out[num_points][5] in the same order. */
+int miqp_reference_trajectory(const double* ref_xy, int n_ref, const double* state5, double dt, int num_points, double line_interp_inc, double vel_desired,
+                              double delta_s_desired, double acc_lat_max, int vel_curve_dep, double* out);
+/* MiqpPlanner::UpdateCar for one car (src/miqp_planner.cpp:284-390): reference rows, possible regions, weights.
+   settings12 = nr_regions, nr_steps, nr_neighbouring_possible_regions, additionalStepsForReferenceLongerHorizon, ts,
+   refLineInterpInc, straight lateral acceleration limit, lambda, positionWeight, velocityWeight, acclerationWeight, jerkWeight;
+   initial_state6 = (x, vx, ax, y, vy, ay); ref4N = x_ref, y_ref, vx_ref, vy_ref rows; weights8 = POS_X, VEL_X, ACC_X, POS_Y,
+   VEL_Y, ACC_Y, JERK_X, JERK_Y.  0 ok, 1 region expansion failed (the reference logs and goes on), < 0 invalid arguments. */
+int miqp_update_car(const double* settings12, const double* fraction_parameters, const double* initial_state6, const double* ref_xy, int n_ref, double desired_velocity,
+                    double delta_s_desired, double timestep, int track_reference_positions, int is_ego, int num_cars, double* ref4N, int* possible_region, double* weights8);
 int miqp_calculate_warmstart(const miqp_raw_results_c* last, miqp_raw_results_c* out, double ts, double minimum_region_change_speed);
 /* MiqpPlanner::Plan, region-combination retry loop            src/miqp_planner.cpp:634-645, 692-766
  * initial_region[C] / possible_region[C*R] are the caller's arrays (p is re-pointed to them) and are updated in place as

@@ -1258,6 +1258,23 @@ int miqp_calculate_possible_regions(const double* fraction_parameters, int nr_re
   if (!fraction_parameters || nr_regions < 1 || !theta_ref || !flags) return -1;
   miqp::calculate_possible_regions(fraction_parameters, nr_regions, theta_ref, n, flags); return 0;
 }
+int miqp_reference_trajectory(const double* ref_xy, int n_ref, const double* state5, double dt, int num_points, double line_interp_inc, double vel_desired,
+                              double delta_s_desired, double acc_lat_max, int vel_curve_dep, double* out) {
+  if (!ref_xy || n_ref < 2 || !state5 || num_points < 1 || !out || !(dt > 0) || delta_s_desired < 0) return -1;
+  miqp::PolyLine line; line.build(ref_xy, n_ref);
+  if (line.x.size() < 2) return -2;
+  miqp::reference_trajectory(line, state5, dt, num_points, line_interp_inc, vel_desired, delta_s_desired, acc_lat_max, vel_curve_dep != 0, out);
+  return 0;
+}
+int miqp_update_car(const double* settings12, const double* fraction_parameters, const double* initial_state6, const double* ref_xy, int n_ref, double desired_velocity,
+                    double delta_s_desired, double timestep, int track_reference_positions, int is_ego, int num_cars, double* ref4N, int* possible_region, double* weights8) {
+  if (!settings12 || !fraction_parameters || !initial_state6 || !ref_xy || n_ref < 2 || !ref4N || !possible_region || !weights8 || num_cars < 1) return -1;
+  miqp::CarUpdateSettings S{(int)settings12[0], (int)settings12[1], (int)settings12[2], (int)settings12[3], settings12[4], settings12[5], settings12[6], settings12[7],
+                            settings12[8], settings12[9], settings12[10], settings12[11]};
+  if (S.nr_regions < 1 || S.nr_steps < 2 || !(S.ts > 0)) return -1;
+  return miqp::update_car(S, fraction_parameters, initial_state6, ref_xy, n_ref, desired_velocity, delta_s_desired, timestep, track_reference_positions != 0, is_ego != 0,
+                          num_cars, ref4N, possible_region, weights8) ? 0 : 1;
+}
 int miqp_calculate_warmstart(const miqp_raw_results_c* last, miqp_raw_results_c* out, double ts, double minimum_region_change_speed) {
   if (!last || !out || last->N != out->N || last->NrCars != out->NrCars || last->NrRegions != out->NrRegions || last->N < 2) return -1;
   miqp::calculate_warmstart(*last, *out, ts, minimum_region_change_speed); return 0;

@@ -2,6 +2,7 @@
 //   * region tables and region bookkeeping   common/parameter/parameter_preparer.cpp:37-143, regions.cpp:16-127
 //   * receding-horizon warm start (shift by one step)                src/miqp_planner.cpp:787-1051
 //   * the region-combination retry loop of MiqpPlanner::Plan         src/miqp_planner.cpp:633-766
+//   * ReferenceTrajectoryGenerator on a polyline, MiqpPlanner::UpdateCar   common/reference/reference_trajectory_generator.cpp:51-148, src/miqp_planner.cpp:284-390
 // Plain arrays in, plain arrays out; float where the reference computes in float (the rotated limits, the region test).
 #pragma once
 #include <algorithm>
@@ -114,6 +115,132 @@ inline void region_combinations(const std::vector<std::vector<int>>& per_car, st
     if (c == pc.size()) { out.push_back(cur); return; }
     for (int r : pc[c]) { cur.push_back(r); go(pc, c + 1, cur, out); cur.pop_back(); } } };
   Rec::go(per_car, 0, cur, out);
+}
+
+// ---------------------------------------------------------------- ReferenceTrajectoryGenerator on a polyline
+// common/reference/reference_trajectory_generator.cpp:51-148 (GenerateTrajectoryInternal).  The reference walks a
+// bark::geometry::Line (third-party: bark-simulator/bark @ 53562ac, util/deps.bzl:7-10, absent from the checkout) that it
+// first passes through bark's SmoothLine (spline resampling at line_interp_inc).  Restated here on the POLYLINE itself -
+// nearest point by projection onto the segments, point and tangent at arc length s by linear interpolation inside the
+// segment, curvature by finite differences of the resampled vertices: identical to the reference on straight reference
+// lines (the case its tests and the C-API test K8 pin numerically), an approximation of the spline on curved ones.
+struct PolyLine {
+  std::vector<double> x, y, s;
+  void build(const double* xy, int n) {
+    x.clear(); y.clear(); s.clear();
+    for (int k = 0; k < n; ++k) {
+      if (k && xy[2 * k] == x.back() && xy[2 * k + 1] == y.back()) continue;
+      x.push_back(xy[2 * k]); y.push_back(xy[2 * k + 1]);
+      s.push_back(k && !s.empty() ? s.back() + std::hypot(x.back() - x[x.size() - 2], y.back() - y[y.size() - 2]) : 0.0);
+    }
+  }
+  PolyLine resampled(double inc) const {   // vertices every `inc` of arc length (and the end point)
+    PolyLine r; if (x.size() < 2 || !(inc > 0)) return *this;
+    for (double t = 0.0; t < s.back(); t += inc) { double px, py; point_at(t, px, py); r.x.push_back(px); r.y.push_back(py); r.s.push_back(t); }
+    r.x.push_back(x.back()); r.y.push_back(y.back()); r.s.push_back(s.back());
+    return r;
+  }
+  int segment_of(double t) const { int k = 0; while (k + 2 < (int)s.size() && t >= s[k + 1]) ++k; return k; }
+  void point_at(double t, double& px, double& py) const {
+    if (x.size() < 2) { px = x.empty() ? 0 : x[0]; py = y.empty() ? 0 : y[0]; return; }
+    t = std::min(std::max(t, 0.0), s.back());
+    const int k = segment_of(t); const double L = s[k + 1] - s[k], a = L > 0 ? (t - s[k]) / L : 0.0;
+    px = x[k] + a * (x[k + 1] - x[k]); py = y[k] + a * (y[k + 1] - y[k]);
+  }
+  double tangent_at(double t) const {
+    if (x.size() < 2) return 0.0;
+    t = std::min(std::max(t, 0.0), s.back());
+    const int k = segment_of(t); return std::atan2(y[k + 1] - y[k], x[k + 1] - x[k]);
+  }
+  double nearest_s(double px, double py) const {
+    double best = 1e300, bs = 0.0;
+    for (size_t k = 0; k + 1 < x.size(); ++k) {
+      const double dx = x[k + 1] - x[k], dy = y[k + 1] - y[k], L2 = dx * dx + dy * dy;
+      double a = L2 > 0 ? ((px - x[k]) * dx + (py - y[k]) * dy) / L2 : 0.0; a = std::min(std::max(a, 0.0), 1.0);
+      const double d = std::hypot(px - (x[k] + a * dx), py - (y[k] + a * dy));
+      if (d < best) { best = d; bs = s[k] + a * std::sqrt(L2); }
+    }
+    return bs;
+  }
+  int nearest_idx(double px, double py) const {
+    int b = 0; double best = 1e300;
+    for (size_t k = 0; k < x.size(); ++k) { const double d = std::hypot(px - x[k], py - y[k]); if (d < best) { best = d; b = (int)k; } }
+    return b;
+  }
+  double curvature(int k) const {   // finite differences at vertex k (one-sided at the ends)
+    const int n = (int)x.size(); if (n < 3) return 0.0;
+    const int a = std::max(0, std::min(k - 1, n - 3));
+    const double x1 = x[a + 1] - x[a], y1 = y[a + 1] - y[a], x2 = x[a + 2] - x[a + 1], y2 = y[a + 2] - y[a + 1];
+    const double cr = x1 * y2 - y1 * x2, l1 = std::hypot(x1, y1), l2 = std::hypot(x2, y2), l3 = std::hypot(x[a + 2] - x[a], y[a + 2] - y[a]);
+    const double den = l1 * l2 * l3; return den > 0 ? 2.0 * cr / den : 0.0;
+  }
+};
+
+inline double interpolate_with_bounds(double x0, double y0, double x1, double y1, double xi) {   // common/math/math.hpp:34-46
+  if (xi > x1) return y1;
+  if (xi < x0) return y0;
+  return (y1 - y0) / (x1 - x0) * (xi - x0) + y0;
+}
+
+// out[num_points][5] = (time, x, y, theta, v) (bark's StateDefinition order); state = the same five of the start
+inline void reference_trajectory(const PolyLine& center, const double* state, double dt, int num_points, double line_interp_inc, double vel_desired,
+                                 double delta_s_desired, double acc_lat_max, bool vel_curve_dep, double* out) {
+  const PolyLine line = center.resampled(line_interp_inc);
+  for (int q = 0; q < 5; ++q) out[q] = state[q];   // the state at t = 0
+  const double s_start = line.nearest_s(state[1], state[2]);
+  const double s_end = line.s.empty() ? 0.0 : line.s.back();
+  double s_desired_vel = std::min(s_end, s_start + delta_s_desired);
+  const double start_time = state[0];
+  double s_i = s_start;
+  const double vel_0 = delta_s_desired <= 0.0 ? vel_desired : state[4];
+  double vel_i = vel_0, vel_end = vel_desired;
+  if (vel_i * num_points * dt + s_i > s_end) {
+    if (vel_end > 0 || s_desired_vel > s_end) { vel_end = 0; s_desired_vel = s_end; }   // the line ends inside the horizon
+  }
+  for (int i = 1; i < num_points; ++i) {
+    s_i += vel_i * dt;
+    double px, py; line.point_at(s_i, px, py);
+    const double ang = line.tangent_at(s_i);
+    if ((s_desired_vel - s_start) < 1e-2) vel_i = 0;
+    else vel_i = interpolate_with_bounds(s_start, vel_0, s_desired_vel, vel_end, s_i);
+    if (vel_curve_dep) {
+      const double kap = std::fabs(line.curvature(line.nearest_idx(px, py)));
+      if (kap > 0) vel_i = std::min(vel_i, std::sqrt(acc_lat_max / kap));
+    }
+    double* o = out + i * 5;
+    o[0] = (double)i * dt + start_time; o[1] = px; o[2] = py; o[3] = ang; o[4] = vel_i;
+  }
+}
+
+// MiqpPlanner::UpdateCar (src/miqp_planner.cpp:284-390) for one car, without bark types: reference rows of the model from the
+// generated reference trajectory, possible regions from the headings of the longer-horizon reference plus their
+// neighbours, and the weights; `initial` = (x, vx, ax, y, vy, ay).  Outputs: ref[4][N] = x_ref, y_ref, vx_ref, vy_ref;
+// possible[R]; weights[8] = POS_X, VEL_X, ACC_X, POS_Y, VEL_Y, ACC_Y, JERK_X, JERK_Y.  Returns false when the region
+// expansion fails (the reference only logs that).
+struct CarUpdateSettings {   // the fields of MiqpPlannerSettings this function reads (src/miqp_planner_settings.h)
+  int nr_regions, nr_steps, nr_neighbouring_possible_regions, additional_steps_longer_horizon;
+  double ts, ref_line_interp_inc, acc_lat_max, lambda, position_weight, velocity_weight, acceleration_weight, jerk_weight;
+};
+inline bool update_car(const CarUpdateSettings& S, const double* F, const double* initial, const double* ref_xy, int n_ref, double desired_velocity,
+                       double delta_s_desired, double timestep, bool track_reference_positions, bool is_ego, int num_cars, double* ref, int* possible, double* weights) {
+  PolyLine line; line.build(ref_xy, n_ref);
+  const double st[5] = {timestep, initial[0], initial[3], std::atan2(initial[4], initial[1]), std::sqrt(initial[1] * initial[1] + initial[4] * initial[4])};
+  const int N = S.nr_steps, NL = S.nr_steps + S.additional_steps_longer_horizon;
+  std::vector<double> tr((size_t)NL * 5);
+  reference_trajectory(line, st, S.ts, N, S.ref_line_interp_inc, desired_velocity, delta_s_desired, S.acc_lat_max, false, tr.data());
+  for (int i = 0; i < N; ++i) {
+    ref[0 * N + i] = tr[i * 5 + 1]; ref[1 * N + i] = tr[i * 5 + 2];
+    ref[2 * N + i] = tr[i * 5 + 4] * std::cos(tr[i * 5 + 3]); ref[3 * N + i] = tr[i * 5 + 4] * std::sin(tr[i * 5 + 3]);
+  }
+  reference_trajectory(line, st, S.ts, NL, S.ref_line_interp_inc, desired_velocity, delta_s_desired, S.acc_lat_max, false, tr.data());
+  std::vector<double> th(NL); for (int i = 0; i < NL; ++i) th[i] = tr[i * 5 + 3];
+  calculate_possible_regions(F, S.nr_regions, th.data(), NL, possible);
+  const bool ok = reserve_neighbor_regions(possible, S.nr_regions, S.nr_neighbouring_possible_regions);
+  const double scale = is_ego ? S.lambda : (1.0 - S.lambda) / (num_cars - 1);
+  if (track_reference_positions) { weights[0] = weights[3] = scale * S.position_weight; weights[1] = weights[4] = scale * S.velocity_weight; }
+  else { weights[0] = weights[3] = 0.0; weights[1] = weights[4] = 2.0; }
+  weights[2] = weights[5] = scale * S.acceleration_weight; weights[6] = weights[7] = scale * S.jerk_weight;
+  return ok;
 }
 
 // ---------------------------------------------------------------- MiqpPlanner::CalculateWarmstart (miqp_planner.cpp:787-1051)

@@ -145,3 +145,155 @@ def plan(wrapper, params, warmstart: RawResults = None, warmstart_type=Warmstart
     status = wrapper._collect(st.value)
     del keep
     return bool(ok), status
+
+
+def reference_trajectory(ref_xy, state, dt, num_points, line_interp_inc, vel_desired, delta_s_desired, acc_lat_max, vel_curve_dep=False):
+    """ReferenceTrajectoryGenerator::GenerateTrajectory on a polyline (common/reference/reference_trajectory_generator.cpp:
+    51-148); ``state`` = (time, x, y, theta, v); returns [num_points, 5] in the same order.  bark's spline smoothing of the
+    centre line is replaced by the polyline itself: identical on straight reference lines."""
+    L = _lib()
+    if not hasattr(L, "_ref_proto"):
+        L.miqp_reference_trajectory.restype = C.c_int
+        L.miqp_reference_trajectory.argtypes = [c_double_p, C.c_int, c_double_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, c_double_p]
+        L.miqp_update_car.restype = C.c_int
+        L.miqp_update_car.argtypes = [c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, c_double_p, c_int_p, c_double_p]
+        L._ref_proto = True
+    xy = np.ascontiguousarray(np.asarray(ref_xy, dtype=np.float64).reshape(-1, 2))
+    st = np.ascontiguousarray(np.asarray(state, dtype=np.float64).reshape(5))
+    out = np.zeros((int(num_points), 5))
+    rc = L.miqp_reference_trajectory(_d(xy), xy.shape[0], _d(st), float(dt), int(num_points), float(line_interp_inc), float(vel_desired),
+                                     float(delta_s_desired), float(acc_lat_max), int(bool(vel_curve_dep)), _d(out))
+    if rc != 0:
+        raise ValueError("invalid reference line or arguments (%d)" % rc)
+    return out
+
+
+def DefaultSettings():
+    """miqp::planner::DefaultSettings() (src/miqp_planner_data.hpp:190-242), the fields this mirror reads"""
+    return dict(nr_regions=16, nr_steps=20, nr_neighbouring_possible_regions=1, ts=0.25, max_solution_time=10.0, relative_mip_gap_tolerance=0.1,
+                mipdisplay=2, mipemphasis=0, relobjdif=0.0, cutpass=0, probe=0, repairtries=0, rinsheur=0, varsel=0, mircuts=0, precision=12,
+                constant_agent_safety_distance_slack=3.0, minimum_region_change_speed=2.0, lambda_=0.5, wheelBase=2.8, collisionRadius=1.0,
+                slackWeight=30.0, slackWeightObstacle=2000.0, jerkWeight=1.0, positionWeight=2.0, velocityWeight=0.0, acclerationWeight=0.0,
+                accLonMaxLimit=2.0, accLonMinLimit=-4.0, jerkLonMaxLimit=3.0, accLatMinMaxLimit=1.6, jerkLatMinMaxLimit=1.4, refLineInterpInc=0.2,
+                additionalStepsForReferenceLongerHorizon=4, max_velocity_fitting=20.0, parallelMode=1, warmstartType=WarmstartType.NO_WARMSTART)
+
+
+class MiqpPlanner:
+    """Bark-free mirror of the part of miqp::planner::MiqpPlanner that feeds the solve path (src/miqp_planner.cpp: constructor
+    :27-147, AddCar :180-281, UpdateCar :284-390, Plan :633-766, and the raw trajectory read-out of the C API,
+    src/miqp_planner_c_api.cpp:101-136) for a planner WITHOUT map and obstacles (empty environment polygon, as the reference's
+    C-API test uses it).  Reference lines are polylines (see reference_trajectory)."""
+    EPS = 0.000001   # MiqpPlanner::eps_ (src/miqp_planner.hpp:415)
+
+    def __init__(self, settings=None, **wrapper_args):
+        from .ctypes_types import ModelParameters
+        from .wrapper import CplexWrapper
+        S = dict(DefaultSettings()); S.update(settings or {})
+        self.settings = S
+        self.pp = ParameterPreparer(S["nr_regions"], S["max_velocity_fitting"], S["minimum_region_change_speed"], S["accLonMaxLimit"], S["accLonMinLimit"],
+                                    S["jerkLonMaxLimit"], S["accLatMinMaxLimit"], S["jerkLatMinMaxLimit"])
+        fit = FittingPolynomialParameters(S["nr_regions"], S["max_velocity_fitting"], S["minimum_region_change_speed"])
+        p = ModelParameters()
+        R, N = S["nr_regions"], S["nr_steps"]
+        p.nr_regions, p.NumSteps, p.NumCars, p.nr_obstacles, p.nr_environments, p.max_lines_obstacles = R, N, 0, 0, 0, 0
+        for k in FittingPolynomialParameters._ORDER:
+            setattr(p, k, getattr(fit, "Get" + k)())
+        for k in ("max_solution_time", "relative_mip_gap_tolerance", "mipdisplay", "mipemphasis", "relobjdif", "cutpass", "probe", "repairtries", "rinsheur",
+                  "varsel", "mircuts", "ts", "minimum_region_change_speed"):
+            setattr(p, k, S[k])
+        p.parallelmode = int(S["parallelMode"])
+        p.agent_safety_distance = np.zeros(N); p.agent_safety_distance_slack = np.full(N, float(S["constant_agent_safety_distance_slack"]))
+        p.maximum_slack = S["constant_agent_safety_distance_slack"]; p.WEIGHTS_SLACK = S["slackWeight"]; p.WEIGHTS_SLACK_OBSTACLE = S["slackWeightObstacle"]
+        p.min_vel_x_y = -S["max_velocity_fitting"] - self.EPS; p.max_vel_x_y = S["max_velocity_fitting"] + self.EPS
+        p.fraction_parameters = self.pp.GetFractionParameters()
+        for k in ModelParameters.VEC_C:
+            setattr(p, k, np.zeros(0))
+        p.IntitialState = np.zeros((0, 6))
+        for k in ModelParameters.MAT_CN:
+            setattr(p, k, np.zeros((0, N)))
+        for k in ModelParameters.MAT_CR:
+            setattr(p, k, np.zeros((0, R)))
+        p.initial_region = np.zeros(0, dtype=np.int32); p.possible_region = np.zeros((0, R), dtype=np.int32)
+        self.parameters = p
+        self.egoCarIdx = 0
+        self._refs = []          # per car: (reference line, desired velocity, delta s)
+        self.wrapper = CplexWrapper("cplexmodel.mod", precision=S["precision"], **wrapper_args)
+        self.status = None
+
+    def GetN(self):
+        return self.settings["nr_steps"]
+
+    def GetTs(self):
+        return self.settings["ts"]
+
+    def GetParameters(self):
+        return self.parameters
+
+    def AddCar(self, initialState, referencePath, desiredVelocity, deltaSForDesiredVel, timestep=0.0, track_reference_positions=True):
+        p, S = self.parameters, self.settings
+        idx = p.NumCars; p.NumCars = idx + 1
+        R, N = p.nr_regions, p.NumSteps
+
+        def grow(a, shape):
+            b = np.zeros(shape, dtype=np.asarray(a).dtype); b[tuple(slice(0, n) for n in np.asarray(a).shape)] = a
+            return b
+        p.CollisionRadius = grow(p.CollisionRadius, (idx + 1,)); p.CollisionRadius[idx] = S["collisionRadius"]
+        p.WheelBase = grow(p.WheelBase, (idx + 1,)); p.WheelBase[idx] = S["wheelBase"]
+        p.IntitialState = grow(p.IntitialState, (idx + 1, 6))
+        acc, jerk = self.pp.CalculateAccLimitsPerCar(), self.pp.CalculateJerkLimitsPerCar()
+        for nm, d in (("acc", acc), ("jerk", jerk)):
+            for k in ("min_x", "max_x", "min_y", "max_y"):
+                key = "%s_%s_%s" % (k[:3], nm, k[-1])
+                m = grow(getattr(p, key), (idx + 1, R)); m[idx] = d[k]; setattr(p, key, m)
+        p.total_max_acc = max(p.max_acc_x.max(), p.max_acc_y.max()) + self.EPS; p.total_min_acc = min(p.min_acc_x.min(), p.min_acc_y.min()) - self.EPS
+        p.total_max_jerk = max(p.max_jerk_x.max(), p.max_jerk_y.max()) + self.EPS; p.total_min_jerk = min(p.min_jerk_x.min(), p.min_jerk_y.min()) - self.EPS
+        for k in ModelParameters_MAT_CN:
+            setattr(p, k, grow(getattr(p, k), (idx + 1, N)))
+        p.possible_region = grow(p.possible_region, (idx + 1, R)); p.initial_region = grow(p.initial_region, (idx + 1,))
+        for k in ("WEIGHTS_POS_X", "WEIGHTS_VEL_X", "WEIGHTS_ACC_X", "WEIGHTS_POS_Y", "WEIGHTS_VEL_Y", "WEIGHTS_ACC_Y", "WEIGHTS_JERK_X", "WEIGHTS_JERK_Y"):
+            setattr(p, k, grow(getattr(p, k), (idx + 1,)))
+        self._refs.append((desiredVelocity, deltaSForDesiredVel))
+        self.UpdateCar(idx, initialState, referencePath, timestep, track_reference_positions)
+        return idx
+
+    def UpdateCar(self, idx, initialState, referencePath, timestep=0.0, track_reference_positions=True):
+        p, S = self.parameters, self.settings
+        reference_trajectory([[0, 0], [1, 0]], [0, 0, 0, 0, 1], 1.0, 2, 1.0, 1.0, 0.0, 1.0)   # (declares the prototypes)
+        L = _lib()
+        st = np.ascontiguousarray(np.asarray(initialState, dtype=np.float64).reshape(6))
+        p.IntitialState[idx] = st
+        xy = np.ascontiguousarray(np.asarray(referencePath, dtype=np.float64).reshape(-1, 2))
+        s12 = np.array([S["nr_regions"], S["nr_steps"], S["nr_neighbouring_possible_regions"], S["additionalStepsForReferenceLongerHorizon"], S["ts"],
+                        S["refLineInterpInc"], S["accLatMinMaxLimit"], S["lambda_"], S["positionWeight"], S["velocityWeight"], S["acclerationWeight"], S["jerkWeight"]], dtype=np.float64)
+        F = np.ascontiguousarray(p.fraction_parameters, dtype=np.float64)
+        ref = np.zeros((4, p.NumSteps)); poss = np.zeros(p.nr_regions, dtype=np.int32); w8 = np.zeros(8)
+        vdes, ds = self._refs[idx]
+        rc = L.miqp_update_car(_d(s12), _d(F), _d(st), _d(xy), xy.shape[0], float(vdes), float(ds), float(timestep), int(bool(track_reference_positions)),
+                               int(idx == self.egoCarIdx), int(p.NumCars), _d(ref), _i(poss), _d(w8))
+        if rc < 0:
+            raise ValueError("invalid car update (%d)" % rc)
+        p.x_ref[idx], p.y_ref[idx], p.vx_ref[idx], p.vy_ref[idx] = ref
+        p.possible_region[idx] = poss
+        for k, nm in enumerate(("WEIGHTS_POS_X", "WEIGHTS_VEL_X", "WEIGHTS_ACC_X", "WEIGHTS_POS_Y", "WEIGHTS_VEL_Y", "WEIGHTS_ACC_Y", "WEIGHTS_JERK_X", "WEIGHTS_JERK_Y")):
+            getattr(p, nm)[idx] = w8[k]
+        return rc == 0
+
+    def Plan(self, timestamp=0.0):
+        ok, self.status = plan(self.wrapper, self.parameters, None, WarmstartType.NO_WARMSTART, timestamp)
+        return ok
+
+    def GetSolution(self):
+        return self.wrapper.getRawResults()
+
+    def GetRawCMiqpTrajectory(self, carIdx, start_time=0.0):
+        """rows (time, x, y, vx, vy, ax, ay, ux, uy) as GetRawCMiqpTrajectoryCMiqpPlanner (src/miqp_planner_c_api.cpp:101-136)"""
+        r = self.GetSolution()
+        N = r.N
+        out = np.zeros((N, 9))
+        out[:, 0] = start_time + self.parameters.ts * np.arange(N)
+        for k, nm in enumerate(("pos_x", "pos_y", "vel_x", "vel_y", "acc_x", "acc_y", "u_x", "u_y")):
+            out[:, 1 + k] = getattr(r, nm)[carIdx]
+        return out
+
+
+ModelParameters_MAT_CN = ["x_ref", "vx_ref", "y_ref", "vy_ref"]

@@ -86,7 +86,7 @@ EXPORTED_SYMBOLS = ["miqp_solver_create", "miqp_solver_destroy", "miqp_solver_se
                     "miqp_solver_write_mst", "miqp_solver_read_mst", "miqp_fraction_parameters", "miqp_mean_angles",
                     "miqp_limits_per_region", "miqp_calculate_region_idx", "miqp_reserve_neighbor_regions",
                     "miqp_calculate_possible_regions", "miqp_calculate_warmstart", "miqp_plan",
-                    "miqp_solver_solve_batch_multi", "miqp_solver_raw_sizes", "miqp_solver_lift_tables", "miqp_fitting_polynomial_parameters",
+                    "miqp_solver_solve_batch_multi", "miqp_solver_raw_sizes", "miqp_solver_lift_tables", "miqp_reference_trajectory", "miqp_update_car", "miqp_fitting_polynomial_parameters",
                     "miqp_solver_solve_split", "miqp_solver_solve_split_rccl", "miqp_solver_split_roots", "miqp_comm_unique_id",
                     "miqp_comm_init", "miqp_comm_finalize", "miqp_comm_selftest"]
 

@@ -175,3 +175,60 @@ def test_fixture_tables_are_the_fitted_variants():
         for n in names:
             a = np.array(t[n], float).reshape(R, 3); b = getattr(f, "Get" + n)()
             assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (R, n, np.abs(a - b).max())
+
+
+# ---- ReferenceTrajectoryGenerator on a polyline: the expectations of common/tests/reference_trajectory_generator_test.cc
+def test_reference_generator_straight_ref_line():
+    """:22-59 - start at 5 m/s, desired 10 m/s reached 0.1 m ahead: velocity and integrated positions"""
+    from planner_miqp_amd import planner_core as K
+    dt = 0.2
+    t = K.reference_trajectory([[0, 0], [50, 0], [100, 0]], [0, 0, 0, 0, 5.0], dt, 20, 0.2, 10.0, 0.1, 1.0, True)
+    assert abs(t[0, 4] - 5.0) < 1e-3 and abs(t[1, 4] - 10.0) < 1e-3 and abs(t[-1, 4] - 10.0) < 1e-3
+    assert abs(t[1, 1] - 5.0 * dt) < 1e-3 and abs(t[2, 1] - (5.0 * dt + 10.0 * dt)) < 1e-3
+    assert np.allclose(t[:, 0], dt * np.arange(20)) and np.allclose(t[:, 2], 0) and np.allclose(t[:, 3], 0)
+
+
+def test_reference_generator_starting():
+    """:61-92 - start at 0.1 m/s: the velocity rises at once and ends at the desired one"""
+    from planner_miqp_amd import planner_core as K
+    t = K.reference_trajectory([[0, 0], [50, 0], [100, 0]], [0, 0, 0, 0, 0.1], 0.2, 20, 0.2, 10.0, 0.1, 1.0, True)
+    assert abs(t[0, 4] - 0.1) < 1e-3 and t[1, 4] > 0.1 and abs(t[-1, 4] - 10.0) < 1e-3
+
+
+def test_reference_generator_stops_on_a_short_line():
+    """:135-166 (onept) - desired velocity 0 on a 2 m line: one step of travel at the current speed, then standstill"""
+    from planner_miqp_amd import planner_core as K
+    dt = 0.2
+    t = K.reference_trajectory([[1, 0], [2, 0], [3, 0]], [0, 1.0, 1.0, 0, 5.0], dt, 20, 0.2, 0.0, 0.1, 1.0, True)
+    assert abs(t[0, 4] - 5.0) < 1e-3
+    assert abs(t[1, 1] - (1.0 + 5.0 * dt)) < 1e-3 and abs(t[19, 1] - (1.0 + 5.0 * dt)) < 1e-3
+
+
+def test_reference_generator_follows_a_bend():
+    """curved reference line of :94-133.  bark smooths the line with a spline before walking it; the restatement walks the
+    polyline itself: positions and headings follow the segments, the curvature-dependent speed limit (which MiqpPlanner never
+    switches on, src/miqp_planner.cpp:245-253) only acts at the corners and never raises the velocity"""
+    from planner_miqp_amd import planner_core as K
+    line = [[0, 0], [5, 0], [10, 1.5], [20, 1.5], [30, 1.5], [40, 1.5], [50, 1.5], [60, 1.5]]
+    u = K.reference_trajectory(line, [0, 0, 0, 0, 10.0], 0.2, 20, 0.2, 10.0, 0.1, 1.8, False)
+    assert abs(u[0, 4] - 10.0) < 1e-3 and np.allclose(u[1:, 4], 10.0)
+    assert np.all(np.diff(u[:, 1]) > 0) and abs(u[-1, 2] - 1.5) < 1e-9
+    assert abs(u[3, 3] - np.arctan2(1.5, 5.0)) < 1e-9 and u[8, 3] == 0.0          # on the ramp, behind it
+    t = K.reference_trajectory(line, [0, 0, 0, 0, 10.0], 0.2, 20, 0.2, 10.0, 0.1, 1.8, True)
+    assert np.all(t[:, 4] <= 10.0 + 1e-12) and np.allclose(t[:, 1:4], u[:, 1:4])
+
+
+def test_add_car_fills_the_model_like_update_car():
+    """MiqpPlanner::AddCar / UpdateCar (src/miqp_planner.cpp:180-390) on the start of the C-API test
+    (test/miqp_planner_c_api_test.cc:164-172): references, possible regions, weights, limits"""
+    from planner_miqp_amd import planner_core as K
+    pl = K.MiqpPlanner()
+    idx = pl.AddCar([0, 0, 0, 1, 0.01, 0], [[0, 0], [5, 0], [30, 0]], 5, 1, 0.0, True)
+    p = pl.GetParameters()
+    assert idx == 0 and p.NumCars == 1 and p.NumSteps == 20 and p.nr_regions == 16 and p.nr_environments == 0
+    assert p.x_ref.shape == (1, 20) and abs(p.x_ref[0, 0]) < 1e-12 and np.all(np.diff(p.x_ref[0]) > 0) and np.allclose(p.y_ref[0, 1:], 0)
+    assert abs(p.vx_ref[0, -1] - 5.0) < 1e-9 and np.allclose(p.vy_ref[0, 1:], 0)        # desired velocity reached 1 m ahead
+    assert p.possible_region[0, 0] == 1 and p.possible_region[0, 4] == 1                   # heading of the reference and of the start (vy > 0)
+    assert p.WEIGHTS_POS_X[0] == 1.0 and p.WEIGHTS_JERK_X[0] == 0.5 and p.WEIGHTS_VEL_X[0] == 0.0      # lambda 0.5 x (2, 1, 0)
+    assert abs(p.total_max_jerk - (max(p.max_jerk_x.max(), p.max_jerk_y.max()) + 1e-6)) < 1e-12
+    assert p.WheelBase[0] == 2.8 and p.CollisionRadius[0] == 1.0
