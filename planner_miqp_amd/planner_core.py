@@ -219,6 +219,7 @@ class MiqpPlanner:
         self._refs = []          # per car: (reference line, desired velocity, delta s)
         self.wrapper = CplexWrapper("cplexmodel.mod", precision=S["precision"], **wrapper_args)
         self.status = None
+        self._ws = None          # start for the next plan (receding horizon)
 
     def GetN(self):
         return self.settings["nr_steps"]
@@ -279,8 +280,19 @@ class MiqpPlanner:
         return rc == 0
 
     def Plan(self, timestamp=0.0):
-        ok, self.status = plan(self.wrapper, self.parameters, None, WarmstartType.NO_WARMSTART, timestamp)
+        """MiqpPlanner::Plan (src/miqp_planner.cpp:633-785): the region-combination loop with the start derived from the last
+        solution when the settings ask for a warm start; a successful plan prepares the start of the next one (:768-779)"""
+        wt = self.settings["warmstartType"]
+        ws = self._ws if (wt != WarmstartType.NO_WARMSTART and self._ws is not None and self._ws.dims == self._dims()) else None
+        ok, self.status = plan(self.wrapper, self.parameters, ws, wt if ws is not None else WarmstartType.NO_WARMSTART, timestamp)
+        self._ws = None
+        if ok and wt != WarmstartType.NO_WARMSTART:
+            self._ws = calculate_warmstart(self.GetSolution(), self.parameters.ts, self.parameters.minimum_region_change_speed)
         return ok
+
+    def _dims(self):
+        p = self.parameters
+        return (p.NumCars, p.NumSteps, p.nr_regions, p.nr_environments, p.nr_obstacles, p.max_lines_obstacles)
 
     def GetSolution(self):
         return self.wrapper.getRawResults()

@@ -699,3 +699,31 @@ def test_c_api_known_answer_k8():
     # the same model through the oracle: the device result is its optimum
     p = pl.GetParameters()
     assert abs(traj[1, 1] - traj[1, 7] * 0 - traj[0, 7] * 0.25 ** 3 / 6.0) < 1e-9      # x(0.25) = u_x(0) ts^3 / 6 from rest
+
+
+def test_planner_mirror_receding_horizon_two_cars():
+    """planner_core.MiqpPlanner as MiqpPlanner is used (test/miqp_planner_test.cc:795-898 pattern): two cars on parallel
+    straight lanes, plan, move every car to the second step of its plan, update, plan again with the receding-horizon start:
+    every plan succeeds, the trajectories are dynamically consistent (triple integrator) and the second plan continues the
+    first (positions of the overlap agree within what the moved reference allows)."""
+    from planner_miqp_amd import planner_core as K
+    S = dict(K.DefaultSettings(), warmstartType=P.WarmstartType.RECEDING_HORIZON_WARMSTART, nr_regions=32)
+    pl = K.MiqpPlanner(S)
+    lanes = ([[0, 0], [100, 0]], [[0, 3.5], [100, 3.5]])
+    cars = [pl.AddCar([0, 5.0, 0, 0, 0.0, 0], lanes[0], 8.0, 10.0), pl.AddCar([4.0, 6.0, 0, 3.5, 0.0, 0], lanes[1], 6.0, 10.0)]
+    ts = pl.GetTs()
+    last = None
+    for step in range(3):
+        assert pl.Plan(step * ts), (step, pl.status)
+        trajs = [pl.GetRawCMiqpTrajectory(c, step * ts) for c in cars]
+        for t in trajs:   # x_{i+1} = x_i + ts v_i + ts^2/2 a_i + ts^3/6 u_i, per axis
+            for (p_, v_, a_, u_) in ((1, 3, 5, 7), (2, 4, 6, 8)):
+                pred = t[:-1, p_] + ts * t[:-1, v_] + ts * ts / 2 * t[:-1, a_] + ts ** 3 / 6 * t[:-1, u_]
+                assert np.allclose(pred, t[1:, p_], atol=1e-6)
+        if last is not None:
+            for a, b in zip(last, trajs):
+                assert np.allclose(a[1, 1:7], b[0, 1:7], atol=1e-9)            # the new start is the old second step
+                assert np.abs(a[2:8, 1] - b[1:7, 1]).max() < 0.5                # and the plan goes on from there
+        last = trajs
+        for c, t in zip(cars, trajs):
+            pl.UpdateCar(c, [t[1, 1], t[1, 3], t[1, 5], t[1, 2], t[1, 4], t[1, 6]], lanes[c], (step + 1) * ts)
