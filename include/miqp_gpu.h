@@ -71,6 +71,14 @@ int miqp_solver_solve(miqp_solver_t* s, double timestamp);
  * is what a scenario-parallel caller binds.) */
 int miqp_solver_solve_batch(miqp_solver_t* const* solvers, int n, int* statuses);
 
+/* The same call as a QUEUE drained with at most `inflight` instances in flight on the device (<= 0 or >= n: all at once =
+ * miqp_solver_solve_batch): an instance that is proven - or has used up its own max_solution_time, counted from its
+ * admission - hands its slot (open lists in HBM) to the next instance of the queue at the following branch-and-bound
+ * round, so the device never idles behind the hardest instances of a batch.  SolutionProperties.time of an instance is the
+ * time from its admission to its proof.  (No reference counterpart: MiqpPlanner issues one callCplex at a time,
+ * src/miqp_planner.cpp:731; this is the entry a scenario-parallel caller binds to keep one GPU saturated.) */
+int miqp_solver_solve_stream(miqp_solver_t* const* solvers, int n, int inflight, int* statuses);
+
 /* The same batch sharded over the first `gpus` HIP devices of this process (<= 0: all visible): instance b runs on
  * device b mod gpus with one host thread per device and no exchange between the shards;
  * opts.device of every handle is set to the device it ran on. */

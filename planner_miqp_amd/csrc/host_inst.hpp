@@ -7,6 +7,7 @@
 //   cplexmodel/model_region_constraints.mod:43-114 region block (sector, front polynomials, boxes, curvature)
 //   cplexmodel/minimum_speed_constraints.mod:9-49 low-speed freeze -> non-slow half-planes per sector
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdio>
@@ -20,6 +21,7 @@ namespace miqp {
 
 constexpr int MAXC = 4;          // cars supported by the device kernels (stage vector of at most 32 entries)
 constexpr int REGSZ = 32;        // doubles per (car, possible region) table entry
+constexpr int HULLSZ = 16;       // doubles per (car, step) of the hull of the region alternatives: acc box 4, jerk box 4, two velocity rows (g_vx, g_vy, rhs) 6, valid flag, pad
 constexpr double BIGM_JERK = 10.0, BIGM_ACC = 10.0;
 
 struct HostInst {
@@ -247,7 +249,7 @@ struct Layout {
   int C, N, R, P, E, EL, O, L, NP;   // P = max possible regions per car, EL = max edges per environment piece
   int nx, nu, nz, SC, NSLOT, ROWCAP;
   // double offsets
-  int d_x0, d_wd, d_ref, d_glob, d_u0box, d_misc, d_dsep, d_ssl, d_smax, d_reg, d_env, d_obs, d_theta, d_lift, dstride;
+  int d_x0, d_wd, d_ref, d_glob, d_u0box, d_misc, d_dsep, d_ssl, d_smax, d_reg, d_env, d_obs, d_theta, d_lift, d_hull, dstride;
   // int offsets
   int i_nposs, i_regj, i_nhs, i_hs, i_envn, i_obssoft, i_initj, i_dom, i_allow, i_boxskip, i_c2callow, istride;
   // fix record (bytes)
@@ -262,7 +264,7 @@ inline Layout make_layout(int C, int N, int R, int P, int E, int EL, int O, int 
   int o = 0;
   Y.d_x0 = o; o += C * 6; Y.d_wd = o; o += Y.nz; Y.d_ref = o; o += N * Y.nz; Y.d_glob = o; o += 8; Y.d_u0box = o; o += C * 4;
   Y.d_misc = o; o += 4; Y.d_dsep = o; o += Y.NP * N; Y.d_ssl = o; o += N; Y.d_smax = o; o += N; Y.d_reg = o; o += C * P * REGSZ;
-  Y.d_env = o; o += E * EL * 3; Y.d_obs = o; o += O * N * L * 3; Y.d_theta = o; o += C * 4; Y.d_lift = o; o += C * 2 * N * 16; Y.dstride = (o + 7) & ~7;
+  Y.d_env = o; o += E * EL * 3; Y.d_obs = o; o += O * N * L * 3; Y.d_theta = o; o += C * 4; Y.d_lift = o; o += C * 2 * N * 16; Y.d_hull = o; o += C * N * HULLSZ; Y.dstride = (o + 7) & ~7;
   o = 0;
   Y.i_nposs = o; o += C; Y.i_regj = o; o += C * P; Y.i_nhs = o; o += C * P; Y.i_hs = o; o += C * P * 4; Y.i_envn = o; o += E;
   Y.i_obssoft = o; o += O; Y.i_initj = o; o += C; Y.i_dom = o; o += C * P * 4; Y.i_allow = o; o += C * N * 2; Y.i_boxskip = o; o += C * N; Y.i_c2callow = o; o += Y.NP * N; Y.istride = (o + 3) & ~3;
@@ -485,6 +487,73 @@ inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int*
         }
       }
       T[Y.i_allow + (c * N + i) * 2] = (int)(mask & 0xFFFFFFFFull); T[Y.i_allow + (c * N + i) * 2 + 1] = (int)(mask >> 32);
+    }
+  }
+  // Hull of the region disjunction (exact, valid inequalities of the MIQP): exactly one possible region is active at every step
+  // (model_region_constraints.mod:43-117, sum_j active_region = 1), so while the region of (car, step) is undecided
+  //   * acceleration and jerk lie in the smallest box around the boxes of the regions that can still hold there (instead of
+  //     total_min/max_acc/jerk, the extreme over ALL regions of the table: 4.3 against 2.4 m/s^2 forward on the bench instances -
+  //     the relaxation of an undecided step used to accelerate twice as hard as any region allows), and
+  //   * the velocity lies in the cone spanned by their sectors (when that cone is convex), widened by the slow square when a
+  //     slow alternative is possible (|vx|, |vy| <= v_m leaves every sector row relaxed: minimum_speed_constraints.mod:9-49).
+  // "Can still hold": some alternative of the region passes the reachability presolve above.
+  for (int c = 0; c < C; ++c) {
+    const int np = T[Y.i_nposs + c];
+    for (int i = 0; i < N; ++i) {
+      double* H = D + Y.d_hull + (size_t)(c * N + i) * HULLSZ;
+      H[0] = I.amin; H[1] = I.amax; H[2] = I.amin; H[3] = I.amax; H[4] = I.jmin; H[5] = I.jmax; H[6] = I.jmin; H[7] = I.jmax;
+      for (int k = 8; k < HULLSZ; ++k) H[k] = 0.0;
+      if (i < 1) continue;
+      const unsigned long long mask = ((unsigned long long)(unsigned int)T[Y.i_allow + (c * N + i) * 2 + 1] << 32) | (unsigned int)T[Y.i_allow + (c * N + i) * 2];
+      double lo[8]; bool any = false, any_slow = false;
+      std::vector<std::array<double, 2>> cones; std::vector<int> cone_q;
+      for (int q = 0; q < np; ++q) {
+        const unsigned m4 = (unsigned)((mask >> (q * 4)) & 15ull);
+        if (!m4) continue;
+        const double* g = D + Y.d_reg + (c * Y.P + q) * REGSZ;
+        const double b[8] = {g[11], g[12], g[13], g[14], g[15], g[16], g[17], g[18]};
+        for (int k = 0; k < 8; ++k) lo[k] = !any ? b[k] : ((k & 1) ? std::max(lo[k], b[k]) : std::min(lo[k], b[k]));
+        any = true;
+        if (m4 & 8u) any_slow = true;
+        if (m4 & 7u) {
+          const double* F = &I.frac[T[Y.i_regj + c * Y.P + q] * 4];
+          double t1 = std::atan2(F[1], F[0]), t2 = std::atan2(F[3], F[2]);
+          if (t1 < 0) t1 += 2 * M_PI;
+          while (t2 < t1) t2 += 2 * M_PI;
+          cones.push_back({t1, t2}); cone_q.push_back(q);
+        }
+      }
+      if (!any) continue;   // (no alternative is reachable: the instance is infeasible and the search will say so)
+      // never wider than the global rows that stay in force anyway
+      H[0] = std::max(H[0], lo[0]); H[1] = std::min(H[1], lo[1]); H[2] = std::max(H[2], lo[2]); H[3] = std::min(H[3], lo[3]);
+      H[4] = std::max(H[4], lo[4]); H[5] = std::min(H[5], lo[5]); H[6] = std::max(H[6], lo[6]); H[7] = std::min(H[7], lo[7]);
+      if (cones.empty()) continue;
+      // the cone around all sectors = complement of the widest angular gap between them
+      std::vector<int> ord(cones.size()); for (size_t k = 0; k < ord.size(); ++k) ord[k] = (int)k;
+      std::sort(ord.begin(), ord.end(), [&](int a, int b) { return cones[a][0] < cones[b][0]; });
+      double best_gap = -1.0; int first = 0;   // the hull starts at the sector that follows the widest gap
+      double reach = cones[ord[0]][1];          // running end of the covered arc
+      for (size_t k = 0; k < ord.size(); ++k) {
+        const size_t nx = (k + 1) % ord.size();
+        double end_k = cones[ord[k]][1]; if (k == 0) reach = end_k; else reach = std::max(reach, end_k);
+        double start_n = cones[ord[nx]][0] + (nx == 0 ? 2 * M_PI : 0.0);
+        const double gap = start_n - reach;
+        if (gap > best_gap) { best_gap = gap; first = (int)nx; }
+      }
+      const int qa = cone_q[ord[first]];
+      // last sector of the hull: the one whose end is the largest when walking from `first` around the circle
+      double a0 = cones[ord[first]][0], amax_end = -1e300; int qb = qa;
+      for (size_t k = 0; k < ord.size(); ++k) {
+        double st = cones[ord[k]][0], en = cones[ord[k]][1];
+        while (st < a0 - 1e-12) { st += 2 * M_PI; en += 2 * M_PI; }
+        if (en > amax_end) { amax_end = en; qb = cone_q[ord[k]]; }
+      }
+      if (!(amax_end - a0 < M_PI - 1e-6)) continue;   // not a convex cone: no rows
+      const double* ga = D + Y.d_reg + (c * Y.P + qa) * REGSZ; const double* gb = D + Y.d_reg + (c * Y.P + qb) * REGSZ;
+      const double pad = 1e-9;
+      H[8] = ga[0]; H[9] = ga[1]; H[10] = pad + (any_slow ? I.vm * (std::fabs(ga[0]) + std::fabs(ga[1])) : 0.0);
+      H[11] = gb[2]; H[12] = gb[3]; H[13] = pad + (any_slow ? I.vm * (std::fabs(gb[2]) + std::fabs(gb[3])) : 0.0);
+      H[14] = 1.0;
     }
   }
   // Box presolve (exact): interval propagation of (a, v) per axis from the initial state with the jerk and acceleration

@@ -70,15 +70,16 @@ __device__ inline bool box_of_slot(const Layout& Y, const double* D, const int* 
   const int c = slot / Y.SC, rr = slot - c * Y.SC;
   const int code = i >= 1 ? (int)fix[Y.f_reg + c * N + i] : -1;
   const double* rt = code >= 0 ? D + Y.d_reg + (c * Y.P + (code >> 2)) * REGSZ : nullptr;
+  const double* Hc = D + Y.d_hull + (c * N + i) * HULLSZ;
   if (rr < 7) {
     switch (rr) {
       case 0: col = 6 * c + 1; sgn = -1; rhs = -G[0]; break;
       case 1: col = 6 * c + 4; sgn = -1; rhs = -G[0]; break;
       case 2: col = 6 * c + 1; sgn = 1; rhs = G[1]; break;
-      case 3: col = 6 * c + 2; sgn = 1; rhs = rt ? rt[12] : G[3]; break;
-      case 4: col = 6 * c + 2; sgn = -1; rhs = -(rt ? rt[11] : G[2]); break;
-      case 5: col = 6 * c + 5; sgn = 1; rhs = rt ? rt[14] : G[3]; break;
-      default: col = 6 * c + 5; sgn = -1; rhs = -(rt ? rt[13] : G[2]); break;
+      case 3: col = 6 * c + 2; sgn = 1; rhs = rt ? rt[12] : Hc[1]; break;
+      case 4: col = 6 * c + 2; sgn = -1; rhs = -(rt ? rt[11] : Hc[0]); break;
+      case 5: col = 6 * c + 5; sgn = 1; rhs = rt ? rt[14] : Hc[3]; break;
+      default: col = 6 * c + 5; sgn = -1; rhs = -(rt ? rt[13] : Hc[2]); break;
     }
     return true;
   }
@@ -87,11 +88,12 @@ __device__ inline bool box_of_slot(const Layout& Y, const double* D, const int* 
     double lo, hi;
     if (i == 0) { lo = D[Y.d_u0box + c * 4 + 2 * s]; hi = D[Y.d_u0box + c * 4 + 2 * s + 1]; }
     else if (rt) { lo = rt[15 + 2 * s]; hi = rt[16 + 2 * s]; }
-    else { lo = G[4]; hi = G[5]; }
+    else { lo = Hc[4 + 2 * s]; hi = Hc[5 + 2 * s]; }
     col = 6 * C + 2 * c + s; sgn = up ? 1.0 : -1.0; rhs = up ? hi : -lo;
     return true;
   }
   if (rr < 16) {
+    if (code < 0) return false;   // the hull rows of an undecided region are general rows
     const int h = code & 3, k = rr - 11;
     if (h == 3) { col = 6 * c + (k < 2 ? 1 : 4); sgn = (k & 1) ? -1.0 : 1.0; rhs = G[6]; return true; }
     if (k == 2) {
@@ -155,7 +157,7 @@ __device__ inline bool slot_maybe(const Layout& Y, const signed char* fix, int i
     if (rr < 11) return true;
     if (i < 1) return false;
     const int code = (int)fix[Y.f_reg + c * N + i];
-    if (rr < 16) return code >= 0 && ((code & 3) != 3 || rr - 11 <= 3);
+    if (rr < 16) return code >= 0 ? ((code & 3) != 3 || rr - 11 <= 3) : rr - 11 <= 1;
     int q = rr - 16;
     if (q < 5 * Y.EL) {
       if (Y.E < 1) return false;
@@ -909,7 +911,7 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
     if (tid == 0) {
       const int itc = it > QP_MAXIT ? QP_MAXIT : it;
       B.batch_obj[node] = obj; B.batch_viol[node] = viol; B.batch_ok[node] = ok;
-      B.batch_bound[node] = (double)ncomp * comp;
+      B.batch_bound[node] = (double)ncomp * comp + resid_fac * R0 * 1.0e4;   // (see ipm_kernel: complementarity + stationarity residual allowance)
       B.batch_it[node] = itc;
       atomicAdd((unsigned long long*)&B.inst_iters[inst], (unsigned long long)itc);
       atomicAdd((unsigned long long*)&B.inst_nodes[inst], 1ull);

@@ -122,7 +122,23 @@ struct DevBuf {
   double* rowcache;              // [grid][NCACHE][ROWCAP] decoded sparse rows of the node being solved
   double* kgain;                 // [grid][N][NU][NX+2] feedback gains K and feed-forward k of the Riccati sweep
   int* active_insts;             // number of instances not yet done
-  int nodes_per_round; int n_inst;
+  int nodes_per_round; int n_inst;   // n_inst: instances of the call (the queue); every per-instance array has that many entries
+  // Streaming admission: the list storage (near buffers, keys, far tier) exists per SLOT, n_slots of them = the instances in
+  // flight; an instance occupies a slot from its admission to its proof (or its time limit) and the slot is then handed to
+  // the next instance of the queue.  Without streaming n_slots == n_inst and slot == instance.
+  int n_slots; int* inst_slot; int* slot_inst;   // -1: not in flight / empty
+  int* inst_kill;                // set by the host when an instance has used up its time limit: select_kernel retires it
+  // Share of a round's batch per instance: select_kernel publishes how many nodes every slot could use (its live near list),
+  // share_kernel turns the demands into the shares of the next round.  Every instance is granted a small base share (all make
+  // progress; the easy ones - a handful of open nodes - finish within a few rounds).  The rest of the batch goes to the
+  // instances IN ORDER OF ADMISSION, each up to min(demand, share_cap): the hard instances of this workload need 10^5..10^6
+  // node relaxations whatever the width of their rounds (measured: +10..30 % nodes at 4096 per round against 64, +50..150 % at
+  // 16384), so an instance that gets 4096 nodes per round is done in a few hundred rounds, while hundreds of hard instances
+  // sharing the batch evenly all run into their max_solution_time (which counts from the admission) and their work is lost.
+  // Earliest deadline first finishes what it starts; the cap keeps one pathological instance from holding more than an
+  // eighth of the device.
+  int* slot_demand; int* slot_take; int share_cap; int base_take; int window_pct;
+  const int* root_cnt; const int* root_node; int root_stride;   // root records of every instance (uploaded once; admit_kernel writes them into the slot's list)
   double qp_tol;
   int use_cutoff;                // 0: solve every node to convergence (polish of the incumbent, solve_fixed)
   int seq_kinds;                 // bit k set: first-deviation (time family) branching for disjunction kind k, else single step
@@ -238,6 +254,7 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
     int c = slot / Y.SC, rr = slot - c * Y.SC;
     int code = i >= 1 ? (int)fix[Y.f_reg + c * N + i] : -1;
     const double* rt = code >= 0 ? D + Y.d_reg + (c * Y.P + (code >> 2)) * REGSZ : nullptr;
+    const double* Hc = D + Y.d_hull + (c * N + i) * HULLSZ;   // undecided region: the hull of the alternatives that can still hold (host_inst.hpp)
     if (rr < 7) {
       if (i < 1 || ((T[Y.i_boxskip + c * N + i] >> rr) & 1)) return r;   // implied by the earlier steps (host box presolve)
       r.active = true;
@@ -246,10 +263,10 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
         case 0: g[6 * c + 1] = -1; r.rhs = -G[0]; break;
         case 1: g[6 * c + 4] = -1; r.rhs = -G[0]; break;
         case 2: g[6 * c + 1] = 1; r.rhs = G[1]; break;
-        case 3: g[6 * c + 2] = 1; r.rhs = rt ? rt[12] : G[3]; break;
-        case 4: g[6 * c + 2] = -1; r.rhs = -(rt ? rt[11] : G[2]); break;
-        case 5: g[6 * c + 5] = 1; r.rhs = rt ? rt[14] : G[3]; break;
-        default: g[6 * c + 5] = -1; r.rhs = -(rt ? rt[13] : G[2]); break;
+        case 3: g[6 * c + 2] = 1; r.rhs = rt ? rt[12] : Hc[1]; break;
+        case 4: g[6 * c + 2] = -1; r.rhs = -(rt ? rt[11] : Hc[0]); break;
+        case 5: g[6 * c + 5] = 1; r.rhs = rt ? rt[14] : Hc[3]; break;
+        default: g[6 * c + 5] = -1; r.rhs = -(rt ? rt[13] : Hc[2]); break;
       }
       return r;
     }
@@ -259,14 +276,22 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
       double lo, hi;
       if (i == 0) { lo = D[Y.d_u0box + c * 4 + 2 * s]; hi = D[Y.d_u0box + c * 4 + 2 * s + 1]; }
       else if (rt) { lo = rt[15 + 2 * s]; hi = rt[16 + 2 * s]; }
-      else { lo = G[4]; hi = G[5]; }
+      else { lo = Hc[4 + 2 * s]; hi = Hc[5 + 2 * s]; }
       r.active = true;
       if (!BUILD) return r;
       g[6 * C + 2 * c + s] = up ? 1.0 : -1.0; r.rhs = up ? hi : -lo;
       return r;
     }
     if (rr < 16) {
-      if (i < 1 || code < 0) return r;
+      if (i < 1) return r;
+      if (code < 0) {   // undecided region: the velocity stays inside the cone around the sectors that can still hold
+        const int k = rr - 11;
+        if (k > 1 || Hc[14] == 0.0) return r;
+        r.active = true; r.rhs = Hc[10 + 3 * k];
+        if (!BUILD) return r;
+        g[6 * c + 1] = Hc[8 + 3 * k]; g[6 * c + 4] = Hc[9 + 3 * k];
+        return r;
+      }
       int h = code & 3, k = rr - 11;
       if (h == 3) {
         if (k > 3) return r;
@@ -1113,7 +1138,10 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   for (int k = tid; k < N * NZ; k += NT) Zo[k] = Z[k];
   if (tid == 0) {
     B.batch_obj[node] = obj; B.batch_viol[node] = viol; B.batch_ok[node] = ok;
-    B.batch_bound[node] = (double)ncomp * comp;   // primal - dual value of the final iterate (total complementarity)
+    // primal - dual value of the final iterate: total complementarity, plus what a stationarity residual r of the iterate can
+    // add to the Lagrangian over the trajectories a child may reach (|r|_inf x |z' - z|_1, the latter below 1e4: positions
+    // within the road, 8 C N entries) - the dual value and the bound lifting built on it stay rigorous at loose tolerances
+    B.batch_bound[node] = (double)ncomp * comp + resid_fac * R0 * 1.0e4;
     B.batch_it[node] = it > QP_MAXIT ? QP_MAXIT : it;
     atomicAdd((unsigned long long*)&B.inst_iters[inst], (unsigned long long)(it > QP_MAXIT ? QP_MAXIT : it));
     atomicAdd((unsigned long long*)&B.inst_nodes[inst], 1ull);
@@ -1215,7 +1243,7 @@ __device__ inline double region_alt_lift(const Layout& Y, const double* D, const
   return l;
 }
 
-struct BranchDesc { int prio; int kind; int c; int o; int i; int pt; };  // kind: 0 region 1 env 2 obs 3 c2c
+struct BranchDesc { int prio; int kind; int c; int o; int i; int pt; int cause; };  // kind: 0 region 1 env 2 obs 3 c2c; cause (diagnostic): what flagged a region disjunction - 0 its own rows, 1 / 2 / 3 an environment / obstacle / car-car row on a front point of a car whose region is undecided
 
 template <int C>
 __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
@@ -1225,6 +1253,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   if (node >= *B.batch_count || node >= B.batch_cap) return;
 #define FREE_NODE() do { if (lane == 0) { unsigned int q_ = atomicAdd(B.free_tail, 1u); B.free_q[q_ % (unsigned int)B.pool_cap] = B.batch_node[node]; } } while (0)
   const int inst = B.batch_inst[node];
+  const int slot = B.inst_slot[inst];                // where the instance's open lists live
   const double* D = B.inst_d + (size_t)inst * Y.dstride;
   const int* T = B.inst_i + (size_t)inst * Y.istride;
   const int N = Y.N, P = Y.P;
@@ -1258,6 +1287,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   if (B.stats && lane == 0) {   // diagnostic (MIQP_STATS): outcome of the node and the iterations it took
     const int oc_ = okq == 2 ? 1 : (viol > FEAS_TOL ? 0 : (okq != 1 ? 2 : 3));   // infeasible, cut off, not converged, solved
     atomicAdd(&B.stats[32 + oc_], 1ull); atomicAdd(&B.stats[36 + oc_], (unsigned long long)B.batch_it[node]);
+    if (B.pool_origin) { const int og_ = (int)B.pool_origin[B.batch_node[node]] & 15; atomicAdd(&B.stats[80 + og_], 1ull); atomicAdd(&B.stats[96 + 16 * oc_ + og_], 1ull); }   // the same by the branching that created the node
   }
   if (viol > FEAS_TOL || okq != 1) { FREE_NODE(); return; }  // infeasible relaxation, or abandoned at the incumbent cutoff
   // soft obstacles that this node ignores cost WEIGHTS_SLACK_OBSTACLE each (obstacle_environment_constraints.mod:85-91)
@@ -1328,7 +1358,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   }
   __syncthreads();
   // ---------------- phase L: leaf disjunctions; every lane keeps its most urgent violated disjunction
-  BranchDesc mine; mine.prio = 0x7FFFFFFF; mine.kind = 0; mine.c = 0; mine.o = 0; mine.i = 0; mine.pt = 0;
+  BranchDesc mine; mine.prio = 0x7FFFFFFF; mine.kind = 0; mine.c = 0; mine.o = 0; mine.i = 0; mine.pt = 0; mine.cause = 0;
   // branching order.  Until an incumbent exists: earliest violated step first (a dive then fixes the horizon front to
   // back and reaches a feasible leaf fast).  Afterwards the order selected by bits 8..11 of seq_kinds; default 5 =
   // car/car disjunctions before obstacle, environment and region ones, the most violated first within a kind (measured:
@@ -1336,7 +1366,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   // many region alternatives are only enumerated inside a class).
   const int prio_mode = inc_now < 1e300 ? ((B.seq_kinds >> 8) & 15) : 0;
   double myvmax = 0.0;   // largest violation this lane saw (the rounding probe is only worth its QP at nearly integral nodes)
-  auto consider = [&](int step, int kind, int c, int o, int pt, double vv, double sc = 0.0) {
+  auto consider = [&](int step, int kind, int c, int o, int pt, double vv, double sc = 0.0, int cause = 0) {
     myvmax = fmax(myvmax, vv);
     int major = step * 4 + kind;
     // score modes: sc = the smallest lift over the alternatives of the disjunction, i.e. what the bound gains at least on
@@ -1355,7 +1385,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     else if (prio_mode == 9) major = (kind == 3 ? 0 : 1 + kind) * 32768 + (30000 - (int)(fmin(vv, 29.0) * 1000.0));  // car/car, region, env, obstacle; most violated
     else if (prio_mode == 7) major = (kind == 3 ? 0 : 1 + kind) * 32 + step;                          // car/car, then region, env, obstacle
     int prio = (major << 12) | ((c & 7) << 9) | ((o & 31) << 4) | (pt & 15);
-    if (prio < mine.prio) { mine.prio = prio; mine.kind = kind; mine.c = c; mine.o = o; mine.i = step; mine.pt = pt; }
+    if (prio < mine.prio) { mine.prio = prio; mine.kind = kind; mine.c = c; mine.o = o; mine.i = step; mine.pt = pt; mine.cause = cause; }
   };
   for (int L0 = 0; L0 < NCI; L0 += 64) {
     int L = L0 + lane;
@@ -1373,7 +1403,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         for (int pt = 0; pt < 5; ++pt) {
           double X, Yc; point_xy(s, rt, ENV_PT_D[pt][0], ENV_PT_D[pt][1], X, Yc);
           if (Y.E == 1) {
-            if (pt > 0 && runfixed) { double v = env_alt_viol(Y, D, T, 0, X, Yc); if (v > tol) consider(i, 0, c, 0, 0, v, rsc); }
+            if (pt > 0 && runfixed) { double v = env_alt_viol(Y, D, T, 0, X, Yc); if (v > tol) consider(i, 0, c, 0, 0, v, rsc, 1); }
             comp[Y.f_env + (c * N + i) * 5 + pt] = 0;
             continue;
           }
@@ -1393,7 +1423,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
             }
             okk = bv <= tol; comp[Y.f_env + (c * N + i) * 5 + pt] = (signed char)be;
           }
-          if (!okk) { if (pt > 0 && runfixed) consider(i, 0, c, 0, 0, bv, rsc); else consider(i, 1, c, 0, pt, bv, sc < 1e300 ? sc : 0.0); }
+          if (!okk) { if (pt > 0 && runfixed) consider(i, 0, c, 0, 0, bv, rsc, 1); else consider(i, 1, c, 0, pt, bv, sc < 1e300 ? sc : 0.0); }
         }
       for (int o = 0; o < Y.O; ++o)
         for (int pt = 0; pt < 5; ++pt) {
@@ -1410,7 +1440,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
             }
             okk = bv <= tol; comp[Y.f_obs + ((c * Y.O + o) * N + i) * 5 + pt] = (signed char)bk;
           }
-          if (!okk) { if (pt > 0 && runfixed) consider(i, 0, c, 0, 0, bv, rsc); else consider(i, 2, c, o, pt, bv, sc < 1e300 ? sc : 0.0); }
+          if (!okk) { if (pt > 0 && runfixed) consider(i, 0, c, 0, 0, bv, rsc, 2); else consider(i, 2, c, o, pt, bv, sc < 1e300 ? sc : 0.0); }
         }
     }
   }
@@ -1445,7 +1475,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
             }
             okk = bv <= tol; comp[Y.f_c2c + (p * N + i) * 4 + g] = (signed char)ba;
           }
-          if (!okk) { if (unf >= 0) consider(i, 0, unf, 0, 0, bv, rlift[unf * N + i]); else consider(i, 3, p, g, 0, bv, sc < 1e300 ? sc : 0.0); }
+          if (!okk) { if (unf >= 0) consider(i, 0, unf, 0, 0, bv, rlift[unf * N + i], 3); else consider(i, 3, p, g, 0, bv, sc < 1e300 ? sc : 0.0); }
         }
       }
     }
@@ -1484,6 +1514,28 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   int nalt = 0;
   if (lane == 0) {
     BranchDesc d = chosen; const int i = d.i;
+    if (B.stats && d.kind == 0) {   // diagnostic: what flagged the region disjunction, and for its own rows the class of the worst one
+      atomicAdd(&B.stats[64 + (d.cause & 3)], 1ull);
+      atomicAdd(&B.stats[160 + (i < 31 ? i : 31)], 1ull);
+      if (d.cause == 0) {
+        const int code = (int)comp[Y.f_reg + d.c * N + i], q = code >> 2, h = code & 3;
+        const double* z = Z + i * NZ; const double* rt = D + Y.d_reg + (d.c * P + q) * REGSZ; const double vm = D[Y.d_glob + 6];
+        const CarState s = {z[6 * d.c], z[6 * d.c + 1], z[6 * d.c + 2], z[6 * d.c + 3], z[6 * d.c + 4], z[6 * d.c + 5], z[6 * C + 2 * d.c], z[6 * C + 2 * d.c + 1]};
+        double cv[6];
+        cv[0] = fmax(fmax(s.ax - rt[12], rt[11] - s.ax), fmax(s.ay - rt[14], rt[13] - s.ay));
+        cv[1] = i <= N - 2 ? fmax(fmax(s.ux - rt[16], rt[15] - s.ux), fmax(s.uy - rt[18], rt[17] - s.uy)) : -1e300;
+        if (h == 3) { cv[2] = cv[3] = cv[4] = -1e300; cv[5] = fmax(fabs(s.vx) - vm, fabs(s.vy) - vm); }
+        else {
+          const int* hs = T + Y.i_hs + ((d.c * P + q) * 2 + h) * 2;
+          cv[2] = fmax(rt[0] * s.vx + rt[1] * s.vy, rt[2] * s.vx + rt[3] * s.vy);
+          cv[3] = vm - hs[1] * (hs[0] == 0 ? s.vx : s.vy);
+          cv[4] = fmax(s.ay - rt[4] * s.ax - rt[6] * s.vx - rt[7] * s.vy - rt[5], -s.ay + rt[4] * s.ax + rt[9] * s.vx + rt[10] * s.vy + rt[8]);
+          cv[5] = -1e300;
+        }
+        int bk = 0; for (int k = 1; k < 6; ++k) if (cv[k] > cv[bk]) bk = k;
+        atomicAdd(&B.stats[70 + bk], 1ull);
+      }
+    }
     int base, stride;
     if (d.kind == 0) { base = Y.f_reg + d.c * N; stride = 1; }
     else if (d.kind == 1) { base = Y.f_env + (d.c * N) * 5 + d.pt; stride = 5; }
@@ -1630,11 +1682,11 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       if (tf) fmin_ = fmin(fmin_, cb - cst);
       nk++;
     }
-    int fbase = 0, obase = 0; bool okalloc = true;
+    int fbase = 0, obase = 0, ob2 = 0, extra2 = 0; bool okalloc = true;
     if (nnear > 0) {
       obase = atomicAdd(&B.open_count[inst], nnear);
       if (obase + nnear > B.open_cap) {   // near list full: its reserved slots below the capacity become dead entries, the children wait in the far tier
-        for (int q = obase; q < obase + nnear && q < B.open_cap; ++q) { size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + q; B.open_bound[oi] = 1e300; B.open_node[oi] = -1; B.open_depth[oi] = 0; }
+        for (int q = obase; q < obase + nnear && q < B.open_cap; ++q) { size_t oi = ((size_t)B.open_sel * B.n_slots + slot) * B.open_cap + q; B.open_bound[oi] = 1e300; B.open_node[oi] = -1; B.open_depth[oi] = 0; }
         if (B.far_cap > 0) { for (int q = 0; q < nk; ++q) if (!(k_pos[q] & 0x40000000)) { k_pos[q] = 0x40000000 | nfar++; fmin_ = fmin(fmin_, k_bnd[q]); } }
         else okalloc = false;
         nnear = 0; obase = 0;
@@ -1645,14 +1697,14 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       fbase = atomicAdd(&B.far_count[inst], nfar);
       if (fbase + nfar <= B.far_cap) atomicMin(&B.far_minkey[inst], d2key(fmin_));
       else {   // tier full: the reserved slots below the capacity become dead entries, the children go to the near list
-        for (int q = fbase; q < fbase + nfar && q < B.far_cap; ++q) { B.far_bound[(size_t)inst * B.far_cap + q] = 1e300; B.far_node[(size_t)inst * B.far_cap + q] = -1; }
+        for (int q = fbase; q < fbase + nfar && q < B.far_cap; ++q) { B.far_bound[(size_t)slot * B.far_cap + q] = 1e300; B.far_node[(size_t)slot * B.far_cap + q] = -1; }
         int extra = 0;
         for (int q = 0; q < nk; ++q) if (k_pos[q] & 0x40000000) k_pos[q] = 0x20000000 | extra++;   // second near reservation behind the first
         nfar = 0;
-        const int ob2 = atomicAdd(&B.open_count[inst], extra);
+        ob2 = atomicAdd(&B.open_count[inst], extra); extra2 = extra;
         if (ob2 + extra > B.open_cap) {
           okalloc = false;
-          for (int q = ob2; q < ob2 + extra && q < B.open_cap; ++q) { size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + q; B.open_bound[oi] = 1e300; B.open_node[oi] = -1; B.open_depth[oi] = 0; }
+          for (int q = ob2; q < ob2 + extra && q < B.open_cap; ++q) { size_t oi = ((size_t)B.open_sel * B.n_slots + slot) * B.open_cap + q; B.open_bound[oi] = 1e300; B.open_node[oi] = -1; B.open_depth[oi] = 0; }
         }
         sh_base[3] = ob2;
       }
@@ -1669,8 +1721,9 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     }
     if (!okalloc) {   // list or record pool exhausted: the instance is flagged incomplete; the reserved list slots become dead entries
       atomicOr(&B.inst_flags[inst], 1);
-      for (int q = fbase; q < fbase + nfar; ++q) { B.far_bound[(size_t)inst * B.far_cap + q] = 1e300; B.far_node[(size_t)inst * B.far_cap + q] = -1; }
-      for (int q = obase; q < obase + nnear_kept && q < B.open_cap; ++q) { size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + q; B.open_bound[oi] = 1e300; B.open_node[oi] = -1; B.open_depth[oi] = 0; }
+      for (int q = fbase; q < fbase + nfar; ++q) { B.far_bound[(size_t)slot * B.far_cap + q] = 1e300; B.far_node[(size_t)slot * B.far_cap + q] = -1; }
+      for (int q = obase; q < obase + nnear_kept && q < B.open_cap; ++q) { size_t oi = ((size_t)B.open_sel * B.n_slots + slot) * B.open_cap + q; B.open_bound[oi] = 1e300; B.open_node[oi] = -1; B.open_depth[oi] = 0; }
+      for (int q = ob2; q < ob2 + extra2 && q < B.open_cap; ++q) { size_t oi = ((size_t)B.open_sel * B.n_slots + slot) * B.open_cap + q; B.open_bound[oi] = 1e300; B.open_node[oi] = -1; B.open_depth[oi] = 0; }   // the second near reservation (far tier overflow)
       nk = 0;
     }
     if (B.stats && nk > 0) { atomicAdd(&B.stats[43], 1ull); atomicAdd(&B.stats[44], (unsigned long long)nk); atomicAdd(&B.stats[48 + chosen.kind], 1ull); atomicAdd(&B.stats[52 + chosen.kind], (unsigned long long)nk); }
@@ -1703,9 +1756,12 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         }
         dst[k] = v;
       }
-#ifdef MIQP_PROFILE
-      if (lane == 0) B.pool_origin[slots[q]] = (signed char)(2 * chosen.kind + (k_ord[q] > 0 ? 1 : 0));
-#endif
+      if (B.pool_origin && lane == 0) {   // diagnostic: 4 kind + class of the child (0 the reference alternative; region: 1 an adjacent sector, 2 another, 3 slow); 15 the rounding probe
+        int cls = k_ord[q] > 0 ? 1 : 0;
+        if (chosen.kind == 0 && cls) { const int rq = (int)comp[base + chosen.i * stride] >> 2, cq = k_ca[q] >> 2; const int dq = T[Y.i_regj + chosen.c * P + cq] - T[Y.i_regj + chosen.c * P + rq]; const int ad = abs(dq) % Y.R;
+          cls = (k_ca[q] & 3) == 3 ? 3 : ((ad == 1 || ad == Y.R - 1) ? 1 : 2); }
+        B.pool_origin[slots[q]] = (signed char)(kk == -2 ? 15 : 4 * chosen.kind + cls);
+      }
     }
     if (lane < nk) {
       // depth word: (tree depth << 6) | preference among siblings (child_inf first) - used by the dive ordering
@@ -1717,11 +1773,11 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       }
       const int dw = k_ck[lane] == -2 ? (((pd + 2) << 6) | 63) : (((pd + 1) << 6) | (63 - pref));   // the probe is dived into first
       if (k_pos[lane] & 0x40000000) {
-        size_t oi = (size_t)inst * B.far_cap + sh_base[0] + (k_pos[lane] & 0x3FFFFFFF);
+        size_t oi = (size_t)slot * B.far_cap + sh_base[0] + (k_pos[lane] & 0x3FFFFFFF);
         B.far_bound[oi] = k_bnd[lane]; B.far_node[oi] = slots[lane]; B.far_depth[oi] = dw;
       } else {
         const int np_ = (k_pos[lane] & 0x20000000) ? sh_base[3] + (k_pos[lane] & 0x1FFFFFFF) : sh_base[1] + k_pos[lane];
-        size_t oi = ((size_t)B.open_sel * B.n_inst + inst) * B.open_cap + np_;
+        size_t oi = ((size_t)B.open_sel * B.n_slots + slot) * B.open_cap + np_;
         B.open_bound[oi] = k_bnd[lane]; B.open_node[oi] = slots[lane]; B.open_depth[oi] = dw;
       }
     }
@@ -1750,17 +1806,20 @@ __device__ inline int wave_append(int* counter, bool pred) {
 
 __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round) {
   const Layout& Y = B.Y;
-  const int inst = blockIdx.x, tid = threadIdx.x;
+  const int slot = blockIdx.x, tid = threadIdx.x;
+  const int inst = B.slot_inst[slot];
+  if (inst < 0 || B.inst_done[inst] || B.inst_kill[inst]) { if (tid == 0) B.slot_demand[slot] = 0; }
+  if (inst < 0) return;   // empty slot
   const int cap = B.open_cap;
-  __shared__ int sh_take, sh_base, sh_m, sh_keep, sh_pick, sh_ties, sh_w, sh_mv, sh_all;
+  __shared__ int sh_take, sh_base, sh_m, sh_keep, sh_pick, sh_ties, sh_w, sh_mv, sh_all, sh_elig;
   __shared__ double sh_inc;
   __shared__ unsigned int hist[256], dhist[256];
   __shared__ int sh_dkeep;
   __shared__ unsigned long long sh_prefix, sh_thr, sh_fmin;
   __shared__ double red[SEL_THREADS];
   if (B.inst_done[inst]) return;
-  const size_t src = ((size_t)B.open_sel * B.n_inst + inst) * cap, dst = ((size_t)(1 - B.open_sel) * B.n_inst + inst) * cap;
-  unsigned long long* keys = B.open_key + (size_t)inst * cap;
+  const size_t src = ((size_t)B.open_sel * B.n_slots + slot) * cap, dst = ((size_t)(1 - B.open_sel) * B.n_slots + slot) * cap;
+  unsigned long long* keys = B.open_key + (size_t)slot * cap;
   // ---- incumbent bookkeeping: copy the solution of the atomicMin winner of the last round
   if (tid == 0) {
     unsigned long long key = B.inc_key[inst];
@@ -1771,14 +1830,28 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   }
   __syncthreads();
   if (sh_take >= 0) {
-    int slot = sh_take;
-    const signed char* cf = B.batch_comp + (size_t)slot * Y.fixlen; signed char* df = B.inc_fix + (size_t)inst * Y.fixlen;
+    const int bslot = sh_take;   // batch slot of the node that won the atomicMin
+    const signed char* cf = B.batch_comp + (size_t)bslot * Y.fixlen; signed char* df = B.inc_fix + (size_t)inst * Y.fixlen;
     for (int k = tid; k < Y.fixlen; k += SEL_THREADS) df[k] = cf[k];
-    const double* zs = B.batch_Z + (size_t)slot * Y.N * Y.nz; double* zd = B.inc_Z + (size_t)inst * Y.N * Y.nz;
+    const double* zs = B.batch_Z + (size_t)bslot * Y.N * Y.nz; double* zd = B.inc_Z + (size_t)inst * Y.N * Y.nz;
     for (int k = tid; k < Y.N * Y.nz; k += SEL_THREADS) zd[k] = zs[k];
-    if (tid == 0) B.inc_obj[inst] = B.batch_obj[slot];
+    if (tid == 0) B.inc_obj[inst] = B.batch_obj[bslot];
   }
   __syncthreads();
+  if (B.inst_kill[inst]) {
+    // retired by the host (time limit of the instance): its node records go back to the pool, the lists are emptied, the
+    // instance reports what it has (the incumbent copied above, the bound of the last round) as unfinished and its slot is free for the next one of the queue
+    int nn = B.open_count[inst]; if (nn > cap) nn = cap;
+    for (int k = tid; k < nn; k += SEL_THREADS) { const int nd = B.open_node[src + k]; if (nd >= 0) { unsigned int q_ = atomicAdd(B.free_tail, 1u); B.free_q[q_ % (unsigned int)B.pool_cap] = nd; } }
+    int fn = B.far_cap > 0 ? B.far_count[inst] : 0; if (fn > B.far_cap) fn = B.far_cap;
+    for (int k = tid; k < fn; k += SEL_THREADS) { const int nd = B.far_node[(size_t)slot * (size_t)B.far_cap + k]; if (nd >= 0) { unsigned int q_ = atomicAdd(B.free_tail, 1u); B.free_q[q_ % (unsigned int)B.pool_cap] = nd; } }
+    __syncthreads();
+    if (tid == 0) {
+      B.open_count[inst] = 0; if (B.far_cap > 0) B.far_count[inst] = 0;
+      atomicOr(&B.inst_flags[inst], 2); B.inst_done[inst] = 1; atomicSub(B.active_insts, 1);
+    }
+    return;
+  }
   const double inc = fmin(sh_inc < 1e300 ? B.inc_obj[inst] : 1e300, B.inc_ext[inst]);   // what prunes: the best incumbent known (own or, in a tree split, another rank's)
   const double cst = B.inst_const[inst];
   const double gap = B.inst_gap[inst];
@@ -1818,7 +1891,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   // kernel is linear in it), refills are cheap
   int keep = cap / 4; { const int k2 = 2 * B.batch_cap > 65536 ? 2 * B.batch_cap : 65536; if (keep > k2) keep = k2; }
   const int spill_at = 2 * keep;
-  const size_t fb = (size_t)inst * (size_t)B.far_cap;
+  const size_t fb = (size_t)slot * (size_t)B.far_cap;
   int fc = B.far_cap > 0 ? B.far_count[inst] : 0; if (fc > B.far_cap) fc = B.far_cap;
   // node selection: best bound, interleaved with dives (deepest first) while no incumbent exists, on every 4th
   // round afterwards and whenever the list is full (without a far tier: half full) or the record pool is nearly exhausted (a depth-first
@@ -1862,7 +1935,8 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   // ---- far tier: when the near list cannot fill a batch any more, the far entries with the lowest bounds come back
   // (threshold by radix select on their bounds), the ones the incumbent prunes are dropped and the rest is compacted in
   // place, chunk by chunk (a chunk is read completely before anything is written at or below it)
-  if (fc > 0 && m < keep / 4) {   // (keep / 4 still fills the widest share of a batch: open_cap >= 8 x batch_cap, miqp_gpu.hip)
+  // (skipped while fewer than 64 entries are free behind the list: pass 3 compacts the list, the next round refills)
+  if (fc > 0 && m < keep / 4 && cap - n >= 64) {   // (keep / 4 still fills the widest share of a batch: open_cap >= 8 x batch_cap, miqp_gpu.hip)
     auto fkey = [&](int k) -> unsigned long long {
       const double b = B.far_bound[fb + k];
       if (B.far_node[fb + k] < 0 || prunable(b)) return ~0ull;
@@ -1870,7 +1944,9 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     };
     // a long tier is not radix-selected itself (five passes of one workgroup over millions of entries) but through a strided
     // sample of at most `keep` entries parked behind the near list's keys: the threshold only has to be about right
-    const int stride = fc > 4 * keep ? (fc + keep - 1) / keep : 1;
+    // (the sample never leaves the key array: at most cap - n entries, a longer stride when the space behind the list is short)
+    int stride = fc > 4 * keep ? (fc + keep - 1) / keep : 1;
+    if (stride > 1 && (fc + stride - 1) / stride > cap - n) stride = (fc + (cap - n) - 1) / (cap - n);
     if (stride > 1) {
       const int ns = (fc + stride - 1) / stride;
       for (int j = tid; j < ns; j += SEL_THREADS) keys[n + j] = fkey(j * stride);
@@ -1948,8 +2024,9 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   if (focus) {
     const double gme = (inc - (lb + cst)) / (1e-10 + fabs(inc));
     int cntl = 0;
-    for (int j = tid; j < B.n_inst; j += SEL_THREADS) {
-      if (j == inst || B.inst_done[j]) continue;
+    for (int sj = tid; sj < B.n_slots; sj += SEL_THREADS) {
+      const int j = B.slot_inst[sj];
+      if (j < 0 || j == inst || B.inst_done[j]) continue;
       const double ij = B.inc_obj[j];
       const double gj = ij < 1e299 ? (ij - B.lower_bound[j]) / (1e-10 + fabs(ij)) : 1e300;
       if (gj < gme || (gj == gme && j < inst)) cntl++;
@@ -1959,13 +2036,34 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   __syncthreads();
   const int rank = sh_pick;
   __syncthreads();
+  // Bound window of a best-bound round: only nodes in the lower part of [lower bound, incumbent - gap] are eligible.  The
+  // proof has to process every node below (final incumbent) - gap anyway; nodes above that are only ever touched because the
+  // incumbent of the moment is not the final one - a wide round reaches far up the list, a later round would find them pruned.
+  // Deferring the upper part costs nothing but width, and the width goes to other instances (share_kernel).
+  int m_elig = m;
+  if (!dive && inc < 1e300 && B.window_pct < 100 && m > 0) {
+    const double top = inc - gap * (1e-10 + fabs(inc)) - cst;   // bounds are stored without the instance's constant
+    const double thrw = lb + 0.01 * (double)B.window_pct * fmax(0.0, top - lb);
+    const unsigned long long kw = d2key(thrw);
+    if (tid == 0) sh_elig = 0;
+    __syncthreads();
+    int ce = 0;
+    for (int k = tid; k < n; k += SEL_THREADS) { const unsigned long long key = keys[k]; if (key != ~0ull && key <= kw) ce++; }
+    if (ce) atomicAdd(&sh_elig, ce);
+    __syncthreads();
+    m_elig = sh_elig < 1 ? 1 : sh_elig;
+  }
   if (tid == 0) {
     sh_pick = 0;
     int act = act_now; if (act < 1) act = 1;
-    int w = (focus && !(B.seq_kinds & 0x10000000)) ? (B.batch_cap >> (rank + 1 < 30 ? rank + 1 : 30)) : B.batch_cap / act;
-    if (w < B.nodes_per_round) w = B.nodes_per_round;
+    int w;
+    if (B.seq_kinds & 0x40000000) {   // (experiment switch, bit 30: the equal split and the endgame focus of round 2)
+      w = (focus && !(B.seq_kinds & 0x10000000)) ? (B.batch_cap >> (rank + 1 < 30 ? rank + 1 : 30)) : B.batch_cap / act;
+      if (w < B.nodes_per_round) w = B.nodes_per_round;
+    } else { w = B.slot_take[slot]; if (w < B.base_take) w = B.base_take; }
     if (!(inc < 1e300) && w > 512) w = 512;   // no incumbent yet: a narrow dive (a wide one degenerates into breadth first)
-    int take = m < w ? m : w;
+    B.slot_demand[slot] = inc < 1e300 ? m_elig : (m < 512 ? m : 512);   // what this instance could use next round
+    int take = m_elig < w ? m_elig : w;
     const int maxch = B.far_cap > 0 ? 8 : 64;     // children of one node: at most 63 (eval_kernel); with a far tier behind the list an overflow is absorbed there
     int room = (cap - m) / maxch; if (room < 1) room = 1;
     if (B.far_cap > 0 && room < 1024) room = 1024;   // (children that find the near list full go to the far tier)
@@ -2029,6 +2127,58 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
       // after a spill by depth the near list is no longer "everything below a bound": children go to the far tier until the next refill sets the threshold again
       B.near_thr[inst] = dive ? -1e300 : (thr_spill != ~0ull ? key2d(thr_spill | lowmask) : 1e300);
     }
+  }
+}
+
+// admission of queued instances into free slots (one thread per admission): the instance that held the slot leaves it, the
+// new one's root records become the head of the slot's near list in the buffer the next select_kernel reads
+__global__ void admit_kernel(DevBuf B, const int* pairs, int n, int sel) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int slot = pairs[2 * k], inst = pairs[2 * k + 1];
+  const int old = B.slot_inst[slot];
+  if (old >= 0) B.inst_slot[old] = -1;
+  B.slot_inst[slot] = inst;
+  if (inst < 0) return;   // the slot is only vacated
+  B.inst_slot[inst] = slot;
+  const int nr = B.root_cnt[inst];
+  const size_t base = ((size_t)sel * B.n_slots + slot) * B.open_cap;
+  for (int r = 0; r < nr; ++r) { B.open_bound[base + r] = -1e300; B.open_node[base + r] = B.root_node[(size_t)inst * B.root_stride + r]; B.open_depth[base + r] = 0; }
+  B.open_count[inst] = nr;
+  atomicAdd(B.active_insts, 1);
+}
+
+// shares of the next round's batch (one workgroup; see DevBuf::slot_take)
+__global__ void __launch_bounds__(1024) share_kernel(DevBuf B) {
+  __shared__ long long red[1024];
+  const int tid = threadIdx.x, NSL = B.n_slots;
+  auto bsum = [&](long long v) -> long long {
+    __syncthreads(); red[tid] = v; __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+    return red[0];
+  };
+  const long long target = (long long)B.batch_cap - (long long)B.batch_cap / 16;   // (demands are one round old: a little head room)
+  long long ab = 0, an = 0;
+  for (int k = tid; k < NSL; k += 1024) { const int d = B.slot_demand[k]; ab += d < B.base_take ? d : B.base_take; an += d > B.base_take ? 1 : 0; }
+  const long long SB = bsum(ab), NA = bsum(an);
+  const long long rest = target - SB;
+  long long cap = B.share_cap; if (NA > 0 && rest / NA > cap) cap = rest / NA < 2 * cap ? rest / NA : 2 * cap;   // few instances in flight: up to twice the cap (wider rounds cost more nodes than they save rounds)
+  auto more_of = [&](int k) -> long long {   // what slot k may take beyond its base share
+    const int d = B.slot_demand[k]; const long long c = d < cap ? d : cap;
+    const int b = d < B.base_take ? d : B.base_take;
+    return c > b ? c - b : 0;
+  };
+  for (int k = tid; k < NSL; k += 1024) {
+    const int d = B.slot_demand[k], inst = B.slot_inst[k];
+    int take = d < B.base_take ? d : B.base_take;
+    const long long more = more_of(k);
+    if (inst >= 0 && more > 0 && rest > 0) {
+      long long before = 0;   // what the instances admitted earlier take from the rest
+      for (int j = 0; j < NSL; ++j) { const int ij = B.slot_inst[j]; if (ij >= 0 && ij < inst) before += more_of(j); }
+      long long ex = rest - before; if (ex > more) ex = more;
+      if (ex > 0) take += (int)ex;
+    }
+    B.slot_take[k] = take;
   }
 }
 

