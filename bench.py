@@ -1,9 +1,14 @@
 """bench.py - MIQP solves/sec to 1% gap on 2-agent x 20-step x 32-region instances (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one batch of synthetic instances: every rank solves its own shard of
-independent planning instances (weak scaling: fixed batch per GPU, instance b -> rank b mod G, no data-path
-collective); `value` = instances solved to the gap by all ranks / wall time of the K timed steps (max over ranks).
-Inputs are generated and packed before the timed region; the solve call uploads ~12 KB per instance.
+A "step" is one pass of the hot path over one QUEUE of synthetic instances: every rank drains its own queue of
+independent planning instances with `--batch` of them in flight on its GPU (miqp_solver_solve_stream: a proven instance -
+or one that has used up its own 10 s, counted from its admission - hands its slot to the next one of the queue), so the
+step time is (queue length) / (solve rate), not the time limit of the hardest instance.  Weak scaling: fixed queue per
+GPU, instance b -> rank b mod G, no data-path collective; `value` = instances solved to the gap by all ranks / wall time
+of the K timed steps (max over ranks).  `--no-stream` restores the semantics of rounds 1-2 (the whole batch in flight
+at once, a step ends when its last instance does).  `--total T` is the strong-scaling mode of BASELINE config 4: a fixed
+set of T instances per step (seeds 1000 ...) split b mod G over the ranks.
+Inputs are generated and handed to the solver handles before the timed region; the solve call uploads ~22 KB per instance.
 """
 import argparse
 import json
@@ -127,9 +132,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="instances per GPU and step, all in flight at once (independent planning instances; "
-                    "throughput grows with the batch because the hard tail of a batch runs into the time limit either way: 256 -> 25/s, 1024 -> 99/s, "
-                    "4096 -> 350/s on one MI355X with 99.6 / 99.3 / 95 %% of the instances proven in time; the default is the largest batch that proves >= 98 %% - profiles/r02_batch_sweep.json)")
+    ap.add_argument("--batch", type=int, default=256, help="instances IN FLIGHT per GPU (slots of the streaming admission); every instance has its own time limit "
+                    "from its admission, so the backlog (in flight x mean work per instance) has to stay well below it: 256 keeps >= 99 %% of the instances proven "
+                    "(profiles/r03_batch_sweep.json)")
+    ap.add_argument("--queue-factor", type=int, default=4, help="instances per GPU and step = queue-factor x batch (the queue one step drains)")
+    ap.add_argument("--no-stream", action="store_true", help="rounds 1-2 semantics: a step is one batch, all of it in flight at once")
+    ap.add_argument("--total", type=int, default=0, help="strong scaling (BASELINE config 4): T instances per step in total, seeds 1000 + ..., instance b on rank b mod G")
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--gap", type=float, default=0.01)
     ap.add_argument("--time-limit", type=float, default=10.0, help="max_solution_time per instance (reference default 10 s)")
@@ -172,40 +180,53 @@ def main():
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
 
-    B = a.batch
-    # weak scaling: seeds rank*B .. rank*B+B-1 of step s are offset by s*world*B
+    B = a.batch                                   # in flight
+    Q = B if a.no_stream else B * max(1, a.queue_factor)   # instances per rank and step
+    if a.total > 0:
+        # strong scaling: the same T instances whatever the number of ranks (seeds 1000 + step * T + b), instance b on rank b mod G
+        def seeds_of(step):
+            return [1000 + step * a.total + b for b in range(a.total) if b % world == rank]
+    else:
+        # weak scaling: seeds rank*Q .. rank*Q+Q-1 of step s are offset by s*world*Q
+        def seeds_of(step):
+            return [(step * world + rank) * Q + k for k in range(Q)]
+
     def make_batch(step):
-        ps = [synthetic.generate(a.config, (step * world + rank) * B + k, gap=a.gap, max_time=a.time_limit) for k in range(B)]
+        ps = [synthetic.generate(a.config, sd, gap=a.gap, max_time=a.time_limit) for sd in seeds_of(step)]
         ws = []
         for p in ps:
             w = P.CplexWrapper(device=local); w.resetParameters(p); ws.append(w)
+        P.prepare_batch(ws)   # parameters into the solver handles (host side; the device upload is part of the timed solve call)
         return ps, ws
 
     batches = [make_batch(s) for s in range(a.warmup + a.steps)]
+    infl = None if a.no_stream else B
     lp_files = []
     if a.dump_lp and rank == 0:
         os.makedirs(a.dump_lp, exist_ok=True)
         L = P.load_library()
         for k, w in enumerate(batches[a.warmup][1]):
-            if w._push_inputs() == 0:
-                f = os.path.join(a.dump_lp, "%s_seed%d.lp" % (a.config, (a.warmup * world + rank) * B + k))
+            if True:
+                f = os.path.join(a.dump_lp, "%s_seed%d.lp" % (a.config, seeds_of(a.warmup)[k]))
                 if L.miqp_solver_export_lp(w._h, f.encode()) == 0:
                     lp_files.append(f)
     for s in range(a.warmup):
-        P.solve_batch(batches[s][1])
+        P.solve_batch(batches[s][1], inflight=infl, prepared=True)
     sync()
     t0 = time.time()
     solved = 0; attempted = 0; ipm_s = 0.0; launches = 0; iters = 0; rowit = 0; nodes = 0; lat = []
     for s in range(a.warmup, a.warmup + a.steps):
         ps, ws = batches[s]
-        sts = P.solve_batch(ws)
+        sts = P.solve_batch(ws, inflight=infl, prepared=True) if ws else []
         attempted += len(ws)
+        if not ws:
+            continue
         for w, st in zip(ws, sts):
             pr = w.getSolutionProperties()
             ok = st == P.OptimizationStatus.SUCCESS and pr.status in (101, 102)
             solved += int(ok)
             if ok:
-                lat.append(pr.time)   # seconds from the start of the batch to this instance's proof
+                lat.append(pr.time)   # seconds from the instance's admission to its proof
         tm = ws[0].lastTiming()
         ipm_s += tm["ipm_s"]; launches += tm["ipm_launches"]; iters += tm["ipm_iters"]; rowit += tm["row_iters"]; nodes += tm["nodes"]
     sync()
@@ -223,21 +244,27 @@ def main():
         # L2<->fabric bytes per launch of the interior point kernels: not measurable inside this process; the figure of the
         # committed rocprofv3 --pmc passes of the same configuration (profiles/r02_traffic.json says how it was taken)
         traffic = None; traffic_note = None
-        tj = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        if not os.path.exists(tj):
+            tj = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tj) and a.config == "cfg3":
             tjd = json.load(open(tj)); traffic = tjd.get("bytes_per_round_corrected"); traffic_note = tjd.get("note")
         out = dict(metric="MIQP solves/sec to 1% gap, 2-agent x 20-step x 32-region", value=tot_solved / T, unit="MIQP solves/s",
-                   n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * T / a.steps, higher_is_better=True, scaling="weak",
+                   n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * T / a.steps, higher_is_better=True, scaling="strong" if a.total > 0 else "weak",
                    vs_baseline=None, dtype="f64", data="synthetic",
-                   config=dict(workload="%s: %d cars x %d steps x %d regions, %d env pieces, %d obstacles; %d instances per GPU and step, gap %g, time limit %g s"
-                               % ((a.config,) + synthetic.CONFIGS[a.config] + (B, a.gap, a.time_limit)),
+                   config=dict(workload="%s: %d cars x %d steps x %d regions, %d env pieces, %d obstacles; %s, gap %g, time limit %g s per instance%s"
+                               % ((a.config,) + synthetic.CONFIGS[a.config] + (
+                                   ("%d instances per step in total, split b mod G" % a.total) if a.total > 0 else ("queue of %d instances per GPU and step" % Q),
+                                   a.gap, a.time_limit,
+                                   " (whole batch in flight, the step ends with its last instance)" if a.no_stream else (" from its admission, %d in flight per GPU (streaming admission)" % B))),
+                               in_flight=B, queue_per_gpu_and_step=(None if a.total > 0 else Q), streaming=not a.no_stream,
                                instances_attempted=int(tot_att), instances_solved_to_gap=int(tot_solved),
                                per_rank=[dict(rank=k, seconds=round(x[0], 3), solved=int(x[1]), attempted=int(x[2]), bnb_nodes=int(x[7])) for k, x in enumerate(g)],
                                bnb_nodes=int(sum(x[7] for x in g)), ipm_iterations=int(sum(x[5] for x in g)),
                                solve_latency_s_rank0=dict(p50=float(np.percentile(lat, 50)), p95=float(np.percentile(lat, 95)), max=float(max(lat))) if lat else None),
                    roofline=dict(bound="mfma", achieved=ach / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s", frac=ach / FP64_PEAK, traffic=traffic,
                                  traffic_note=traffic_note, peak_measured=FP64_PEAK_MEASURED / 1e12, frac_of_measured_peak=ach / FP64_PEAK_MEASURED,
-                                 kernel="ipm_onchip_kernel<2,10> followed by ipm_kernel<2,64> on the nodes it hands over (one pair per B&B round)",
+                                 kernel="ipm_onchip_kernel<2,10> followed by ipm_kernel<2,64> on the nodes it hands over (one pair per B&B round)" if a.config in ("cfg3", "cfg4") else "interior point kernels of the configuration (one launch pair per B&B round)",
                                  launches=int(launches), avg_launch_ms=1e3 * ipm_s / max(1, launches), flops_per_launch=flops / max(1, launches)))
         if not a.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(batches[a.warmup][0], a.gap, a.time_limit)

@@ -52,7 +52,7 @@ class CplexWrapper {
   typedef MiqpPlannerParallelMode ParallelMode;
 
   CplexWrapper(std::string modpath, std::string modfile, ParameterSource parameterSource, const int precision)
-      : modfile_(modpath + modfile), precision_(precision), parameterSource_(parameterSource),
+      : modfile_(modpath + modfile), precision_(precision), roundingDecimals_(precision - 2), parameterSource_(parameterSource),
         rawResults_(std::make_shared<RawResults>()), warmstartValues_(std::make_shared<RawResults>()) {}
   CplexWrapper(std::string modfile, ParameterSource parameterSource, const int precision)
       : CplexWrapper("cplexmodel/", modfile, parameterSource, precision) {}
@@ -60,13 +60,21 @@ class CplexWrapper {
   // cheap and side-effect free: BehaviorMiqpAgent default-constructs a spare wrapper per agent
   // (behavior_miqp_agent.cpp:49); the device is touched on the first callCplex only
   CplexWrapper() : CplexWrapper("", ParameterSource::CPPINPUTS, 12) {}
+  // the reference's copy (src/cplex_wrapper.hpp:116-151) takes over the configuration - file names, precision, parameter
+  // source, debug output settings, warm start type, the solution properties, the .mst path, the branching priority settings and
+  // the output buffering flag - and starts with a fresh environment: no parameters (ds_ is new; MiqpPlanner's copy constructor
+  // calls resetParameters right after, src/miqp_planner.cpp:170), no results, no MIP start values, SOS switch at its default.
+  // Its data source is built with cp2.precision_ where the constructors use precision - 2 (:129 against :88): a copy rounds
+  // its inputs to `precision` decimals.
   CplexWrapper(const CplexWrapper& o)
-      : modfile_(o.modfile_), datfile_(o.datfile_), precision_(o.precision_), parameterSource_(o.parameterSource_),
+      : tmpWarmstartFile_(o.tmpWarmstartFile_), modfile_(o.modfile_), datfile_(o.datfile_), precision_(o.precision_),
+        roundingDecimals_(o.precision_), parameterSource_(o.parameterSource_),
         rawResults_(std::make_shared<RawResults>()), print_debug_outputs_(o.print_debug_outputs_), doWarmstart_(o.doWarmstart_),
         warmstartValues_(std::make_shared<RawResults>()), solutionProperties_(o.solutionProperties_),
         debugOutputFilePath_(o.debugOutputFilePath_), debugOutputFilePrefix_(o.debugOutputFilePrefix_),
-        debugOutputParameterFilePath_(o.debugOutputParameterFilePath_), useSpecialOrderedSets_(o.useSpecialOrderedSets_),
-        useBranchingPriorities_(o.useBranchingPriorities_), parameters_(o.parameters_) {}
+        debugOutputParameterFilePath_(o.debugOutputParameterFilePath_),
+        useBranchingPriorities_(o.useBranchingPriorities_), prioValue_(o.prioValue_), prioExtent_(o.prioExtent_),
+        bufferCplexOutputsToStream_(o.bufferCplexOutputsToStream_) {}
   CplexWrapper& operator=(const CplexWrapper& rhs) {  // src/cplex_wrapper.hpp:153-156
     debugOutputParameterFilePath_ = rhs.debugOutputParameterFilePath_;
     return *this;
@@ -95,7 +103,7 @@ class CplexWrapper {
 
   OptimizationStatus callCplex(const double timestemp = 0.0) {
     try {
-      if (!h_) { miqp_solver_opts o{}; o.precision = precision_; o.device = -1; o.gap_override = -1.0; h_ = miqp_solver_create(&o); }
+      if (!h_) { miqp_solver_opts o{}; o.precision = roundingDecimals_ + 2; o.device = -1; o.gap_override = -1.0; h_ = miqp_solver_create(&o); }   // (the C ABI rounds to precision - 2)
       if (!h_) return FAILED_SEG_FAULT;
       if (parameterSource_ == DATFILE || (parameterSource_ == MIXED && !parameters_)) {   // MIXED: the C++ inputs when given, else the file
         if (miqp_solver_load_dat(h_, datfile_.c_str()) != 0) return FAILED_SEG_FAULT;
@@ -142,7 +150,7 @@ class CplexWrapper {
   void setUseBranchingPriorities(bool in) { useBranchingPriorities_ = in; }  // idem
   std::string getTmpWarmstartFile() { return tmpWarmstartFile_; }
   void setBranchingPriorityValueExtent(int value, int extent) { prioValue_ = value; prioExtent_ = extent; }
-  void setBufferCplexOutputsToStream(bool) {}
+  void setBufferCplexOutputsToStream(bool in) { bufferCplexOutputsToStream_ = in; }   // (there is no CPLEX log to buffer; the flag is kept and copied)
 
  private:
   static std::string stampOf(double t) { char b[64]; std::snprintf(b, sizeof(b), "%.15g", t); return b; }  // << setprecision(15)
@@ -267,6 +275,7 @@ class CplexWrapper {
 
   std::string modfile_, datfile_;
   int precision_;
+  int roundingDecimals_;   // decimals the inputs are rounded to: precision - 2, precision for a copy (see the copy constructor)
   ParameterSource parameterSource_;
   std::shared_ptr<RawResults> rawResults_;
   bool print_debug_outputs_ = false;
@@ -276,6 +285,7 @@ class CplexWrapper {
   std::string debugOutputFilePath_, debugOutputFilePrefix_, debugOutputParameterFilePath_;
   bool useSpecialOrderedSets_ = false, useBranchingPriorities_ = false;
   int prioValue_ = 1, prioExtent_ = 1;
+  bool bufferCplexOutputsToStream_ = false;
   std::shared_ptr<ModelParameters> parameters_;
   miqp_solver_t* h_ = nullptr;  // created lazily
 };

@@ -11,6 +11,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -528,6 +529,12 @@ inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int*
       H[0] = std::max(H[0], lo[0]); H[1] = std::min(H[1], lo[1]); H[2] = std::max(H[2], lo[2]); H[3] = std::min(H[3], lo[3]);
       H[4] = std::max(H[4], lo[4]); H[5] = std::min(H[5], lo[5]); H[6] = std::max(H[6], lo[6]); H[7] = std::min(H[7], lo[7]);
       if (cones.empty()) continue;
+      // The cone rows are OFF by default (MIQP_HULL_CONE=1 switches them on): measured on the bench instances they do not change
+      // the node counts (the velocity of an undecided step almost never leaves the cone: 7 % of the region branchings were
+      // flagged by a sector row, and those are settled by the branching itself), but two more general rows per undecided
+      // (car, step) push two thirds of the nodes over the on-chip kernel's 128 general rows into the memory-backed kernel
+      // (+25 % interior point time).  The boxes are box rows of the kernels: free.
+      { static const bool cone = std::getenv("MIQP_HULL_CONE") != nullptr && std::atoi(std::getenv("MIQP_HULL_CONE")) != 0; if (!cone) continue; }
       // the cone around all sectors = complement of the widest angular gap between them
       std::vector<int> ord(cones.size()); for (size_t k = 0; k < ord.size(); ++k) ord[k] = (int)k;
       std::sort(ord.begin(), ord.end(), [&](int a, int b) { return cones[a][0] < cones[b][0]; });

@@ -138,7 +138,7 @@ struct DevBuf {
   // Earliest deadline first finishes what it starts; the cap keeps one pathological instance from holding more than an
   // eighth of the device.
   int* slot_demand; int* slot_take; int share_cap; int base_take; int window_pct;
-  const int* root_cnt; const int* root_node; int root_stride;   // root records of every instance (uploaded once; admit_kernel writes them into the slot's list)
+  const int* root_cnt; const int* root_node; const int* root_depth; int root_stride;   // root records of every instance (uploaded once; admit_kernel writes them into the slot's list)
   double qp_tol;
   int use_cutoff;                // 0: solve every node to convergence (polish of the incumbent, solve_fixed)
   int seq_kinds;                 // bit k set: first-deviation (time family) branching for disjunction kind k, else single step
@@ -1243,6 +1243,7 @@ __device__ inline double region_alt_lift(const Layout& Y, const double* D, const
   return l;
 }
 
+constexpr int REPAIR_ROOT = 62;   // depth word of a MIP-start repair root (tree depth 0, sibling preference 62: no node of the tree carries it)
 struct BranchDesc { int prio; int kind; int c; int o; int i; int pt; int cause; };  // kind: 0 region 1 env 2 obs 3 c2c; cause (diagnostic): what flagged a region disjunction - 0 its own rows, 1 / 2 / 3 an environment / obstacle / car-car row on a front point of a car whose region is undecided
 
 template <int C>
@@ -1585,18 +1586,26 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         total += n; jhi = j;
       }
     }
+    // MIP-start repair (CPLEX repairtries, src/cplex_wrapper.cpp:494-639 with cplexmodel.mod:8-21): the root that carries only the
+    // REGION binaries of a start (depth word REPAIR_ROOT) is not part of the tree - the tree's own root covers it.  When the
+    // completion of its relaxation is not integer feasible it gets one child, the rounding probe (every undecided disjunction
+    // fixed to its completed value: feasible -> incumbent), and nothing else.
+    const bool repair_root = B.batch_depth[node] == REPAIR_ROOT;
+    if (repair_root) nalt = 0;
+    else {
     ck[0] = N; ca[0] = 0; nalt = 1;                       // child_inf
     for (int j = jlo; j <= jhi; ++j) {
       if (fix[base + j * stride] >= 0) continue;
       int n = alts_of(j, tmp);
       for (int q = 0; q < n && nalt < 63; ++q) { ck[nalt] = j; ca[nalt] = tmp[q]; nalt++; }
     }
+    }
     // rounding probe (until the instance has an incumbent, and afterwards at nearly integral nodes - at most K (car | pair, step)
     // sites with a violated disjunction, K = 8: 256 instances 9.1 -> 6.5 s, 90 % quantile of the finish time 1.5 -> 0.75 s):
     // one extra child with EVERY undecided disjunction fixed to its
     // completed value.  It lies inside the first child, so the children stay exhaustive; its relaxation is the exact cost
     // of the rounding and, when feasible, the first incumbent two rounds after the root instead of one dive level per round
-    if ((!(inc_now < 1e300) || (B.opt2 & 1) || (((B.opt2 >> 4) & 15) && __popcll(bal_viol) <= ((B.opt2 >> 4) & 15) && ((B.batch_node[node] * 2654435761u >> 16) & ((1u << (2 * ((B.opt2 >> 2) & 3))) - 1u)) == 0u && (!(B.opt2 >> 8) || vmax_all <= 0.05 * (double)(B.opt2 >> 8)))) && nalt < 63 && (B.seq_kinds & 0x4000000) == 0) { ck[nalt] = -2; ca[nalt] = 0; nalt++; }
+    if ((repair_root || !(inc_now < 1e300) || (B.opt2 & 1) || (((B.opt2 >> 4) & 15) && __popcll(bal_viol) <= ((B.opt2 >> 4) & 15) && ((B.batch_node[node] * 2654435761u >> 16) & ((1u << (2 * ((B.opt2 >> 2) & 3))) - 1u)) == 0u && (!(B.opt2 >> 8) || vmax_all <= 0.05 * (double)(B.opt2 >> 8)))) && nalt < 63 && (B.seq_kinds & 0x4000000) == 0) { ck[nalt] = -2; ca[nalt] = 0; nalt++; }
     fam[0] = base; fam[1] = stride; fam[2] = jlo; fam[3] = jhi;
     sh_base[2] = nalt;
   }
@@ -2143,7 +2152,7 @@ __global__ void admit_kernel(DevBuf B, const int* pairs, int n, int sel) {
   B.inst_slot[inst] = slot;
   const int nr = B.root_cnt[inst];
   const size_t base = ((size_t)sel * B.n_slots + slot) * B.open_cap;
-  for (int r = 0; r < nr; ++r) { B.open_bound[base + r] = -1e300; B.open_node[base + r] = B.root_node[(size_t)inst * B.root_stride + r]; B.open_depth[base + r] = 0; }
+  for (int r = 0; r < nr; ++r) { B.open_bound[base + r] = -1e300; B.open_node[base + r] = B.root_node[(size_t)inst * B.root_stride + r]; B.open_depth[base + r] = B.root_depth[(size_t)inst * B.root_stride + r]; }
   B.open_count[inst] = nr;
   atomicAdd(B.active_insts, 1);
 }

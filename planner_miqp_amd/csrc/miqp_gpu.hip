@@ -327,7 +327,8 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&B.inst_kill, n_inst)) return false;
   if (!X.alloc(&B.slot_demand, n_slots)) return false;
   if (!X.alloc(&B.slot_take, n_slots)) return false;
-  { int* rc; int* rn; if (!X.alloc(&rc, n_inst)) return false; if (!X.alloc(&rn, (size_t)n_inst * roots_per_inst)) return false; B.root_cnt = rc; B.root_node = rn; }
+  { int* rc; int* rn; int* rd; if (!X.alloc(&rc, n_inst)) return false; if (!X.alloc(&rn, (size_t)n_inst * roots_per_inst)) return false; if (!X.alloc(&rd, (size_t)n_inst * roots_per_inst)) return false;
+    B.root_cnt = rc; B.root_node = rn; B.root_depth = rd; }
   if (!X.alloc(&X.d_pairs, (size_t)2 * n_slots)) return false;
   if (!X.alloc(&B.open_count, n_inst)) return false;
   B.far_cap = X.far_cap;
@@ -657,11 +658,11 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   if (O0.nodes_per_round <= 0 && std::getenv("MIQP_NPR")) npr = std::max(1, std::atoi(std::getenv("MIQP_NPR")));  // tuning knob
   int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (std::getenv("MIQP_OPEN_CAP") ? std::atoi(std::getenv("MIQP_OPEN_CAP")) : std::max(1 << 17, std::min(1 << 20, (1 << 28) / NS)));   // near lists: 1 M entries per instance up to n = 256 (10 GB of list entries), 262144 at n = 1024; records are shared
   if (open_cap < 64) open_cap = 64;
-  if (split && open_cap < SPLIT_MAXROOTS + 2 + 64) open_cap = SPLIT_MAXROOTS + 2 + 64;   // the root records of a tree split are the head of the list
+  if (split && open_cap < SPLIT_MAXROOTS + 4 + 64) open_cap = SPLIT_MAXROOTS + 4 + 64;   // the root records of a tree split are the head of the list
   { size_t free_b = 0, total_b = 0;   // list entries (40 B per open node) must fit an eighth of the free device memory
     if (O0.max_open_nodes <= 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) { size_t lim = free_b / 8 / 40 / (size_t)NS; if ((size_t)open_cap > lim) open_cap = (int)std::max<size_t>(4096, lim); } }
   if ((size_t)NS * npr >= ((size_t)1 << 20)) npr = (int)((((size_t)1 << 20) - 1) / NS);
-  const int MAXR = split ? SPLIT_MAXROOTS + 2 : 3;   // root records per instance: the root (or this rank's roots of a tree split) and the MIP starts
+  const int MAXR = split ? SPLIT_MAXROOTS + 4 : 5;   // root records per instance: the root (or this rank's roots of a tree split), the MIP starts and their repair roots
   size_t l_ipm = ipm_lds_bytes(Y), l_eval = eval_lds_bytes(Y);
   {
     // the fallible part of the set-up (device buffers, kernel attributes).  In a tree split the ranks agree on its outcome with
@@ -683,12 +684,13 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   std::vector<double> h_const(n, 0.0), h_gap(n), h_tlim(n);
   std::vector<int> h_done(n, 0);
   std::vector<signed char> roots; roots.reserve((size_t)MAXR * n * Y.fixlen);
-  std::vector<int> on((size_t)n * MAXR, 0), oc(n, 0);   // root records of every instance: the head of its open list at admission
+  std::vector<int> on((size_t)n * MAXR, 0), od((size_t)n * MAXR, 0), oc(n, 0);   // root records of every instance: the head of its open list at admission
   int nrec = 0;
-  auto add_root = [&](int k, const std::vector<signed char>& fx) { roots.insert(roots.end(), fx.begin(), fx.end()); on[(size_t)k * MAXR + oc[k]] = nrec++; oc[k]++; };
+  auto add_root = [&](int k, const std::vector<signed char>& fx, int depth_word) { roots.insert(roots.end(), fx.begin(), fx.end()); on[(size_t)k * MAXR + oc[k]] = nrec++; od[(size_t)k * MAXR + oc[k]] = depth_word; oc[k]++; };
   int active = 0;
   // per instance (independent, spread over host threads): tables, step-0 check, the fix records of its roots
   std::vector<std::vector<std::vector<signed char>>> inst_roots(n);
+  std::vector<std::vector<int>> inst_root_depth(n);
   std::vector<char> h_feas0(n, 0);
   auto prepare_one = [&](int k) {
     miqp_solver* s = S[k]; s->lay = Y; s->has_sol = false;
@@ -714,8 +716,14 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       if (!s->ws[w] || !dims_match(s->ws[w]->r, s->inst)) continue;
       std::vector<signed char> fx;
       if (!fix_from_results(s->inst, Y, &hT[(size_t)k * Y.istride], &s->ws[w]->r, fx)) continue;
+      // repair root of the start (CPLEX: repairtries): its region binaries alone; the search completes the rest by rounding
+      std::vector<signed char> rx(Y.fixlen, (signed char)-1);
+      bool any_reg = false;
+      for (int q = Y.f_reg; q < Y.f_reg + Y.C * Y.N; ++q) { rx[q] = fx[q]; any_reg = any_reg || fx[q] >= 0; }
       if ((int)R.size() < MAXR) R.push_back(std::move(fx));
+      if (any_reg && (int)R.size() < MAXR) { R.push_back(std::move(rx)); inst_root_depth[k].resize(R.size(), 0); inst_root_depth[k].back() = REPAIR_ROOT; }
     }
+    inst_root_depth[k].resize(R.size(), 0);
     int rows, bin, cont, nnz; raw_sizes(s->inst, rows, bin, cont, nnz);
     s->props = miqp_solution_properties_c{}; s->props.NrConstraints = rows; s->props.NrBinaryVariables = bin; s->props.NrFloatVariables = cont;
     s->props.NonZeroCoefficients = nnz;
@@ -729,7 +737,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     } }
   for (int k = 0; k < n; ++k) {
     if (!h_feas0[k]) h_done[k] = 1;
-    for (auto& fx : inst_roots[k]) add_root(k, fx);
+    for (size_t q = 0; q < inst_roots[k].size(); ++q) add_root(k, inst_roots[k][q], inst_root_depth[k][q]);
     if (oc[k] > 0) active++; else h_done[k] = 1;   // (a rank of a tree split may own no root)
   }
   const double t_tables = wall_s() - t_enter - t_ctx;
@@ -745,6 +753,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemcpyAsync(B.pool_count, &pool0, 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemsetAsync(B.free_head, 0, 4, st)); HIP_OK(hipMemsetAsync(B.free_tail, 0, 4, st)); HIP_OK(hipMemsetAsync(B.free_limit, 0, 4, st));
   HIP_OK(hipMemcpyAsync((void*)B.root_node, on.data(), on.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync((void*)B.root_depth, od.data(), od.size() * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync((void*)B.root_cnt, oc.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemsetAsync(B.open_count, 0, (size_t)n * 4, st));
   HIP_OK(hipMemsetAsync(B.inst_slot, 0xFF, (size_t)n * 4, st)); HIP_OK(hipMemsetAsync(B.slot_inst, 0xFF, (size_t)NS * 4, st));

@@ -25,12 +25,16 @@ sys.path.insert(0, ROOT)
 
 INSTANCES = [  # (config tuple (cars, steps, regions, env pieces, obstacles), seed, modifier)
     # sizes the plain B&B below finishes (the big-M relaxations are weak: every extra step multiplies the tree); each worker
-    # process is stopped after LIMIT_S and its instance left out
+    # process is stopped after LIMIT_S and its instance left out.  Instances already in highs_fixtures.json are kept, not re-solved.
     ((2, 4, 16, 1, 0), 0, None), ((2, 3, 16, 1, 0), 1, "close"), ((2, 3, 16, 1, 0), 2, "cross"), ((2, 4, 16, 1, 0), 3, "cross"),
-    ((1, 7, 32, 1, 1), 1, "obstacle"), ((1, 5, 16, 1, 1), 2, "obstacle"), ((3, 3, 16, 1, 0), 0, "close"), ((2, 3, 32, 2, 0), 4, "close"),
-    ((2, 4, 16, 1, 0), 1, "close"), ((2, 3, 16, 1, 1), 3, "obstacle"),
+    ((1, 7, 32, 1, 1), 1, "obstacle"),
+    # round 3: three and four cars, 32 regions with a two-piece environment, a soft obstacle, cars that have to accelerate hard
+    # (the hull of the region boxes binds), an obstacle between two cars
+    ((3, 3, 16, 1, 0), 0, "close"), ((4, 2, 16, 1, 0), 0, "close"), ((3, 2, 16, 1, 0), 1, "close"), ((4, 3, 16, 1, 0), 1, "close"),
+    ((2, 3, 32, 2, 0), 4, "close"), ((2, 3, 32, 2, 0), 5, "cross"), ((1, 5, 16, 1, 1), 2, "soft"), ((1, 4, 32, 1, 1), 3, "soft"),
+    ((2, 3, 16, 1, 1), 3, "obstacle"), ((1, 6, 16, 1, 0), 7, "accel"), ((2, 4, 16, 1, 0), 6, "accel"), ((2, 3, 16, 2, 0), 8, "accel"),
 ]
-LIMIT_S = 1500
+LIMIT_S = 3300
 
 
 def build(cfg, seed, mod):
@@ -47,7 +51,13 @@ def build(cfg, seed, mod):
         p.IntitialState[1, 0] = p.IntitialState[0, 0] - 5.0; p.IntitialState[1, 1] = 9.0; p.IntitialState[0, 1] = 5.0
         p.x_ref[1] = p.IntitialState[1, 0] + 10.0 * p.ts * np.arange(N); p.vx_ref[1] = 10.0
         p.x_ref[0] = p.IntitialState[0, 0] + 5.0 * p.ts * np.arange(N); p.vx_ref[0] = 5.0
-    if mod == "obstacle":     # static box on the reference path a few metres ahead
+    if mod == "accel":        # slow start, fast reference: the acceleration boxes of the regions bind along the whole horizon
+        for c in range(p.NumCars):
+            p.IntitialState[c, 1] = 4.0 + 0.5 * c
+            p.x_ref[c] = p.IntitialState[c, 0] + 10.0 * p.ts * np.arange(N); p.vx_ref[c] = 10.0
+    if mod == "soft":         # the obstacle of "obstacle", declared soft (obstacle_environment_constraints.mod:85-91)
+        p.obstacle_is_soft = [1] * p.nr_obstacles
+    if mod in ("obstacle", "soft"):     # static box on the reference path a few metres ahead
         cx, cy, hl, hw = float(p.IntitialState[0, 0]) + 7.0, -1.75, 3.4, 1.9
         box = np.array([[cx - hl, cy - hw], [cx + hl, cy - hw], [cx + hl, cy + hw], [cx - hl, cy + hw]])
         p.ObstacleConvexPolygon = [[box.copy() for _ in range(N)] for _ in range(p.nr_obstacles)]
@@ -216,9 +226,13 @@ def main():
     import planner_miqp_amd as P
     P.build_library()
     ctx = mp.get_context("fork")
-    res, running, todo = [], [], list(INSTANCES)
+    have = {}
+    if os.path.exists(os.path.join(HERE, "highs_fixtures.json")):
+        for r in json.load(open(os.path.join(HERE, "highs_fixtures.json")))["instances"]:
+            have[(tuple(r["config"]), r["seed"], r["modifier"])] = r
+    res, running, todo = [have[k] for k in INSTANCES if k in have], [], [k for k in INSTANCES if k not in have]
     while todo or running:
-        while todo and len(running) < 6:
+        while todo and len(running) < int(os.environ.get('WORKERS', '6')):
             q = ctx.Queue(); pr = ctx.Process(target=_worker, args=(todo.pop(0), q)); pr.start(); running.append((pr, q, time.time()))
         time.sleep(2)
         for item in list(running):

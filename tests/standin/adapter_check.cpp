@@ -63,6 +63,17 @@ int main(int argc, char** argv) {
     cw.resetParameters(P);
     st = cw.callCplex(); pr = cw.getSolutionProperties(); res = cw.getRawResults();
     std::printf("status %d objective %.17g gap %.17g nnz %d\n", st, pr.objective, pr.gap, pr.NonZeroCoefficients);
+    {
+      // the copy of a configured wrapper (MiqpPlanner's copy constructor, src/miqp_planner.cpp:153-171) carries the configuration
+      // but no parameters: it cannot solve before resetParameters, and solves the same instance after it
+      cw.setBranchingPriorityValueExtent(3, 7); cw.setUseBranchingPriorities(true);
+      CplexWrapper cp(cw);
+      int stc0 = cp.callCplex();
+      cp.resetParameters(P);
+      int stc1 = cp.callCplex();
+      std::printf("copy before %d after %d objective %.17g tmpfile_equal %d\n", stc0, stc1, cp.getSolutionProperties().objective,
+                  (int)(cp.getTmpWarmstartFile() == cw.getTmpWarmstartFile()));
+    }
     if (st == cplex::SUCCESS) {
       // the solution fed back as receding-horizon start must be accepted (not worse)
       cw.addRecedingHorizonWarmstart(std::make_shared<RawResults>(*res));

@@ -283,3 +283,18 @@ def test_lift_tables_match_a_dense_computation():
                 assert np.allclose(T[c, ax, i], S, rtol=1e-8, atol=1e-12), (c, ax, i)
                 assert np.allclose(S, S.T) and np.all(np.linalg.eigvalsh(T[c, ax, i]) > -1e-12)
     assert np.all(T[:, :, 0, :3, :] == 0)   # the first state is fixed: only its input responds
+
+
+def test_bench_strong_scaling_mode_on_two_gloo_ranks():
+    """`bench.py --total T --gpus 2` (BASELINE config 4 as written: a fixed set of instances per step split b mod G over the
+    ranks): the launcher starts two ranks, every rank takes its share of the SAME seeds, rank 0 prints one JSON line with
+    "scaling": "strong".  No GPU here: every solve ends in the loud no-device failure, the partition and the gather are real."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "mini", "--total", "7", "--steps", "2", "--warmup", "0",
+                        "--no-cpu", "--time-limit", "1"], capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    o = json.loads(lines[0])
+    assert o["scaling"] == "strong" and o["n_gpus"] == 2 and o["steps"] == 2
+    assert o["config"]["instances_attempted"] == 14 and [p["attempted"] for p in o["config"]["per_rank"]] == [8, 6]
+    assert o["value"] == 0.0 and "no HIP device" in r.stderr

@@ -60,6 +60,8 @@ def run(adapter, *args):
         k = l.split()
         if k[0] == "status":
             out.update(status=int(k[1]), objective=float(k[3]), gap=float(k[5]), nnz=int(k[7]))
+        elif k[0] == "copy":
+            out.update(copy_before=int(k[2]), copy_after=int(k[4]), copy_objective=float(k[6]), copy_tmpfile_equal=int(k[8]))
         elif k[0] == "warm":
             out.update(warm_status=int(k[2]), warm_objective=float(k[4]))
         elif k[0] in ("pos_x", "region"):
@@ -78,6 +80,8 @@ def test_adapter_header_compiles_and_fails_loudly_without_a_device(adapter, tmp_
     dump_params(p, str(tmp_path / "p.txt"))
     o, r = run(adapter, "cpp", str(tmp_path / "p.txt"))
     assert o["status"] == (0 if torch.cuda.is_available() else 2), r.stderr
+    # copy constructor (src/cplex_wrapper.hpp:116-151): the configuration travels, the parameters do not
+    assert o["copy_before"] == 2 and o["copy_tmpfile_equal"] == 1 and o["copy_after"] == o["status"], o
 
 
 @pytest.mark.gpu
@@ -97,3 +101,5 @@ def test_adapter_matches_the_python_mirror(adapter, tmp_path):
         assert np.abs(np.array(o["pos_x"]) - res.pos_x.ravel()).max() <= 1e-7
         assert np.array_equal(np.array(o["region"], int), res.active_region.argmax(-1).ravel())
         assert o["warm_status"] == 0 and o["warm_objective"] <= o["objective"] * (1 + 1e-9)
+        # the copy rounds its inputs to 12 instead of 10 decimals (cp2.precision_, src/cplex_wrapper.hpp:129): same optimum to ~1e-9
+        assert o["copy_before"] == 2 and o["copy_after"] == 0 and abs(o["copy_objective"] - o["objective"]) <= 1e-6 * max(1.0, abs(o["objective"]))
