@@ -205,6 +205,22 @@ int miqp_calculate_warmstart(const miqp_raw_results_c* last, miqp_raw_results_c*
 int miqp_plan(miqp_solver_t* s, miqp_model_params_c* p, int* initial_region, int* possible_region, const miqp_raw_results_c* warmstart,
               int warmstart_type, double timestamp, int* status_out);
 
+/* ---- environment and obstacles of MiqpPlanner, on convex counter-clockwise pieces given as vertex arrays (the convexification of a
+ * bark map polygon, common/map/convexified_map.cpp, is out of scope).  pieces_xy: x0, y0, x1, y1, ... of all pieces, piece_off[n + 1]
+ * vertex offsets ---- */
+/* the initial-pose check of MiqpPlanner::Plan (src/miqp_planner.cpp:654-685): -1 when the rear and the front axle point of every car
+ * lie within a piece of p's environment, else 2 * car + (1: front point, 0: rear point); -2 on invalid arguments.  miqp_plan runs it. */
+int miqp_initial_pose_check(const miqp_model_params_c* p);
+/* MiqpPlanner::ResetEnvironment (src/miqp_planner.cpp:490-537): selected[e] = 1 for the pieces that a reference trajectory (x, y
+ * polylines, traj_off[n_traj + 1] point offsets) touches; returns their number */
+int miqp_select_environment(const double* pieces_xy, const int* piece_off, int n_pieces, const double* traj_xy, const int* traj_off, int n_traj, int* selected);
+/* MiqpPlanner::ObstacleIntersectsEnvironment (src/miqp_planner.cpp:1248-1306, without the region of interest): 1 when the obstacle
+ * (n_steps x 4 vertices) intersects a piece - checked at step 0 only when it is static; an empty environment admits every obstacle */
+int miqp_obstacle_intersects_environment(const double* pieces_xy, const int* piece_off, int n_pieces, const double* obstacle_xy, int n_steps, int is_static);
+/* MiqpPlanner::EnvironmentWarmstart (src/miqp_planner.cpp:1053-1115): the five environment arrays of `last` ([C][n_old][N]) re-indexed
+ * into `out` ([C][n_new][N]) by piece id; new pieces and the last step start as 1 */
+int miqp_environment_warmstart(const miqp_raw_results_c* last, miqp_raw_results_c* out, const int* ids_old, int n_old, const int* ids_new, int n_new);
+
 const char* miqp_gpu_version(void);
 
 #ifdef __cplusplus

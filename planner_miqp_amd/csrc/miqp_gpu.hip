@@ -1367,6 +1367,32 @@ int miqp_calculate_warmstart(const miqp_raw_results_c* last, miqp_raw_results_c*
   miqp::calculate_warmstart(*last, *out, ts, minimum_region_change_speed); return 0;
 }
 
+int miqp_initial_pose_check(const miqp_model_params_c* p) {
+  if (!p || p->NumCars < 1 || !p->IntitialState || !p->WheelBase || (p->nr_environments > 0 && (!p->env_offsets || !p->env_vertices))) return -2;
+  return miqp::initial_pose_check(*p);
+}
+int miqp_select_environment(const double* pieces_xy, const int* piece_off, int n_pieces, const double* traj_xy, const int* traj_off, int n_traj, int* selected) {
+  if (n_pieces < 0 || n_traj < 0 || (n_pieces > 0 && (!pieces_xy || !piece_off || !selected)) || (n_traj > 0 && (!traj_xy || !traj_off))) return -1;
+  int cnt = 0;
+  for (int e = 0; e < n_pieces; ++e) {
+    bool hit = false;
+    for (int t = 0; t < n_traj && !hit; ++t) hit = miqp::polyline_hits_convex(traj_xy + 2 * traj_off[t], traj_off[t + 1] - traj_off[t], pieces_xy + 2 * piece_off[e], piece_off[e + 1] - piece_off[e]);
+    selected[e] = hit ? 1 : 0; cnt += hit ? 1 : 0;
+  }
+  return cnt;
+}
+int miqp_obstacle_intersects_environment(const double* pieces_xy, const int* piece_off, int n_pieces, const double* obstacle_xy, int n_steps, int is_static) {
+  if (n_pieces < 0 || n_steps < 1 || !obstacle_xy || (n_pieces > 0 && (!pieces_xy || !piece_off))) return -1;
+  return miqp::obstacle_intersects_environment(pieces_xy, piece_off, n_pieces, obstacle_xy, n_steps, is_static != 0) ? 1 : 0;
+}
+int miqp_environment_warmstart(const miqp_raw_results_c* last, miqp_raw_results_c* out, const int* ids_old, int n_old, const int* ids_new, int n_new) {
+  if (!last || !out || n_old < 0 || n_new < 0 || last->NrEnvironments != n_old || out->NrEnvironments != n_new || last->N != out->N || last->NrCars != out->NrCars) return -1;
+  const int* const in[5] = {last->notWithinEnvironmentRear, last->notWithinEnvironmentFrontUbUb, last->notWithinEnvironmentFrontLbUb, last->notWithinEnvironmentFrontUbLb, last->notWithinEnvironmentFrontLbLb};
+  int* const o[5] = {out->notWithinEnvironmentRear, out->notWithinEnvironmentFrontUbUb, out->notWithinEnvironmentFrontLbUb, out->notWithinEnvironmentFrontUbLb, out->notWithinEnvironmentFrontLbLb};
+  miqp::environment_warmstart(in, o, last->NrCars, last->N, ids_old, n_old, ids_new, n_new);
+  return 0;
+}
+
 // MiqpPlanner::Plan, the part between the environment update and the trajectory read-out (src/miqp_planner.cpp:634-645,
 // 692-766): initial regions of every car from its initial velocity, all combinations, one solve per combination until
 // one succeeds; the start region is made possible for the attempt and rolled back when the attempt fails.
@@ -1375,6 +1401,12 @@ int miqp_plan(miqp_solver_t* s, miqp_model_params_c* p, int* initial_region, int
   if (!s || !p || !initial_region || !possible_region || p->NumCars < 1 || p->nr_regions < 1) return 0;
   p->initial_region = initial_region; p->possible_region = possible_region;
   const int C = p->NumCars, R = p->nr_regions;
+  // with an environment: every car's rear and front axle point must lie within one of its pieces, else Plan fails before any
+  // solve (src/miqp_planner.cpp:654-685)
+  if (p->nr_environments > 0 && p->env_offsets && p->env_vertices && p->WheelBase) {
+    const int bad = miqp::initial_pose_check(*p);
+    if (bad >= 0) { std::fprintf(stderr, "[miqp_gpu] Initial pose %s collides for car idx = %d\n", (bad & 1) ? "front" : "rear", bad >> 1); if (status_out) *status_out = MIQP_STATUS_FAILED_NO_SOLUT; return 0; }
+  }
   std::vector<std::vector<int>> per_car(C), combos;
   std::vector<int> idx(R);
   for (int c = 0; c < C; ++c) {

@@ -134,6 +134,38 @@ struct PolyLine {
       s.push_back(k && !s.empty() ? s.back() + std::hypot(x.back() - x[x.size() - 2], y.back() - y[y.size() - 2]) : 0.0);
     }
   }
+  // bark's SmoothLine (bark/geometry/line.hpp @ 53562ac, absent from the checkout) passes a cubic spline through the vertices,
+  // parameterised by the arc length of the polyline, and samples it every `inc`.  Restated as the natural cubic spline (second
+  // derivative zero at both ends) per coordinate: on collinear vertices it reproduces the polyline exactly, on a bent line it
+  // spreads the curvature of a kink over the neighbouring spans - which is what makes the reference's curvature-dependent
+  // velocity drop ahead of a bend (common/tests/reference_trajectory_generator_test.cc:96-136).
+  PolyLine smoothed(double inc) const {
+    const int n = (int)x.size();
+    if (n < 3 || !(inc > 0)) return resampled(inc);
+    auto second = [&](const std::vector<double>& f) {   // Thomas algorithm for the knot second derivatives
+      std::vector<double> M(n, 0.0), cp(n, 0.0), dp(n, 0.0);
+      for (int i = 1; i + 1 < n; ++i) {
+        const double h0 = s[i] - s[i - 1], h1 = s[i + 1] - s[i];
+        const double a = h0, b = 2.0 * (h0 + h1), c = h1, d = 6.0 * ((f[i + 1] - f[i]) / h1 - (f[i] - f[i - 1]) / h0);
+        const double m = b - a * cp[i - 1];
+        cp[i] = c / m; dp[i] = (d - a * dp[i - 1]) / m;
+      }
+      for (int i = n - 2; i >= 1; --i) M[i] = dp[i] - cp[i] * M[i + 1];
+      return M;
+    };
+    const std::vector<double> Mx = second(x), My = second(y);
+    auto eval = [&](double t, double& px, double& py) {
+      t = std::min(std::max(t, 0.0), s.back());
+      const int k = segment_of(t); const double h = s[k + 1] - s[k], A = (s[k + 1] - t) / h, B = 1.0 - A;
+      const double ca = (A * A * A - A) * h * h / 6.0, cb = (B * B * B - B) * h * h / 6.0;
+      px = A * x[k] + B * x[k + 1] + ca * Mx[k] + cb * Mx[k + 1]; py = A * y[k] + B * y[k + 1] + ca * My[k] + cb * My[k + 1];
+    };
+    PolyLine r;
+    auto push = [&](double px, double py) { r.s.push_back(r.x.empty() ? 0.0 : r.s.back() + std::hypot(px - r.x.back(), py - r.y.back())); r.x.push_back(px); r.y.push_back(py); };
+    for (double t = 0.0; t < s.back(); t += inc) { double px, py; eval(t, px, py); push(px, py); }
+    push(x.back(), y.back());
+    return r;
+  }
   PolyLine resampled(double inc) const {   // vertices every `inc` of arc length (and the end point)
     PolyLine r; if (x.size() < 2 || !(inc > 0)) return *this;
     for (double t = 0.0; t < s.back(); t += inc) { double px, py; point_at(t, px, py); r.x.push_back(px); r.y.push_back(py); r.s.push_back(t); }
@@ -185,7 +217,7 @@ inline double interpolate_with_bounds(double x0, double y0, double x1, double y1
 // out[num_points][5] = (time, x, y, theta, v) (bark's StateDefinition order); state = the same five of the start
 inline void reference_trajectory(const PolyLine& center, const double* state, double dt, int num_points, double line_interp_inc, double vel_desired,
                                  double delta_s_desired, double acc_lat_max, bool vel_curve_dep, double* out) {
-  const PolyLine line = center.resampled(line_interp_inc);
+  const PolyLine line = center.smoothed(line_interp_inc);
   for (int q = 0; q < 5; ++q) out[q] = state[q];   // the state at t = 0
   const double s_start = line.nearest_s(state[1], state[2]);
   const double s_end = line.s.empty() ? 0.0 : line.s.back();
@@ -241,6 +273,107 @@ inline bool update_car(const CarUpdateSettings& S, const double* F, const double
   else { weights[0] = weights[3] = 0.0; weights[1] = weights[4] = 2.0; }
   weights[2] = weights[5] = scale * S.acceleration_weight; weights[6] = weights[7] = scale * S.jerk_weight;
   return ok;
+}
+
+// ---------------------------------------------------------------- environment and obstacles of MiqpPlanner (convex pieces given)
+// The reference convexifies a bark map polygon (common/map/convexified_map.cpp, bark + boost::geometry: out of scope); everything
+// after that works on convex counter-clockwise pieces and is restated here on plain vertex arrays (x0, y0, x1, y1, ...).
+
+// boost::geometry::within(point, polygon): strictly inside (a point on the boundary is not within)
+inline bool point_within_convex(const double* v, int n, double px, double py) {
+  for (int k = 0; k < n; ++k) {
+    const int k2 = (k + 1) % n;
+    const double cr = (v[2 * k2] - v[2 * k]) * (py - v[2 * k + 1]) - (px - v[2 * k]) * (v[2 * k2 + 1] - v[2 * k + 1]);
+    if (!(cr > 0.0)) return false;
+  }
+  return n >= 3;
+}
+inline bool point_in_or_on_convex(const double* v, int n, double px, double py) {
+  for (int k = 0; k < n; ++k) {
+    const int k2 = (k + 1) % n;
+    const double cr = (v[2 * k2] - v[2 * k]) * (py - v[2 * k + 1]) - (px - v[2 * k]) * (v[2 * k2 + 1] - v[2 * k + 1]);
+    if (cr < 0.0) return false;
+  }
+  return n >= 3;
+}
+// boost::geometry::intersects of two convex polygons (touching counts): separating axis test over the edge normals of both
+inline bool convex_polygons_intersect(const double* a, int na, const double* b, int nb) {
+  for (int pass = 0; pass < 2; ++pass) {
+    const double* p = pass ? b : a; const int np = pass ? nb : na;
+    for (int k = 0; k < np; ++k) {
+      const int k2 = (k + 1) % np;
+      const double nx = p[2 * k2 + 1] - p[2 * k + 1], ny = -(p[2 * k2] - p[2 * k]);   // a normal of edge k
+      double amin = 1e300, amax = -1e300, bmin = 1e300, bmax = -1e300;
+      for (int q = 0; q < na; ++q) { const double d = nx * a[2 * q] + ny * a[2 * q + 1]; amin = std::min(amin, d); amax = std::max(amax, d); }
+      for (int q = 0; q < nb; ++q) { const double d = nx * b[2 * q] + ny * b[2 * q + 1]; bmin = std::min(bmin, d); bmax = std::max(bmax, d); }
+      if (amax < bmin || bmax < amin) return false;
+    }
+  }
+  return na >= 3 && nb >= 3;
+}
+inline bool segment_hits_convex(const double* v, int n, double x0, double y0, double x1, double y1) {
+  if (point_in_or_on_convex(v, n, x0, y0) || point_in_or_on_convex(v, n, x1, y1)) return true;
+  const double seg[4] = {x0, y0, x1, y1};   // degenerate two-vertex "polygon": the separating axis test needs its normal too
+  for (int k = 0; k < n; ++k) {   // proper crossing with an edge
+    const int k2 = (k + 1) % n;
+    auto orient = [](double ax, double ay, double bx, double by, double cx, double cy) { return (bx - ax) * (cy - ay) - (cx - ax) * (by - ay); };
+    const double d1 = orient(v[2 * k], v[2 * k + 1], v[2 * k2], v[2 * k2 + 1], seg[0], seg[1]), d2 = orient(v[2 * k], v[2 * k + 1], v[2 * k2], v[2 * k2 + 1], seg[2], seg[3]);
+    const double d3 = orient(seg[0], seg[1], seg[2], seg[3], v[2 * k], v[2 * k + 1]), d4 = orient(seg[0], seg[1], seg[2], seg[3], v[2 * k2], v[2 * k2 + 1]);
+    if (((d1 > 0) != (d2 > 0)) && ((d3 > 0) != (d4 > 0))) return true;
+  }
+  return false;
+}
+// ConvexifiedMap::GetIntersectingConvexPolygons for one reference trajectory (its x, y as a polyline): does it touch the piece?
+inline bool polyline_hits_convex(const double* pts, int npts, const double* v, int n) {
+  if (npts == 1) return point_in_or_on_convex(v, n, pts[0], pts[1]);
+  for (int k = 0; k + 1 < npts; ++k) if (segment_hits_convex(v, n, pts[2 * k], pts[2 * k + 1], pts[2 * k + 2], pts[2 * k + 3])) return true;
+  return false;
+}
+
+// The initial-pose check of MiqpPlanner::Plan (src/miqp_planner.cpp:654-685): the rear axle point and the front axle point
+// (wheel base ahead along atan2(vy, vx)) of every car must each lie within one of the environment pieces.  Returns -1 when
+// every car passes, else 2 * car + (1: the front point failed, 0: the rear point failed).
+inline int initial_pose_check(const miqp_model_params_c& p) {
+  for (int c = 0; c < p.NumCars; ++c) {
+    const double x = p.IntitialState[c * 6 + 0], y = p.IntitialState[c * 6 + 3];
+    const double th = std::atan2(p.IntitialState[c * 6 + 4], p.IntitialState[c * 6 + 1]);
+    const double fx = x + std::cos(th) * p.WheelBase[c], fy = y + std::sin(th) * p.WheelBase[c];
+    bool rear = false, front = false;
+    for (int e = 0; e < p.nr_environments; ++e) {
+      const double* v = p.env_vertices + 2 * p.env_offsets[e]; const int n = p.env_offsets[e + 1] - p.env_offsets[e];
+      rear = rear || point_within_convex(v, n, x, y); front = front || point_within_convex(v, n, fx, fy);
+    }
+    if (!rear) return 2 * c;
+    if (!front) return 2 * c + 1;
+  }
+  return -1;
+}
+
+// MiqpPlanner::ObstacleIntersectsEnvironment (src/miqp_planner.cpp:1248-1306) without the region of interest: does the
+// obstacle (T time steps of 4 vertices) intersect one of the pieces - at step 0 only when it is static
+inline bool obstacle_intersects_environment(const double* pieces, const int* off, int n_pieces, const double* obstacle, int T, bool is_static) {
+  if (n_pieces == 0) return true;   // empty environment: every obstacle is added
+  for (int t = 0; t < T; ++t) {
+    for (int e = 0; e < n_pieces; ++e)
+      if (convex_polygons_intersect(pieces + 2 * off[e], off[e + 1] - off[e], obstacle + (size_t)t * 8, 4)) return true;
+    if (is_static) return false;
+  }
+  return false;
+}
+
+// MiqpPlanner::EnvironmentWarmstart (src/miqp_planner.cpp:1053-1115): the environment binaries of the warm start follow the
+// piece ids - pieces that stay keep their columns (steps 0 .. N-2: the reference copies an extent of NumSteps - 1), new pieces
+// and the last step start as 1 ("not within").  in / out are the five [C][E][N] arrays with E_old / E_new pieces.
+inline void environment_warmstart(const int* const in[5], int* const out[5], int C, int N, const int* ids_old, int n_old, const int* ids_new, int n_new) {
+  for (int f = 0; f < 5; ++f) {
+    for (int q = 0; q < C * n_new * N; ++q) out[f][q] = 1;
+    for (int c = 0; c < C; ++c)
+      for (int e = 0; e < n_new; ++e) {
+        int from = -1; for (int k = 0; k < n_old; ++k) if (ids_old[k] == ids_new[e]) { from = k; break; }
+        if (from < 0) continue;
+        for (int i = 0; i + 1 < N; ++i) out[f][(c * n_new + e) * N + i] = in[f][(c * n_old + from) * N + i];
+      }
+  }
 }
 
 // ---------------------------------------------------------------- MiqpPlanner::CalculateWarmstart (miqp_planner.cpp:787-1051)

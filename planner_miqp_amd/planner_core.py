@@ -28,6 +28,11 @@ def _lib():
         L.miqp_calculate_warmstart.argtypes = [C.POINTER(RawResultsC), C.POINTER(RawResultsC), C.c_double, C.c_double]
         L.miqp_plan.restype = C.c_int
         L.miqp_plan.argtypes = [C.c_void_p, C.POINTER(ModelParamsC), ip, ip, C.POINTER(RawResultsC), C.c_int, C.c_double, C.POINTER(C.c_int)]
+        L.miqp_initial_pose_check.restype = C.c_int; L.miqp_initial_pose_check.argtypes = [C.POINTER(ModelParamsC)]
+        L.miqp_select_environment.restype = C.c_int; L.miqp_select_environment.argtypes = [dp, ip, C.c_int, dp, ip, C.c_int, ip]
+        L.miqp_obstacle_intersects_environment.restype = C.c_int; L.miqp_obstacle_intersects_environment.argtypes = [dp, ip, C.c_int, dp, C.c_int, C.c_int]
+        L.miqp_environment_warmstart.restype = C.c_int
+        L.miqp_environment_warmstart.argtypes = [C.POINTER(RawResultsC), C.POINTER(RawResultsC), ip, C.c_int, ip, C.c_int]
         _PROTO = True
     return L
 
@@ -129,6 +134,60 @@ def calculate_warmstart(last: RawResults, ts, minimum_region_change_speed, out: 
     return out
 
 
+def _flat_polys(polys):
+    """list of [n, 2] vertex arrays -> (x0, y0, ... of all, vertex offsets)"""
+    off = np.zeros(len(polys) + 1, dtype=np.int32)
+    for k, q in enumerate(polys):
+        off[k + 1] = off[k] + len(q)
+    xy = np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.float64).reshape(-1, 2) for q in polys]).reshape(-1)) if polys else np.zeros(0)
+    return xy, off
+
+
+def initial_pose_check(params):
+    """the check of MiqpPlanner::Plan (src/miqp_planner.cpp:654-685): None when the rear and the front axle point of every car lie
+    within a piece of the environment, else (car, "rear" | "front")"""
+    s, keep = params.to_c()
+    r = _lib().miqp_initial_pose_check(C.byref(s))
+    del keep
+    if r == -2:
+        raise ValueError("invalid parameters")
+    return None if r < 0 else (r >> 1, "front" if (r & 1) else "rear")
+
+
+def select_environment(pieces, trajectories):
+    """MiqpPlanner::ResetEnvironment's choice (src/miqp_planner.cpp:490-505): indices of the convex pieces that one of the reference
+    trajectories (arrays of x, y points) touches"""
+    if not pieces:
+        return []
+    pxy, poff = _flat_polys(pieces); txy, toff = _flat_polys(trajectories)
+    sel = np.zeros(len(pieces), dtype=np.int32)
+    _lib().miqp_select_environment(_d(pxy), _i(poff), len(pieces), _d(txy), _i(toff), len(trajectories), _i(sel))
+    return np.nonzero(sel)[0].tolist()
+
+
+def obstacle_intersects_environment(pieces, dynamic_obstacle, is_static):
+    """MiqpPlanner::ObstacleIntersectsEnvironment (src/miqp_planner.cpp:1248-1306) without the region of interest"""
+    pxy, poff = _flat_polys(pieces)
+    ob = np.ascontiguousarray(np.asarray(dynamic_obstacle, dtype=np.float64).reshape(-1, 4, 2))
+    return _lib().miqp_obstacle_intersects_environment(_d(pxy), _i(poff), len(pieces), _d(ob), ob.shape[0], int(bool(is_static))) == 1
+
+
+def environment_warmstart(last: RawResults, ids_old, ids_new):
+    """MiqpPlanner::EnvironmentWarmstart (src/miqp_planner.cpp:1053-1115): a copy of ``last`` whose five environment arrays follow
+    the new list of piece ids (kept pieces keep their columns for the steps 0 .. N-2, everything else is 1)"""
+    Cn, N, R, E, O, Lo = last.dims
+    out = RawResults(Cn, N, R, len(ids_new), O, Lo)
+    for nm in out.__dict__:
+        a, b = getattr(out, nm), getattr(last, nm, None)
+        if isinstance(a, np.ndarray) and isinstance(b, np.ndarray) and a.shape == b.shape:
+            a[...] = b
+    io, in_ = np.ascontiguousarray(ids_old, dtype=np.int32), np.ascontiguousarray(ids_new, dtype=np.int32)
+    a, b = last.to_c(), out.to_c()
+    if _lib().miqp_environment_warmstart(C.byref(a), C.byref(b), _i(io), len(io), _i(in_), len(in_)) != 0:
+        raise ValueError("records and id lists do not fit")
+    return out
+
+
 def plan(wrapper, params, warmstart: RawResults = None, warmstart_type=WarmstartType.NO_WARMSTART, timestamp=0.0):
     """MiqpPlanner::Plan's region-combination loop on the solver of ``wrapper``; ``params.initial_region`` and
     ``params.possible_region`` are updated like the reference updates its ModelParameters.  Returns (ok, status)."""
@@ -185,7 +244,7 @@ class MiqpPlanner:
     C-API test uses it).  Reference lines are polylines (see reference_trajectory)."""
     EPS = 0.000001   # MiqpPlanner::eps_ (src/miqp_planner.hpp:415)
 
-    def __init__(self, settings=None, **wrapper_args):
+    def __init__(self, settings=None, mapPieces=None, **wrapper_args):
         from .ctypes_types import ModelParameters
         from .wrapper import CplexWrapper
         S = dict(DefaultSettings()); S.update(settings or {})
@@ -220,6 +279,12 @@ class MiqpPlanner:
         self.wrapper = CplexWrapper("cplexmodel.mod", precision=S["precision"], **wrapper_args)
         self.status = None
         self._ws = None          # start for the next plan (receding horizon)
+        self._car_ref = {}       # per car: what its reference trajectories are generated from
+        self._map = []           # convex pieces of the map (ids = their index), see UpdateConvexifiedMap
+        self._env_ids = []       # ids of the pieces in the parameters / in the warm start
+        self._ws_env_ids = []
+        if mapPieces:
+            self.UpdateConvexifiedMap(mapPieces)
 
     def GetN(self):
         return self.settings["nr_steps"]
@@ -264,6 +329,7 @@ class MiqpPlanner:
         st = np.ascontiguousarray(np.asarray(initialState, dtype=np.float64).reshape(6))
         p.IntitialState[idx] = st
         xy = np.ascontiguousarray(np.asarray(referencePath, dtype=np.float64).reshape(-1, 2))
+        self._car_ref[idx] = (xy.copy(), st.copy(), float(timestep))
         s12 = np.array([S["nr_regions"], S["nr_steps"], S["nr_neighbouring_possible_regions"], S["additionalStepsForReferenceLongerHorizon"], S["ts"],
                         S["refLineInterpInc"], S["accLatMinMaxLimit"], S["lambda_"], S["positionWeight"], S["velocityWeight"], S["acclerationWeight"], S["jerkWeight"]], dtype=np.float64)
         F = np.ascontiguousarray(p.fraction_parameters, dtype=np.float64)
@@ -283,12 +349,89 @@ class MiqpPlanner:
         """MiqpPlanner::Plan (src/miqp_planner.cpp:633-785): the region-combination loop with the start derived from the last
         solution when the settings ask for a warm start; a successful plan prepares the start of the next one (:768-779)"""
         wt = self.settings["warmstartType"]
+        if self._map:   # convexifiedMap_.HasValidPolygon(): the environment follows the reference trajectories (:648-652)
+            self.ResetEnvironment(self.CalculateReferenceTrajectoriesLongerHorizon())
         ws = self._ws if (wt != WarmstartType.NO_WARMSTART and self._ws is not None and self._ws.dims == self._dims()) else None
         ok, self.status = plan(self.wrapper, self.parameters, ws, wt if ws is not None else WarmstartType.NO_WARMSTART, timestamp)
         self._ws = None
         if ok and wt != WarmstartType.NO_WARMSTART:
             self._ws = calculate_warmstart(self.GetSolution(), self.parameters.ts, self.parameters.minimum_region_change_speed)
+            self._ws_env_ids = list(self._env_ids)
         return ok
+
+    # ---- environment (src/miqp_planner.cpp:490-537, 1053-1115, 1207-1221) on convex pieces
+    def UpdateConvexifiedMap(self, pieces):
+        """the reference convexifies a bark map polygon here (ConvexifiedMap::Convert, out of scope); this mirror takes the convex
+        counter-clockwise pieces themselves - e.g. the map polygon itself when it is convex, as in the reference's planner tests"""
+        self._map = [np.asarray(q, dtype=np.float64).reshape(-1, 2).copy() for q in pieces]
+        return all(len(q) >= 3 for q in self._map)
+
+    def CalculateReferenceTrajectoriesLongerHorizon(self):
+        S = self.settings; out = []
+        for idx in range(self.parameters.NumCars):
+            xy, st, t0 = self._car_ref[idx]; vdes, ds = self._refs[idx]
+            st5 = [t0, st[0], st[3], np.arctan2(st[4], st[1]), np.hypot(st[1], st[4])]
+            tr = reference_trajectory(xy, st5, S["ts"], S["nr_steps"] + S["additionalStepsForReferenceLongerHorizon"], S["refLineInterpInc"], vdes, ds, S["accLatMinMaxLimit"])
+            out.append(tr[:, 1:3].copy())
+        return out
+
+    def ResetEnvironment(self, referenceTrajectories):
+        p = self.parameters
+        sel = select_environment(self._map, referenceTrajectories)
+        p.MultiEnvironmentConvexPolygon = [self._map[k] for k in sel]
+        p.nr_environments = len(sel)
+        self._env_ids = list(sel)
+        if self._ws is not None and self._ws_env_ids != self._env_ids:   # EnvironmentWarmstart
+            self._ws = environment_warmstart(self._ws, self._ws_env_ids, self._env_ids)
+            self._ws_env_ids = list(self._env_ids)
+
+    # ---- obstacles (src/miqp_planner.cpp:392-488, 617-629)
+    def CreateMiqpObstacle(self, predicted_traj, shape_xy):
+        """CreateMiqpObstacle for a rectangular shape (vertices in the obstacle's frame): placed at every (x, y, theta) of the predicted
+        trajectory (rows time, x, y, theta, v) and inflated by the collision radius - bark's BufferPolygon + simplification to four
+        edges, restated as the outward offset of the four edges (exact for a rectangle with mitred corners); counter-clockwise"""
+        sh = np.asarray(shape_xy, dtype=np.float64).reshape(-1, 2)[:4]
+        c = sh.mean(0); r = self.settings["collisionRadius"]
+        d = sh - c
+        infl = c + d + r * np.sign(d)          # axis-aligned rectangle in its own frame: every side moves out by r
+        area = 0.5 * np.sum(infl[:, 0] * np.roll(infl[:, 1], -1) - np.roll(infl[:, 0], -1) * infl[:, 1])
+        if area < 0:
+            infl = infl[::-1]
+        out = []
+        for row in np.asarray(predicted_traj, dtype=np.float64).reshape(-1, 5):
+            cs, sn = np.cos(row[3]), np.sin(row[3])
+            out.append(np.stack([row[1] + cs * infl[:, 0] - sn * infl[:, 1], row[2] + sn * infl[:, 0] + cs * infl[:, 1]], 1))
+        return out
+
+    def AddObstacle(self, dynamic_obstacle, is_soft=False, is_static=False):
+        """dynamic_obstacle: N arrays of 4 counter-clockwise vertices; returns the obstacle id, -1 when it does not touch the environment"""
+        p = self.parameters
+        ob = [np.asarray(q, dtype=np.float64).reshape(4, 2).copy() for q in dynamic_obstacle]
+        assert len(ob) == p.NumSteps
+        env = list(p.MultiEnvironmentConvexPolygon) if p.nr_environments > 0 else list(self._map)
+        if not obstacle_intersects_environment(env, ob, is_static):
+            return -1
+        p.ObstacleConvexPolygon = list(p.ObstacleConvexPolygon) + [ob]
+        p.obstacle_is_soft = list(p.obstacle_is_soft) + [int(bool(is_soft))]
+        p.nr_obstacles = len(p.ObstacleConvexPolygon); p.max_lines_obstacles = 4
+        self._ws = None          # the sizes have changed: the previous warm start cannot be used
+        return p.nr_obstacles - 1
+
+    def AddStaticObstacle(self, shape_xy, pose=(0.0, 0.0, 0.0)):
+        tr = np.tile(np.array([0.0, pose[0], pose[1], pose[2], 0.0]), (self.parameters.NumSteps, 1))
+        return self.AddObstacle(self.CreateMiqpObstacle(tr, shape_xy), False, True)
+
+    def UpdateObstacle(self, id, dynamic_obstacle):
+        ob = [np.asarray(q, dtype=np.float64).reshape(4, 2).copy() for q in dynamic_obstacle]
+        self.parameters.ObstacleConvexPolygon[id] = ob
+
+    def RemoveObstacle(self, id):
+        raise NotImplementedError("RemoveObstacle")   # NotImplementedException (src/miqp_planner.cpp:617)
+
+    def RemoveAllObstacles(self):
+        p = self.parameters
+        p.ObstacleConvexPolygon = []; p.nr_obstacles = 0; p.obstacle_is_soft = []; p.max_lines_obstacles = 0
+        self._ws = None
 
     def _dims(self):
         p = self.parameters

@@ -806,6 +806,49 @@ def test_c_api_known_answer_k8():
     assert abs(traj[1, 1] - traj[1, 7] * 0 - traj[0, 7] * 0.25 ** 3 / 6.0) < 1e-9      # x(0.25) = u_x(0) ts^3 / 6 from rest
 
 
+def test_c_api_plan_with_a_dynamic_obstacle_and_after_removing_it():
+    """`plan1` of the reference's C-API test (test/miqp_planner_c_api_test.cc:102-147): default settings, no map, the car of K8, an
+    obstacle given by its four corner points per step (1 x 1 m at x = 10 .. 11 on the reference line, not static, hard):
+    AddObstacle returns id 0, Plan succeeds with the obstacle and again after RemoveAllObstacles"""
+    from planner_miqp_amd import planner_core as K
+    pl = K.MiqpPlanner()
+    pl.AddCar([0, 0, 0, 1, 0.01, 0], [[0, 0], [5, 0], [30, 0]], 5, 1, 0.0, True)
+    N = pl.GetN()
+    ob = [np.array([[10, -0.5], [11, -0.5], [11, 0.5], [10, 0.5]], float) for _ in range(N)]      # p1 .. p4 of the test, counter-clockwise
+    assert pl.AddObstacle(ob, is_soft=False, is_static=False) == 0
+    p = pl.GetParameters()
+    assert p.nr_obstacles == 1 and p.max_lines_obstacles == 4
+    assert pl.Plan(0.0), pl.status
+    r = pl.GetSolution()
+    # the rear axle point stays outside the box at every step (obstacle_environment_constraints.mod:52-96)
+    inside = (r.pos_x[0] > 10 + 1e-6) & (r.pos_x[0] < 11 - 1e-6) & (np.abs(r.pos_y[0]) < 0.5 - 1e-6)
+    assert not inside.any()
+    pl.RemoveAllObstacles()
+    assert p.nr_obstacles == 0
+    assert pl.Plan(0.0), pl.status
+
+
+def test_two_static_obstacles_are_passed_left_then_right():
+    """testTwoStaticObstacles_matlab (test/miqp_planner_test.cc:561-611): DefaultTestSettings (= the mirror's defaults, gap 0.1), a
+    straight road -10 .. 80 x +-4 m (given here as the convex piece the reference's map shrinking by the collision radius leaves:
+    -9 .. 79 x +-3), the car at 10 m/s on the centre line, two 1 x 1 m static boxes at (20, -1.5) and (40, +1.5), inflated by the
+    collision radius.  Expected: y(2.5 s) in (0, 0.3) - the first box is passed on the left -, y(4.75 s) in (-0.3, 0) - the
+    second on the right -, x advances, Plan succeeds"""
+    from planner_miqp_amd import planner_core as K
+    pl = K.MiqpPlanner(mapPieces=[[[-9, -3], [79, -3], [79, 3], [-9, 3]]])
+    idx = pl.AddCar([0, 10, 0, 0, 0.1, 0], [[0, 0], [100, 0]], 10, 1)
+    box = [[-0.5, -0.5], [-0.5, 0.5], [0.5, 0.5], [0.5, -0.5]]
+    assert pl.AddStaticObstacle(box, (20.0, -1.5, 0.0)) == 0
+    assert pl.AddStaticObstacle(box, (40.0, 1.5, 0.0)) == 1
+    p = pl.GetParameters()
+    assert p.nr_obstacles == 2
+    assert pl.Plan(), pl.status
+    assert p.nr_environments == 1
+    traj = pl.GetRawCMiqpTrajectory(idx)
+    y, x = traj[:, 2], traj[:, 1]
+    assert 0 < y[10] < 0.3 and -0.3 < y[19] < 0 and x[19] > x[0], (y[10], y[19])
+
+
 def test_planner_mirror_receding_horizon_two_cars():
     """planner_core.MiqpPlanner as MiqpPlanner is used (test/miqp_planner_test.cc:795-898 pattern): two cars on parallel
     straight lanes, plan, move every car to the second step of its plan, update, plan again with the receding-horizon start:

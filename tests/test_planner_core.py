@@ -205,17 +205,69 @@ def test_reference_generator_stops_on_a_short_line():
 
 
 def test_reference_generator_follows_a_bend():
-    """curved reference line of :94-133.  bark smooths the line with a spline before walking it; the restatement walks the
-    polyline itself: positions and headings follow the segments, the curvature-dependent speed limit (which MiqpPlanner never
-    switches on, src/miqp_planner.cpp:245-253) only acts at the corners and never raises the velocity"""
+    """curved reference line of :94-136.  bark smooths the line with a spline before walking it (SmoothLine); the restatement
+    passes the natural cubic spline through the vertices: the curvature of the bend at x = 5 .. 10 reaches back over the first
+    span, so that with the curvature-dependent limit switched on the velocity one step ahead (x = 2) is already BELOW the desired
+    one - the reference's own expectation `traj(1).v < vel_desired` (:135), not weakened"""
     from planner_miqp_amd import planner_core as K
     line = [[0, 0], [5, 0], [10, 1.5], [20, 1.5], [30, 1.5], [40, 1.5], [50, 1.5], [60, 1.5]]
     u = K.reference_trajectory(line, [0, 0, 0, 0, 10.0], 0.2, 20, 0.2, 10.0, 0.1, 1.8, False)
-    assert abs(u[0, 4] - 10.0) < 1e-3 and np.allclose(u[1:, 4], 10.0)
-    assert np.all(np.diff(u[:, 1]) > 0) and abs(u[-1, 2] - 1.5) < 1e-9
-    assert abs(u[3, 3] - np.arctan2(1.5, 5.0)) < 1e-9 and u[8, 3] == 0.0          # on the ramp, behind it
+    assert abs(u[0, 4] - 10.0) < 1e-3 and np.allclose(u[1:, 4], 10.0)               # :131 and the unlimited profile
+    assert np.all(np.diff(u[:, 1]) > 0) and abs(u[-1, 2] - 1.5) < 0.05              # walks forward, ends on the upper straight
+    assert 0.1 < u[4, 3] < 0.45 and abs(u[-1, 3]) < 0.02                             # heading on the ramp (atan(1.5 / 5) = 0.29), level again at the end
     t = K.reference_trajectory(line, [0, 0, 0, 0, 10.0], 0.2, 20, 0.2, 10.0, 0.1, 1.8, True)
-    assert np.all(t[:, 4] <= 10.0 + 1e-12) and np.allclose(t[:, 1:4], u[:, 1:4])
+    assert abs(t[0, 4] - 10.0) < 1e-3
+    assert t[1, 4] < 10.0                                                            # :135, strict
+    assert np.all(t[:, 4] <= 10.0 + 1e-12) and t[:, 4].min() > 1.0
+    # a straight line is reproduced exactly by the spline: nothing changes for the straight-line tests above and for K8
+    v = K.reference_trajectory([[0, 0], [5, 0], [30, 0], [300, 0]], [0, 0, 0, 0, 10.0], 0.2, 20, 0.2, 10.0, 0.1, 1.8, True)
+    assert np.allclose(v[1:, 4], 10.0) and np.allclose(v[:, 2], 0.0) and np.allclose(v[:, 3], 0.0)
+
+
+def test_environment_pieces_pose_check_and_obstacles_of_the_planner():
+    """MiqpPlanner's environment and obstacle bookkeeping on convex pieces (src/miqp_planner.cpp:405-488, 490-537, 617-629,
+    654-685, 1053-1115, 1248-1306): pieces are chosen by the reference trajectories, the initial pose must lie within one,
+    obstacles outside the environment are refused with id -1, environment binaries of a warm start follow the piece ids"""
+    from planner_miqp_amd import planner_core as K
+    from planner_miqp_amd.ctypes_types import RawResults
+    A = [[-10, -4], [40, -4], [40, 4], [-10, 4]]; B = [[30, -4], [80, -4], [80, 4], [30, 4]]; Cc = [[200, -4], [300, -4], [300, 4], [200, 4]]
+    assert K.select_environment([A, B, Cc], [np.array([[0.0, 0.0], [20.0, 0.0]])]) == [0]
+    assert K.select_environment([A, B, Cc], [np.array([[0.0, 0.0], [35.0, 0.0]]), np.array([[70.0, 1.0], [75.0, 1.0]])]) == [0, 1]
+    assert K.select_environment([A, B, Cc], [np.array([[100.0, 0.0], [120.0, 0.0]])]) == []
+    ob_in = [np.array([[10, -0.5], [11, -0.5], [11, 0.5], [10, 0.5]], float)] * 20
+    ob_out = [np.array([[100, -0.5], [101, -0.5], [101, 0.5], [100, 0.5]], float)] * 20
+    ob_later = [np.array([[100 - 4.0 * i, -0.5], [101 - 4.0 * i, -0.5], [101 - 4.0 * i, 0.5], [100 - 4.0 * i, 0.5]], float) for i in range(20)]
+    assert K.obstacle_intersects_environment([A], ob_in, True) and not K.obstacle_intersects_environment([A], ob_out, True)
+    assert K.obstacle_intersects_environment([A], ob_later, False) and not K.obstacle_intersects_environment([A], ob_later, True)   # static: step 0 only
+    assert K.obstacle_intersects_environment([], ob_out, True)                                                        # empty environment admits everything
+
+    pl = K.MiqpPlanner(mapPieces=[A, B, Cc])
+    idx = pl.AddCar([0, 5, 0, 0, 0.01, 0], [[0, 0], [100, 0]], 5, 1, 0.0, True)
+    pl.ResetEnvironment(pl.CalculateReferenceTrajectoriesLongerHorizon())
+    p = pl.GetParameters()
+    assert p.nr_environments == 1 and pl._env_ids == [0]                       # 24 steps at 5 m/s stay inside the first piece
+    assert K.initial_pose_check(p) is None
+    assert pl.AddObstacle(ob_out, False, True) == -1 and p.nr_obstacles == 0   # outside the environment of the last reset
+    assert pl.AddObstacle(ob_in, False, False) == 0 and p.nr_obstacles == 1 and p.max_lines_obstacles == 4
+    assert pl.AddObstacle(ob_later, True, False) == 1 and p.obstacle_is_soft == [0, 1]
+    pl.UpdateObstacle(0, ob_later); assert np.allclose(p.ObstacleConvexPolygon[0][3], ob_later[3])
+    with pytest.raises(NotImplementedError):
+        pl.RemoveObstacle(0)
+    pl.RemoveAllObstacles(); assert p.nr_obstacles == 0 and p.max_lines_obstacles == 0 and p.ObstacleConvexPolygon == []
+    # the rear point inside, the front point (2.8 m ahead) outside; then the rear point on the boundary (within is strict)
+    p.IntitialState[0] = [38.5, 5, 0, 0, 0.0, 0]; assert K.initial_pose_check(p) == (0, "front")
+    p.IntitialState[0] = [-10.0, 5, 0, 0, 0.0, 0]; assert K.initial_pose_check(p) == (0, "rear")
+    # inflated rectangle of CreateMiqpObstacle: 1 x 1 box at (20, -1.5), collision radius 1 -> 3 x 3, counter-clockwise
+    ob = pl.CreateMiqpObstacle(np.tile([0.0, 20.0, -1.5, 0.0, 0.0], (20, 1)), [[-0.5, -0.5], [-0.5, 0.5], [0.5, 0.5], [0.5, -0.5]])
+    q = ob[0]; assert np.allclose(sorted(q[:, 0]), [18.5, 18.5, 21.5, 21.5]) and np.allclose(sorted(q[:, 1]), [-3.0, -3.0, 0.0, 0.0])
+    assert 0.5 * np.sum(q[:, 0] * np.roll(q[:, 1], -1) - np.roll(q[:, 0], -1) * q[:, 1]) > 0
+    # EnvironmentWarmstart: piece ids (0, 1) -> (1, 2): piece 1 keeps its column for the steps 0 .. N-2, the rest is 1
+    last = RawResults(1, 20, 16, 2, 0, 0)
+    for nm in ("notWithinEnvironmentRear", "notWithinEnvironmentFrontUbUb", "notWithinEnvironmentFrontLbUb", "notWithinEnvironmentFrontUbLb", "notWithinEnvironmentFrontLbLb"):
+        getattr(last, nm)[...] = 1; getattr(last, nm)[0, 1, :] = 0
+    out = K.environment_warmstart(last, [0, 1], [1, 2])
+    assert out.dims[3] == 2 and np.all(out.notWithinEnvironmentRear[0, 0, :19] == 0) and out.notWithinEnvironmentRear[0, 0, 19] == 1
+    assert np.all(out.notWithinEnvironmentRear[0, 1] == 1) and np.all(out.notWithinEnvironmentFrontLbLb[0, 0, :19] == 0)
 
 
 def test_add_car_fills_the_model_like_update_car():
