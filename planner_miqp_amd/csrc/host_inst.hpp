@@ -22,6 +22,7 @@ namespace miqp {
 
 constexpr int MAXC = 4;          // cars supported by the device kernels (stage vector of at most 32 entries)
 constexpr int REGSZ = 32;        // doubles per (car, possible region) table entry
+constexpr int HULLM_MAXBITS = 8;   // region sets of up to 2^8 members are tabulated (d_hullm); beyond that the static hull of the step is used
 constexpr int HULLSZ = 16;       // doubles per (car, step) of the hull of the region alternatives: acc box 4, jerk box 4, two velocity rows (g_vx, g_vy, rhs) 6, valid flag, pad
 constexpr double BIGM_JERK = 10.0, BIGM_ACC = 10.0;
 
@@ -250,11 +251,16 @@ struct Layout {
   int C, N, R, P, E, EL, O, L, NP;   // P = max possible regions per car, EL = max edges per environment piece
   int nx, nu, nz, SC, NSLOT, ROWCAP;
   // double offsets
-  int d_x0, d_wd, d_ref, d_glob, d_u0box, d_misc, d_dsep, d_ssl, d_smax, d_reg, d_env, d_obs, d_theta, d_lift, d_hull, dstride;
+  int d_x0, d_wd, d_ref, d_glob, d_u0box, d_misc, d_dsep, d_ssl, d_smax, d_reg, d_env, d_obs, d_theta, d_lift, d_hull, d_hullm, dstride;
+  int PT;   // bits of the region-set index of d_hullm: min(P, HULLM_MAXBITS)
   // int offsets
-  int i_nposs, i_regj, i_nhs, i_hs, i_envn, i_obssoft, i_initj, i_dom, i_allow, i_boxskip, i_c2callow, istride;
+  int i_nposs, i_regj, i_nhs, i_hs, i_envn, i_obssoft, i_initj, i_dom, i_allow, i_boxskip, i_c2callow, i_rallow, istride;
   // fix record (bytes)
-  int f_reg, f_env, f_obs, f_c2c, f_c2n, fixlen;   // f_c2n: per (pair, step, group) bit mask of excluded car/car alternatives
+  int f_reg, f_env, f_obs, f_c2c, f_c2n, f_rmask, fixlen;   // f_c2n: per (pair, step, group) bit mask of excluded car/car alternatives
+  // f_rmask: per (car, step) two bytes = bit set of the possible regions the node still allows there (0xFFFF in a root: every
+  // region; the kernels intersect it with the static reachability set i_rallow).  eval_kernel clears the bits of regions whose
+  // cheapest alternative, priced by the bound lifting from the node's dual solution, cannot beat the incumbent any more; the
+  // children inherit the set, and the relaxation of an undecided step uses the hull of the boxes of the regions LEFT (d_hullm).
 };
 
 inline Layout make_layout(int C, int N, int R, int P, int E, int EL, int O, int L) {
@@ -265,13 +271,15 @@ inline Layout make_layout(int C, int N, int R, int P, int E, int EL, int O, int 
   int o = 0;
   Y.d_x0 = o; o += C * 6; Y.d_wd = o; o += Y.nz; Y.d_ref = o; o += N * Y.nz; Y.d_glob = o; o += 8; Y.d_u0box = o; o += C * 4;
   Y.d_misc = o; o += 4; Y.d_dsep = o; o += Y.NP * N; Y.d_ssl = o; o += N; Y.d_smax = o; o += N; Y.d_reg = o; o += C * P * REGSZ;
-  Y.d_env = o; o += E * EL * 3; Y.d_obs = o; o += O * N * L * 3; Y.d_theta = o; o += C * 4; Y.d_lift = o; o += C * 2 * N * 16; Y.d_hull = o; o += C * N * HULLSZ; Y.dstride = (o + 7) & ~7;
+  Y.d_env = o; o += E * EL * 3; Y.d_obs = o; o += O * N * L * 3; Y.d_theta = o; o += C * 4; Y.d_lift = o; o += C * 2 * N * 16; Y.d_hull = o; o += C * N * HULLSZ;
+  Y.PT = P < HULLM_MAXBITS ? P : HULLM_MAXBITS; Y.d_hullm = o; o += C * (1 << Y.PT) * 8; Y.dstride = (o + 7) & ~7;
   o = 0;
   Y.i_nposs = o; o += C; Y.i_regj = o; o += C * P; Y.i_nhs = o; o += C * P; Y.i_hs = o; o += C * P * 4; Y.i_envn = o; o += E;
-  Y.i_obssoft = o; o += O; Y.i_initj = o; o += C; Y.i_dom = o; o += C * P * 4; Y.i_allow = o; o += C * N * 2; Y.i_boxskip = o; o += C * N; Y.i_c2callow = o; o += Y.NP * N; Y.istride = (o + 3) & ~3;
+  Y.i_obssoft = o; o += O; Y.i_initj = o; o += C; Y.i_dom = o; o += C * P * 4; Y.i_allow = o; o += C * N * 2; Y.i_boxskip = o; o += C * N; Y.i_c2callow = o; o += Y.NP * N; Y.i_rallow = o; o += C * N; Y.istride = (o + 3) & ~3;
   Y.f_reg = 0; Y.f_env = Y.f_reg + C * N; Y.f_obs = Y.f_env + C * N * 5; Y.f_c2c = Y.f_obs + C * O * N * 5;
   Y.f_c2n = Y.f_c2c + Y.NP * N * 4;
-  Y.fixlen = (Y.f_c2n + Y.NP * N * 4 + 15) & ~15;
+  Y.f_rmask = Y.f_c2n + Y.NP * N * 4;
+  Y.fixlen = (Y.f_rmask + C * N * 2 + 15) & ~15;
   return Y;
 }
 
@@ -561,6 +569,29 @@ inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int*
       H[8] = ga[0]; H[9] = ga[1]; H[10] = pad + (any_slow ? I.vm * (std::fabs(ga[0]) + std::fabs(ga[1])) : 0.0);
       H[11] = gb[2]; H[12] = gb[3]; H[13] = pad + (any_slow ? I.vm * (std::fabs(gb[2]) + std::fabs(gb[3])) : 0.0);
       H[14] = 1.0;
+    }
+  }
+  // Region sets: i_rallow[c][i] = possible regions with a reachable alternative at step i (the static part of a node's region
+  // set); d_hullm[c][set] = smallest box around the acceleration / jerk boxes of the regions of `set` (bit q = possible region
+  // q; the empty set and sets beyond the table get the global box)
+  for (int c = 0; c < C; ++c) {
+    const int np = T[Y.i_nposs + c];
+    for (int i = 0; i < N; ++i) {
+      const unsigned long long mask = ((unsigned long long)(unsigned int)T[Y.i_allow + (c * N + i) * 2 + 1] << 32) | (unsigned int)T[Y.i_allow + (c * N + i) * 2];
+      int rm = 0; for (int q = 0; q < np; ++q) if ((mask >> (q * 4)) & 15ull) rm |= 1 << q;
+      T[Y.i_rallow + c * N + i] = rm;
+    }
+    for (int m = 0; m < (1 << Y.PT); ++m) {
+      double* H = D + Y.d_hullm + (size_t)(c * (1 << Y.PT) + m) * 8;
+      const double glob[8] = {I.amin, I.amax, I.amin, I.amax, I.jmin, I.jmax, I.jmin, I.jmax};
+      bool any = false; double b[8];
+      for (int q = 0; q < np && q < Y.PT; ++q) {
+        if (!((m >> q) & 1)) continue;
+        const double* g = D + Y.d_reg + (c * Y.P + q) * REGSZ;
+        for (int k = 0; k < 8; ++k) b[k] = !any ? g[11 + k] : ((k & 1) ? std::max(b[k], g[11 + k]) : std::min(b[k], g[11 + k]));
+        any = true;
+      }
+      for (int k = 0; k < 8; ++k) H[k] = !any ? glob[k] : ((k & 1) ? std::min(glob[k], b[k]) : std::max(glob[k], b[k]));
     }
   }
   // Box presolve (exact): interval propagation of (a, v) per axis from the initial state with the jerk and acceleration

@@ -70,8 +70,8 @@ __device__ inline bool box_of_slot(const Layout& Y, const double* D, const int* 
   const int c = slot / Y.SC, rr = slot - c * Y.SC;
   const int code = i >= 1 ? (int)fix[Y.f_reg + c * N + i] : -1;
   const double* rt = code >= 0 ? D + Y.d_reg + (c * Y.P + (code >> 2)) * REGSZ : nullptr;
-  const double* Hc = D + Y.d_hull + (c * N + i) * HULLSZ;
   if (rr < 7) {
+    const double* Hc = (rt || rr < 3) ? D : region_hull(Y, D, T, fix, c, i);   // (only read when the region is undecided)
     switch (rr) {
       case 0: col = 6 * c + 1; sgn = -1; rhs = -G[0]; break;
       case 1: col = 6 * c + 4; sgn = -1; rhs = -G[0]; break;
@@ -88,7 +88,7 @@ __device__ inline bool box_of_slot(const Layout& Y, const double* D, const int* 
     double lo, hi;
     if (i == 0) { lo = D[Y.d_u0box + c * 4 + 2 * s]; hi = D[Y.d_u0box + c * 4 + 2 * s + 1]; }
     else if (rt) { lo = rt[15 + 2 * s]; hi = rt[16 + 2 * s]; }
-    else { lo = Hc[4 + 2 * s]; hi = Hc[5 + 2 * s]; }
+    else { const double* Hc = region_hull(Y, D, T, fix, c, i); lo = Hc[4 + 2 * s]; hi = Hc[5 + 2 * s]; }
     col = 6 * C + 2 * c + s; sgn = up ? 1.0 : -1.0; rhs = up ? hi : -lo;
     return true;
   }

@@ -237,6 +237,18 @@ __device__ inline void pair_cars(int p, int C, int& c1, int& c2) {
 
 struct RowOut { double rhs; double aq; bool active; };
 
+// region set of (car, step) in a node: the bits of its fix record that the static reachability presolve allows
+__device__ inline int region_set(const Layout& Y, const int* T, const signed char* fix, int c, int i) {
+  const int m = (int)(unsigned char)fix[Y.f_rmask + 2 * (c * Y.N + i)] | ((int)(unsigned char)fix[Y.f_rmask + 2 * (c * Y.N + i) + 1] << 8);
+  return m & T[Y.i_rallow + c * Y.N + i];
+}
+// acceleration / jerk box of an undecided step: the hull over the regions the node still allows there (host_inst.hpp: d_hullm),
+// or the static hull of the step when the car has more possible regions than the table indexes
+__device__ inline const double* region_hull(const Layout& Y, const double* D, const int* T, const signed char* fix, int c, int i) {
+  if (T[Y.i_nposs + c] > Y.PT) return D + Y.d_hull + (c * Y.N + i) * HULLSZ;
+  return D + Y.d_hullm + (c * (1 << Y.PT) + region_set(Y, T, fix, c, i)) * 8;
+}
+
 // rows of the relaxation of a node (only alternatives that are fixed); g is this lane's LDS row.  BUILD = false only
 // decides whether slot (i, slot) carries a row (same tests, nothing written): the kernel first collects the active
 // slots of a node and then builds 64 rows at a time with every lane busy.
@@ -254,7 +266,7 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
     int c = slot / Y.SC, rr = slot - c * Y.SC;
     int code = i >= 1 ? (int)fix[Y.f_reg + c * N + i] : -1;
     const double* rt = code >= 0 ? D + Y.d_reg + (c * Y.P + (code >> 2)) * REGSZ : nullptr;
-    const double* Hc = D + Y.d_hull + (c * N + i) * HULLSZ;   // undecided region: the hull of the alternatives that can still hold (host_inst.hpp)
+    const double* Hc = D + Y.d_hull + (c * N + i) * HULLSZ;   // undecided region: the cone rows of the alternatives that can still hold (host_inst.hpp; off by default)
     if (rr < 7) {
       if (i < 1 || ((T[Y.i_boxskip + c * N + i] >> rr) & 1)) return r;   // implied by the earlier steps (host box presolve)
       r.active = true;
@@ -263,10 +275,10 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
         case 0: g[6 * c + 1] = -1; r.rhs = -G[0]; break;
         case 1: g[6 * c + 4] = -1; r.rhs = -G[0]; break;
         case 2: g[6 * c + 1] = 1; r.rhs = G[1]; break;
-        case 3: g[6 * c + 2] = 1; r.rhs = rt ? rt[12] : Hc[1]; break;
-        case 4: g[6 * c + 2] = -1; r.rhs = -(rt ? rt[11] : Hc[0]); break;
-        case 5: g[6 * c + 5] = 1; r.rhs = rt ? rt[14] : Hc[3]; break;
-        default: g[6 * c + 5] = -1; r.rhs = -(rt ? rt[13] : Hc[2]); break;
+        case 3: g[6 * c + 2] = 1; r.rhs = rt ? rt[12] : region_hull(Y, D, T, fix, c, i)[1]; break;
+        case 4: g[6 * c + 2] = -1; r.rhs = -(rt ? rt[11] : region_hull(Y, D, T, fix, c, i)[0]); break;
+        case 5: g[6 * c + 5] = 1; r.rhs = rt ? rt[14] : region_hull(Y, D, T, fix, c, i)[3]; break;
+        default: g[6 * c + 5] = -1; r.rhs = -(rt ? rt[13] : region_hull(Y, D, T, fix, c, i)[2]); break;
       }
       return r;
     }
@@ -276,7 +288,8 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
       double lo, hi;
       if (i == 0) { lo = D[Y.d_u0box + c * 4 + 2 * s]; hi = D[Y.d_u0box + c * 4 + 2 * s + 1]; }
       else if (rt) { lo = rt[15 + 2 * s]; hi = rt[16 + 2 * s]; }
-      else { lo = Hc[4 + 2 * s]; hi = Hc[5 + 2 * s]; }
+      else if (!BUILD) { lo = hi = 0.0; }
+      else { const double* Hm = region_hull(Y, D, T, fix, c, i); lo = Hm[4 + 2 * s]; hi = Hm[5 + 2 * s]; }
       r.active = true;
       if (!BUILD) return r;
       g[6 * C + 2 * c + s] = up ? 1.0 : -1.0; r.rhs = up ? hi : -lo;
@@ -1243,7 +1256,71 @@ __device__ inline double region_alt_lift(const Layout& Y, const double* D, const
   return l;
 }
 
+constexpr double LIFT_MARGIN = 0.5;   // a row of the child joins the multi-row lifting when it is violated or within this slack of active
+constexpr int LIFT_ROWS = 24;     // rows per child that enter the multi-row bound lifting (eval_kernel)
 constexpr int REPAIR_ROOT = 62;   // depth word of a MIP-start repair root (tree depth 0, sibling preference 62: no node of the tree carries it)
+// Lower bound on what it costs a node to take region alternative (q, h) of (car, step): the largest single-row lift over the
+// rows of the alternative, with the EXACT response g Sigma g' of every row (the chains of a car are independent, a row touches
+// at most velocity and acceleration of a chain) - unlike region_alt_lift, whose diagonal form is only a branching score.
+// node set of the alternatives of a car/car group, kept in the (negative) undecided value of its fix byte: -1 = all four,
+// -(16 + set) = the alternatives of `set` (bit a) - eval_kernel removes alternatives that cannot pay off below a node
+__device__ inline int c2c_set(int fx) { return fx >= 0 ? 0 : (fx == -1 ? 15 : ((-fx - 16) & 15)); }
+__device__ inline signed char c2c_set_byte(int set) { return (signed char)(set == 15 ? -1 : -(16 + set)); }
+// response g Sigma g' of the separation row of car/car alternative (group, alt) at a step: the row is coord(A) - coord(B) <= ...,
+// a rear point contributes the position of its chain, a front point position + p1 vx + p2 vy (chains of one car are independent,
+// the two cars are independent)
+struct PosBlk { double pp, pv, vv; };
+__device__ inline void pos_blocks(const Layout& Y, const double* D, int c, int i, PosBlk& X, PosBlk& Yd) {
+  const double* S = D + Y.d_lift + ((c * 2) * Y.N + i) * 16;
+  X.pp = S[0]; X.pv = S[1]; X.vv = S[5];
+  S += Y.N * 16;
+  Yd.pp = S[0]; Yd.pv = S[1]; Yd.vv = S[5];
+}
+__device__ inline double point_gamma(const PosBlk& X, const PosBlk& Yd, const double* rt, int t, bool isx) {
+  if (t == PT_R) return isx ? X.pp : Yd.pp;
+  const double* p = rt + (isx ? 19 : 25) + (t == PT_U ? 0 : 3);   // coordinate + p[0] + p[1] vx + p[2] vy
+  return isx ? X.pp + 2.0 * p[1] * X.pv + p[1] * p[1] * X.vv + p[2] * p[2] * Yd.vv
+             : Yd.pp + 2.0 * p[2] * Yd.pv + p[2] * p[2] * Yd.vv + p[1] * p[1] * X.vv;
+}
+__device__ inline double c2c_alt_gamma(int grp, int alt, const PosBlk& X1, const PosBlk& Y1, const double* rt1, const PosBlk& X2, const PosBlk& Y2, const double* rt2) {
+  const bool isx = alt < 2, lo = (alt == 0 || alt == 2);
+  int a1, ta, tb;   // as in c2c_alt_viol: A is car a1 (1 or 2), B the other
+  if (grp == 0) { ta = tb = PT_R; a1 = lo ? 1 : 2; }
+  else if (grp == 1) { if (lo) { a1 = 1; ta = PT_R; tb = PT_L; } else { a1 = 2; ta = PT_U; tb = PT_R; } }
+  else if (grp == 2) { if (lo) { a1 = 2; ta = PT_R; tb = PT_L; } else { a1 = 1; ta = PT_U; tb = PT_R; } }
+  else { if (lo) { a1 = 2; ta = PT_U; tb = PT_L; } else { a1 = 1; ta = PT_U; tb = PT_L; } }
+  return a1 == 1 ? point_gamma(X1, Y1, rt1, ta, isx) + point_gamma(X2, Y2, rt2, tb, isx)
+                 : point_gamma(X2, Y2, rt2, ta, isx) + point_gamma(X1, Y1, rt1, tb, isx);
+}
+
+struct LiftBlk { double vv, va, aa, uu; };
+__device__ inline void lift_blocks(const Layout& Y, const double* D, int c, int i, LiftBlk& X, LiftBlk& Yd) {
+  const double* S = D + Y.d_lift + ((c * 2) * Y.N + i) * 16;
+  X.vv = S[5]; X.va = S[6]; X.aa = S[10]; X.uu = S[15];
+  S += Y.N * 16;
+  Yd.vv = S[5]; Yd.va = S[6]; Yd.aa = S[10]; Yd.uu = S[15];
+}
+__device__ inline double region_alt_lift_exact(const Layout& Y, const double* D, const int* T, int c, int q, int h, const CarState& s, bool with_jerk,
+                                               const LiftBlk& X, const LiftBlk& Yd) {
+  const double* rt = D + Y.d_reg + (c * Y.P + q) * REGSZ;
+  const double vm = D[Y.d_glob + 6];
+  double l = fmax(lift1(fmax(s.ax - rt[12], rt[11] - s.ax), X.aa), lift1(fmax(s.ay - rt[14], rt[13] - s.ay), Yd.aa));
+  if (with_jerk) l = fmax(l, fmax(lift1(fmax(s.ux - rt[16], rt[15] - s.ux), X.uu), lift1(fmax(s.uy - rt[18], rt[17] - s.uy), Yd.uu)));
+  if (h == 3) return fmax(l, fmax(lift1(fabs(s.vx) - vm, X.vv), lift1(fabs(s.vy) - vm, Yd.vv)));
+  l = fmax(l, lift1(rt[0] * s.vx + rt[1] * s.vy, rt[0] * rt[0] * X.vv + rt[1] * rt[1] * Yd.vv));
+  l = fmax(l, lift1(rt[2] * s.vx + rt[3] * s.vy, rt[2] * rt[2] * X.vv + rt[3] * rt[3] * Yd.vv));
+  const int* hs = T + Y.i_hs + ((c * Y.P + q) * 2 + h) * 2;
+  l = fmax(l, lift1(vm - hs[1] * (hs[0] == 0 ? s.vx : s.vy), hs[0] == 0 ? X.vv : Yd.vv));
+  // curvature rows: +-(ay - rho ax - k2 vx - k3 vy) <= ...: chain x carries (v: -+k2, a: -+rho), chain y (v: -+k3, a: +-1)
+  { const double rho = rt[4], k2 = rt[6], k3 = rt[7];
+    const double gam = k2 * k2 * X.vv + 2.0 * k2 * rho * X.va + rho * rho * X.aa + k3 * k3 * Yd.vv - 2.0 * k3 * Yd.va + Yd.aa;
+    l = fmax(l, lift1(s.ay - rho * s.ax - k2 * s.vx - k3 * s.vy - rt[5], gam)); }
+  { const double rho = rt[4], k2 = rt[9], k3 = rt[10];
+    const double gam = k2 * k2 * X.vv + 2.0 * k2 * rho * X.va + rho * rho * X.aa + k3 * k3 * Yd.vv - 2.0 * k3 * Yd.va + Yd.aa;
+    l = fmax(l, lift1(-s.ay + rho * s.ax + k2 * s.vx + k3 * s.vy + rt[8], gam)); }
+  return l;
+}
+
 struct BranchDesc { int prio; int kind; int c; int o; int i; int pt; int cause; };  // kind: 0 region 1 env 2 obs 3 c2c; cause (diagnostic): what flagged a region disjunction - 0 its own rows, 1 / 2 / 3 an environment / obstacle / car-car row on a front point of a car whose region is undecided
 
 template <int C>
@@ -1271,6 +1348,14 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   signed char* comp = fix + Y.fixlen;                // [fixlen]
   signed char* cfix = comp + Y.fixlen;               // [fixlen] fix record of the child whose rows are being lifted
   double* gsc = (double*)(cfix + Y.fixlen);          // [64][NZ + 1] one dense row per lane
+  // multi-row lifting: up to LIFT_ROWS rows of a child at the branching stage - coefficients g, response y = Sigma g, violation
+  // v at the node's solution, diagonal g Sigma g', multiplier; and the running vector w = sum_r lambda_r y_r
+  double* mr_g = gsc + 64 * (NZ + 1);                // [LIFT_ROWS][NZ]
+  double* mr_y = mr_g + LIFT_ROWS * NZ;              // [LIFT_ROWS][NZ]
+  double* mr_v = mr_y + LIFT_ROWS * NZ;              // [LIFT_ROWS]
+  double* mr_d = mr_v + LIFT_ROWS;                   // [LIFT_ROWS]
+  double* mr_l = mr_d + LIFT_ROWS;                   // [LIFT_ROWS]
+  double* mr_w = mr_l + LIFT_ROWS;                   // [NZ]
   __shared__ BranchDesc chosen;
   __shared__ int sh_base[4];
   __shared__ int slots[64];
@@ -1304,6 +1389,8 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   if (B.stats && lane == 0 && inc_now < 1e300 && (inc_now - objlb) <= B.inst_gap[inst] * (1e-10 + fabs(inc_now))) atomicAdd(&B.stats[41], 1ull);   // (children will be pruned by the gap)
   const double tol = FEAS_TOL;
   const int NCI = C * (N - 1);
+  const double gapi_ = B.inst_gap[inst];
+  bool dead_lane = false;
   // ---------------- phase R: region alternatives per (c, i)
   for (int L0 = 0; L0 < NCI; L0 += 64) {
     int L = L0 + lane;
@@ -1322,6 +1409,37 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       double ml = 1e300;
       const bool want_score = ((B.seq_kinds >> 8) & 15) >= 10;
       const unsigned long long allow = ((unsigned long long)(unsigned int)T[Y.i_allow + (c * N + i) * 2 + 1] << 32) | (unsigned int)T[Y.i_allow + (c * N + i) * 2];
+      int rset = region_set(Y, T, fix, c, i);
+      // Region set tightening (bound propagation from the node's dual solution): a region of an undecided step whose every
+      // alternative costs more than the incumbent allows can never hold in an improving descendant of this node - it leaves the
+      // set, for the children and everything below them.  The smaller set tightens the hull boxes of the step in their
+      // relaxations (region_hull) and shortens their region branchings.
+      if (fix[Y.f_reg + c * N + i] < 0 && inc_now < 1e300 && !(B.seq_kinds & 0x8000)) {
+        LiftBlk BX, BY; lift_blocks(Y, D, c, i, BX, BY);
+        const double room = inc_now - gapi_ * (1e-10 + fabs(inc_now)) - objlb;   // what a descendant may cost on top of this node's dual value
+        int nleft = 0, last_code = -1;
+        for (int q = 0; q < np; ++q) {
+          if (!((rset >> q) & 1)) continue;
+          if (nxtq >= 0 && nxtq != q) { rset &= ~(1 << q); continue; }   // the next step is frozen to another region (slow alternative fixed there)
+          bool any = false;
+          const int nhq = T[Y.i_nhs + c * P + q];
+          for (int h = 0; h < 4; ++h) {
+            if ((h < 3 && h >= nhq) || !((allow >> (q * 4 + h)) & 1ull)) continue;
+            if (region_alt_lift_exact(Y, D, T, c, q, h, s, wj, BX, BY) * (1.0 - 1e-6) >= room && region_alt_viol(Y, D, T, c, q, h, s, wj) > tol) continue;   // this alternative cannot pay off below this node (one that holds at the node's solution always stays)
+            any = true; nleft++; last_code = q * 4 + h;
+          }
+          if (!any) rset &= ~(1 << q);
+        }
+        (void)nleft; (void)last_code;   // (deciding the last alternative for the children was tried: no gain, and it can label a tie differently from the canonical completion)
+        if (rset != region_set(Y, T, fix, c, i)) {
+          const int idx = Y.f_rmask + 2 * (c * N + i);
+          fix[idx] = comp[idx] = (signed char)(rset & 255); fix[idx + 1] = comp[idx + 1] = (signed char)((rset >> 8) & 255);
+          if (B.stats) atomicAdd(&B.stats[58], 1ull);
+        }
+      }
+      if (rset == 0 && fix[Y.f_reg + c * N + i] < 0) dead_lane = true;   // no region left at this undecided step: nothing below this node can improve the incumbent
+      // (the completion below looks at every statically possible alternative, whatever the node's set: it labels the solution
+      // of THIS node, and the labels stay the canonical ones - first alternative in order that holds)
       for (int q = 0; q < np; ++q) {
         slowv[(c * N + i) * P + q] = ((nxtq >= 0 && nxtq != q) || !((allow >> (q * 4 + 3)) & 1ull)) ? 1e300 : region_alt_viol(Y, D, T, c, q, 3, s, wj);
         if (nxtq >= 0 && nxtq != q) continue;
@@ -1338,6 +1456,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     }
   }
   __syncthreads();
+  if (__ballot(dead_lane)) { if (B.stats && lane == 0) atomicAdd(&B.stats[59], 1ull); FREE_NODE(); return; }
   if (lane < C) {  // sequential resolution of the freeze (slow => same region as the previous step)
     int c = lane; int prevj = T[Y.i_initj + c];
     int np = T[Y.i_nposs + c];
@@ -1458,6 +1577,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         const double* rt1 = D + Y.d_reg + (c1 * P + (code1 >> 2)) * REGSZ; const double* rt2 = D + Y.d_reg + (c2 * P + (code2 >> 2)) * REGSZ;
         double gx12, gy12;
         { LiftDiag A1, B1, A2, B2; lift_diag(Y, D, c1, i, A1, B1); lift_diag(Y, D, c2, i, A2, B2); gx12 = A1.p + A2.p; gy12 = B1.p + B2.p; }
+        PosBlk PX1, PY1, PX2, PY2; pos_blocks(Y, D, c1, i, PX1, PY1); pos_blocks(Y, D, c2, i, PX2, PY2);
         for (int g = 0; g < 4; ++g) {
           bool need1 = g >= 2, need2 = (g == 1 || g == 3);
           int unf = -1;
@@ -1468,9 +1588,27 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
           if (fx >= 0) { bv = c2c_alt_viol(Y, D, p, i, g, fx, s1, rt1, s2, rt2); okk = bv <= tol; }
           else {
             int ba = 0;
-            const int am = (T[Y.i_c2callow + p * N + i] >> (4 * g)) & 15;   // alternatives some reachable positions can satisfy (host presolve)
+            int am = (T[Y.i_c2callow + p * N + i] >> (4 * g)) & 15;   // alternatives some reachable positions can satisfy (host presolve)
+            if (!am) am = 15;
+            const int amc = am;
+            am &= c2c_set(fx);                                         // ... that the ancestors of this node have not ruled out
+            // set tightening (as for the regions): an alternative whose separation row, priced by the bound lifting, costs more
+            // than the incumbent allows leaves the group's set for the whole subtree (no child is created for it).  Only for
+            // groups whose rows are known (front points need the region of their car).
+            if (unf < 0 && inc_now < 1e300 && !(B.seq_kinds & 0x8000)) {
+              const double room = inc_now - gapi_ * (1e-10 + fabs(inc_now)) - objlb;
+              const bool softg = (g == 0 || g == 3); const double smx = softg ? D[Y.d_smax + i] : 0.0;
+              const int am0 = am;
+              for (int a = 0; a < 4; ++a) {
+                if (!((am >> a) & 1)) continue;
+                const double hv = c2c_alt_viol(Y, D, p, i, g, a, s1, rt1, s2, rt2) - smx;   // violation of the hard row of the alternative
+                if (hv > tol && lift1(hv, c2c_alt_gamma(g, a, PX1, PY1, rt1, PX2, PY2, rt2)) * (1.0 - 1e-6) >= room) am &= ~(1 << a);
+              }
+              if (am != am0) { fix[Y.f_c2c + (p * N + i) * 4 + g] = c2c_set_byte(am); if (B.stats) atomicAdd(&B.stats[61], 1ull); }
+              if (am == 0) dead_lane = true;
+            }
             for (int a = 0; a < 4; ++a) {
-              if (am && !((am >> a) & 1)) continue;
+              if (!((amc >> a) & 1)) continue;   // (the completion labels this node's own solution: every statically possible alternative)
               double v = c2c_alt_viol(Y, D, p, i, g, a, s1, rt1, s2, rt2); if (v < bv) { bv = v; ba = a; }
               sc = fmin(sc, lift1(v, a < 2 ? gx12 : gy12));
             }
@@ -1481,6 +1619,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       }
     }
   }
+  if (__ballot(dead_lane)) { if (B.stats && lane == 0) atomicAdd(&B.stats[59], 1ull); FREE_NODE(); return; }   // a car/car group without an alternative left
   // wave-wide most urgent disjunction
   int best = mine.prio;
   for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
@@ -1552,7 +1691,9 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         int nxt = (j + 1 < N) ? (int)fix[base + (j + 1) * stride] : -1;
         int nxtq = (nxt >= 0 && (nxt & 3) == 3) ? (nxt >> 2) : -1;
         const unsigned long long allow_b = ((unsigned long long)(unsigned int)T[Y.i_allow + (c * N + j) * 2 + 1] << 32) | (unsigned int)T[Y.i_allow + (c * N + j) * 2];
+        const int rset_j = region_set(Y, T, fix, c, j);
         for (int q = 0; q < np; ++q) {
+          if (!((rset_j >> q) & 1)) continue;   // the node has ruled this region out at step j
           if (nxtq >= 0 && nxtq != q) continue;
           int nh = T[Y.i_nhs + c * P + q];
           for (int h = 0; h < 4; ++h) {
@@ -1565,7 +1706,8 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         }
       } else if (d.kind == 1) { for (int e = 0; e < Y.E && n < 63; ++e) if (e != refv) tmp[n++] = e; }
       else if (d.kind == 2) { int na = Y.L + (T[Y.i_obssoft + d.o] ? 1 : 0); for (int k = 0; k < na && n < 63; ++k) if (k != refv) tmp[n++] = k; }
-      else { const int am = (T[Y.i_c2callow + d.c * N + j] >> (4 * d.o)) & 15; for (int a2 = 0; a2 < 4; ++a2) if (a2 != refv && ((am >> a2) & 1)) tmp[n++] = a2; }
+      else { int am = (T[Y.i_c2callow + d.c * N + j] >> (4 * d.o)) & 15; if (!am) am = 15; am &= c2c_set((int)fix[base + j * stride]);
+             for (int a2 = 0; a2 < 4; ++a2) if (a2 != refv && ((am >> a2) & 1)) tmp[n++] = a2; }
       return n;
     };
     // window of undecided steps: all of them when the children fit, else the steps from the violated one onwards
@@ -1627,7 +1769,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     double* gl = gsc + lane * (NZ + 1);
     for (int a = 0; a < nalt; ++a) {
       const int kk = ck[a];
-      if (kk == -2) { if (lane == 0) clift[a] = 0.0; continue; }
+      if (kk == -2) { if (lane == 0) clift[a] = (a > 0 && ck[0] != -2) ? clift[0] : 0.0; continue; }   // the probe lies inside the first child: it costs at least what that one costs
       int negidx = -1, negm = 0;
       if (chosen.kind == 3 && kk >= 0 && kk < N && (B.seq_kinds & 0x10000) == 0) {
         negidx = Y.f_c2n + (chosen.c * N + kk) * 4 + chosen.o;
@@ -1645,28 +1787,87 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       else if (chosen.kind == 2) { s0 = chosen.c * Y.SC + 16 + 5 * Y.EL + chosen.o * 5 + chosen.pt; s1 = s0 + 1; }
       else { s0 = C * Y.SC + chosen.c * 8 + chosen.o * 2; s1 = s0 + 2; s2 = C * Y.SC + 8 * Y.NP + chosen.c * 16 + chosen.o * 4; s3 = s2 + 4; }
       const int n01 = s1 - s0, ntot = n01 + (s3 - s2);
-      for (int e = lane; e < ntot; e += 64) {
-        const int sl = e < n01 ? s0 + e : s2 + (e - n01);
-        const RowOut r = decode_row<C, true>(Y, D, T, cfix, i, sl, gl);
-        if (!r.active || r.aq != 0.0) continue;
-        double v = -r.rhs;
+      // Single-row lift of every violated row, and the rows for the multi-row lift: with the node's multipliers fixed the child
+      // costs at least  max_{lambda >= 0}  lambda' v - 1/2 lambda' (G Sigma G') lambda  over ANY set of its rows (weak duality of
+      // min { 1/2 dz' H dz : G dz <= -v } on the trajectories; every lambda >= 0 gives a valid bound, so a few coordinate-ascent
+      // sweeps suffice).  Rows of the child at the branching stage that are violated or close to active are collected - rows the
+      // node already satisfies matter too: the step that repairs one row runs into the others (sector against half-plane,
+      // curvature against the acceleration box).
+      const bool multi = (B.seq_kinds & 0x80000000u) != 0u;   // OFF by default (bit 31 of MIQP_SEQ_KINDS switches it on): measured without effect on the node counts (17.2 M against 17.4 M nodes on a 1024-instance queue; tools/lift_ab.sh) - what a child costs beyond its single-row lift comes from the rows of the OTHER stages
+      int ncand = 0;
+      for (int e0 = 0; e0 < ntot; e0 += 64) {
+        const int e = e0 + lane;
+        bool cand = false; double v = 0.0, gam = 0.0;
+        if (e < ntot) {
+          const int sl = e < n01 ? s0 + e : s2 + (e - n01);
+          const RowOut r = decode_row<C, true>(Y, D, T, cfix, i, sl, gl);
+          if (r.active && r.aq == 0.0) {
+            v = -r.rhs;
 #pragma unroll
-        for (int q = 0; q < NZ; ++q) v += gl[q] * Z[i * NZ + q];
-        if (!(v > 1e-7)) continue;
-        double gam = 0.0;
-        for (int c = 0; c < C; ++c)
-          for (int ax = 0; ax < 2; ++ax) {
-            const double g4[4] = {gl[6 * c + 3 * ax], gl[6 * c + 3 * ax + 1], gl[6 * c + 3 * ax + 2], gl[6 * C + 2 * c + ax]};
-            if (g4[0] == 0.0 && g4[1] == 0.0 && g4[2] == 0.0 && g4[3] == 0.0) continue;
-            const double* S4 = LT + ((c * 2 + ax) * N + i) * 16;
+            for (int q = 0; q < NZ; ++q) v += gl[q] * Z[i * NZ + q];
+            if (v > -LIFT_MARGIN) {
+              for (int c = 0; c < C; ++c)
+                for (int ax = 0; ax < 2; ++ax) {
+                  const double g4[4] = {gl[6 * c + 3 * ax], gl[6 * c + 3 * ax + 1], gl[6 * c + 3 * ax + 2], gl[6 * C + 2 * c + ax]};
+                  if (g4[0] == 0.0 && g4[1] == 0.0 && g4[2] == 0.0 && g4[3] == 0.0) continue;
+                  const double* S4 = LT + ((c * 2 + ax) * N + i) * 16;
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
+                  for (int p = 0; p < 4; ++p)
 #pragma unroll
-              for (int q = 0; q < 4; ++q) gam += g4[p] * S4[p * 4 + q] * g4[q];
+                    for (int q = 0; q < 4; ++q) gam += g4[p] * S4[p * 4 + q] * g4[q];
+                }
+              if (gam > 1e-300 && gam < 1e200) { cand = true; if (v > 1e-7) lift = fmax(lift, 0.5 * v * v / gam); }
+            }
           }
-        if (gam > 1e-300) lift = fmax(lift, 0.5 * v * v / gam);
+        }
+        if (multi) {   // the candidates of this pass join the list (violated rows and nearly active ones alike; first come, first served)
+          const unsigned long long mk = __ballot(cand);
+          const int pos = ncand + __popcll(mk & ((1ull << lane) - 1ull));
+          if (cand && pos < LIFT_ROWS) {
+#pragma unroll
+            for (int q = 0; q < NZ; ++q) mr_g[pos * NZ + q] = gl[q];
+            for (int c = 0; c < C; ++c)
+              for (int ax = 0; ax < 2; ++ax) {
+                const int ix[4] = {6 * c + 3 * ax, 6 * c + 3 * ax + 1, 6 * c + 3 * ax + 2, 6 * C + 2 * c + ax};
+                const double* S4 = LT + ((c * 2 + ax) * N + i) * 16;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { double y = 0.0;
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) y += S4[p * 4 + q] * gl[ix[q]];
+                  mr_y[pos * NZ + ix[p]] = y; }
+              }
+            mr_v[pos] = v; mr_d[pos] = gam; mr_l[pos] = 0.0;
+          }
+          ncand += __popcll(mk);
+        }
       }
       lift = wave_max(lift);
+      if (ncand > LIFT_ROWS) ncand = LIFT_ROWS;
+      if (multi && ncand >= 2) {
+        if (lane < NZ) mr_w[lane] = 0.0;
+        __syncthreads();
+        for (int sweep = 0; sweep < 3; ++sweep)
+          for (int k = 0; k < ncand; ++k) {
+            double t = lane < NZ ? mr_g[k * NZ + lane] * mr_w[lane] : 0.0;
+            t = wave_sum(t);                                        // g_k . w = sum_s M_ks lambda_s
+            const double lk = mr_l[k], dk = mr_d[k];
+            double ln = (mr_v[k] - (t - dk * lk)) / dk; if (!(ln > 0.0)) ln = 0.0;
+            __syncthreads();
+            if (lane < NZ) mr_w[lane] += (ln - lk) * mr_y[k * NZ + lane];
+            if (lane == 0) mr_l[k] = ln;
+            __syncthreads();
+          }
+        // value of the dual at the final multipliers: lambda' v - 1/2 (sum lambda g) . w
+        double acc = 0.0;
+        if (lane < ncand) {
+          double gw = 0.0;
+          for (int q = 0; q < NZ; ++q) gw += mr_g[lane * NZ + q] * mr_w[q];
+          acc = mr_l[lane] * (mr_v[lane] - 0.5 * gw);
+        }
+        acc = wave_sum(acc);
+        if (acc > lift) { lift = acc; if (B.stats && lane == 0) atomicAdd(&B.stats[57], 1ull); }
+        __syncthreads();
+      }
       if (lane == 0) { clift[a] = lift * (1.0 - 1e-6); cfix[base + i * stride] = fix[base + i * stride]; if (negidx >= 0) cfix[negidx] = fix[negidx]; }
       __syncthreads();
     }

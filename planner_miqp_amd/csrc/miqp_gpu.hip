@@ -307,7 +307,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   DevBuf& B = X.B; std::memset(&B, 0, sizeof(B));
   B.qp_tol = QP_TOL; B.use_cutoff = 1;
   B.opt2 = std::getenv("MIQP_OPT2") ? std::atoi(std::getenv("MIQP_OPT2")) : (8 << 4);   // rounding probe at nodes with at most 8 violated sites (eval_kernel)
-  B.seq_kinds = std::getenv("MIQP_SEQ_KINDS") ? std::atoi(std::getenv("MIQP_SEQ_KINDS")) : (5 << 8);   // plain K-way children, branching order 5 (see eval_kernel)
+  B.seq_kinds = std::getenv("MIQP_SEQ_KINDS") ? (int)std::strtoul(std::getenv("MIQP_SEQ_KINDS"), nullptr, 0) : (5 << 8);   // plain K-way children, branching order 5 (see eval_kernel)
   B.Y = Y; B.pool_cap = X.pool_cap; B.open_cap = open_cap; B.batch_cap = batch_cap; B.nodes_per_round = npr; B.n_inst = n_inst; B.n_slots = n_slots; B.root_stride = roots_per_inst;
   double* dd; int* ii;
   if (!X.alloc(&dd, (size_t)n_inst * Y.dstride)) return false; B.inst_d = dd;
@@ -397,7 +397,8 @@ size_t ipm_lds_bytes(const Layout& Y) {
 }
 size_t eval_lds_bytes(const Layout& Y) {
   size_t d = (size_t)Y.N * Y.nz + (size_t)Y.C * Y.N * Y.P + 2 * (size_t)Y.C * Y.N;
-  return d * 8 + (size_t)(2 * Y.C * Y.N + 64) * 4 + 64 * 8 + 3 * (size_t)Y.fixlen + (size_t)64 * (Y.nz + 1) * 8 + 64;
+  return d * 8 + (size_t)(2 * Y.C * Y.N + 64) * 4 + 64 * 8 + 3 * (size_t)Y.fixlen + (size_t)64 * (Y.nz + 1) * 8 + 64
+         + (size_t)(LIFT_ROWS * (2 * Y.nz + 3) + Y.nz) * 8 + 64;   // rows of the multi-row lifting
 }
 
 template <int C> void launch_ipm(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { (void)hipMemsetAsync(B.work_counter, 0, 4, st); hipLaunchKernelGGL((ipm_kernel<C, IPM_NT>), dim3(nblocks), dim3(IPM_NT), lds, st, B); }
@@ -974,6 +975,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
                  hs[32], hs[36] / (double)std::max(1ull, hs[32]), hs[33], hs[37] / (double)std::max(1ull, hs[33]), hs[34], hs[38] / (double)std::max(1ull, hs[34]), hs[35], hs[39] / (double)std::max(1ull, hs[35]),
                  hs[40], hs[41], hs[42], hs[43], hs[44] / (double)std::max(1ull, hs[43]), hs[48], hs[52] / (double)std::max(1ull, hs[48]), hs[49], hs[53] / (double)std::max(1ull, hs[49]),
                  hs[50], hs[54] / (double)std::max(1ull, hs[50]), hs[51], hs[55] / (double)std::max(1ull, hs[51]));
+    std::fprintf(stderr, "[miqp_gpu stats] region sets: tightened at %llu (car, step) sites, %llu nodes closed because a step had no region left; children not created because of their lifted bound %llu (multi-row lift larger than the single-row one: %llu), car/car sets tightened at %llu groups\n", hs[58], hs[59], hs[56], hs[57], hs[61]);
     std::fprintf(stderr, "[miqp_gpu stats] region branchings flagged by: own rows %llu (worst class acc box %llu, jerk box %llu, sector %llu, half-plane %llu, curvature %llu, slow square %llu), environment front rows %llu, obstacle front rows %llu, car/car front rows %llu; by step:",
                  hs[64], hs[70], hs[71], hs[72], hs[73], hs[74], hs[75], hs[65], hs[66], hs[67]);
     for (int q = 0; q < 32 && q < Y.N; ++q) std::fprintf(stderr, " %llu", hs[160 + q]);
