@@ -130,12 +130,13 @@ def cplex_baseline(lp_files, gap, time_limit, budget_s=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="instances IN FLIGHT per GPU (slots of the streaming admission); every instance has its own time limit "
-                    "from its admission, so the backlog (in flight x mean work per instance) has to stay well below it: 256 keeps >= 99 %% of the instances proven "
-                    "(profiles/r03_batch_sweep.json)")
-    ap.add_argument("--queue-factor", type=int, default=4, help="instances per GPU and step = queue-factor x batch (the queue one step drains)")
+    ap.add_argument("--batch", type=int, default=1024, help="instances IN FLIGHT per GPU (slots of the streaming admission); every instance has its own time limit "
+                    "from its admission, so the backlog (in flight x mean work per instance) has to stay below it: 1024 in flight prove >= 99 %% of the instances "
+                    "(128 .. 512: 100 .. 99.9 %% at a lower rate - fewer instances offer less parallel work and the hardest 0.5 %% are finished instead of "
+                    "abandoned; 2048: 97 %%; profiles/r03_batch_sweep.json)")
+    ap.add_argument("--queue-factor", type=int, default=2, help="instances per GPU and step = queue-factor x batch (the queue one step adds to the stream)")
     ap.add_argument("--no-stream", action="store_true", help="rounds 1-2 semantics: a step is one batch, all of it in flight at once")
     ap.add_argument("--total", type=int, default=0, help="strong scaling (BASELINE config 4): T instances per step in total, seeds 1000 + ..., instance b on rank b mod G")
     ap.add_argument("--config", default="cfg3")
@@ -210,13 +211,22 @@ def main():
                 f = os.path.join(a.dump_lp, "%s_seed%d.lp" % (a.config, seeds_of(a.warmup)[k]))
                 if L.miqp_solver_export_lp(w._h, f.encode()) == 0:
                     lp_files.append(f)
-    for s in range(a.warmup):
-        P.solve_batch(batches[s][1], inflight=infl, prepared=True)
+    if a.warmup > 0:
+        wws = [w for s in range(a.warmup) for w in batches[s][1]]
+        if a.no_stream:
+            for s in range(a.warmup):
+                P.solve_batch(batches[s][1], prepared=True)
+        elif wws:
+            P.solve_batch(wws, inflight=infl, prepared=True)
     sync()
     t0 = time.time()
     solved = 0; attempted = 0; ipm_s = 0.0; launches = 0; iters = 0; rowit = 0; nodes = 0; lat = []
-    for s in range(a.warmup, a.warmup + a.steps):
-        ps, ws = batches[s]
+    # streaming: the queues of the K timed steps are drained as ONE stream (a step = its queue of instances; no idle tail
+    # between steps: the slots freed by the last instances of one queue go to the first of the next); --no-stream: step by step
+    timed = [batches[s] for s in range(a.warmup, a.warmup + a.steps)]
+    if not a.no_stream:
+        timed = [([p for ps, _ in timed for p in ps], [w for _, ws in timed for w in ws])]
+    for ps, ws in timed:
         sts = P.solve_batch(ws, inflight=infl, prepared=True) if ws else []
         attempted += len(ws)
         if not ws:
@@ -254,7 +264,7 @@ def main():
                    vs_baseline=None, dtype="f64", data="synthetic",
                    config=dict(workload="%s: %d cars x %d steps x %d regions, %d env pieces, %d obstacles; %s, gap %g, time limit %g s per instance%s"
                                % ((a.config,) + synthetic.CONFIGS[a.config] + (
-                                   ("%d instances per step in total, split b mod G" % a.total) if a.total > 0 else ("queue of %d instances per GPU and step" % Q),
+                                   ("%d instances per step in total, split b mod G" % a.total) if a.total > 0 else ("queue of %d instances per GPU and step, the %d timed steps drained as one stream" % (Q, a.steps)),
                                    a.gap, a.time_limit,
                                    " (whole batch in flight, the step ends with its last instance)" if a.no_stream else (" from its admission, %d in flight per GPU (streaming admission)" % B))),
                                in_flight=B, queue_per_gpu_and_step=(None if a.total > 0 else Q), streaming=not a.no_stream,

@@ -133,10 +133,10 @@ struct DevBuf {
   // progress; the easy ones - a handful of open nodes - finish within a few rounds).  The rest of the batch goes to the
   // instances IN ORDER OF ADMISSION, each up to min(demand, share_cap): the hard instances of this workload need 10^5..10^6
   // node relaxations whatever the width of their rounds (measured: +10..30 % nodes at 4096 per round against 64, +50..150 % at
-  // 16384), so an instance that gets 4096 nodes per round is done in a few hundred rounds, while hundreds of hard instances
+  // 16384), so an instance that gets ~1000 nodes per round is done in a few hundred rounds, while hundreds of hard instances
   // sharing the batch evenly all run into their max_solution_time (which counts from the admission) and their work is lost.
-  // Earliest deadline first finishes what it starts; the cap keeps one pathological instance from holding more than an
-  // eighth of the device.
+  // Earliest deadline first finishes what it starts; the cap (1024: narrow rounds waste the fewest nodes - every round prunes
+  // with the incumbents of the one before) keeps a pathological instance to 3 % of the device.
   int* slot_demand; int* slot_take; int share_cap; int base_take; int window_pct;
   const int* root_cnt; const int* root_node; const int* root_depth; int root_stride;   // root records of every instance (uploaded once; admit_kernel writes them into the slot's list)
   double qp_tol;
@@ -2361,6 +2361,7 @@ __global__ void admit_kernel(DevBuf B, const int* pairs, int n, int sel) {
 // shares of the next round's batch (one workgroup; see DevBuf::slot_take)
 __global__ void __launch_bounds__(1024) share_kernel(DevBuf B) {
   __shared__ long long red[1024];
+  __shared__ int sh_lo, sh_hi;
   const int tid = threadIdx.x, NSL = B.n_slots;
   auto bsum = [&](long long v) -> long long {
     __syncthreads(); red[tid] = v; __syncthreads();
@@ -2368,16 +2369,18 @@ __global__ void __launch_bounds__(1024) share_kernel(DevBuf B) {
     return red[0];
   };
   const long long target = (long long)B.batch_cap - (long long)B.batch_cap / 16;   // (demands are one round old: a little head room)
-  long long ab = 0, an = 0;
-  for (int k = tid; k < NSL; k += 1024) { const int d = B.slot_demand[k]; ab += d < B.base_take ? d : B.base_take; an += d > B.base_take ? 1 : 0; }
-  const long long SB = bsum(ab), NA = bsum(an);
+  long long ab = 0;
+  for (int k = tid; k < NSL; k += 1024) { const int d = B.slot_demand[k]; ab += d < B.base_take ? d : B.base_take; }
+  const long long SB = bsum(ab);
   const long long rest = target - SB;
-  long long cap = B.share_cap; if (NA > 0 && rest / NA > cap) cap = rest / NA < 2 * cap ? rest / NA : 2 * cap;   // few instances in flight: up to twice the cap (wider rounds cost more nodes than they save rounds)
-  auto more_of = [&](int k) -> long long {   // what slot k may take beyond its base share
+  const long long cap = B.share_cap;
+  auto more_of = [&](int k) -> long long {   // what slot k may take beyond its base share in the pass by admission order
     const int d = B.slot_demand[k]; const long long c = d < cap ? d : cap;
     const int b = d < B.base_take ? d : B.base_take;
     return c > b ? c - b : 0;
   };
+  // pass by admission order (earliest deadline first), every instance up to the cap
+  long long at = 0;
   for (int k = tid; k < NSL; k += 1024) {
     const int d = B.slot_demand[k], inst = B.slot_inst[k];
     int take = d < B.base_take ? d : B.base_take;
@@ -2388,7 +2391,28 @@ __global__ void __launch_bounds__(1024) share_kernel(DevBuf B) {
       long long ex = rest - before; if (ex > more) ex = more;
       if (ex > 0) take += (int)ex;
     }
-    B.slot_take[k] = take;
+    B.slot_take[k] = take; at += take;
+  }
+  // capacity still free (few hard instances in flight): the same extra allowance for every instance that can use it, so that the
+  // batch is full - an idle device is worse than the nodes a wider round wastes - up to 8192 nodes per instance
+  const long long left = target - bsum(at);
+  if (left <= 0) return;
+  if (tid == 0) { sh_lo = 0; sh_hi = 8192; }
+  __syncthreads();
+  for (int itn = 0; itn < 16; ++itn) {
+    const int lo = sh_lo, hi = sh_hi;
+    if (lo >= hi) break;
+    const int mid = lo + (hi - lo + 1) / 2;
+    long long a = 0;
+    for (int k = tid; k < NSL; k += 1024) { long long r = (long long)B.slot_demand[k] - B.slot_take[k]; if (r > 8192 - B.slot_take[k]) r = 8192 - B.slot_take[k]; a += r < mid ? (r > 0 ? r : 0) : mid; }
+    const long long tot = bsum(a);
+    if (tid == 0) { if (tot <= left) sh_lo = mid; else sh_hi = mid - 1; }
+    __syncthreads();
+  }
+  const int L = sh_lo;
+  for (int k = tid; k < NSL; k += 1024) {
+    long long r = (long long)B.slot_demand[k] - B.slot_take[k]; if (r > 8192 - B.slot_take[k]) r = 8192 - B.slot_take[k];
+    if (r > 0) B.slot_take[k] += (int)(r < L ? r : L);
   }
 }
 

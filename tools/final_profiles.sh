@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collects the round's profile artefacts on the GPU box into gpurun_out/final/ (copied to profiles/ afterwards):
-#   kernel trace + stats of the default bench step, three separate PMC passes (FETCH_SIZE, WRITE_SIZE, SQ counters; no
-#   tracing together with --pmc), all on `bench.py --steps 1 --warmup 0 --no-cpu --time-limit 3` for the counters.
+#   kernel trace + stats of one default bench step (1024 in flight, queue of 2048), three separate PMC passes (FETCH_SIZE, WRITE_SIZE, SQ counters;
+#   no tracing together with --pmc) on `bench.py --steps 1 --warmup 0 --no-cpu --time-limit 3` for the counters.
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/final; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $O/trace_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu > $O/trace_bench.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -o p -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --time-limit 3 > $O/pmc_$c.log 2>&1
 done
@@ -17,4 +17,5 @@ find $O/trace -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 grep "^{" $O/trace_bench.log > $O/trace_bench.json
 rm -rf $O/trace/*/*_kernel_trace.csv $O/pmc_*/*/*counter_collection.csv 2>/dev/null
 find $O -name "*.db" -delete 2>/dev/null
+find $O -name "*kernel_trace.csv" -delete 2>/dev/null; find $O -name "*counter_collection.csv" -delete 2>/dev/null
 ls -la $O | head -30; head -8 $O/kernel_stats.csv
