@@ -249,7 +249,13 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
       for (int k = tid; k < N * 32; k += 64) bkey[k] = ~0ull;
       for (int k = tid; k <= N + 1; k += 64) sstart[k] = 0;
     }
+    const bool warm = B.ws_on && B.pool_Z && (B.batch_depth[node] >> 6) >= 1;   // roots (and the polish) start cold
     __syncthreads();
+    if (warm) {   // the parent's solution, into the kernel's column order
+      const double* zp = B.pool_Z + (size_t)B.batch_node[node] * N * NZ;
+      for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) Z[k] = zp[(k >> 4) * NZ + oc_lcol<C, CM>(q)]; }
+      OC_WAVE_SYNC();
+    } else {
     if (tid < NX) Z[tid] = D[Y.d_x0 + oc_lcol<C, CM>(tid)];
     OC_WAVE_SYNC();
     for (int i = 0; i + 1 < N; ++i) {  // free rollout (u = 0)
@@ -260,6 +266,7 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
         Z[(i + 1) * 16 + tid] = acc;
       }
       OC_WAVE_SYNC();
+    }
     }
     const double* Rf = D + Y.d_ref;
     double cutoff = 1e300;
@@ -399,10 +406,10 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
         const unsigned long long key = bkey[(i * 2 + side) * 16 + lc];
         if (key != ~0ull) {
           const double rh = key2d(key), c = rh - bsgn * Z[i * 16 + lc];
-          double s, t;
-          if (c > QP_T0) { t = QP_T0; s = c + QP_T0; } else { s = MIQP_S0 * QP_T0; t = s - c; }
-          bs[k] = s; bl[k] = MIQP_LAM0; bt[k] = t; bact |= 1u << k;
-          csum += s * MIQP_LAM0 + t * (RHO_EL - MIQP_LAM0); cnt += 2; tsum += t;
+          double s, t, l0;
+          init_elastic(c, warm, B.ws_mu, B.ws_delta, s, l0, t);
+          bs[k] = s; bl[k] = l0; bt[k] = t; bact |= 1u << k;
+          csum += s * l0 + t * (RHO_EL - l0); cnt += 2; tsum += t;
         }
       }
     }
@@ -420,10 +427,10 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) if (k < nn) c -= gcoef[off + k] * Z[i * 16 + ((m4.w >> (4 * k)) & 15u)];
         if (!(m4.z & 0x80000000u)) {
-          double s, t;
-          if (c > QP_T0) { t = QP_T0; s = c + QP_T0; } else { s = MIQP_S0 * QP_T0; t = s - c; }
-          gs_[q] = s; gl_[q] = MIQP_LAM0; gt_[q] = t;
-          csum += s * MIQP_LAM0 + t * (RHO_EL - MIQP_LAM0); cnt += 2; tsum += t;
+          double s, t, l0;
+          init_elastic(c, warm, B.ws_mu, B.ws_delta, s, l0, t);
+          gs_[q] = s; gl_[q] = l0; gt_[q] = t;
+          csum += s * l0 + t * (RHO_EL - l0); cnt += 2; tsum += t;
         } else {
           const double lam = fmax(1.0, -2.0 * c * aqs + 1.0), s = c + lam / aqs;
           gs_[q] = s; gl_[q] = lam; gt_[q] = 1.0; csum += s * lam; cnt += 1;   // t of a soft row is never used

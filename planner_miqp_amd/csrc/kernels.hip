@@ -151,6 +151,12 @@ struct DevBuf {
   int ovf_mode;                  // 1: ipm_kernel works through ovf_list instead of the whole batch
   unsigned long long* stats;     // [32] diagnostic counters of the on-chip kernel (MIQP_STATS=1), else null
   signed char* pool_origin;      // diagnostic build: 2*kind + (deviating child) of the branching that created a node record
+  // Warm start of the node relaxations: every child record carries the primal solution Z of its parent (a trajectory that
+  // satisfies the dynamics and every row of the parent; only the rows the branching adds are violated).  The interior point
+  // starts there with every row centred at complementarity ws_mu - slack s = max(residual, ws_delta), elastic slack t = s -
+  // residual, multiplier ws_mu / s - instead of at the free rollout with the same multiplier on every row.
+  double* pool_Z;                // [pool_cap][N * nz] in the model's column order (null: cold starts only)
+  double ws_mu, ws_delta; int ws_on;
 };
 
 __device__ inline unsigned long long d2key(double v) {
@@ -468,6 +474,23 @@ __device__ inline double frsq(double x) {
   return fma(0.5 * r, fma(-x * r, r, 1.0), r);
 }
 
+// initial state (s, lambda, t) of an elastic row with residual c = rhs - g.z at the starting point (s - t = c at every iterate).
+// Cold (free rollout): the slack follows the residual, the same multiplier everywhere.  Warm (the parent's solution): the row is
+// put on the central path at mu0 - an inactive row (large residual) gets a small multiplier, an active or violated one a slack
+// of delta and the matching multiplier (capped well inside (0, rho)).
+__device__ inline void init_elastic(double c, bool warm, double mu0, double delta, double& s, double& lam, double& t) {
+  if (!warm) {
+    if (c > QP_T0) { t = QP_T0; s = c + QP_T0; } else { s = MIQP_S0 * QP_T0; t = s - c; }
+    lam = MIQP_LAM0;
+    return;
+  }
+  s = c > delta ? c : delta;
+  lam = mu0 / s; if (lam > 0.5 * RHO_EL) lam = 0.5 * RHO_EL;
+  double tt = mu0 / (RHO_EL - lam);          // central value of the elastic slack
+  if (s - c > tt) tt = s - c;                // ... or what the violated row needs
+  t = tt; s = c + tt;                        // (s - t = c exactly)
+}
+
 // ------------------------------------------------------------------------------------------------
 //  Newton step of one row (elastic: aq == 0, quadratic-soft: aq > 0) given g.dz
 __device__ inline void row_step(double s, double lam, double t, double aq, double gd, double tau, double& ds, double& dl, double& dt) {
@@ -535,7 +558,13 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     for (int k = tid; k < NZ; k += NT) Wd[k] = D[Y.d_wd + k];
     for (int k = tid; k < N * NZ; k += NT) Z[k] = 0.0;
   }
+  const bool warm = B.ws_on && B.pool_Z && (B.batch_depth[node] >> 6) >= 1;   // roots (and the polish) start cold
   __syncthreads();
+  if (warm) {
+    const double* zp = B.pool_Z + (size_t)B.batch_node[node] * N * NZ;
+    for (int k = tid; k < N * NZ; k += NT) Z[k] = zp[k];
+    __syncthreads();
+  } else {
   if (tid < NX) Z[tid] = D[Y.d_x0 + tid];
   __syncthreads();
   for (int i = 0; i + 1 < N; ++i) {  // free rollout (u = 0)
@@ -545,6 +574,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
       Z[(i + 1) * NZ + tid] = acc;
     }
     __syncthreads();
+  }
   }
   const double* Rf = D + Y.d_ref;
   // cutoff: a node whose dual bound already exceeds what can still improve the incumbent by more than the gap is
@@ -605,7 +635,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
       cols |= ((unsigned long long)i << 48) | ((unsigned long long)nn << 56);
       double s, lam = MIQP_LAM0, t;
       if (r.aq == 0.0) {
-        if (c > QP_T0) { t = QP_T0; s = c + QP_T0; } else { s = MIQP_S0 * QP_T0; t = s - c; }
+        init_elastic(c, warm, B.ws_mu, B.ws_delta, s, lam, t);
         csum += s * lam + t * (RHO_EL - lam); cnt += 2; tsum += t;
       } else { lam = fmax(1.0, -2.0 * c * r.aq + 1.0); s = c + lam / r.aq; t = 0.0; csum += s * lam; cnt += 1; }
       rc_rhs[idx] = r.rhs; rc_col[idx] = __longlong_as_double((long long)cols);
@@ -1972,6 +2002,9 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
           cls = (k_ca[q] & 3) == 3 ? 3 : ((ad == 1 || ad == Y.R - 1) ? 1 : 2); }
         B.pool_origin[slots[q]] = (signed char)(kk == -2 ? 15 : 4 * chosen.kind + cls);
       }
+    }
+    if (B.pool_Z) {   // the children start their relaxation from this node's solution (see DevBuf::pool_Z)
+      for (int q = 0; q < nk; ++q) { double* zd = B.pool_Z + (size_t)slots[q] * N * NZ; for (int k = lane; k < N * NZ; k += 64) zd[k] = Z[k]; }
     }
     if (lane < nk) {
       // depth word: (tree depth << 6) | preference among siblings (child_inf first) - used by the dive ordering

@@ -302,7 +302,9 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
     if (const char* e = std::getenv("MIQP_FAR_CAP")) fc = (size_t)std::max(0LL, std::atoll(e));
     X.far_cap = fc < 4096 ? 0 : (int)fc; }
   size_t want = (size_t)n_slots * ((size_t)open_cap + (size_t)X.far_cap + (size_t)npr * 64 + 64) + (size_t)n_inst * roots_per_inst;
-  size_t maxrec = std::min<size_t>((size_t)64 << 30, free_b / 4) / (size_t)Y.fixlen;   // node records: up to 64 GB of the 288 GB, at most a quarter of what is free
+  const bool ws_on = !(std::getenv("MIQP_WARM") && std::atoi(std::getenv("MIQP_WARM")) == 0);   // warm start of the node relaxations (MIQP_WARM=0: cold)
+  const size_t zbytes = ws_on ? (size_t)Y.N * Y.nz * 8 : 0;
+  size_t maxrec = std::min<size_t>((size_t)96 << 30, free_b / 3) / ((size_t)Y.fixlen + zbytes);   // node records (fix record + the parent's solution): up to 96 GB of the 288 GB, at most a third of what is free
   X.pool_cap = (int)std::min<size_t>(std::min(want, maxrec), (size_t)0x7FFFFFF0);
   DevBuf& B = X.B; std::memset(&B, 0, sizeof(B));
   B.qp_tol = QP_TOL; B.use_cutoff = 1;
@@ -313,6 +315,10 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&dd, (size_t)n_inst * Y.dstride)) return false; B.inst_d = dd;
   if (!X.alloc(&ii, (size_t)n_inst * Y.istride)) return false; B.inst_i = ii;
   if (!X.alloc(&B.pool_fix, (size_t)X.pool_cap * Y.fixlen)) return false;
+  if (ws_on) { if (!X.alloc(&B.pool_Z, (size_t)X.pool_cap * Y.N * Y.nz)) return false; }
+  B.ws_on = ws_on ? 1 : 0;
+  B.ws_mu = std::getenv("MIQP_WS_MU") ? std::atof(std::getenv("MIQP_WS_MU")) : 1.0;
+  B.ws_delta = std::getenv("MIQP_WS_DELTA") ? std::atof(std::getenv("MIQP_WS_DELTA")) : 1.0e-3;
   if (!X.alloc(&B.pool_count, 1)) return false;
   if (!X.alloc(&B.free_q, (size_t)X.pool_cap)) return false;
   if (!X.alloc(&B.free_head, 1)) return false;
@@ -940,7 +946,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     HIP_OK(hipMemcpyAsync(B.batch_inst, ids.data(), n * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(B.batch_count, &n, 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipStreamSynchronize(st));
-    DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL; Bp.use_cutoff = 0; Bp.batch_cap = X.batch_alloc;
+    DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL; Bp.use_cutoff = 0; Bp.batch_cap = X.batch_alloc; Bp.ws_on = 0;
     int nb = std::min(n, X.batch_alloc);
     launch_ipm_batch(X, Bp, nb, st);
     HIP_OK(hipMemcpyAsync(h_pobj.data(), B.batch_obj, nb * 8, hipMemcpyDeviceToHost, st));
@@ -1495,7 +1501,7 @@ int miqp_solver_solve_fixed(miqp_solver_t* s, const miqp_raw_results_c* fixed, m
   (void)hipMemcpyAsync(B.batch_node, &zero, 4, hipMemcpyHostToDevice, st);
   (void)hipMemcpyAsync(B.batch_inst, &zero, 4, hipMemcpyHostToDevice, st);
   (void)hipMemsetAsync(B.inst_nodes, 0, 8, st); (void)hipMemsetAsync(B.inst_iters, 0, 8, st); (void)hipMemsetAsync(B.stat_rowiters, 0, 8, st);
-  { DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL; Bp.use_cutoff = 0;
+  { DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL; Bp.use_cutoff = 0; Bp.ws_on = 0;
     launch_ipm_batch(X, Bp, 1, st); }
   std::vector<double> Z((size_t)Y.N * Y.nz); double obj = 0, viol = 0; int ok = 0, it = 0;
   (void)hipMemcpyAsync(Z.data(), B.batch_Z, Z.size() * 8, hipMemcpyDeviceToHost, st);
