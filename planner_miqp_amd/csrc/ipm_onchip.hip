@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
       for (int k = tid; k < N * 32; k += 64) bkey[k] = ~0ull;
       for (int k = tid; k <= N + 1; k += 64) sstart[k] = 0;
     }
-    const bool warm = B.ws_on && B.pool_Z && (B.batch_depth[node] >> 6) >= 1;   // roots (and the polish) start cold
+    const bool warm = B.ws_on && B.pool_Z && (B.batch_depth[node] >> 6) >= 1 && B.batch_node[node] < B.z_cap;   // roots (and the polish) start cold
     __syncthreads();
     if (warm) {   // the parent's solution, into the kernel's column order
       const double* zp = B.pool_Z + (size_t)B.batch_node[node] * N * NZ;

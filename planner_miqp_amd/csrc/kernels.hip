@@ -155,8 +155,8 @@ struct DevBuf {
   // satisfies the dynamics and every row of the parent; only the rows the branching adds are violated).  The interior point
   // starts there with every row centred at complementarity ws_mu - slack s = max(residual, ws_delta), elastic slack t = s -
   // residual, multiplier ws_mu / s - instead of at the free rollout with the same multiplier on every row.
-  double* pool_Z;                // [pool_cap][N * nz] in the model's column order (null: cold starts only)
-  double ws_mu, ws_delta; int ws_on;
+  double* pool_Z;                // [z_cap][N * nz] in the model's column order (null: cold starts only); records beyond z_cap start cold
+  double ws_mu, ws_delta; int ws_on; int z_cap;
 };
 
 __device__ inline unsigned long long d2key(double v) {
@@ -558,7 +558,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     for (int k = tid; k < NZ; k += NT) Wd[k] = D[Y.d_wd + k];
     for (int k = tid; k < N * NZ; k += NT) Z[k] = 0.0;
   }
-  const bool warm = B.ws_on && B.pool_Z && (B.batch_depth[node] >> 6) >= 1;   // roots (and the polish) start cold
+  const bool warm = B.ws_on && B.pool_Z && (B.batch_depth[node] >> 6) >= 1 && B.batch_node[node] < B.z_cap;   // roots (and the polish) start cold
   __syncthreads();
   if (warm) {
     const double* zp = B.pool_Z + (size_t)B.batch_node[node] * N * NZ;
@@ -2004,7 +2004,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       }
     }
     if (B.pool_Z) {   // the children start their relaxation from this node's solution (see DevBuf::pool_Z)
-      for (int q = 0; q < nk; ++q) { double* zd = B.pool_Z + (size_t)slots[q] * N * NZ; for (int k = lane; k < N * NZ; k += 64) zd[k] = Z[k]; }
+      for (int q = 0; q < nk; ++q) { if (slots[q] >= B.z_cap) continue; double* zd = B.pool_Z + (size_t)slots[q] * N * NZ; for (int k = lane; k < N * NZ; k += 64) zd[k] = Z[k]; }
     }
     if (lane < nk) {
       // depth word: (tree depth << 6) | preference among siblings (child_inf first) - used by the dive ordering

