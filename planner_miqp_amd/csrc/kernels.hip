@@ -212,12 +212,22 @@ __device__ inline double wave_sum(double v) {   // quad, quad pairs, half rows, 
 }
 
 // alpha*X + beta*Y of car c added to a dense row over the stage vector
-__device__ inline void add_point(double* g, double& rhs, int c, const double* rt, int tx, int ty, double al, double be) {
+// rt == nullptr (the region of the step is undecided): the offset of a front point is replaced by its bound over the regions
+// still possible, K = d_fpk entry of the car's region set (host_inst.hpp) - the minimum where the offset enters the row
+// "g.z <= rhs" with a positive coefficient, the maximum otherwise: a row implied by the exact row of whichever region is active
+__device__ inline void add_point(double* g, double& rhs, int c, const double* rt, int tx, int ty, double al, double be, const double* K = nullptr) {
   g[6 * c + 0] += al;
-  if (tx != PT_R) { const double* p = rt + 19 + (tx == PT_U ? 0 : 3); rhs -= al * p[0]; g[6 * c + 1] += al * p[1]; g[6 * c + 4] += al * p[2]; }
+  if (tx != PT_R) {
+    if (rt) { const double* p = rt + 19 + (tx == PT_U ? 0 : 3); rhs -= al * p[0]; g[6 * c + 1] += al * p[1]; g[6 * c + 4] += al * p[2]; }
+    else if (al != 0.0) rhs -= al * K[(tx == PT_U ? 0 : 2) + (al > 0.0 ? 0 : 1)];
+  }
   g[6 * c + 3] += be;
-  if (ty != PT_R) { const double* p = rt + 25 + (ty == PT_U ? 0 : 3); rhs -= be * p[0]; g[6 * c + 1] += be * p[1]; g[6 * c + 4] += be * p[2]; }
+  if (ty != PT_R) {
+    if (rt) { const double* p = rt + 25 + (ty == PT_U ? 0 : 3); rhs -= be * p[0]; g[6 * c + 1] += be * p[1]; g[6 * c + 4] += be * p[2]; }
+    else if (be != 0.0) rhs -= be * K[(ty == PT_U ? 4 : 6) + (be > 0.0 ? 0 : 1)];
+  }
 }
+
 
 // corner index of a front point with x/y types (tx, ty) in the environment / obstacle corner orders
 __device__ inline int env_corner(int tx, int ty) { return tx == PT_U ? (ty == PT_U ? 1 : 3) : (ty == PT_U ? 2 : 4); }
@@ -253,6 +263,11 @@ __device__ inline int region_set(const Layout& Y, const int* T, const signed cha
 __device__ inline const double* region_hull(const Layout& Y, const double* D, const int* T, const signed char* fix, int c, int i) {
   if (T[Y.i_nposs + c] > Y.PT) return D + Y.d_hull + (c * Y.N + i) * HULLSZ;
   return D + Y.d_hullm + (c * (1 << Y.PT) + region_set(Y, T, fix, c, i)) * 8;
+}
+// front-point offset ranges of (car, step) over its region set (nullptr: the car has more possible regions than the table indexes)
+__device__ inline const double* region_fpk(const Layout& Y, const double* D, const int* T, const signed char* fix, int c, int i) {
+  if (T[Y.i_nposs + c] > Y.PT) return nullptr;
+  return D + Y.d_fpk + (c * (1 << Y.PT) + region_set(Y, T, fix, c, i)) * 8;
 }
 
 // rows of the relaxation of a node (only alternatives that are fixed); g is this lane's LDS row.  BUILD = false only
@@ -388,7 +403,11 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
   int c1, c2; pair_cars(p, C, c1, c2);
   int code1 = (int)fix[Y.f_reg + c1 * N + i], code2 = (int)fix[Y.f_reg + c2 * N + i];
   bool need1 = grp >= 2, need2 = (grp == 1 || grp == 3);
-  if ((need1 && code1 < 0) || (need2 && code2 < 0)) return r;
+  // a front point of a car whose region is undecided: the row stays in the relaxation with the offset bounded over the car's
+  // region set (add_point); the exclusion rows (they bound from the other side) wait for the region
+  const double* K1 = nullptr; const double* K2 = nullptr;
+  if (need1 && code1 < 0) { if (excl || Y.relax_front_off) return r; K1 = region_fpk(Y, D, T, fix, c1, i); if (!K1) return r; }
+  if (need2 && code2 < 0) { if (excl || Y.relax_front_off) return r; K2 = region_fpk(Y, D, T, fix, c2, i); if (!K2) return r; }
   const double* rt1 = code1 >= 0 ? D + Y.d_reg + (c1 * Y.P + (code1 >> 2)) * REGSZ : nullptr;
   const double* rt2 = code2 >= 0 ? D + Y.d_reg + (c2 * Y.P + (code2 >> 2)) * REGSZ : nullptr;
   double Dsep = D[Y.d_dsep + p * N + i], S = D[Y.d_ssl + i], smax = D[Y.d_smax + i], wsl = D[Y.d_misc + 0];
@@ -408,8 +427,8 @@ __device__ inline RowOut decode_row(const Layout& Y, const double* D, const int*
   if (!BUILD) return r;
   r.rhs = soft ? (which == 0 ? -(Dsep + S) + smax : -(Dsep + S)) : -Dsep;
   r.aq = (!excl && soft && which == 1) ? 2.0 * wsl : 0.0;
-  add_point(g, r.rhs, ca, ca == c1 ? rt1 : rt2, ta, ta, al, be);
-  add_point(g, r.rhs, cb, cb == c1 ? rt1 : rt2, tb, tb, -al, -be);
+  add_point(g, r.rhs, ca, ca == c1 ? rt1 : rt2, ta, ta, al, be, ca == c1 ? K1 : K2);
+  add_point(g, r.rhs, cb, cb == c1 ? rt1 : rt2, tb, tb, -al, -be, cb == c1 ? K1 : K2);
   if (excl) {   // g.z >= rhs
 #pragma unroll
     for (int k = 0; k < NZ; ++k) g[k] = -g[k];
@@ -1208,10 +1227,11 @@ namespace miqp {
 //  eval kernel helpers: violation of alternatives evaluated directly from the stage state
 struct CarState { double px, vx, ax, py, vy, ay, ux, uy; };
 
-__device__ inline void point_xy(const CarState& s, const double* rt, int tx, int ty, double& X, double& Y) {
+// rt == nullptr: the bound of the point over the car's region set (K = d_fpk entry; lower: the smallest coordinate, else the largest)
+__device__ inline void point_xy(const CarState& s, const double* rt, int tx, int ty, double& X, double& Y, const double* K = nullptr, bool lower = true) {
   X = s.px; Y = s.py;
-  if (tx != PT_R) { const double* p = rt + 19 + (tx == PT_U ? 0 : 3); X += p[0] + p[1] * s.vx + p[2] * s.vy; }
-  if (ty != PT_R) { const double* p = rt + 25 + (ty == PT_U ? 0 : 3); Y += p[0] + p[1] * s.vx + p[2] * s.vy; }
+  if (tx != PT_R) { if (rt) { const double* p = rt + 19 + (tx == PT_U ? 0 : 3); X += p[0] + p[1] * s.vx + p[2] * s.vy; } else X += K[(tx == PT_U ? 0 : 2) + (lower ? 0 : 1)]; }
+  if (ty != PT_R) { if (rt) { const double* p = rt + 25 + (ty == PT_U ? 0 : 3); Y += p[0] + p[1] * s.vx + p[2] * s.vy; } else Y += K[(ty == PT_U ? 4 : 6) + (lower ? 0 : 1)]; }
 }
 
 __device__ inline double box_viol(const CarState& s, const double* rt, bool with_jerk) {
@@ -1242,8 +1262,9 @@ __device__ inline double env_alt_viol(const Layout& Y, const double* D, const in
 }
 
 // zero-slack violation of c2c alternative; (s1, rt1) / (s2, rt2) are the two cars of pair p
+// (rt1 / rt2 == nullptr with K1 / K2: the violation of the RELAXED row of a car whose region is undecided, see add_point)
 __device__ inline double c2c_alt_viol(const Layout& Y, const double* D, int p, int i, int grp, int alt, const CarState& s1, const double* rt1,
-                                      const CarState& s2, const double* rt2) {
+                                      const CarState& s2, const double* rt2, const double* K1 = nullptr, const double* K2 = nullptr) {
   double Dsep = D[Y.d_dsep + p * Y.N + i], S = D[Y.d_ssl + i];
   bool isx = alt < 2, lo = (alt == 0 || alt == 2);
   bool soft = (grp == 0 || grp == 3);
@@ -1253,8 +1274,8 @@ __device__ inline double c2c_alt_viol(const Layout& Y, const double* D, int p, i
   else if (grp == 2) { if (lo) { a1 = 2; ta = PT_R; tb = PT_L; } else { a1 = 1; ta = PT_U; tb = PT_R; } }
   else { if (lo) { a1 = 2; ta = PT_U; tb = PT_L; } else { a1 = 1; ta = PT_U; tb = PT_L; } }
   double XA, YA, XB, YB;
-  if (a1 == 1) { point_xy(s1, rt1, ta, ta, XA, YA); point_xy(s2, rt2, tb, tb, XB, YB); }
-  else { point_xy(s2, rt2, ta, ta, XA, YA); point_xy(s1, rt1, tb, tb, XB, YB); }
+  if (a1 == 1) { point_xy(s1, rt1, ta, ta, XA, YA, K1, true); point_xy(s2, rt2, tb, tb, XB, YB, K2, false); }
+  else { point_xy(s2, rt2, ta, ta, XA, YA, K2, true); point_xy(s1, rt1, tb, tb, XB, YB, K1, false); }
   double lhs = isx ? XA - XB : YA - YB;
   return lhs + (soft ? Dsep + S : Dsep);
 }
@@ -1307,7 +1328,7 @@ __device__ inline void pos_blocks(const Layout& Y, const double* D, int c, int i
   Yd.pp = S[0]; Yd.pv = S[1]; Yd.vv = S[5];
 }
 __device__ inline double point_gamma(const PosBlk& X, const PosBlk& Yd, const double* rt, int t, bool isx) {
-  if (t == PT_R) return isx ? X.pp : Yd.pp;
+  if (t == PT_R || !rt) return isx ? X.pp : Yd.pp;   // (no region table: the relaxed row of an undecided region carries the position only)
   const double* p = rt + (isx ? 19 : 25) + (t == PT_U ? 0 : 3);   // coordinate + p[0] + p[1] vx + p[2] vy
   return isx ? X.pp + 2.0 * p[1] * X.pv + p[1] * p[1] * X.vv + p[2] * p[2] * Yd.vv
              : Yd.pp + 2.0 * p[2] * Yd.pv + p[2] * p[2] * Yd.vv + p[1] * p[1] * X.vv;
@@ -1625,14 +1646,19 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
             // set tightening (as for the regions): an alternative whose separation row, priced by the bound lifting, costs more
             // than the incumbent allows leaves the group's set for the whole subtree (no child is created for it).  Only for
             // groups whose rows are known (front points need the region of their car).
-            if (unf < 0 && inc_now < 1e300 && !(B.seq_kinds & 0x8000)) {
+            // rows as the relaxation of a child would carry them: exact where the region of the car is decided, with the
+            // front-point offset bounded over the region set where it is not (add_point)
+            const double* rr1 = fix[Y.f_reg + c1 * N + i] >= 0 ? rt1 : nullptr; const double* rr2 = fix[Y.f_reg + c2 * N + i] >= 0 ? rt2 : nullptr;
+            const double* K1 = rr1 ? nullptr : region_fpk(Y, D, T, fix, c1, i); const double* K2 = rr2 ? nullptr : region_fpk(Y, D, T, fix, c2, i);
+            const bool relax_ok = !Y.relax_front_off && (rr1 || K1) && (rr2 || K2);
+            if ((unf < 0 || relax_ok) && inc_now < 1e300 && !(B.seq_kinds & 0x8000)) {
               const double room = inc_now - gapi_ * (1e-10 + fabs(inc_now)) - objlb;
               const bool softg = (g == 0 || g == 3); const double smx = softg ? D[Y.d_smax + i] : 0.0;
               const int am0 = am;
               for (int a = 0; a < 4; ++a) {
                 if (!((am >> a) & 1)) continue;
-                const double hv = c2c_alt_viol(Y, D, p, i, g, a, s1, rt1, s2, rt2) - smx;   // violation of the hard row of the alternative
-                if (hv > tol && lift1(hv, c2c_alt_gamma(g, a, PX1, PY1, rt1, PX2, PY2, rt2)) * (1.0 - 1e-6) >= room) am &= ~(1 << a);
+                const double hv = c2c_alt_viol(Y, D, p, i, g, a, s1, rr1, s2, rr2, K1, K2) - smx;   // violation of the hard row of the alternative
+                if (hv > tol && lift1(hv, c2c_alt_gamma(g, a, PX1, PY1, rr1, PX2, PY2, rr2)) * (1.0 - 1e-6) >= room) am &= ~(1 << a);
               }
               if (am != am0) { fix[Y.f_c2c + (p * N + i) * 4 + g] = c2c_set_byte(am); if (B.stats) atomicAdd(&B.stats[61], 1ull); }
               if (am == 0) dead_lane = true;
@@ -1644,7 +1670,23 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
             }
             okk = bv <= tol; comp[Y.f_c2c + (p * N + i) * 4 + g] = (signed char)ba;
           }
-          if (!okk) { if (unf >= 0) consider(i, 0, unf, 0, 0, bv, rlift[unf * N + i], 3); else consider(i, 3, p, g, 0, bv, sc < 1e300 ? sc : 0.0); }
+          if (!okk) {
+            // an undecided group on a front point of a car without region: when the relaxed rows of all its alternatives cut the
+            // node's solution off, the group itself is branched (its children carry those rows: progress without the 3 - 5
+            // children of a region decision); when a relaxed row holds and only the exact one fails, the region comes first
+            bool branch_group = unf < 0;
+            if (unf >= 0 && fx < 0 && !Y.relax_front_off) {
+              const double* rr1 = fix[Y.f_reg + c1 * N + i] >= 0 ? rt1 : nullptr; const double* rr2 = fix[Y.f_reg + c2 * N + i] >= 0 ? rt2 : nullptr;
+              const double* K1 = rr1 ? nullptr : region_fpk(Y, D, T, fix, c1, i); const double* K2 = rr2 ? nullptr : region_fpk(Y, D, T, fix, c2, i);
+              if ((rr1 || K1) && (rr2 || K2)) {
+                int amr = (T[Y.i_c2callow + p * N + i] >> (4 * g)) & 15; if (!amr) amr = 15; amr &= c2c_set((int)fix[Y.f_c2c + (p * N + i) * 4 + g]);
+                double best_rel = 1e300;   // zero-slack violation of the relaxed rows (a soft group's child pays for it through its quadratic-soft row)
+                for (int a = 0; a < 4; ++a) if ((amr >> a) & 1) best_rel = fmin(best_rel, c2c_alt_viol(Y, D, p, i, g, a, s1, rr1, s2, rr2, K1, K2));
+                branch_group = best_rel > tol;
+              }
+            }
+            if (!branch_group) consider(i, 0, unf, 0, 0, bv, rlift[unf * N + i], 3); else consider(i, 3, p, g, 0, bv, sc < 1e300 ? sc : 0.0);
+          }
         }
       }
     }

@@ -1,7 +1,9 @@
 #!/bin/bash
-# region-set tightening on / off (bit 15 of MIQP_SEQ_KINDS switches it off) (GPU): hard single seeds at rounds of 4096 nodes and a streaming queue
-for sk in 1280 $((1280 + 0x8000)); do
-  echo "== MIQP_SEQ_KINDS=$sk"
-  MIQP_SEQ_KINDS=$sk WIDTHS=4096 python tools/width_probe.py 118 307 503 179 165 20 2>&1 | tail -n 6
-  MIQP_SEQ_KINDS=$sk MIQP_STATS=1 python tools/stream_check.py 1024 256 2>&1 | grep "^{\|node outcomes:\|region sets" | cut -c1-600
+# relaxed front-point rows on / off (MIQP_RELAX_FRONT=0) (GPU): hard single seeds at rounds of 4096 nodes, a streaming queue, cfg4, cfg5
+for rf in 1 0; do
+  echo "== MIQP_RELAX_FRONT=$rf"
+  MIQP_RELAX_FRONT=$rf WIDTHS=4096 python tools/width_probe.py 118 307 503 179 165 20 2>&1 | tail -n 6
+  MIQP_RELAX_FRONT=$rf MIQP_STATS=1 python tools/stream_check.py 2048 512 2>&1 | grep "^{\|node outcomes:\|region branchings" | cut -c1-700
+  MIQP_RELAX_FRONT=$rf python tools/stream_check.py 256 256 1000 10 cfg4 2>&1 | tail -n 1 | cut -c1-330
+  MIQP_RELAX_FRONT=$rf python tools/stream_check.py 16 16 0 10 cfg5 2>&1 | tail -n 1 | cut -c1-330
 done
