@@ -249,10 +249,10 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
       for (int k = tid; k < N * 32; k += 64) bkey[k] = ~0ull;
       for (int k = tid; k <= N + 1; k += 64) sstart[k] = 0;
     }
-    const bool warm = B.ws_on && B.pool_Z && (B.batch_depth[node] >> 6) >= 1 && B.batch_node[node] < B.z_cap;   // roots (and the polish) start cold
+    const bool warm = B.ws_on == 2 || (B.ws_on && B.pool_Z && (B.batch_depth[node] >> 6) >= 1 && B.batch_node[node] < B.z_cap);   // roots start cold; 2: the polish starts from the incumbent's solution
     __syncthreads();
     if (warm) {   // the parent's solution, into the kernel's column order
-      const double* zp = B.pool_Z + (size_t)B.batch_node[node] * N * NZ;
+      const double* zp = B.ws_on == 2 ? B.inc_Z + (size_t)inst * N * NZ : B.pool_Z + (size_t)B.batch_node[node] * N * NZ;
       for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) Z[k] = zp[(k >> 4) * NZ + oc_lcol<C, CM>(q)]; }
       OC_WAVE_SYNC();
     } else {

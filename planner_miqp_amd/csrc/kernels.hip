@@ -577,10 +577,11 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     for (int k = tid; k < NZ; k += NT) Wd[k] = D[Y.d_wd + k];
     for (int k = tid; k < N * NZ; k += NT) Z[k] = 0.0;
   }
-  const bool warm = B.ws_on && B.pool_Z && (B.batch_depth[node] >> 6) >= 1 && B.batch_node[node] < B.z_cap;   // roots (and the polish) start cold
+  // roots start cold; ws_on == 2 (the polish of the incumbents): from the incumbent's own solution
+  const bool warm = B.ws_on == 2 || (B.ws_on && B.pool_Z && (B.batch_depth[node] >> 6) >= 1 && B.batch_node[node] < B.z_cap);
   __syncthreads();
   if (warm) {
-    const double* zp = B.pool_Z + (size_t)B.batch_node[node] * N * NZ;
+    const double* zp = B.ws_on == 2 ? B.inc_Z + (size_t)inst * N * NZ : B.pool_Z + (size_t)B.batch_node[node] * N * NZ;
     for (int k = tid; k < N * NZ; k += NT) Z[k] = zp[k];
     __syncthreads();
   } else {

@@ -955,7 +955,10 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     HIP_OK(hipMemcpyAsync(B.batch_inst, ids.data(), n * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(B.batch_count, &n, 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipStreamSynchronize(st));
-    DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL; Bp.use_cutoff = 0; Bp.batch_cap = X.batch_alloc; Bp.ws_on = 0;
+    DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL; Bp.use_cutoff = 0; Bp.batch_cap = X.batch_alloc;
+    // the polish starts at the incumbent's own solution (integer feasible: every row of the completed record holds there), centred
+    // at a small complementarity - a third of the iterations of a cold solve to 1e-13 (the last thing a single solve waits for)
+    Bp.ws_on = (B.ws_on && !std::getenv("MIQP_POLISH_COLD")) ? 2 : 0; Bp.ws_mu = 1.0e-2; Bp.ws_delta = 1.0e-4;
     int nb = std::min(n, X.batch_alloc);
     launch_ipm_batch(X, Bp, nb, st);
     HIP_OK(hipMemcpyAsync(h_pobj.data(), B.batch_obj, nb * 8, hipMemcpyDeviceToHost, st));
