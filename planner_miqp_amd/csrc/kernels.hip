@@ -137,7 +137,7 @@ struct DevBuf {
   // sharing the batch evenly all run into their max_solution_time (which counts from the admission) and their work is lost.
   // Earliest deadline first finishes what it starts; the cap (1024: narrow rounds waste the fewest nodes - every round prunes
   // with the incumbents of the one before) keeps a pathological instance to 3 % of the device.
-  int* slot_demand; int* slot_take; int share_cap; int base_take; int window_pct;
+  int* slot_demand; int* slot_take; int share_cap; int base_take; int window_pct; double probe_room;
   const int* root_cnt; const int* root_node; const int* root_depth; int root_stride;   // root records of every instance (uploaded once; admit_kernel writes them into the slot's list)
   double qp_tol;
   int use_cutoff;                // 0: solve every node to convergence (polish of the incumbent, solve_fixed)
@@ -694,7 +694,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
 #ifdef MIQP_PROFILE
     if (it > 1 && first_proxy == 0 && obj + RHO_EL * tsum - (double)ncomp * comp > cutoff + 1e-9 * fabs(cutoff)) first_proxy = it;
 #endif
-    if (!(MIQP_ABL) && it > 1 && resid_fac * R0 < 1e-9 * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }
+    if (!(MIQP_ABL) && it > 1 && resid_fac * R0 < 1e-5 * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp - resid_fac * R0 * 1.0e4 > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }   // (dual value minus the allowance for the stationarity residual still left, see batch_bound)
     const double tau = sigma * comp;
     // ================= backward sweep: Riccati recursion, the whole stage algebra stays in the registers of the wave.
     // Matrices live in the D layout of v_mfma_f64_16x16x4_f64 (lane l: g = l>>4, c = l&15, register r <-> M[g+4r][c]).
@@ -1820,7 +1820,9 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     // one extra child with EVERY undecided disjunction fixed to its
     // completed value.  It lies inside the first child, so the children stay exhaustive; its relaxation is the exact cost
     // of the rounding and, when feasible, the first incumbent two rounds after the root instead of one dive level per round
-    if ((repair_root || !(inc_now < 1e300) || (B.opt2 & 1) || (((B.opt2 >> 4) & 15) && __popcll(bal_viol) <= ((B.opt2 >> 4) & 15) && ((B.batch_node[node] * 2654435761u >> 16) & ((1u << (2 * ((B.opt2 >> 2) & 3))) - 1u)) == 0u && (!(B.opt2 >> 8) || vmax_all <= 0.05 * (double)(B.opt2 >> 8)))) && nalt < 63 && (B.seq_kinds & 0x4000000) == 0) { ck[nalt] = -2; ca[nalt] = 0; nalt++; }
+    // (a probe at a node whose dual value is within probe_room gaps of the incumbent can only improve the incumbent by that little: not worth its QP - one of the large ones)
+    const bool probe_room_ok = !(inc_now < 1e300) || (inc_now - objlb) > B.probe_room * B.inst_gap[inst] * (1e-10 + fabs(inc_now));
+    if (probe_room_ok && (repair_root || !(inc_now < 1e300) || (B.opt2 & 1) || (((B.opt2 >> 4) & 15) && __popcll(bal_viol) <= ((B.opt2 >> 4) & 15) && ((B.batch_node[node] * 2654435761u >> 16) & ((1u << (2 * ((B.opt2 >> 2) & 3))) - 1u)) == 0u && (!(B.opt2 >> 8) || vmax_all <= 0.05 * (double)(B.opt2 >> 8)))) && nalt < 63 && (B.seq_kinds & 0x4000000) == 0) { ck[nalt] = -2; ca[nalt] = 0; nalt++; }
     fam[0] = base; fam[1] = stride; fam[2] = jlo; fam[3] = jhi;
     sh_base[2] = nalt;
   }
