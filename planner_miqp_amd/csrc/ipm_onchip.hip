@@ -236,6 +236,7 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
     __syncthreads();
     const int node = __builtin_amdgcn_readfirstlane(sh_node);   // wave-uniform by construction: said so, everything derived from it
     if (node >= nbatch) break;                                    // (instance tables, references) is then addressed from SGPRs
+    if (B.skip_probes && is_probe_word(B.batch_depth[node])) continue;   // solved by the concurrent memory-backed launch (every row of a probe is there: far beyond the on-chip capacity)
     const int inst = __builtin_amdgcn_readfirstlane(B.batch_inst[node]);
     const double* D = B.inst_d + (size_t)inst * Y.dstride;
     const int* T = B.inst_i + (size_t)inst * Y.istride;

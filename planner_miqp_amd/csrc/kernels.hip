@@ -138,6 +138,8 @@ struct DevBuf {
   // Earliest deadline first finishes what it starts; the cap (1024: narrow rounds waste the fewest nodes - every round prunes
   // with the incumbents of the one before) keeps a pathological instance to 3 % of the device.
   int* slot_demand; int* slot_take; int share_cap; int base_take; int window_pct; double probe_room;
+  int det_ties;                  // 1: ties of the node selection are broken by the nodes' own low key bits and sibling preference (reproducible), 0: by arrival
+  int live_inc;                  // 1: node evaluation prunes with the incumbent as other nodes of the same round update it (order dependent); 0: with the incumbent of the start of the round (reproducible)
   const int* root_cnt; const int* root_node; const int* root_depth; int root_stride;   // root records of every instance (uploaded once; admit_kernel writes them into the slot's list)
   double qp_tol;
   int use_cutoff;                // 0: solve every node to convergence (polish of the incumbent, solve_fixed)
@@ -148,7 +150,8 @@ struct DevBuf {
   unsigned long long* prof;      // [40] cycle counters of the phases of ipm_kernel (diagnostic build -DMIQP_PROFILE only)
   unsigned long long* stat_rowiters;
   int* ovf_count; int* ovf_list;  // nodes the on-chip interior point kernel handed to the memory-backed one (more general rows than its LDS holds)
-  int ovf_mode;                  // 1: ipm_kernel works through ovf_list instead of the whole batch
+  int ovf_mode;                  // 1: ipm_kernel works through ovf_list instead of the whole batch; 2: through the batch, rounding probes only
+  int skip_probes;               // on-chip kernel: the rounding probes of the batch (depth word: sibling preference 63) are solved by a concurrent launch of ipm_kernel (ovf_mode 2)
   unsigned long long* stats;     // [32] diagnostic counters of the on-chip kernel (MIQP_STATS=1), else null
   signed char* pool_origin;      // diagnostic build: 2*kind + (deviating child) of the branching that created a node record
   // Warm start of the node relaxations: every child record carries the primal solution Z of its parent (a trajectory that
@@ -252,6 +255,8 @@ __device__ inline void pair_cars(int p, int C, int& c1, int& c2) {
 }
 
 struct RowOut { double rhs; double aq; bool active; };
+// depth word of a rounding probe: tree depth >= 1, sibling preference 63 (eval_kernel)
+__device__ inline bool is_probe_word(int dw) { return (dw & 63) == 63 && (dw >> 6) >= 1; }
 
 // region set of (car, step) in a node: the bits of its fix record that the static reachability presolve allows
 __device__ inline int region_set(const Layout& Y, const int* T, const signed char* fix, int c, int i) {
@@ -538,7 +543,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   constexpr int RU = NX / 4, GU0 = NX % 4;  // register / first lane group holding the input rows NX..NZ-1  // rows are zero padded to the 16 columns of the MFMA tile
   const Layout& Y = B.Y;
   const int tid = threadIdx.x;
-  const int nbatch = B.ovf_mode ? *B.ovf_count : (*B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap);   // select may over-count when the batch is full
+  const int nbatch = B.ovf_mode == 1 ? *B.ovf_count : (*B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap);   // select may over-count when the batch is full
   const int N = Y.N, NSLOT = Y.NSLOT;
   extern __shared__ double lds[];
   double* Z = lds;                       // [N][NZ]
@@ -566,7 +571,8 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   if (tid == 0) sh_node = atomicAdd(B.work_counter, 1);
   __syncthreads();
   if (sh_node >= nbatch) break;
-  const int node = __builtin_amdgcn_readfirstlane(B.ovf_mode ? B.ovf_list[sh_node] : sh_node);   // wave-uniform: addressed from SGPRs
+  const int node = __builtin_amdgcn_readfirstlane(B.ovf_mode == 1 ? B.ovf_list[sh_node] : sh_node);   // wave-uniform: addressed from SGPRs
+  if (B.ovf_mode == 2 && !is_probe_word(B.batch_depth[node])) continue;   // (this launch takes the rounding probes only)
   const int inst = __builtin_amdgcn_readfirstlane(B.batch_inst[node]);
   const double* D = B.inst_d + (size_t)inst * Y.dstride;
   const int* T = B.inst_i + (size_t)inst * Y.istride;
@@ -1436,7 +1442,10 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   // what the node proves: the dual value of its relaxation (the primal value of an interior point iterate lies above the
   // optimum of the relaxation by the remaining complementarity)
   const double objlb = obj - fmax(0.0, B.batch_bound[node]);
-  const double inc_now = fmin(inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]), B.inc_ext[inst]);   // own incumbent or the one another rank of a tree split found
+  // own incumbent or the one another rank of a tree split found.  The incumbent of the START of the round (select_kernel
+  // copied it): nodes of one round are evaluated in no fixed order, and pruning with an incumbent another node of the same
+  // round has just found would make the tree - and with it the returned solution within the gap - differ from run to run.
+  const double inc_now = fmin(B.live_inc ? inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]) : B.inc_obj[inst], B.inc_ext[inst]);
   if (inc_now < 1e300 && !(objlb < inc_now - 1e-12 * fabs(inc_now))) { if (B.stats && lane == 0) atomicAdd(&B.stats[40], 1ull); FREE_NODE(); return; }  // bound not better than the incumbent
   if (B.stats && lane == 0 && inc_now < 1e300 && (inc_now - objlb) <= B.inst_gap[inst] * (1e-10 + fabs(inc_now))) atomicAdd(&B.stats[41], 1ull);   // (children will be pruned by the gap)
   const double tol = FEAS_TOL;
@@ -1821,8 +1830,11 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     // completed value.  It lies inside the first child, so the children stay exhaustive; its relaxation is the exact cost
     // of the rounding and, when feasible, the first incumbent two rounds after the root instead of one dive level per round
     // (a probe at a node whose dual value is within probe_room gaps of the incumbent can only improve the incumbent by that little: not worth its QP - one of the large ones)
+    // which nodes get a sampled probe: by the bits of the node's own objective (its record id is handed out in no fixed order
+    // and would make the tree differ from run to run)
+    const unsigned int probe_hash = (unsigned int)((unsigned long long)__double_as_longlong(obj) >> 6);
     const bool probe_room_ok = !(inc_now < 1e300) || (inc_now - objlb) > B.probe_room * B.inst_gap[inst] * (1e-10 + fabs(inc_now));
-    if (probe_room_ok && (repair_root || !(inc_now < 1e300) || (B.opt2 & 1) || (((B.opt2 >> 4) & 15) && __popcll(bal_viol) <= ((B.opt2 >> 4) & 15) && ((B.batch_node[node] * 2654435761u >> 16) & ((1u << (2 * ((B.opt2 >> 2) & 3))) - 1u)) == 0u && (!(B.opt2 >> 8) || vmax_all <= 0.05 * (double)(B.opt2 >> 8)))) && nalt < 63 && (B.seq_kinds & 0x4000000) == 0) { ck[nalt] = -2; ca[nalt] = 0; nalt++; }
+    if (probe_room_ok && (repair_root || !(inc_now < 1e300) || (B.opt2 & 1) || (((B.opt2 >> 4) & 15) && __popcll(bal_viol) <= ((B.opt2 >> 4) & 15) && ((probe_hash * 2654435761u >> 16) & ((1u << (2 * ((B.opt2 >> 2) & 3))) - 1u)) == 0u && (!(B.opt2 >> 8) || vmax_all <= 0.05 * (double)(B.opt2 >> 8)))) && nalt < 63 && (B.seq_kinds & 0x4000000) == 0) { ck[nalt] = -2; ca[nalt] = 0; nalt++; }
     fam[0] = base; fam[1] = stride; fam[2] = jlo; fam[3] = jhi;
     sh_base[2] = nalt;
   }
@@ -2102,7 +2114,8 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   __shared__ int sh_take, sh_base, sh_m, sh_keep, sh_pick, sh_ties, sh_w, sh_mv, sh_all, sh_elig;
   __shared__ double sh_inc;
   __shared__ unsigned int hist[256], dhist[256];
-  __shared__ int sh_dkeep;
+  __shared__ int sh_dkeep, sh_tiecnt;
+  __shared__ unsigned long long sh_thr2;
   __shared__ unsigned long long sh_prefix, sh_thr, sh_fmin;
   __shared__ double red[SEL_THREADS];
   if (B.inst_done[inst]) return;
@@ -2166,6 +2179,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
         if (bin > 255) { bin = 255; if (shift == 56) sh_all = 1; }
         sh_prefix = prefix | ((unsigned long long)bin << shift);
         sh_pick = need - (int)cum;   // how many of the keys with this prefix are still needed
+        sh_tiecnt = (int)hist[bin];  // (after the last pass: how many keys share the resolved bits of the threshold)
       }
       __syncthreads();
       need = sh_pick;
@@ -2369,14 +2383,48 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   __syncthreads();
   const int take = sh_take, base = sh_base;
   // ---- radix select: smallest key value T such that count(key <= T) >= take
+  // Keys that agree in the resolved bits are ties.  Which of them are taken is decided by a second select on what the node
+  // itself carries - the unresolved low bits of its key and its sibling preference - not by the order the lanes arrive in:
+  // the list order is not reproducible (children are appended as their parents' evaluations finish), and a pick by arrival
+  // would make the tree, and with it which solution within the gap is returned, differ from run to run.
+  auto second_key = [&](unsigned long long key, int dp) -> unsigned long long { return (((key & lowmask) << 6) | (unsigned long long)(63 - (dp & 63))) << 34; };
   if (take > 0 && take < m) {
-    const int need = radix([&](int k) { return keys[k]; }, n, take);
-    if (tid == 0) { sh_thr = sh_prefix; sh_ties = need; sh_pick = 0; }   // threshold on the resolved (high) bits
+    int need = radix([&](int k) { return keys[k]; }, n, take);
+    const unsigned long long thr1 = sh_prefix; const int tiecnt = sh_tiecnt;
     __syncthreads();
-  } else if (tid == 0) { sh_thr = take >= m ? ~0ull : 0ull;   /* ~0: above every masked key */ sh_ties = 0x7FFFFFFF; sh_pick = 0; }
+    unsigned long long thr2 = ~0ull;
+    if (B.det_ties && need < tiecnt) {
+      if (tiecnt <= SEL_THREADS) {
+        // the usual case, a handful of siblings: the ties are collected (one pass over the keys) and ranked in LDS
+        unsigned long long* tie = (unsigned long long*)red;
+        if (tid == 0) sh_elig = 0;
+        __syncthreads();
+        for (int k = tid; k < n; k += SEL_THREADS) {
+          const unsigned long long key = keys[k];
+          if (key != ~0ull && (key & ~lowmask) == thr1) { const int t = atomicAdd(&sh_elig, 1); if (t < SEL_THREADS) tie[t] = second_key(key, B.open_depth[src + k]); }
+        }
+        __syncthreads();
+        const int tc = sh_elig < SEL_THREADS ? sh_elig : SEL_THREADS;
+        if (tid < tc) {
+          const unsigned long long v = tie[tid]; int lt = 0, le = 0;
+          for (int j = 0; j < tc; ++j) { const unsigned long long u = tie[j]; lt += u < v ? 1 : 0; le += u <= v ? 1 : 0; }
+          if (lt < need && need <= le) { sh_thr2 = v; sh_ties = need - lt; }   // (equal values write the same)
+        }
+        __syncthreads();
+        thr2 = sh_thr2; need = sh_ties;
+        __syncthreads();
+      } else {
+        need = radix([&](int k) -> unsigned long long { const unsigned long long key = keys[k]; if (key == ~0ull || (key & ~lowmask) != thr1) return ~0ull; return second_key(key, B.open_depth[src + k]); }, n, need);
+        thr2 = sh_prefix;
+        __syncthreads();
+      }
+    }
+    if (tid == 0) { sh_thr = thr1; sh_thr2 = thr2; sh_ties = need; sh_pick = 0; }   // threshold on the resolved (high) bits
+    __syncthreads();
+  } else if (tid == 0) { sh_thr = take >= m ? ~0ull : 0ull;   /* ~0: above every masked key */ sh_thr2 = ~0ull; sh_ties = 0x7FFFFFFF; sh_pick = 0; }
   __syncthreads();
   // ---- pass 3: emit the selected nodes, keep the rest (near list, or far tier when the round spills)
-  const unsigned long long thr = sh_thr;
+  const unsigned long long thr = sh_thr, thr2 = sh_thr2;
   for (int k0 = 0; k0 < n; k0 += SEL_THREADS) {
     const int k = k0 + tid;
     unsigned long long key = k < n ? keys[k] : ~0ull;
@@ -2388,7 +2436,11 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
       if (take > 0) {
         const unsigned long long kh = key & (~0ull << SEL_LOWSHIFT);
         if (kh < thr) pick = true;
-        else if (kh == thr) { int t = atomicAdd(&sh_ties, -1); pick = t > 0; }
+        else if (kh == thr) {
+          const unsigned long long s2 = thr2 != ~0ull ? second_key(key, dp) : 0ull;
+          if (thr2 != ~0ull && s2 < thr2) pick = true;
+          else if (thr2 == ~0ull || s2 == thr2) { int t = atomicAdd(&sh_ties, -1); pick = t > 0; }
+        }
       }
       if (pick) {
         int pos = atomicAdd(&sh_pick, 1);

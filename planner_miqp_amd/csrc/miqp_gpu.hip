@@ -232,6 +232,10 @@ struct DevCtx {
   int* d_pairs = nullptr;   // admissions of one round: (slot, instance) pairs
   int* h_pin = nullptr; size_t h_pin_n = 0;   // pinned host buffer for the per-round read-back (batch count + done flags)
   hipEvent_t ev_sel = nullptr;
+  // concurrent launch of the memory-backed kernel on the rounding probes of a batch (second stream, its own work counter and
+  // per-block buffers): see launch_ipm_batch
+  hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int* work_counter2 = nullptr; double* rowstate2 = nullptr; double* rowcache2 = nullptr; double* kgain2 = nullptr; int probe_grid = 0;
   int oc_grid = 0;   // resident wavefronts of the on-chip interior point kernel (0: the shape does not qualify)
   DevBuf B{};
   std::vector<void*> allocs;
@@ -388,6 +392,16 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&B.rowcache, (size_t)std::min(batch_alloc, X.ipm_grid_max) * NCACHE * Y.ROWCAP)) return false;
   if (!X.alloc(&B.kgain, (size_t)std::min(batch_alloc, X.ipm_grid_max) * std::max(Y.N * Y.nu * (Y.nx + 2), oc_gain_doubles(Y.N)))) return false;
   if (!X.alloc(&B.work_counter, 1)) return false;
+  // buffers of the concurrent probe launch (two cars and fewer, on-chip kernel in use): 1024 resident blocks
+  X.probe_grid = 0;
+  if (X.oc_grid > 0 && !(std::getenv("MIQP_PROBE_OVERLAP") && std::atoi(std::getenv("MIQP_PROBE_OVERLAP")) == 0)) {
+    X.probe_grid = std::min(batch_alloc, 1536);
+    if (!X.alloc(&X.work_counter2, 1)) return false;
+    if (!X.alloc(&X.rowstate2, (size_t)X.probe_grid * NFIELD * Y.ROWCAP)) return false;
+    if (!X.alloc(&X.rowcache2, (size_t)X.probe_grid * NCACHE * Y.ROWCAP)) return false;
+    if (!X.alloc(&X.kgain2, (size_t)X.probe_grid * Y.N * Y.nu * (Y.nx + 2))) return false;
+    if (!X.stream2) { HIP_OK(hipStreamCreate(&X.stream2)); HIP_OK(hipEventCreate(&X.ev_fork)); HIP_OK(hipEventCreate(&X.ev_join)); }
+  }
   if (!X.alloc(&B.ovf_count, 1)) return false;
   if (!X.alloc(&B.ovf_list, batch_alloc)) return false;
   HIP_OK(hipMemset(B.ovf_count, 0, 4));
@@ -433,12 +447,27 @@ void launch_ipm_c(int C, const DevBuf& B, int nblocks, size_t lds, hipStream_t s
 // interior point solves of the first `bc` batch entries: the on-chip kernel where the shape qualifies, followed by the
 // memory-backed kernel on the nodes it handed over (their count stays on the device: no host round trip); else the
 // memory-backed kernel on everything
-void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st) {
+// The rounding probes of the batch (every disjunction fixed: >= 480 general rows, always beyond the on-chip capacity) are known
+// before the launch - their depth word says so - and go to a launch of the memory-backed kernel on a SECOND stream that runs
+// beside the on-chip kernel: that kernel waits on memory for most of its cycles (58 % in s_waitcnt), the on-chip kernel is bound
+// by VALU issue, and the probes no longer cost a generation of their own behind it.  `overlap` false (the polish, solve_fixed): the
+// serial order of round 2.
+void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool overlap = false) {
   const Layout& Y = X.Y;
   const size_t l_ipm = ipm_lds_bytes(Y);
   if (X.oc_grid > 0) {
     const size_t l_oc = (size_t)oc_lds_layout(Y.N, Y.fixlen).total;
-    if (Y.C == 1) launch_ipm_oc<1>(B, std::min(bc, X.oc_grid), l_oc, st); else launch_ipm_oc<2>(B, std::min(bc, X.oc_grid), l_oc, st);
+    const bool ov = overlap && X.probe_grid > 0 && X.stream2 && bc <= 4096;   // (a full batch keeps the device busy on its own: measured no gain there, 5.4 against 5.1 s on a 2048-instance queue; single solves: median 6.0 instead of 7.0 ms)
+    DevBuf Bc = B;
+    if (ov) {
+      (void)hipEventRecord(X.ev_fork, st); (void)hipStreamWaitEvent(X.stream2, X.ev_fork, 0);
+      DevBuf Bp = B; Bp.ovf_mode = 2; Bp.work_counter = X.work_counter2; Bp.rowstate = X.rowstate2; Bp.rowcache = X.rowcache2; Bp.kgain = X.kgain2;
+      launch_ipm_c(Y.C, Bp, std::min(bc, X.probe_grid), l_ipm, X.stream2);
+      (void)hipEventRecord(X.ev_join, X.stream2);
+      Bc.skip_probes = 1;
+    }
+    if (Y.C == 1) launch_ipm_oc<1>(Bc, std::min(bc, X.oc_grid), l_oc, st); else launch_ipm_oc<2>(Bc, std::min(bc, X.oc_grid), l_oc, st);
+    if (ov) (void)hipStreamWaitEvent(st, X.ev_join, 0);   // (the launch below and the evaluation need the probes' results; it also keeps the two memory-backed launches apart)
     DevBuf Bo = B; Bo.ovf_mode = 1;
     launch_ipm_c(Y.C, Bo, std::min(bc, X.ipm_grid_max), l_ipm, st);   // blocks without a node read the count and leave
   } else {
@@ -782,6 +811,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   B.base_take = std::max(1, std::min(npr, std::getenv("MIQP_BASE_TAKE") ? std::atoi(std::getenv("MIQP_BASE_TAKE")) : 8));
   B.share_cap = std::max(1, std::getenv("MIQP_SHARE_CAP") ? std::atoi(std::getenv("MIQP_SHARE_CAP")) : 1024);
   B.probe_room = std::getenv("MIQP_PROBE_ROOM") ? std::atof(std::getenv("MIQP_PROBE_ROOM")) : 0.0;
+  B.live_inc = std::getenv("MIQP_LIVE_INC") ? std::atoi(std::getenv("MIQP_LIVE_INC")) : 0;
+  B.det_ties = std::getenv("MIQP_DET_TIES") ? std::atoi(std::getenv("MIQP_DET_TIES")) : 1;
   B.window_pct = std::max(1, std::min(100, std::getenv("MIQP_WINDOW") ? std::atoi(std::getenv("MIQP_WINDOW")) : 100));
   HIP_OK(hipMemsetAsync(B.far_count, 0, (size_t)n * 4, st)); HIP_OK(hipMemsetAsync(B.far_minkey, 0xFF, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_mode, 0, (size_t)n * 4, st));
@@ -860,7 +891,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       HIP_OK(hipEventRecord(X.ev_sel, st));
       if (X.ipm_ev.size() < nev + 2) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); X.ipm_ev.push_back(a); X.ipm_ev.push_back(b); }
       HIP_OK(hipEventRecord(X.ipm_ev[nev], st));
-      launch_ipm_batch(X, B, X.batch_cap, st);
+      launch_ipm_batch(X, B, X.batch_cap, st, false);
       HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
       { DevBuf Be = B; Be.open_sel = 1 - (rounds & 1); launch_eval_c(Y.C, Be, X.batch_cap, l_eval, st); }
       HIP_OK(hipEventSynchronize(X.ev_sel));
@@ -912,7 +943,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     }
     if (X.ipm_ev.size() < nev + 2) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); X.ipm_ev.push_back(a); X.ipm_ev.push_back(b); }
     HIP_OK(hipEventRecord(X.ipm_ev[nev], st));
-    launch_ipm_batch(X, B, bc, st);
+    launch_ipm_batch(X, B, bc, st, true);
     HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
     nev += 2;
     if (bc == X.batch_cap) {   // MIQP_REPLAY=k (diagnostic): the first full batch is solved k more times under a timer - the kernels
@@ -948,6 +979,17 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       }
     }
     if (std::getenv("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d ipm (%d nodes): %s\n", rounds, bc, hipGetErrorString(e_)); }
+    if (std::getenv("MIQP_TRACE")) {   // diagnostic: the solved batch of the round in an order that does not depend on the batch slots, for diffing two runs
+      HIP_OK(hipStreamSynchronize(st));
+      if (X.stream2) HIP_OK(hipStreamSynchronize(X.stream2));
+      std::vector<int> hd(bc), hi(bc), hk(bc); std::vector<double> ho(bc), hb(bc), hv(bc);
+      HIP_OK(hipMemcpy(hd.data(), B.batch_depth, bc * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(hi.data(), B.batch_it, bc * 4, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(hk.data(), B.batch_ok, bc * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(ho.data(), B.batch_obj, bc * 8, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(hb.data(), B.batch_bound, bc * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(hv.data(), B.batch_viol, bc * 8, hipMemcpyDeviceToHost));
+      std::vector<int> ord(bc); for (int k = 0; k < bc; ++k) ord[k] = k;
+      std::sort(ord.begin(), ord.end(), [&](int a, int b) { return hd[a] != hd[b] ? hd[a] < hd[b] : (ho[a] != ho[b] ? ho[a] < ho[b] : hi[a] < hi[b]); });
+      for (int k : ord) std::fprintf(stderr, "[trace] r%d depth %d.%d ok %d it %d obj %a bound %a viol %.3e\n", rounds, hd[k] >> 6, hd[k] & 63, hk[k], hi[k], ho[k], hb[k], hv[k]);
+    }
     { DevBuf Be = B; Be.open_sel = 1 - (rounds & 1); launch_eval_c(Y.C, Be, bc, l_eval, st); }
     if (std::getenv("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d eval: %s\n", rounds, hipGetErrorString(e_)); }
     launched_nodes += bc; rounds++;

@@ -175,6 +175,21 @@ def test_debug_outputs_round_trip(tmp_path):
     assert "pos_x = [[" in txt and "active_region = [[[" in txt
 
 
+def test_repeated_single_solves_are_bit_identical():
+    """CPLEX's default parallel mode is deterministic (the reference's test_hardcoded_data_versus_datfile relies on it,
+    test/cplex_wrapper_test.cc:474-505): the same instance solved again returns the same objective, gap and node count,
+    bit for bit - ties of the node selection are broken by the nodes' own keys and evaluation prunes with the incumbent
+    of the start of the round, not by the order concurrent workgroups finish in"""
+    for p in (synthetic.generate("cfg3", 5, gap=0.01, max_time=10), synthetic.generate("cfg3", 11, gap=0.1, max_time=10)):
+        seen = set()
+        for _ in range(4):
+            w = P.CplexWrapper(); w.resetParameters(p)
+            assert int(w.callCplex()) == 0
+            s = w.getSolutionProperties()
+            seen.add((float(s.objective).hex(), float(s.gap).hex(), int(s.nodes), int(s.NrIterations)))
+        assert len(seen) == 1, seen
+
+
 def test_last_solution_warmstart_through_mst_file(tmp_path):
     """LAST_SOLUTION_WARMSTART (src/cplex_wrapper.cpp:128-138, 206-209): the solve writes an .mst, the next solve reads
     it as MIP start; the start is accepted as first incumbent (objective not worse, far fewer nodes)"""
