@@ -26,11 +26,16 @@ def build(f):
 
 def test_fixture_file_is_there_and_covers_multi_car_cases():
     fx = fixtures()
-    assert len(fx) >= 4 and sum(f["config"][0] >= 2 for f in fx) >= 3 and any(f["config"][4] >= 1 for f in fx)
+    assert len(fx) >= 10 and sum(f["config"][0] >= 2 for f in fx) >= 3 and any(f["config"][4] >= 1 for f in fx)
+    # config = (cars, steps past the first, regions, environment pieces, obstacles): three and four cars, the bench's 32
+    # regions over a two-piece environment, a soft obstacle (the slack branch of obstacle_environment_constraints.mod:85-91)
+    assert any(f["config"][0] == 3 for f in fx) and any(f["config"][0] == 4 for f in fx)
+    assert any(f["config"][2] == 32 and f["config"][3] == 2 for f in fx)
+    assert any(f["modifier"] == "soft" and f["config"][4] >= 1 for f in fx)
     assert all(f["bound"] <= f["objective"] + 1e-9 and f["objective"] - f["bound"] <= 2e-6 * max(1.0, abs(f["objective"])) for f in fx)
 
 
-@pytest.mark.parametrize("k", range(12))
+@pytest.mark.parametrize("k", range(16))
 def test_oracle_brackets_the_independent_optimum(oracle, k):
     fx = fixtures()
     if k >= len(fx):
