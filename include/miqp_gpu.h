@@ -164,6 +164,11 @@ int miqp_solver_solve_fixed(miqp_solver_t* s, const miqp_raw_results_c* fixed, m
  * out[3] = node relaxations solved, out[4] = IPM iterations (summed over nodes), out[5] = rows x iterations */
 int miqp_solver_last_timing(const miqp_solver_t* s, double* out6);
 
+/* host set-up of the last solve / batch / stream call this handle took part in: out[0] = seconds from the entry of the call to
+ * the first round, out[1] = of which building the device context (pools, lists: reused by a call of the same shape with no more
+ * instances than its per-instance arrays hold), out[2] = 1 when the context was built or rebuilt by that call, else 0 */
+int miqp_solver_last_setup(const miqp_solver_t* s, double* out3);
+
 /* ---- planner core: the host logic directly above the solve ---- */
 
 /* ParameterPreparer::CalculateFractionParameters             common/parameter/parameter_preparer.cpp:37-52; out[R*4] */

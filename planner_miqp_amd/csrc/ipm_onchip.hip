@@ -22,7 +22,7 @@ namespace miqp {
 
 constexpr int OC_GCAP = 128;      // general rows kept on chip (2 register slots per lane)
 constexpr int OC_GSLOTS = OC_GCAP / 64;
-constexpr int OC_GCOEF = 448;     // their packed coefficients
+constexpr int OC_GCOEF = 432;     // their packed coefficients (with N = 20 and a 480-byte fix record the block stays within 160 KB / 8: 2 wavefronts per SIMD)
 constexpr int OC_SCR = 32;        // rows decoded per round through the dense scratch rows
 constexpr int OC_SSTR = 17;       // stride of a scratch row (conflict free)
 constexpr int OC_KL0 = 6;         // stages whose gains stay in LDS

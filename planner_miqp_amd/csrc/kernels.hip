@@ -138,6 +138,8 @@ struct DevBuf {
   // Earliest deadline first finishes what it starts; the cap (1024: narrow rounds waste the fewest nodes - every round prunes
   // with the incumbents of the one before) keeps a pathological instance to 3 % of the device.
   int* slot_demand; int* slot_take; int share_cap; int base_take; int window_pct; double probe_room;
+  int probe_itcap;               // iterations after which an unconverged rounding probe is abandoned (0: never)
+  int probe_every;               // rounding probes are eligible every probe_every-th round (1: always)
   int det_ties;                  // 1: ties of the node selection are broken by the nodes' own low key bits and sibling preference (reproducible), 0: by arrival
   int live_inc;                  // 1: node evaluation prunes with the incumbent as other nodes of the same round update it (order dependent); 0: with the incumbent of the start of the round (reproducible)
   const int* root_cnt; const int* root_node; const int* root_depth; int root_stride;   // root records of every instance (uploaded once; admit_kernel writes them into the slot's list)
@@ -696,6 +698,10 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     }
     if (MIQP_ABL) { if (it > (((MIQP_ABL) & 512) ? 0 : 20)) { ok = 1; break; } }
     else if (comp < B.qp_tol * fmax(1.0, fabs(obj)) && resid_fac * R0 < 1e-7) { ok = 1; break; }
+    // A rounding probe is a heuristic (it lies inside the first child, the children stay exhaustive without it): one that has
+    // not converged after probe_itcap iterations - nearly always an infeasible rounding, 27 iterations to prove - is abandoned.
+    // The launch of this kernel lasts as long as its slowest node.
+    if (B.probe_itcap > 0 && it > B.probe_itcap && B.ws_on != 2 && is_probe_word(B.batch_depth[node])) { ok = 2; break; }
     // dual bound of the penalised problem: primal value - total complementarity (valid once the iterate is dual feasible)
 #ifdef MIQP_PROFILE
     if (it > 1 && first_proxy == 0 && obj + RHO_EL * tsum - (double)ncomp * comp > cutoff + 1e-9 * fabs(cutoff)) first_proxy = it;
@@ -1431,7 +1437,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   if (B.stats && lane == 0) {   // diagnostic (MIQP_STATS): outcome of the node and the iterations it took
     const int oc_ = okq == 2 ? 1 : (viol > FEAS_TOL ? 0 : (okq != 1 ? 2 : 3));   // infeasible, cut off, not converged, solved
     atomicAdd(&B.stats[32 + oc_], 1ull); atomicAdd(&B.stats[36 + oc_], (unsigned long long)B.batch_it[node]);
-    if (B.pool_origin) { const int og_ = (int)B.pool_origin[B.batch_node[node]] & 15; atomicAdd(&B.stats[80 + og_], 1ull); atomicAdd(&B.stats[96 + 16 * oc_ + og_], 1ull); }   // the same by the branching that created the node
+    if (B.pool_origin) { const int og_ = (int)B.pool_origin[B.batch_node[node]] & 15; atomicAdd(&B.stats[80 + og_], 1ull); atomicAdd(&B.stats[96 + 16 * oc_ + og_], 1ull); if (og_ == 15) { const int ib_ = B.batch_it[node] / 3; atomicAdd(&B.stats[192 + 16 * oc_ + (ib_ > 15 ? 15 : ib_)], 1ull); } }   // the same by the branching that created the node
   }
   if (viol > FEAS_TOL || okq != 1) { FREE_NODE(); return; }  // infeasible relaxation, or abandoned at the incumbent cutoff
   // soft obstacles that this node ignores cost WEIGHTS_SLACK_OBSTACLE each (obstacle_environment_constraints.mod:85-91)
@@ -2114,7 +2120,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   __shared__ int sh_take, sh_base, sh_m, sh_keep, sh_pick, sh_ties, sh_w, sh_mv, sh_all, sh_elig;
   __shared__ double sh_inc;
   __shared__ unsigned int hist[256], dhist[256];
-  __shared__ int sh_dkeep, sh_tiecnt;
+  __shared__ int sh_dkeep, sh_tiecnt, sh_ndef;
   __shared__ unsigned long long sh_thr2;
   __shared__ unsigned long long sh_prefix, sh_thr, sh_fmin;
   __shared__ double red[SEL_THREADS];
@@ -2127,7 +2133,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     sh_inc = inc_from_key(key);
     sh_take = -1;
     if (key != B.inc_seen[inst]) { sh_take = (int)(key & 0xFFFFFull); B.inc_seen[inst] = key; }
-    sh_m = 0; sh_keep = 0; sh_pick = 0; sh_ties = 0;
+    sh_m = 0; sh_keep = 0; sh_pick = 0; sh_ties = 0; sh_ndef = 0;
   }
   __syncthreads();
   if (sh_take >= 0) {
@@ -2216,7 +2222,11 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   // ---- pass 1: prune, keys, lower bound, population per tree depth
   for (int k = tid; k < 256; k += SEL_THREADS) dhist[k] = 0u;
   __syncthreads();
-  double lb = 1e300; int mloc = 0;
+  double lb = 1e300; int mloc = 0, ndef = 0;
+  // Rounding probes are the large nodes (every region fixed: >= 480 general rows) that the on-chip kernel hands to the
+  // memory-backed one, whose launch lasts as long as its slowest node however few there are.  With many instances in flight
+  // they are only eligible every probe_every-th round: the same launch then takes the probes of several rounds.
+  const bool big_round = B.probe_every <= 1 || (round % B.probe_every) == B.probe_every - 1;
   for (int k = tid; k < n; k += SEL_THREADS) {
     double b = B.open_bound[src + k]; int nd = B.open_node[src + k]; int dp = B.open_depth[src + k];
     unsigned long long key = ~0ull;
@@ -2226,12 +2236,14 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     } else {
       lb = fmin(lb, b);
       key = order_key(b, dp);
+      if (!big_round && is_probe_word(dp)) { key = ~0ull - 1; ndef++; }   // waits for its round behind every other key
       atomicAdd(&dhist[(dp >> 6) > 255 ? 255 : (dp >> 6)], 1u);
       mloc++;
     }
     keys[k] = key;
   }
   if (mloc) atomicAdd(&sh_m, mloc);
+  if (ndef) atomicAdd(&sh_ndef, ndef);
   __syncthreads();
   int m = sh_m;
   // ---- far tier: when the near list cannot fill a batch any more, the far entries with the lowest bounds come back
@@ -2342,7 +2354,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   // proof has to process every node below (final incumbent) - gap anyway; nodes above that are only ever touched because the
   // incumbent of the moment is not the final one - a wide round reaches far up the list, a later round would find them pruned.
   // Deferring the upper part costs nothing but width, and the width goes to other instances (share_kernel).
-  int m_elig = m;
+  int m_elig = m - sh_ndef;   // (probes that wait for their round are not offered)
   if (!dive && inc < 1e300 && B.window_pct < 100 && m > 0) {
     const double top = inc - gap * (1e-10 + fabs(inc)) - cst;   // bounds are stored without the instance's constant
     const double thrw = lb + 0.01 * (double)B.window_pct * fmax(0.0, top - lb);
@@ -2354,6 +2366,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     if (ce) atomicAdd(&sh_elig, ce);
     __syncthreads();
     m_elig = sh_elig < 1 ? 1 : sh_elig;
+    if (m_elig > m - sh_ndef) m_elig = m - sh_ndef;
   }
   if (tid == 0) {
     sh_pick = 0;

@@ -77,6 +77,7 @@ struct miqp_solver {
   std::vector<double> Z; std::vector<signed char> comp; bool has_sol = false;
   Layout lay{};
   double timing[6] = {0, 0, 0, 0, 0, 0};
+  double setup[3] = {0, 0, 0};   // host set-up of the last call: seconds, of which the device context, 1 when the context was (re)built
   // MIP starts (each tried as an additional root: binaries fixed, QP solved, accepted as incumbent when feasible).
   // Slot 0: receding-horizon start (addRecedingHorizonWarmstart), slot 1: last-solution start (.mst file); with
   // BOTH_WARMSTART_STRATEGIES the reference applies both (src/cplex_wrapper.cpp:124-138)
@@ -229,12 +230,17 @@ struct DevCtx {
   bool ready = false; int device = -1;
   hipStream_t stream = nullptr;
   Layout Y{}; int n_inst = 0, n_slots = 0, open_cap = 0, far_cap = 0, batch_cap = 0, batch_alloc = 0, pool_cap = 0, npr = 0, ipm_grid_max = 1024;
+  int n_inst_cap = 0;      // instances the per-instance arrays hold: a call with fewer reuses the context as it is
+  int open_cap_req = 0;    // near-list capacity the caller asked for (open_cap: what the free memory allowed when the context was built)
+  int mem_div = 1;         // contexts that share the device (lanes of one stream call): each sizes its pools for its share of the free memory
+  int lane = 0;
   int* d_pairs = nullptr;   // admissions of one round: (slot, instance) pairs
   int* h_pin = nullptr; size_t h_pin_n = 0;   // pinned host buffer for the per-round read-back (batch count + done flags)
   hipEvent_t ev_sel = nullptr;
   // concurrent launch of the memory-backed kernel on the rounding probes of a batch (second stream, its own work counter and
   // per-block buffers): see launch_ipm_batch
   hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_mid = nullptr;   // MIQP_LAUNCH_TRACE
   int* work_counter2 = nullptr; double* rowstate2 = nullptr; double* rowcache2 = nullptr; double* kgain2 = nullptr; int probe_grid = 0;
   int oc_grid = 0;   // resident wavefronts of the on-chip interior point kernel (0: the shape does not qualify)
   DevBuf B{};
@@ -262,14 +268,14 @@ std::mutex g_ctx_table_mu;
 std::map<int, std::unique_ptr<DevCtx>> g_ctx_table;
 
 // resolves `device` (-1: the current device) and returns its context; nullptr without a HIP device
-DevCtx* ctx_for_device(int device) {
+DevCtx* ctx_for_device(int device, int lane = 0) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { std::fprintf(stderr, "[miqp_gpu] no HIP device: the solver has no CPU path\n"); return nullptr; }
   if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
   if (device >= ndev) { std::fprintf(stderr, "[miqp_gpu] device %d requested, %d visible\n", device, ndev); return nullptr; }
   std::lock_guard<std::mutex> lk(g_ctx_table_mu);
-  auto& slot = g_ctx_table[device];
-  if (!slot) { slot.reset(new DevCtx()); slot->device = device; }
+  auto& slot = g_ctx_table[device * 16 + (lane & 15)];   // lane 0: the context of the device; lanes 1..: the further contexts of a stream call that shares the device
+  if (!slot) { slot.reset(new DevCtx()); slot->device = device; slot->lane = lane; }
   return slot.get();
 }
 
@@ -279,15 +285,33 @@ bool same_layout(const Layout& a, const Layout& b) { return std::memcmp(&a, &b, 
 
 // caller holds X.mu; X.device is the resolved device ordinal
 // n_inst instances in the call (the queue), n_slots of them in flight at a time (list storage per slot), roots_per_inst root records each
-bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_cap, int npr, int roots_per_inst) {
+// `clamp_open`: the near-list capacity may be cut to what an eighth of the free memory holds (40 B per entry)
+// A ready context of the same shape is reused as it is when the call has no more instances than its per-instance arrays hold
+// (built for 64 queues' worth at least, within 4 GB): releasing and reallocating the pools - most of the device memory - costs
+// seconds, and a service that drains one queue after the other must not pay them per call (measured: 4.3 s of a 17 s bench stream).
+std::mutex g_ctx_build_mu;   // contexts are built one at a time: each sizes its pools from the memory that is free at that moment
+bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_cap, int npr, int roots_per_inst, bool clamp_open = false, int mem_div = 1) {
   int batch_cap = n_slots * npr;
-  const int batch_alloc = std::max(batch_cap, n_inst);   // the final polish solves one node per instance in one launch
   HIP_OK(hipSetDevice(X.device));   // the calling thread's current device (threads of solve_batch_multi each set their own)
-  if (X.ready && same_layout(X.Y, Y) && X.n_inst == n_inst && X.n_slots == n_slots && X.open_cap == open_cap && X.npr == npr && X.B.root_stride == roots_per_inst) return true;
+  if (X.ready && same_layout(X.Y, Y) && n_inst <= X.n_inst_cap && X.n_slots == n_slots && X.open_cap_req == open_cap && X.npr == npr && X.B.root_stride == roots_per_inst && X.mem_div == mem_div) {
+    X.n_inst = n_inst; X.B.n_inst = n_inst;
+    return true;
+  }
+  std::lock_guard<std::mutex> build_lock(g_ctx_build_mu);
   if (X.ready || !X.allocs.empty()) X.release();
   if (!X.stream) HIP_OK(hipStreamCreate(&X.stream));
   if (!X.ev0) { HIP_OK(hipEventCreate(&X.ev0)); HIP_OK(hipEventCreate(&X.ev1)); }
-  X.Y = Y; X.n_inst = n_inst; X.n_slots = n_slots; X.open_cap = open_cap; X.npr = npr; X.batch_cap = batch_cap; X.batch_alloc = batch_alloc;
+  X.open_cap_req = open_cap; X.mem_div = mem_div < 1 ? 1 : mem_div;
+  if (clamp_open) { size_t fb = 0, tb = 0; if (hipMemGetInfo(&fb, &tb) == hipSuccess) { const size_t lim = fb / (size_t)X.mem_div / 8 / 40 / (size_t)n_slots; if ((size_t)open_cap > lim) open_cap = (int)std::max<size_t>(4096, lim); } }
+  {   // capacity of the per-instance arrays (tables, incumbent records: dstride * 8 + istride * 4 + fix record + solution per instance)
+    const size_t per = (size_t)Y.dstride * 8 + (size_t)Y.istride * 4 + (size_t)Y.fixlen * 2 + (size_t)Y.N * Y.nz * 16 + 256;
+    size_t cap = std::min<size_t>((size_t)64 * (size_t)n_slots, ((size_t)4 << 30) / per);
+    X.n_inst_cap = (int)std::max<size_t>((size_t)n_inst, cap);
+  }
+  const int n_call = n_inst;
+  n_inst = X.n_inst_cap;   // everything below is sized for the capacity
+  const int batch_alloc = std::max(batch_cap, n_inst);   // the final polish solves one node per instance in one launch
+  X.Y = Y; X.n_inst = n_call; X.n_slots = n_slots; X.open_cap = open_cap; X.npr = npr; X.batch_cap = batch_cap; X.batch_alloc = batch_alloc;
   { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); int cus = 256; if (hipGetDeviceProperties(&pr, dv) == hipSuccess) cus = pr.multiProcessorCount;
     size_t l = ipm_lds_bytes(Y); int per = (int)std::max<size_t>(1, std::min<size_t>(4 * (Y.C <= 2 ? MIQP_IPM_WPE : 1), (160 * 1024) / std::max<size_t>(l + 8, 1))); X.ipm_grid_max = cus * per;
     // on-chip kernel: up to two cars, horizon within its register slots; 2 wavefronts per SIMD, as many as its LDS admits
@@ -297,12 +321,14 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
     if (Y.C <= 2 && Y.N <= 2 * OC_NSL && bitmap_b + 1024 <= (size_t)(ol.r - ol.u) && !std::getenv("MIQP_IPM_V1")) {
       size_t lo = (size_t)ol.total + 16;
       int perc = (int)std::min<size_t>(8, (160 * 1024) / lo);
+      if (std::getenv("MIQP_OC_WAVES")) perc = std::max(1, std::min(perc, std::atoi(std::getenv("MIQP_OC_WAVES"))));   // (experiment: resident wavefronts of the on-chip kernel per CU)
       if (perc >= 1) X.oc_grid = cus * perc;
     }
     if (X.oc_grid > X.ipm_grid_max) X.ipm_grid_max = X.oc_grid;   // the per-block buffers are sized for the larger grid
   }
   // node pool: live nodes are bounded by the open lists plus one round of children; processed records are recycled
   size_t free_b = 0, total_b = 0; if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
+  free_b /= (size_t)X.mem_div;
   // far tier of the open lists (16 B per entry): up to 2^24 entries per instance within a tenth of the free memory
   // (256 instances: 4 M entries each, 16 GB); MIQP_FAR_CAP overrides, 0 switches the tier off
   { size_t fc = std::min<size_t>((size_t)1 << 24, free_b / 10 / 16 / (size_t)n_slots);
@@ -316,7 +342,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   B.qp_tol = QP_TOL; B.use_cutoff = 1;
   B.opt2 = std::getenv("MIQP_OPT2") ? std::atoi(std::getenv("MIQP_OPT2")) : (8 << 4);   // rounding probe at nodes with at most 8 violated sites (eval_kernel)
   B.seq_kinds = std::getenv("MIQP_SEQ_KINDS") ? (int)std::strtoul(std::getenv("MIQP_SEQ_KINDS"), nullptr, 0) : (5 << 8);   // plain K-way children, branching order 5 (see eval_kernel)
-  B.Y = Y; B.pool_cap = X.pool_cap; B.open_cap = open_cap; B.batch_cap = batch_cap; B.nodes_per_round = npr; B.n_inst = n_inst; B.n_slots = n_slots; B.root_stride = roots_per_inst;
+  B.Y = Y; B.pool_cap = X.pool_cap; B.open_cap = open_cap; B.batch_cap = batch_cap; B.nodes_per_round = npr; B.n_inst = n_call; B.n_slots = n_slots; B.root_stride = roots_per_inst;
   double* dd; int* ii;
   if (!X.alloc(&dd, (size_t)n_inst * Y.dstride)) return false; B.inst_d = dd;
   if (!X.alloc(&ii, (size_t)n_inst * Y.istride)) return false; B.inst_i = ii;
@@ -467,6 +493,7 @@ void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool o
       Bc.skip_probes = 1;
     }
     if (Y.C == 1) launch_ipm_oc<1>(Bc, std::min(bc, X.oc_grid), l_oc, st); else launch_ipm_oc<2>(Bc, std::min(bc, X.oc_grid), l_oc, st);
+    if (X.ev_mid) (void)hipEventRecord(X.ev_mid, st);   // (diagnostic, MIQP_LAUNCH_TRACE: where the on-chip kernel ends)
     if (ov) (void)hipStreamWaitEvent(st, X.ev_join, 0);   // (the launch below and the evaluation need the probes' results; it also keeps the two memory-backed launches apart)
     DevBuf Bo = B; Bo.ovf_mode = 1;
     launch_ipm_c(Y.C, Bo, std::min(bc, X.ipm_grid_max), l_ipm, st);   // blocks without a node read the count and leave
@@ -687,7 +714,8 @@ void split_roots(const Layout& Y, const int* T, std::vector<std::vector<std::pai
 // `inflight`: instances solved concurrently (<= 0 or >= n: all of them).  With fewer than n the call is a queue drained by
 // streaming admission: an instance that is proven (or has used up its own max_solution_time, counted from its admission)
 // hands its slot to the next one at the following round.
-bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const SplitCtx* split = nullptr, int inflight = 0) {
+// `lane` / `lanes`: this call is one of `lanes` concurrent calls that share the device, each with its own context (miqp_solver_solve_stream)
+bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const SplitCtx* split = nullptr, int inflight = 0, int lane = 0, int lanes = 1) {
   if (split && n != 1) { for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
   BatchShape bs = batch_layout(S, n);
   if (!bs.ok) { for (int k = 0; k < n; ++k) { if (S[k]) S[k]->err = bs.err; statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; } std::fprintf(stderr, "[miqp_gpu] %s\n", bs.err.c_str()); return false; }
@@ -696,26 +724,28 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   auto fail_all = [&](const char* why) { if (why) std::fprintf(stderr, "[miqp_gpu] %s\n", why); for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; };
   for (int k = 1; k < n; ++k) if (S[k]->opts.device != O0.device) return fail_all("instances of one batch must name the same device (use miqp_solver_solve_batch_multi to span devices)");
   const double t_enter = wall_s();
-  DevCtx* Xp = ctx_for_device(O0.device);
+  DevCtx* Xp = ctx_for_device(O0.device, lane);
   if (!Xp) return fail_all(nullptr);
   DevCtx& X = *Xp;
   std::lock_guard<std::mutex> ctx_lock(X.mu);
   if (hipSetDevice(X.device) != hipSuccess) return fail_all("hipSetDevice failed");
   const int NS = (split || inflight <= 0 || inflight >= n) ? n : inflight;   // slots = instances in flight
-  int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(16384, 32768 / NS));
+  int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(16384, 32768 / (NS * lanes)));   // (the lanes of a call keep the round width of the undivided call)
   if (O0.nodes_per_round <= 0 && std::getenv("MIQP_NPR")) npr = std::max(1, std::atoi(std::getenv("MIQP_NPR")));  // tuning knob
   int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (std::getenv("MIQP_OPEN_CAP") ? std::atoi(std::getenv("MIQP_OPEN_CAP")) : std::max(1 << 17, std::min(1 << 20, (1 << 28) / NS)));   // near lists: 1 M entries per instance up to n = 256 (10 GB of list entries), 262144 at n = 1024; records are shared
   if (open_cap < 64) open_cap = 64;
   if (split && open_cap < SPLIT_MAXROOTS + 4 + 64) open_cap = SPLIT_MAXROOTS + 4 + 64;   // the root records of a tree split are the head of the list
-  { size_t free_b = 0, total_b = 0;   // list entries (40 B per open node) must fit an eighth of the free device memory
-    if (O0.max_open_nodes <= 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) { size_t lim = free_b / 8 / 40 / (size_t)NS; if ((size_t)open_cap > lim) open_cap = (int)std::max<size_t>(4096, lim); } }
+  // (list entries - 40 B per open node - must fit an eighth of the free device memory: ctx_prepare cuts the capacity when it builds the context)
   if ((size_t)NS * npr >= ((size_t)1 << 20)) npr = (int)((((size_t)1 << 20) - 1) / NS);
   const int MAXR = split ? SPLIT_MAXROOTS + 4 : 5;   // root records per instance: the root (or this rank's roots of a tree split), the MIP starts and their repair roots
   size_t l_ipm = ipm_lds_bytes(Y), l_eval = eval_lds_bytes(Y);
+  bool ctx_built = false;
   {
     // the fallible part of the set-up (device buffers, kernel attributes).  In a tree split the ranks agree on its outcome with
     // one exchange before the first round: a rank that failed alone would otherwise leave its peers waiting in their all-reduce
-    bool setup_ok = ctx_prepare(X, Y, n, NS, open_cap, npr, MAXR);
+    ctx_built = !(X.ready && same_layout(X.Y, Y) && n <= X.n_inst_cap && X.n_slots == NS && X.open_cap_req == open_cap && X.npr == npr && X.B.root_stride == MAXR && X.mem_div == lanes);
+    bool setup_ok = ctx_prepare(X, Y, n, NS, open_cap, npr, MAXR, O0.max_open_nodes <= 0, lanes);
+    open_cap = X.open_cap;
     if (setup_ok && (l_ipm > 160 * 1024 || l_eval > 160 * 1024)) { std::fprintf(stderr, "[miqp_gpu] instance too large for LDS (%zu bytes)\n", l_ipm); setup_ok = false; }
     if (setup_ok && !set_kernel_lds(Y, l_ipm, l_eval)) setup_ok = false;
     if (split) {
@@ -812,6 +842,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   B.share_cap = std::max(1, std::getenv("MIQP_SHARE_CAP") ? std::atoi(std::getenv("MIQP_SHARE_CAP")) : 1024);
   B.probe_room = std::getenv("MIQP_PROBE_ROOM") ? std::atof(std::getenv("MIQP_PROBE_ROOM")) : 0.0;
   B.live_inc = std::getenv("MIQP_LIVE_INC") ? std::atoi(std::getenv("MIQP_LIVE_INC")) : 0;
+  B.probe_every = std::getenv("MIQP_PROBE_EVERY") ? std::atoi(std::getenv("MIQP_PROBE_EVERY")) : 1;
+  B.probe_itcap = std::getenv("MIQP_PROBE_ITCAP") ? std::atoi(std::getenv("MIQP_PROBE_ITCAP")) : 0;
   B.det_ties = std::getenv("MIQP_DET_TIES") ? std::atoi(std::getenv("MIQP_DET_TIES")) : 1;
   B.window_pct = std::max(1, std::min(100, std::getenv("MIQP_WINDOW") ? std::atoi(std::getenv("MIQP_WINDOW")) : 100));
   HIP_OK(hipMemsetAsync(B.far_count, 0, (size_t)n * 4, st)); HIP_OK(hipMemsetAsync(B.far_minkey, 0xFF, (size_t)n * 8, st));
@@ -942,9 +974,26 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       continue;
     }
     if (X.ipm_ev.size() < nev + 2) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); X.ipm_ev.push_back(a); X.ipm_ev.push_back(b); }
+    static const bool launch_trace = std::getenv("MIQP_LAUNCH_TRACE") != nullptr;
+    if (launch_trace && !X.ev_mid) HIP_OK(hipEventCreate(&X.ev_mid));
     HIP_OK(hipEventRecord(X.ipm_ev[nev], st));
     launch_ipm_batch(X, B, bc, st, true);
     HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
+    if (launch_trace) {   // diagnostic: the two interior point launches of the round apart, and what the memory-backed one had to solve
+      HIP_OK(hipStreamSynchronize(st));
+      float m1 = 0, m2 = 0; HIP_OK(hipEventElapsedTime(&m1, X.ipm_ev[nev], X.ev_mid)); HIP_OK(hipEventElapsedTime(&m2, X.ev_mid, X.ipm_ev[nev + 1]));
+      int oc = 0; HIP_OK(hipMemcpy(&oc, B.ovf_count, 4, hipMemcpyDeviceToHost));
+      std::vector<int> ol(std::max(oc, 1)), hit(bc), hdw(bc), hok(bc);
+      if (oc > 0) HIP_OK(hipMemcpy(ol.data(), B.ovf_list, (size_t)oc * 4, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(hit.data(), B.batch_it, (size_t)bc * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(hdw.data(), B.batch_depth, (size_t)bc * 4, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(hok.data(), B.batch_ok, (size_t)bc * 4, hipMemcpyDeviceToHost));
+      int np = 0, mxp = 0, mxo = 0, mxc = 0; long long sp = 0, so = 0, sc = 0;
+      for (int q = 0; q < oc; ++q) { const int k = ol[q]; if ((hdw[k] & 63) == 63 && (hdw[k] >> 6) >= 1) { np++; sp += hit[k]; mxp = std::max(mxp, hit[k]); } else { so += hit[k]; mxo = std::max(mxo, hit[k]); } }
+      std::vector<char> isov(bc, 0); for (int q = 0; q < oc; ++q) isov[ol[q]] = 1;
+      for (int k = 0; k < bc; ++k) if (!isov[k]) { sc += hit[k]; mxc = std::max(mxc, hit[k]); }
+      std::fprintf(stderr, "[launch] round %d nodes %d: on-chip %.2f ms (%d nodes, mean it %.1f, max %d); memory-backed %.2f ms: %d probes (mean it %.1f, max %d), %d others (mean it %.1f, max %d)\n",
+                   rounds, bc, m1, bc - oc, (double)sc / std::max(1, bc - oc), mxc, m2, np, (double)sp / std::max(1, np), mxp, oc - np, (double)so / std::max(1, oc - np), mxo);
+    }
     nev += 2;
     if (bc == X.batch_cap) {   // MIQP_REPLAY=k (diagnostic): the first full batch is solved k more times under a timer - the kernels
       static int replay = std::getenv("MIQP_REPLAY") ? std::atoi(std::getenv("MIQP_REPLAY")) : 0;   // only read and write batch slots
@@ -1034,7 +1083,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL; Bp.use_cutoff = 0; Bp.batch_cap = X.batch_alloc;
     // the polish starts at the incumbent's own solution (integer feasible: every row of the completed record holds there), centred
     // at a small complementarity - a third of the iterations of a cold solve to 1e-13 (the last thing a single solve waits for)
-    Bp.ws_on = (B.ws_on && !std::getenv("MIQP_POLISH_COLD")) ? 2 : 0; Bp.ws_mu = 1.0e-2; Bp.ws_delta = 1.0e-4;
+    Bp.ws_on = (B.ws_on && !std::getenv("MIQP_POLISH_COLD")) ? 2 : 0; Bp.ws_mu = std::getenv("MIQP_POLISH_MU") ? std::atof(std::getenv("MIQP_POLISH_MU")) : 1.0e-2; Bp.ws_delta = std::getenv("MIQP_POLISH_DELTA") ? std::atof(std::getenv("MIQP_POLISH_DELTA")) : 1.0e-4;
     int nb = std::min(n, X.batch_alloc);
     launch_ipm_batch(X, Bp, nb, st);
     HIP_OK(hipMemcpyAsync(h_pobj.data(), B.batch_obj, nb * 8, hipMemcpyDeviceToHost, st));
@@ -1076,6 +1125,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     std::fprintf(stderr, "\n[miqp_gpu stats] node outcomes by origin (processed: infeasible / cut off / not converged / solved):");
     const char* on_[16] = {"root|reg-ref", "reg-adjacent", "reg-other", "reg-slow", "env-ref", "env-other", "-", "-", "obs-ref", "obs-other", "-", "-", "c2c-ref", "c2c-other", "-", "probe"};
     for (int q = 0; q < 16; ++q) if (hs[80 + q]) std::fprintf(stderr, " %s %llu: %llu / %llu / %llu / %llu;", on_[q], hs[80 + q], hs[96 + q], hs[112 + q], hs[128 + q], hs[144 + q]);
+    std::fprintf(stderr, "\n[miqp_gpu stats] rounding probes by iterations / 3 (0-2, 3-5, ..., 45+):");
+    { const char* oc_n[4] = {"infeasible", "cut off", "not converged", "solved"};
+      for (int o = 0; o < 4; ++o) { std::fprintf(stderr, " %s", oc_n[o]); for (int q = 0; q < 16; ++q) std::fprintf(stderr, " %llu", hs[192 + 16 * o + q]); std::fprintf(stderr, ";"); } }
     std::fprintf(stderr, "\n");
   }
   double ms_ipm = 0;
@@ -1133,6 +1185,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     s->props.NrSolutionPool = h_ninc[k];
     s->timing[0] = ms_all * 1e-3; s->timing[1] = ms_ipm * 1e-3; s->timing[2] = (double)(nev / 2); s->timing[3] = (double)launched_nodes;
     s->timing[4] = (double)tot_iters; s->timing[5] = (double)rowiters;
+    s->setup[0] = t_setup; s->setup[1] = t_ctx; s->setup[2] = ctx_built ? 1.0 : 0.0;
     if (have) {
       s->status = MIQP_STATUS_SUCCESS; s->has_sol = true;
       s->props.objective = h_inc[k];
@@ -1220,9 +1273,37 @@ int miqp_solver_solve_batch(miqp_solver_t* const* solvers, int n, int* statuses)
   return solve_batch_impl(solvers, n, statuses) ? 0 : -2;
 }
 
+// A long queue is drained by LANES: the instances are dealt round robin to `lanes` sub-queues, each with its share of the slots,
+// its own device context (pools, streams) and its own host thread, all on the same device.  The rounds of the lanes are not
+// synchronised with each other, so the phases of a round that leave most of the device idle - the memory-backed launch on
+// the few large nodes (it lasts as long as its slowest node), selection, the host's look at the counters between two
+// rounds - run beside the on-chip launch of another lane.  Measured on one MI355X (tools/lanes_sweep.sh, the bench queue):
+// 633 solves/s with one lane, 660 with two, 649 with three, 571 with four - the on-chip kernel fills the register files, so
+// what hides is little, and the per-launch times of concurrent lanes no longer say what a kernel costs.  OFF by default
+// (MIQP_LANES=2 switches it on); lanes are used when every lane keeps at least 128 instances in flight and the queue is
+// longer than the slots.
 int miqp_solver_solve_stream(miqp_solver_t* const* solvers, int n, int inflight, int* statuses) {
   if (!solvers || n < 1 || !statuses) return -1;
-  return solve_batch_impl(solvers, n, statuses, nullptr, inflight) ? 0 : -2;
+  int lanes = std::getenv("MIQP_LANES") ? std::atoi(std::getenv("MIQP_LANES")) : 1;
+  if (lanes > 8) lanes = 8;
+  while (lanes > 1 && (inflight <= 0 || inflight >= n || inflight / lanes < 128)) lanes--;
+  if (lanes <= 1) return solve_batch_impl(solvers, n, statuses, nullptr, inflight) ? 0 : -2;
+  for (int b = 0; b < n; ++b) { if (!solvers[b]) return -1; if (solvers[b]->opts.device != solvers[0]->opts.device) lanes = 1; }
+  if (lanes <= 1) return solve_batch_impl(solvers, n, statuses, nullptr, inflight) ? 0 : -2;
+  std::vector<std::vector<miqp_solver_t*>> sub(lanes); std::vector<std::vector<int>> st(lanes);
+  for (int b = 0; b < n; ++b) sub[b % lanes].push_back(solvers[b]);
+  std::vector<char> ok(lanes, 0);
+  std::vector<std::thread> th;
+  for (int l = 0; l < lanes; ++l) {
+    st[l].assign(sub[l].size(), MIQP_STATUS_FAILED_SEG_FAULT);
+    const int infl = (inflight + lanes - 1 - l) / lanes;   // the slots are dealt like the instances
+    th.emplace_back([&, l, infl] { ok[l] = solve_batch_impl(sub[l].data(), (int)sub[l].size(), st[l].data(), nullptr, infl, l, lanes) ? 1 : 0; });
+  }
+  for (auto& t : th) t.join();
+  int rc = 0;
+  for (int b = 0; b < n; ++b) statuses[b] = st[b % lanes][b / lanes];
+  for (int l = 0; l < lanes; ++l) if (!ok[l]) rc = -2;
+  return rc;
 }
 
 int miqp_solver_solve_batch_multi(miqp_solver_t* const* solvers, int n, int gpus, int* statuses) {
@@ -1403,6 +1484,12 @@ int miqp_solver_get_properties(const miqp_solver_t* s, miqp_solution_properties_
 int miqp_solver_last_timing(const miqp_solver_t* s, double* out6) {
   if (!s || !out6) return -1;
   for (int k = 0; k < 6; ++k) out6[k] = s->timing[k];
+  return 0;
+}
+
+int miqp_solver_last_setup(const miqp_solver_t* s, double* out3) {
+  if (!s || !out3) return -1;
+  for (int k = 0; k < 3; ++k) out3[k] = s->setup[k];
   return 0;
 }
 

@@ -77,6 +77,7 @@ def load_library():
     L.miqp_solver_solve_fixed.restype = C.c_int
     L.miqp_solver_solve_fixed.argtypes = [vp, C.POINTER(RawResultsC), C.POINTER(RawResultsC), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.miqp_solver_last_timing.restype = C.c_int; L.miqp_solver_last_timing.argtypes = [vp, C.POINTER(C.c_double)]
+    L.miqp_solver_last_setup.restype = C.c_int; L.miqp_solver_last_setup.argtypes = [vp, C.POINTER(C.c_double)]
     L.miqp_gpu_version.restype = C.c_char_p
     _LIB = L
     return L
@@ -86,7 +87,7 @@ EXPORTED_SYMBOLS = ["miqp_solver_create", "miqp_solver_destroy", "miqp_solver_se
                     "miqp_solver_override_settings", "miqp_solver_set_warmstart", "miqp_solver_solve",
                     "miqp_solver_solve_batch", "miqp_solver_get_results", "miqp_solver_get_properties",
                     "miqp_solver_get_dims", "miqp_solver_export_lp", "miqp_solver_solve_fixed",
-                    "miqp_solver_last_timing", "miqp_gpu_version", "miqp_solver_write_dat", "miqp_solver_write_solution",
+                    "miqp_solver_last_timing", "miqp_solver_last_setup", "miqp_gpu_version", "miqp_solver_write_dat", "miqp_solver_write_solution",
                     "miqp_solver_write_mst", "miqp_solver_read_mst", "miqp_fraction_parameters", "miqp_mean_angles",
                     "miqp_limits_per_region", "miqp_calculate_region_idx", "miqp_reserve_neighbor_regions",
                     "miqp_calculate_possible_regions", "miqp_calculate_warmstart", "miqp_plan",
@@ -375,7 +376,10 @@ class CplexWrapper:
     def lastTiming(self):
         t = (C.c_double * 6)()
         self._L.miqp_solver_last_timing(self._h, t)
-        return dict(solve_s=t[0], ipm_s=t[1], ipm_launches=int(t[2]), nodes=int(t[3]), ipm_iters=int(t[4]), row_iters=int(t[5]))
+        u = (C.c_double * 3)()
+        self._L.miqp_solver_last_setup(self._h, u)
+        return dict(solve_s=t[0], ipm_s=t[1], ipm_launches=int(t[2]), nodes=int(t[3]), ipm_iters=int(t[4]), row_iters=int(t[5]),
+                    setup_s=u[0], context_s=u[1], context_built=bool(u[2]))
 
 
 def prepare_batch(wrappers):

@@ -281,6 +281,38 @@ def test_streaming_admission_equals_the_batch():
         assert np.abs(ra.pos_x - rb.pos_x).max() < 0.5   # (the same optimum up to the gap; lazily fetched result records)
 
 
+def test_context_is_reused_between_queues_and_lanes_prove_the_same(monkeypatch):
+    """(a) a second queue of another length on the same slots reuses the device context (no reallocation of the pools: the
+    set-up of the second call is a small fraction of the first) and proves the same optima as a fresh solve; (b) MIQP_LANES=2:
+    the queue dealt to two contexts that share the device proves every instance to its gap with the same optimum"""
+    import time
+    G = 1e-3
+    ps = [synthetic.generate("cfg2", s, gap=G, max_time=20) for s in range(700, 700 + 640)]
+
+    def run(lo, hi, inflight):
+        ws = []
+        for p in ps[lo:hi]:
+            w = P.CplexWrapper(); w.resetParameters(p); ws.append(w)
+        t = time.time(); sts = P.solve_batch(ws, inflight=inflight); dt = time.time() - t
+        assert all(int(s) == 0 and w.getSolutionProperties().status in (101, 102) for w, s in zip(ws, sts))
+        return ws, dt, ws[0].lastTiming()
+    wa, _, _ = run(0, 520, 256)            # builds the context for 256 slots
+    wb, _, tb = run(0, 640, 256)           # longer queue, same slots: reused
+    wc, _, tc = run(100, 420, 256)         # shorter queue: reused
+    assert not tb["context_built"] and not tc["context_built"] and tb["context_s"] < 0.05 and tc["context_s"] < 0.05, (tb, tc)
+    for a, b in zip(wa, wb[:520]):
+        pa, pb = a.getSolutionProperties(), b.getSolutionProperties()
+        assert pa.objective == pb.objective and pa.nodes == pb.nodes   # the same instance on the same slots: the same solve, bit for bit
+    for a, c in zip(wa[100:420], wc):
+        assert abs(a.getSolutionProperties().objective - c.getSolutionProperties().objective) <= 2 * G * max(1.0, abs(a.getSolutionProperties().objective))
+    monkeypatch.setenv("MIQP_LANES", "2")
+    wl, _, _ = run(0, 640, 256)
+    for b, l in zip(wb, wl):
+        pb, pl = b.getSolutionProperties(), l.getSolutionProperties()
+        assert pl.gap <= G + 1e-12 and abs(pb.objective - pl.objective) <= 2 * G * max(1.0, abs(pb.objective))
+        assert pl.best_bound <= pb.objective * (1 + 1e-9) and pb.best_bound <= pl.objective * (1 + 1e-9)
+
+
 def test_streaming_retires_an_instance_at_its_own_time_limit():
     """every instance of a queue has ITS OWN max_solution_time, counted from its admission: one that cannot finish (gap 1e-9,
     0.4 s) is retired - it reports its incumbent with status 107 - and its slot goes to the next one; the others are proven"""
