@@ -184,9 +184,11 @@ def main():
     B = a.batch                                   # in flight
     Q = B if a.no_stream else B * max(1, a.queue_factor)   # instances per rank and step
     if a.total > 0:
-        # strong scaling: the same T instances whatever the number of ranks (seeds 1000 + step * T + b), instance b on rank b mod G
+        # strong scaling: the same T instances whatever the number of ranks, instance b on rank b mod G.  The first TIMED step is
+        # BASELINE config 4 as written (seeds 1000 .. 1000 + T - 1), later timed steps follow on; the warm-up steps use the seeds after them
         def seeds_of(step):
-            return [1000 + step * a.total + b for b in range(a.total) if b % world == rank]
+            k = step - a.warmup if step >= a.warmup else a.steps + step
+            return [1000 + k * a.total + b for b in range(a.total) if b % world == rank]
     else:
         # weak scaling: seeds rank*Q .. rank*Q+Q-1 of step s are offset by s*world*Q
         def seeds_of(step):

@@ -617,7 +617,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) abr[kb] = (4 * kb + (tid >> 4) < NX && (tid & 15) < NZ) ? ab_entry<C>(4 * kb + (tid >> 4), tid & 15, ts) : 0.0;
 #ifdef MIQP_PROFILE
-  unsigned long long pr_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long pr_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int first_proxy = 0;
 #endif
   PROF_T(tb0);
@@ -739,6 +739,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
       acc = d4_t{0.0, 0.0, 0.0, 0.0};
       double racc = 0.0;
       if (tid < 32) dgq[tid] = 0.0;
+      PROF_T(tq0);
       for (int c0 = 0; c0 == 0 || c0 < nrj; c0 += GROWS) {
         const int nr = nrj - c0 < GROWS ? nrj - c0 : GROWS;
         const int nsl4 = (nr + 3) & ~3;
@@ -770,6 +771,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
         }
         if (c0 == 0 && j > 0) { int rp = sstart[j - 1] + tid; if (!((MIQP_ABL) & 1024) && tid < GROWS && rp < rb) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, rp); }
         __syncthreads();
+        PROF_T(tq1); PROF_ACC(12, tq0, tq1);
         if (c0 == 0) {
           const int sb = sst[j], nsj = sst[j + 1] - sb;
           for (int q0 = 0; q0 < nsj; q0 += NT) {
@@ -784,6 +786,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
           }
           if (j > 0) { int q = sst[j - 1] + tid; if (!((MIQP_ABL) & 1024) && q < sb) load_single(q); }
         }
+        PROF_T(tq2); PROF_ACC(13, tq1, tq2);
         for (int kb = 0; kb < (((MIQP_ABL) & 4) ? 0 : nsl4); kb += 16) {  // operands of up to 4 MFMAs are fetched before the dependent chain
           double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
           a0 = Gh[(kb + lg) * GS + lc]; f0 = fs[kb + lg];
@@ -797,7 +800,9 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
           if (kb + 12 < nsl4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, a3, acc, 0, 0, 0);
         }
         if (c0 + GROWS < nrj) __syncthreads();   // the next chunk overwrites the staging rows
+        PROF_T(tq3); PROF_ACC(14, tq2, tq3);
       }
+      PROF_T(tq4);
       racc += __shfl_xor(racc, 16); racc += __shfl_xor(racc, 32);
       __syncthreads();   // the single-entry contributions are complete
       { const double dd = lc < NZ ? 2.0 * Wd[lc] + dgq[lc] : 0.0;
@@ -806,6 +811,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
       rrc = lc < NZ ? racc + dgq[16 + lc] + 2.0 * Wd[lc] * (Z[j * NZ + lc] - rfn) : 0.0;  // rr[c], replicated over groups
       if (j > 0 && lc < NZ) rfn = Rf[(j - 1) * NZ + lc];
       if (it == 1) rmax = fmax(rmax, fabs(rrc));
+      PROF_T(tq5); PROF_ACC(15, tq4, tq5);
     };
 
     // Software pipeline over the stages: while the VALU chain of the elimination of stage i runs, the matrix core works
@@ -1223,6 +1229,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     atomicAdd(B.stat_rowiters, rowiters);
 #ifdef MIQP_PROFILE
     for (int q = 0; q < 9; ++q) atomicAdd(&B.prof[q], pr_[q]);
+    for (int q = 12; q < 16; ++q) atomicAdd(&B.prof[q], pr_[q]);   // (parts of the stage-Hessian chain, inside phase 3)
     atomicAdd(&B.prof[9], (unsigned long long)(it > QP_MAXIT ? QP_MAXIT : it)); atomicAdd(&B.prof[10], 1ull); atomicAdd(&B.prof[11], (unsigned long long)NROWS);
     { int hb = (it > QP_MAXIT ? QP_MAXIT : it) / 10; if (hb > 8) hb = 8; atomicAdd(&B.prof[16 + hb], 1ull); if (viol > FEAS_TOL) atomicAdd(&B.prof[25 + hb], 1ull); }
     if (ok == 2) { atomicAdd(&B.prof[36], (unsigned long long)first_proxy); atomicAdd(&B.prof[37], (unsigned long long)it); atomicAdd(&B.prof[38], 1ull); }

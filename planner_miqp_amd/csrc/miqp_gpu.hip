@@ -1103,7 +1103,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       const char* no[9] = {"build", "bw.rows/assemble", "bw.mfma", "bw.TS", "bw.cholK", "bw.P", "forward", "step", "update"};
       double to = 0; for (int q = 0; q < 9; ++q) to += (double)po[q];
       if (po[10]) { std::fprintf(stderr, "[miqp_gpu profile] memory-backed kernel nodes %llu iters %llu cycles/node-iter %.0f :", po[10], po[9], to / std::max(1ull, po[9]));
-        for (int q = 0; q < 9; ++q) std::fprintf(stderr, " %s %.1f%% (%.0f)", no[q], 100.0 * po[q] / to, (double)po[q] / std::max(1ull, po[9])); std::fprintf(stderr, "\n"); } }
+        for (int q = 0; q < 9; ++q) std::fprintf(stderr, " %s %.1f%% (%.0f)", no[q], 100.0 * po[q] / to, (double)po[q] / std::max(1ull, po[9]));
+        std::fprintf(stderr, "; inside bw.TS, the stage-Hessian chain: weights + staging %.0f, single-entry rows %.0f, MFMA loop %.0f, reductions + diagonal %.0f", (double)po[12] / std::max(1ull, po[9]), (double)po[13] / std::max(1ull, po[9]), (double)po[14] / std::max(1ull, po[9]), (double)po[15] / std::max(1ull, po[9]));
+        std::fprintf(stderr, "\n"); } }
     std::fprintf(stderr, "[miqp_gpu profile] on-chip nodes %llu iters %llu cycles/node-iter %.0f :", pf[11], pf[10], tot / std::max(1ull, pf[10]));
     for (int q = 0; q < 10; ++q) std::fprintf(stderr, " %s %.1f%% (%.0f)", nm[q], 100.0 * pf[q] / tot, (double)pf[q] / std::max(1ull, pf[10]));
     std::fprintf(stderr, "\n"); HIP_OK(hipMemset(B.prof, 0, 128 * 8)); }
