@@ -135,6 +135,26 @@ def test_synthetic_parity_tight_gap(oracle, cfg, seeds):
         oracle.free(h)
 
 
+def test_cfg5s_four_cars_against_the_oracle(oracle):
+    """cfg5s (4 cars x 10 steps x 32 regions: the largest 4-car shape the CPU oracle proves in seconds; the 4-car interior point
+    kernel with the 2x2-tiled stage algebra): at gap 1e-3 both prove their gap, the objectives agree within the two gaps, each
+    side's bound lies below the other side's solution, and the device result is feasible for the raw big-M model"""
+    G = 1e-3
+    for seed in range(4):
+        p = synthetic.generate("cfg5s", seed, gap=G, max_time=60)
+        w = P.CplexWrapper(); w.resetParameters(p)
+        assert int(w.callCplex()) == 0, seed
+        pr = w.getSolutionProperties(); res = w.getRawResults()
+        h = oracle.from_params(p, 10)
+        ost, ores, op = oracle.solve(h, oracle.dims(p), gap=G, time_limit=120)
+        assert ost == 0 and pr.status in (101, 102) and pr.gap <= G + 1e-12 and op.gap <= G + 1e-12, (seed, pr.status, pr.gap, op.gap)
+        assert abs(pr.objective - op.objective) <= 2 * G * abs(op.objective), (seed, pr.objective, op.objective)
+        assert pr.best_bound <= op.objective * (1 + 1e-9) and op.best_bound <= pr.objective * (1 + 1e-9), (seed, pr.best_bound, op.best_bound)
+        v, obj, worst = oracle.raw_eval(h, res)
+        assert v < 1e-5 and abs(obj - pr.objective) <= 1e-6 * max(1.0, abs(obj)), (seed, worst)
+        oracle.free(h)
+
+
 def test_three_car_reference_fixture_beats_the_recorded_cplex_point(oracle):
     """cplexmodel.dat (K5: 3 cars, 8 steps, 11 environment pieces; the reference's modelRun.txt point evaluates to
     741.22 in the raw model): the device result within 5 s is feasible for the raw big-M model and not worse"""
