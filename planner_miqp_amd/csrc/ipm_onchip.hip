@@ -31,7 +31,12 @@ constexpr int OC_GRP = 2;         // box slots whose chains are interleaved in t
 constexpr int OC_NSL = 10;        // box-row slots per lane: horizons of up to 2 * OC_NSL steps
 
 struct OcLds { int z, u, r, gmeta, gcoef, grhs, wd, sstart, cand, fix, total; };   // byte offsets
-__host__ __device__ inline OcLds oc_lds_layout(int N, int fixlen) {
+// capacity of the larger variant of the kernel (the nodes the standard one hands on: rounding probes and the other nodes with up
+// to OC_GCAP_BIG general rows): 5 register slots per lane, one wavefront per SIMD, 4 blocks of ~34 KB per CU
+constexpr int OC_GCAP_BIG = 320;
+__host__ __device__ constexpr int oc_gcoef_of(int gcap) { return gcap == 128 ? 432 : gcap * 7 / 2; }
+__host__ __device__ inline OcLds oc_lds_layout(int N, int fixlen, int OC_GCAP = miqp::OC_GCAP) {
+  const int OC_GCOEF = oc_gcoef_of(OC_GCAP);
   OcLds L; int o = 0;
   L.z = o; o += N * 16 * 8;
   L.u = o; { int a = N * 32 * 8, b = OC_SCR * OC_SSTR * 8; o += a > b ? a : b; }    // D | Gd  /  dZ | gains  /  decode scratch
@@ -190,9 +195,12 @@ __device__ inline void row_weight(double s, double lam, double t, bool soft, dou
 
 // ABL != 0 (diagnostic build -DMIQP_ABLATE, replayed on a batch the real kernel has solved): 15 iterations per node without
 // convergence tests and with the parts named by the mask switched off - only the run time of such an instance is read
-template <int C, int NSL, int ABL = 0>
-__global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
+template <int C, int NSL, int ABL = 0, int GCAP = miqp::OC_GCAP>
+__global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(DevBuf B) {
   constexpr int OC_ABL = ABL;
+  constexpr int OC_GCAP = GCAP, OC_GSLOTS = GCAP / 64, OC_GCOEF = oc_gcoef_of(GCAP);   // (shadow the capacities of the standard variant)
+  constexpr bool BIG = GCAP > 128;   // the larger variant works through the list of the standard one and hands what it cannot hold to the memory-backed kernel
+  static_assert(GCAP % 64 == 0 && GCAP <= 512, "general rows: whole register slots per lane, flags of up to 8 slots");
   constexpr bool CM = C == 2 && !(ABL & 1024);   // chain-major columns, shift form of the Riccati products (mask 1024 of the diagnostic build: the MFMA form)
   static_assert(C <= 2, "one 16 x 16 tile per stage");
   constexpr int NX = 6 * C, NU = 2 * C, NZ = 8 * C;
@@ -202,11 +210,11 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
   const int tid = threadIdx.x, lg = tid >> 4, lc = tid & 15;
   const int par = lg >> 1, side = lg & 1;                   // box rows of this lane: column lc, side, stages 2k + par
   const double bsgn = side ? -1.0 : 1.0;
-  const int nbatch = *B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap;
+  const int nbatch = BIG && B.ovf_mode == 1 ? *B.ovf_count : (*B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap);
   const int N = Y.N, NSLOT = Y.NSLOT;
   extern __shared__ double lds[];
   char* const L0 = (char*)lds;
-  const OcLds LL = oc_lds_layout(N, Y.fixlen);
+  const OcLds LL = oc_lds_layout(N, Y.fixlen, GCAP);
   double* const Z = (double*)(L0 + LL.z);                   // [N][16]
   double* const Dg = (double*)(L0 + LL.u);                  // [N][16] diagonal contributions of the box rows
   double* const Gd = Dg + N * 16;                           // [N][16] their gradient contributions
@@ -234,9 +242,11 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
     __syncthreads();
     if (tid == 0) sh_node = atomicAdd(B.work_counter, 1);
     __syncthreads();
-    const int node = __builtin_amdgcn_readfirstlane(sh_node);   // wave-uniform by construction: said so, everything derived from it
-    if (node >= nbatch) break;                                    // (instance tables, references) is then addressed from SGPRs
-    if (B.skip_probes && is_probe_word(B.batch_depth[node])) continue;   // solved by the concurrent memory-backed launch (every row of a probe is there: far beyond the on-chip capacity)
+    if (__builtin_amdgcn_readfirstlane(sh_node) >= nbatch) break;
+    const int node = __builtin_amdgcn_readfirstlane(BIG && B.ovf_mode == 1 ? B.ovf_list[sh_node] : sh_node);   // wave-uniform by construction: said so, everything derived from it
+                                                                  // (instance tables, references) is then addressed from SGPRs
+    if (BIG && B.ovf_mode == 2 && !is_probe_word(B.batch_depth[node])) continue;   // (a concurrent launch for the rounding probes of a small batch)
+    if (!BIG && B.skip_probes && is_probe_word(B.batch_depth[node])) continue;   // solved by the concurrent memory-backed launch (every row of a probe is there: far beyond the on-chip capacity)
     const int inst = __builtin_amdgcn_readfirstlane(B.batch_inst[node]);
     const double* D = B.inst_d + (size_t)inst * Y.dstride;
     const int* T = B.inst_i + (size_t)inst * Y.istride;
@@ -387,7 +397,7 @@ __global__ void __launch_bounds__(64, 2) ipm_onchip_kernel(DevBuf B) {
       OC_WAVE_SYNC();
     }
     if (overflow) {   // more general rows than fit on chip: the memory-backed kernel takes the node
-      if (tid == 0) { const int q = atomicAdd(B.ovf_count, 1); B.ovf_list[q] = node; if (B.stats) { atomicAdd(&B.stats[3], 1ull); atomicAdd(&B.stats[8 + (ngen >= 512 ? 15 : ngen / 32)], 1ull); } }
+      if (tid == 0) { const int q = atomicAdd(BIG ? B.ovf2_count : B.ovf_count, 1); (BIG ? B.ovf2_list : B.ovf_list)[q] = node; if (B.stats && !BIG) { atomicAdd(&B.stats[3], 1ull); atomicAdd(&B.stats[8 + (ngen >= 512 ? 15 : ngen / 32)], 1ull); if (ngen >= 480) { atomicMax(&B.stats[5], (unsigned long long)ngen); atomicAdd(&B.stats[6], (unsigned long long)ngen); atomicAdd(&B.stats[7], 1ull); } } }
       continue;
     }
     const int NM = sstart[N + 1];

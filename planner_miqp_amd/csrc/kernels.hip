@@ -107,7 +107,9 @@ struct DevBuf {
   double* near_thr;                 // children with bound > near_thr go to the far tier (1e300: tier unused so far)
   int* inst_mode;                   // 1: the round dives (depth first): children stay in the near list whatever their bound
   // per instance state
-  unsigned long long* inc_key;   // orderable(objective) with the batch slot in the low 20 bits
+  unsigned long long* inc_key;   // orderable(objective), the low 20 bits replaced by a hash of the completed record (what wins a tie must not depend on batch slots)
+  unsigned long long* batch_candkey;   // per batch slot: the key of the incumbent candidate evaluated there this round, ~0 otherwise
+  int prev_bc;                   // batch slots of the round before (select_kernel looks the winner of the incumbent key up among them)
   unsigned long long* inc_seen;  // key whose solution has been copied to inc_fix / inc_Z
   double* inc_obj;               // objective of the stored incumbent
   double* inc_ext;               // upper bound from outside (tree split over ranks: the best incumbent of the other ranks), 1e300 otherwise
@@ -138,6 +140,7 @@ struct DevBuf {
   // Earliest deadline first finishes what it starts; the cap (1024: narrow rounds waste the fewest nodes - every round prunes
   // with the incumbents of the one before) keeps a pathological instance to 3 % of the device.
   int* slot_demand; int* slot_take; int share_cap; int base_take; int window_pct; double probe_room;
+  double probe_margin;           // > 0: the rounding probe leaves front-point environment / obstacle disjunctions undecided whose completed alternative holds with this much room
   int probe_itcap;               // iterations after which an unconverged rounding probe is abandoned (0: never)
   int probe_every;               // rounding probes are eligible every probe_every-th round (1: always)
   int det_ties;                  // 1: ties of the node selection are broken by the nodes' own low key bits and sibling preference (reproducible), 0: by arrival
@@ -152,6 +155,7 @@ struct DevBuf {
   unsigned long long* prof;      // [40] cycle counters of the phases of ipm_kernel (diagnostic build -DMIQP_PROFILE only)
   unsigned long long* stat_rowiters;
   int* ovf_count; int* ovf_list;  // nodes the on-chip interior point kernel handed to the memory-backed one (more general rows than its LDS holds)
+  int* ovf2_count; int* ovf2_list;   // nodes the larger variant of the on-chip kernel handed on in its turn
   int ovf_mode;                  // 1: ipm_kernel works through ovf_list instead of the whole batch; 2: through the batch, rounding probes only
   int skip_probes;               // on-chip kernel: the rounding probes of the batch (depth word: sibling preference 63) are solved by a concurrent launch of ipm_kernel (ovf_mode 2)
   unsigned long long* stats;     // [32] diagnostic counters of the on-chip kernel (MIQP_STATS=1), else null
@@ -257,7 +261,7 @@ __device__ inline void pair_cars(int p, int C, int& c1, int& c2) {
 }
 
 struct RowOut { double rhs; double aq; bool active; };
-// depth word of a rounding probe: tree depth >= 1, sibling preference 63 (eval_kernel)
+// depth word of a rounding probe: tree depth >= 1, low bits 63 (eval_kernel: the children of a node carry 62 - their preference)
 __device__ inline bool is_probe_word(int dw) { return (dw & 63) == 63 && (dw >> 6) >= 1; }
 
 // region set of (car, step) in a node: the bits of its fix record that the static reachability presolve allows
@@ -1400,6 +1404,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   const Layout& Y = B.Y;
   const int node = blockIdx.x, lane = threadIdx.x;
   if (node >= *B.batch_count || node >= B.batch_cap) return;
+  if (lane == 0) B.batch_candkey[node] = ~0ull;
 #define FREE_NODE() do { if (lane == 0) { unsigned int q_ = atomicAdd(B.free_tail, 1u); B.free_q[q_ % (unsigned int)B.pool_cap] = B.batch_node[node]; } } while (0)
   const int inst = B.batch_inst[node];
   const int slot = B.inst_slot[inst];                // where the instance's open lists live
@@ -1427,6 +1432,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   double* mr_d = mr_v + LIFT_ROWS;                   // [LIFT_ROWS]
   double* mr_l = mr_d + LIFT_ROWS;                   // [LIFT_ROWS]
   double* mr_w = mr_l + LIFT_ROWS;                   // [NZ]
+  signed char* ploose = (signed char*)(mr_w + NZ);   // [fixlen] 1: the completed alternative of this undecided front-point disjunction holds with room to spare (probe_margin)
   __shared__ BranchDesc chosen;
   __shared__ int sh_base[4];
   __shared__ int slots[64];
@@ -1437,7 +1443,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   const double* Zi = B.batch_Z + (size_t)node * N * NZ;
   const signed char* src = B.pool_fix + (size_t)B.batch_node[node] * Y.fixlen;
   for (int k = lane; k < N * NZ; k += 64) Z[k] = Zi[k];
-  for (int k = lane; k < Y.fixlen; k += 64) { fix[k] = src[k]; comp[k] = src[k]; }
+  for (int k = lane; k < Y.fixlen; k += 64) { fix[k] = src[k]; comp[k] = src[k]; ploose[k] = 0; }
   __syncthreads();
   const double viol = B.batch_viol[node];
   const int okq = B.batch_ok[node];
@@ -1616,6 +1622,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
               }
             }
             okk = bv <= tol; comp[Y.f_env + (c * N + i) * 5 + pt] = (signed char)be;
+            if ((pt > 0 || (B.opt2 & 0x20000)) && B.probe_margin > 0.0 && bv <= -B.probe_margin) ploose[Y.f_env + (c * N + i) * 5 + pt] = 1;   // (experiment, MIQP_OPT2 bit 17: the rear point as well)
           }
           if (!okk) { if (pt > 0 && runfixed) consider(i, 0, c, 0, 0, bv, rsc, 1); else consider(i, 1, c, 0, pt, bv, sc < 1e300 ? sc : 0.0); }
         }
@@ -1633,6 +1640,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
               sc = fmin(sc, lift1(v, ed[0] * ed[0] * LX.p + ed[1] * ed[1] * LYd.p));
             }
             okk = bv <= tol; comp[Y.f_obs + ((c * Y.O + o) * N + i) * 5 + pt] = (signed char)bk;
+            if (pt > 0 && B.probe_margin > 0.0 && bv <= -B.probe_margin) ploose[Y.f_obs + ((c * Y.O + o) * N + i) * 5 + pt] = 1;
           }
           if (!okk) { if (pt > 0 && runfixed) consider(i, 0, c, 0, 0, bv, rsc, 2); else consider(i, 2, c, o, pt, bv, sc < 1e300 ? sc : 0.0); }
         }
@@ -1724,10 +1732,16 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     // integer feasible: candidate incumbent.  The winner of the 64-bit atomicMin owns the low 20 bits (batch slot).
     signed char* dst = B.batch_comp + (size_t)node * Y.fixlen;
     for (int k = lane; k < Y.fixlen; k += 64) dst[k] = comp[k];
+    int hsh = 0;
+    for (int k = lane; k < Y.fixlen; k += 64) hsh += ((int)comp[k] + 3) * (2 * k + 1);
+    for (int o = 32; o > 0; o >>= 1) hsh += __shfl_xor(hsh, o);
     if (lane == 0) {
-      unsigned long long key = (d2key(obj) & ~0xFFFFFull) | (unsigned long long)node;
-      atomicMin(&B.inc_key[inst], key);
+      // ties in the resolved 44 bits of the objective go to the smaller hash of the completed record, not to the smaller batch slot
+      // (slots are handed out in arrival order: the same solve would keep one or the other solution from run to run)
+      unsigned long long key = (d2key(obj) & ~0xFFFFFull) | (unsigned long long)((unsigned int)hsh & 0xFFFFFu);
       B.batch_obj[node] = obj;
+      B.batch_candkey[node] = key;
+      atomicMin(&B.inc_key[inst], key);
       atomicAdd(&B.inst_ninc[inst], 1);
     }
     FREE_NODE();
@@ -2063,6 +2077,11 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
           // (experiment, MIQP_OPT2 bit 16: the probe leaves the front-point environment / obstacle disjunctions undecided - a
           // smaller relaxation; it is then an ordinary node that the completion may still find integer feasible)
           if ((B.opt2 & 0x10000) && fix[k] < 0 && k >= Y.f_env && k < Y.f_c2c && (k - Y.f_env) % 5 != 0) v = fix[k];
+          // Front-point environment / obstacle disjunctions whose completed alternative holds with probe_margin to spare at this
+          // node's solution stay undecided in the probe: their rows - most of a probe's ~570 general rows - would be inactive
+          // anyway.  The probe is then an ordinary node: its own completion checks every disjunction at ITS solution, so it is
+          // only an incumbent when all of them hold (and it is branched like any node when one does not).
+          if (B.probe_margin > 0.0 && fix[k] < 0 && ploose[k]) v = fix[k];
         }
         dst[k] = v;
       }
@@ -2084,7 +2103,11 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         pref = 0;
         for (int q = 0; q < nk; ++q) if (k_bnd[q] < k_bnd[lane] || (k_bnd[q] == k_bnd[lane] && q < lane)) pref++;
       }
-      const int dw = k_ck[lane] == -2 ? (((pd + 2) << 6) | 63) : (((pd + 1) << 6) | (63 - pref));   // the probe is dived into first
+      // the probe is dived into first; 63 in the low bits is ITS mark (is_probe_word), the siblings count down from 62 - so a probe
+      // and the first child it lies in, which carry the same bound, never have the same key and preference (their tie in a
+      // best-bound round went to whichever lane came first: the one source of run-to-run differences of single solves that
+      // was left, 4 % of the repetitions of some instances)
+      const int dw = k_ck[lane] == -2 ? (((pd + 2) << 6) | 63) : (((pd + 1) << 6) | (62 - (pref < 62 ? pref : 62)));
       if (k_pos[lane] & 0x40000000) {
         size_t oi = (size_t)slot * B.far_cap + sh_base[0] + (k_pos[lane] & 0x3FFFFFFF);
         B.far_bound[oi] = k_bnd[lane]; B.far_node[oi] = slots[lane]; B.far_depth[oi] = dw;
@@ -2139,8 +2162,24 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     unsigned long long key = B.inc_key[inst];
     sh_inc = inc_from_key(key);
     sh_take = -1;
-    if (key != B.inc_seen[inst]) { sh_take = (int)(key & 0xFFFFFull); B.inc_seen[inst] = key; }
+    sh_thr = key != B.inc_seen[inst] ? key : ~0ull;   // a new incumbent key: its solution is looked up below
+    sh_fmin = ~0ull;
     sh_m = 0; sh_keep = 0; sh_pick = 0; sh_ties = 0; sh_ndef = 0;
+  }
+  __syncthreads();
+  if (sh_thr != ~0ull) {
+    // the batch slot whose candidate carries the winning key (several with the same key: the same objective to 44 bits and the
+    // same record hash - the smallest full objective, then the smallest slot)
+    const unsigned long long key = sh_thr;
+    const int pbc = B.prev_bc < B.batch_cap ? B.prev_bc : B.batch_cap;
+    for (int k = tid; k < pbc; k += SEL_THREADS) if (B.batch_candkey[k] == key) atomicMin(&sh_fmin, d2key(B.batch_obj[k]));
+    __syncthreads();
+    const unsigned long long bo = sh_fmin;
+    if (tid == 0) sh_dkeep = 0x7FFFFFFF;
+    __syncthreads();
+    if (bo != ~0ull) for (int k = tid; k < pbc; k += SEL_THREADS) if (B.batch_candkey[k] == key && d2key(B.batch_obj[k]) == bo) atomicMin(&sh_dkeep, k);
+    __syncthreads();
+    if (tid == 0 && sh_dkeep != 0x7FFFFFFF) { sh_take = sh_dkeep; B.inc_seen[inst] = key; }
   }
   __syncthreads();
   if (sh_take >= 0) {
@@ -2223,7 +2262,11 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     // best bound; experiment switch (bits 24..25 of seq_kinds): deeper nodes first among nearly equal bounds
     const int dbias = (B.seq_kinds >> 24) & 3;
     const double bb = dbias ? b - (dbias == 1 ? 1e-4 : (dbias == 2 ? 1e-3 : 1e-2)) * fabs(b) * (double)(dp >> 6) : b;
-    const double kv = dive ? (-(double)dp * 1e9 + fmax(b, -1e8)) : fmax(bb, -1e300);
+    // a dive: the depth word in the top 16 bits (deepest, most preferred sibling first), below it the top 48 bits of the bound's
+    // key - NOT -dp * 1e9 + b in one double: at 1e12 the bound was resolved to 1e-4 only, and cousins with nearly equal bounds
+    // tied on all 64 bits (the tie then went to whichever lane came first: the same solve took one of two paths from run to run)
+    if (dive) { const unsigned long long kd = ((unsigned long long)(0xFFFF - (dp < 0xFFFF ? dp : 0xFFFF)) << 48) | (d2key(fmax(b, -1e300)) >> 16); return kd == ~0ull ? ~0ull - 1 : kd; }
+    const double kv = fmax(bb, -1e300);
     const unsigned long long key = d2key(kv); return key == ~0ull ? ~0ull - 1 : key;
   };
   // ---- pass 1: prune, keys, lower bound, population per tree depth

@@ -243,6 +243,7 @@ struct DevCtx {
   hipEvent_t ev_mid = nullptr;   // MIQP_LAUNCH_TRACE
   int* work_counter2 = nullptr; double* rowstate2 = nullptr; double* rowcache2 = nullptr; double* kgain2 = nullptr; int probe_grid = 0;
   int oc_grid = 0;   // resident wavefronts of the on-chip interior point kernel (0: the shape does not qualify)
+  int ocb_grid = 0;  // resident wavefronts of its larger variant (OC_GCAP_BIG general rows, one wavefront per SIMD; 0: not in use)
   DevBuf B{};
   std::vector<void*> allocs;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -323,6 +324,12 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
       int perc = (int)std::min<size_t>(8, (160 * 1024) / lo);
       if (std::getenv("MIQP_OC_WAVES")) perc = std::max(1, std::min(perc, std::atoi(std::getenv("MIQP_OC_WAVES"))));   // (experiment: resident wavefronts of the on-chip kernel per CU)
       if (perc >= 1) X.oc_grid = cus * perc;
+      X.ocb_grid = 0;
+      if (X.oc_grid > 0 && !(std::getenv("MIQP_OC_BIG") && std::atoi(std::getenv("MIQP_OC_BIG")) == 0)) {
+        const size_t lb = (size_t)oc_lds_layout(Y.N, Y.fixlen, OC_GCAP_BIG).total + 16;
+        const int pb = (int)std::min<size_t>(4, (160 * 1024) / lb);
+        if (pb >= 1) X.ocb_grid = cus * pb;
+      }
     }
     if (X.oc_grid > X.ipm_grid_max) X.ipm_grid_max = X.oc_grid;   // the per-block buffers are sized for the larger grid
   }
@@ -405,6 +412,8 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&B.inst_ninc, n_inst)) return false;
   if (!X.alloc(&B.batch_count, 1)) return false;
   if (!X.alloc(&B.batch_node, batch_alloc)) return false;
+  if (!X.alloc(&B.batch_candkey, batch_alloc)) return false;
+  HIP_OK(hipMemset(B.batch_candkey, 0xFF, (size_t)batch_alloc * 8));
   if (!X.alloc(&B.batch_inst, batch_alloc)) return false;
   if (!X.alloc(&B.batch_depth, batch_alloc)) return false;
   if (!X.alloc(&B.batch_Z, (size_t)batch_alloc * Y.N * Y.nz)) return false;
@@ -425,11 +434,14 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
     if (!X.alloc(&X.work_counter2, 1)) return false;
     if (!X.alloc(&X.rowstate2, (size_t)X.probe_grid * NFIELD * Y.ROWCAP)) return false;
     if (!X.alloc(&X.rowcache2, (size_t)X.probe_grid * NCACHE * Y.ROWCAP)) return false;
-    if (!X.alloc(&X.kgain2, (size_t)X.probe_grid * Y.N * Y.nu * (Y.nx + 2))) return false;
+    if (!X.alloc(&X.kgain2, (size_t)X.probe_grid * std::max(Y.N * Y.nu * (Y.nx + 2), oc_gain_doubles(Y.N)))) return false;
     if (!X.stream2) { HIP_OK(hipStreamCreate(&X.stream2)); HIP_OK(hipEventCreate(&X.ev_fork)); HIP_OK(hipEventCreate(&X.ev_join)); }
   }
   if (!X.alloc(&B.ovf_count, 1)) return false;
   if (!X.alloc(&B.ovf_list, batch_alloc)) return false;
+  if (!X.alloc(&B.ovf2_count, 1)) return false;
+  if (!X.alloc(&B.ovf2_list, batch_alloc)) return false;
+  HIP_OK(hipMemset(B.ovf2_count, 0, 4));
   HIP_OK(hipMemset(B.ovf_count, 0, 4));
   if (std::getenv("MIQP_STATS")) {
     if (!X.alloc(&B.stats, 256)) return false; HIP_OK(hipMemset(B.stats, 0, 256 * 8));
@@ -456,13 +468,20 @@ size_t ipm_lds_bytes(const Layout& Y) {
 size_t eval_lds_bytes(const Layout& Y) {
   size_t d = (size_t)Y.N * Y.nz + (size_t)Y.C * Y.N * Y.P + 2 * (size_t)Y.C * Y.N;
   return d * 8 + (size_t)(2 * Y.C * Y.N + 64) * 4 + 64 * 8 + 3 * (size_t)Y.fixlen + (size_t)64 * (Y.nz + 1) * 8 + 64
-         + (size_t)(LIFT_ROWS * (2 * Y.nz + 3) + Y.nz) * 8 + 64;   // rows of the multi-row lifting
+         + (size_t)(LIFT_ROWS * (2 * Y.nz + 3) + Y.nz) * 8 + 64   // rows of the multi-row lifting
+         + (size_t)Y.fixlen + 16;                                  // ploose
 }
 
 template <int C> void launch_ipm(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { (void)hipMemsetAsync(B.work_counter, 0, 4, st); hipLaunchKernelGGL((ipm_kernel<C, IPM_NT>), dim3(nblocks), dim3(IPM_NT), lds, st, B); }
 template <int C> void launch_ipm_oc(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) {
   (void)hipMemsetAsync(B.work_counter, 0, 4, st); (void)hipMemsetAsync(B.ovf_count, 0, 4, st);
   hipLaunchKernelGGL((ipm_onchip_kernel<C, OC_NSL>), dim3(nblocks), dim3(64), lds, st, B);
+}
+// the larger variant: works through the list of the standard one (ovf_mode 1) or through the rounding probes of the batch (ovf_mode 2, on its
+// own stream with its own work counter); the caller has zeroed ovf2_count
+template <int C> void launch_ipm_oc_big(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) {
+  (void)hipMemsetAsync(B.work_counter, 0, 4, st);
+  hipLaunchKernelGGL((ipm_onchip_kernel<C, OC_NSL, 0, OC_GCAP_BIG>), dim3(nblocks), dim3(64), lds, st, B);
 }
 template <int C> void launch_eval(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { hipLaunchKernelGGL(eval_kernel<C>, dim3(nblocks), dim3(64), lds, st, B); }
 
@@ -483,19 +502,30 @@ void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool o
   const size_t l_ipm = ipm_lds_bytes(Y);
   if (X.oc_grid > 0) {
     const size_t l_oc = (size_t)oc_lds_layout(Y.N, Y.fixlen).total;
+    const size_t l_ocb = (size_t)oc_lds_layout(Y.N, Y.fixlen, OC_GCAP_BIG).total;
+    const bool big = X.ocb_grid > 0;
     const bool ov = overlap && X.probe_grid > 0 && X.stream2 && bc <= 4096;   // (a full batch keeps the device busy on its own: measured no gain there, 5.4 against 5.1 s on a 2048-instance queue; single solves: median 6.0 instead of 7.0 ms)
     DevBuf Bc = B;
+    if (big) (void)hipMemsetAsync(B.ovf2_count, 0, 4, st);
     if (ov) {
       (void)hipEventRecord(X.ev_fork, st); (void)hipStreamWaitEvent(X.stream2, X.ev_fork, 0);
       DevBuf Bp = B; Bp.ovf_mode = 2; Bp.work_counter = X.work_counter2; Bp.rowstate = X.rowstate2; Bp.rowcache = X.rowcache2; Bp.kgain = X.kgain2;
-      launch_ipm_c(Y.C, Bp, std::min(bc, X.probe_grid), l_ipm, X.stream2);
+      if (big) { if (Y.C == 1) launch_ipm_oc_big<1>(Bp, std::min(bc, std::min(X.probe_grid, X.ocb_grid)), l_ocb, X.stream2); else launch_ipm_oc_big<2>(Bp, std::min(bc, std::min(X.probe_grid, X.ocb_grid)), l_ocb, X.stream2); }
+      else launch_ipm_c(Y.C, Bp, std::min(bc, X.probe_grid), l_ipm, X.stream2);
       (void)hipEventRecord(X.ev_join, X.stream2);
       Bc.skip_probes = 1;
     }
     if (Y.C == 1) launch_ipm_oc<1>(Bc, std::min(bc, X.oc_grid), l_oc, st); else launch_ipm_oc<2>(Bc, std::min(bc, X.oc_grid), l_oc, st);
     if (X.ev_mid) (void)hipEventRecord(X.ev_mid, st);   // (diagnostic, MIQP_LAUNCH_TRACE: where the on-chip kernel ends)
-    if (ov) (void)hipStreamWaitEvent(st, X.ev_join, 0);   // (the launch below and the evaluation need the probes' results; it also keeps the two memory-backed launches apart)
+    if (ov) (void)hipStreamWaitEvent(st, X.ev_join, 0);   // (the launches below and the evaluation need the probes' results)
     DevBuf Bo = B; Bo.ovf_mode = 1;
+    if (big) {
+      // the nodes the standard variant could not hold go to the larger one (up to OC_GCAP_BIG general rows: the rounding probes
+      // without their slack front-point rows, the other large nodes); what even that one cannot hold - the polish of an
+      // incumbent, every row of it - to the memory-backed kernel
+      if (Y.C == 1) launch_ipm_oc_big<1>(Bo, std::min(bc, X.ocb_grid), l_ocb, st); else launch_ipm_oc_big<2>(Bo, std::min(bc, X.ocb_grid), l_ocb, st);
+      Bo.ovf_count = B.ovf2_count; Bo.ovf_list = B.ovf2_list;
+    }
     launch_ipm_c(Y.C, Bo, std::min(bc, X.ipm_grid_max), l_ipm, st);   // blocks without a node read the count and leave
   } else {
     launch_ipm_c(Y.C, B, std::min(bc, X.ipm_grid_max), l_ipm, st);
@@ -507,8 +537,9 @@ void launch_eval_c(int C, const DevBuf& B, int nblocks, size_t lds, hipStream_t 
                case 3: launch_eval<3>(B, nblocks, lds, st); break; default: launch_eval<4>(B, nblocks, lds, st); }
 }
 
-template <int C> bool set_kernel_lds_oc(size_t lds) {
+template <int C> bool set_kernel_lds_oc(size_t lds, size_t lds_big) {
   HIP_OK(hipFuncSetAttribute((const void*)ipm_onchip_kernel<C, OC_NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIP_OK(hipFuncSetAttribute((const void*)ipm_onchip_kernel<C, OC_NSL, 0, OC_GCAP_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
   return true;
 }
 template <int C> bool set_kernel_lds_c(size_t ipm_lds, size_t eval_lds) {
@@ -518,8 +549,8 @@ template <int C> bool set_kernel_lds_c(size_t ipm_lds, size_t eval_lds) {
 }
 bool set_kernel_lds(const Layout& Y, size_t ipm_lds, size_t eval_lds) {
   if (Y.C <= 2 && Y.N <= 2 * OC_NSL) {
-    const size_t l = (size_t)oc_lds_layout(Y.N, Y.fixlen).total;
-    if (l <= 160 * 1024 && !(Y.C == 1 ? set_kernel_lds_oc<1>(l) : set_kernel_lds_oc<2>(l))) return false;
+    const size_t l = (size_t)oc_lds_layout(Y.N, Y.fixlen).total, lb = (size_t)oc_lds_layout(Y.N, Y.fixlen, OC_GCAP_BIG).total;
+    if (l <= 160 * 1024 && !(Y.C == 1 ? set_kernel_lds_oc<1>(l, lb) : set_kernel_lds_oc<2>(l, lb))) return false;
   }
   switch (Y.C) { case 1: return set_kernel_lds_c<1>(ipm_lds, eval_lds); case 2: return set_kernel_lds_c<2>(ipm_lds, eval_lds);
                  case 3: return set_kernel_lds_c<3>(ipm_lds, eval_lds); default: return set_kernel_lds_c<4>(ipm_lds, eval_lds); }
@@ -844,6 +875,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   B.live_inc = std::getenv("MIQP_LIVE_INC") ? std::atoi(std::getenv("MIQP_LIVE_INC")) : 0;
   B.probe_every = std::getenv("MIQP_PROBE_EVERY") ? std::atoi(std::getenv("MIQP_PROBE_EVERY")) : 1;
   B.probe_itcap = std::getenv("MIQP_PROBE_ITCAP") ? std::atoi(std::getenv("MIQP_PROBE_ITCAP")) : 0;
+  B.probe_margin = std::getenv("MIQP_PROBE_MARGIN") ? std::atof(std::getenv("MIQP_PROBE_MARGIN")) : 0.25;   // (0: every disjunction of a probe fixed, as in round 2)
   B.det_ties = std::getenv("MIQP_DET_TIES") ? std::atoi(std::getenv("MIQP_DET_TIES")) : 1;
   B.window_pct = std::max(1, std::min(100, std::getenv("MIQP_WINDOW") ? std::atoi(std::getenv("MIQP_WINDOW")) : 100));
   HIP_OK(hipMemsetAsync(B.far_count, 0, (size_t)n * 4, st)); HIP_OK(hipMemsetAsync(B.far_minkey, 0xFF, (size_t)n * 8, st));
@@ -909,9 +941,13 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     if (X.h_pin_n < (size_t)n + 16) { if (X.h_pin) (void)hipHostFree(X.h_pin); X.h_pin = nullptr; X.h_pin_n = 0; HIP_OK(hipHostMalloc((void**)&X.h_pin, ((size_t)n + 16) * 4, hipHostMallocDefault)); X.h_pin_n = (size_t)n + 16; }
     if (!X.ev_sel) HIP_OK(hipEventCreate(&X.ev_sel));
   }
+  int prev_bc = 0;
+  static const bool round_log = std::getenv("MIQP_ROUND_LOG") != nullptr;   // diagnostic: the batch sizes of the rounds, printed after the solve (no extra synchronisation)
+  std::vector<int> round_bc;
   for (;;) {
     HIP_OK(hipMemsetAsync(B.batch_count, 0, 4, st));
     B.open_sel = rounds & 1;
+    B.prev_bc = pipelined ? X.batch_cap : prev_bc;
     hipLaunchKernelGGL(select_kernel, dim3(NS), dim3(SEL_THREADS), 0, st, B, rounds);
     if (std::getenv("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d select: %s\n", rounds, hipGetErrorString(e_)); }
     hipLaunchKernelGGL(roll_kernel, dim3(1), dim3(1), 0, st, B);
@@ -963,11 +999,21 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       if (tnow > tlim * (double)((n + NS - 1) / NS + 1) + 30.0) break;   // (safety net: no instance can outlive its limit by more than a round)
       if (bc <= 0) {   // a round may come up empty while a list tier is being reorganised, or right after admissions
         if (++empty_rounds > 64) break;
-        rounds++; continue;
+        rounds++; prev_bc = 0; continue;
       }
       empty_rounds = 0;
     }
     if (bc > X.batch_cap) bc = X.batch_cap;
+    if (std::getenv("MIQP_TRACE") && bc > 0 && bc <= 256) {   // diagnostic: what the selection picked (list bound, depth word), the incumbent it pruned with, its mode
+      std::vector<double> sb(bc); std::vector<int> sd(bc); double io_ = 0; int md_ = 0;
+      HIP_OK(hipMemcpy(sb.data(), B.batch_bound, (size_t)bc * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(sd.data(), B.batch_depth, (size_t)bc * 4, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(&io_, B.inc_obj, 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(&md_, B.inst_mode, 4, hipMemcpyDeviceToHost));
+      std::vector<int> ord(bc); for (int k = 0; k < bc; ++k) ord[k] = k;
+      std::sort(ord.begin(), ord.end(), [&](int a, int b) { return sd[a] != sd[b] ? sd[a] > sd[b] : sb[a] < sb[b]; });
+      std::fprintf(stderr, "[sel] r%d mode %d incumbent %a:", rounds, md_, io_);
+      for (int k : ord) std::fprintf(stderr, " %d.%d/%a", sd[k] >> 6, sd[k] & 63, sb[k]);
+      std::fprintf(stderr, "\n");
+    }
     if (pipelined) {   // (the launches of this round are already in the stream)
       nev += 2; launched_nodes += bc; rounds++;
       if (O0.verbose > 1) std::fprintf(stderr, "[miqp_gpu] round %d: %d nodes\n", rounds, bc);
@@ -1037,11 +1083,16 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       HIP_OK(hipMemcpy(hb.data(), B.batch_bound, bc * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(hv.data(), B.batch_viol, bc * 8, hipMemcpyDeviceToHost));
       std::vector<int> ord(bc); for (int k = 0; k < bc; ++k) ord[k] = k;
       std::sort(ord.begin(), ord.end(), [&](int a, int b) { return hd[a] != hd[b] ? hd[a] < hd[b] : (ho[a] != ho[b] ? ho[a] < ho[b] : hi[a] < hi[b]); });
+      { int oc_ = 0, fc_ = 0, tk_ = 0, dm_ = 0; double nt_ = 0;
+        HIP_OK(hipMemcpy(&oc_, B.open_count, 4, hipMemcpyDeviceToHost)); if (B.far_cap > 0) HIP_OK(hipMemcpy(&fc_, B.far_count, 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(&nt_, B.near_thr, 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(&tk_, B.slot_take, 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(&dm_, B.slot_demand, 4, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[lists] r%d batch %d: near list after selection %d, far tier %d, near_thr %g, share of the next round %d, demand %d\n", rounds, bc, oc_, fc_, nt_, tk_, dm_); }
       for (int k : ord) std::fprintf(stderr, "[trace] r%d depth %d.%d ok %d it %d obj %a bound %a viol %.3e\n", rounds, hd[k] >> 6, hd[k] & 63, hk[k], hi[k], ho[k], hb[k], hv[k]);
     }
     { DevBuf Be = B; Be.open_sel = 1 - (rounds & 1); launch_eval_c(Y.C, Be, bc, l_eval, st); }
     if (std::getenv("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d eval: %s\n", rounds, hipGetErrorString(e_)); }
-    launched_nodes += bc; rounds++;
+    launched_nodes += bc; rounds++; prev_bc = bc;
+    if (round_log) round_bc.push_back(bc);
     if (O0.verbose > 1) std::fprintf(stderr, "[miqp_gpu] round %d: %d nodes\n", rounds, bc);
     if (O0.verbose == 1 && rounds % 25 == 0) {  // progress of the first instance
       double lb0 = 0, io0 = 0; int oc0 = 0; unsigned long long k0 = 0;
@@ -1127,11 +1178,13 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     std::fprintf(stderr, "\n[miqp_gpu stats] node outcomes by origin (processed: infeasible / cut off / not converged / solved):");
     const char* on_[16] = {"root|reg-ref", "reg-adjacent", "reg-other", "reg-slow", "env-ref", "env-other", "-", "-", "obs-ref", "obs-other", "-", "-", "c2c-ref", "c2c-other", "-", "probe"};
     for (int q = 0; q < 16; ++q) if (hs[80 + q]) std::fprintf(stderr, " %s %llu: %llu / %llu / %llu / %llu;", on_[q], hs[80 + q], hs[96 + q], hs[112 + q], hs[128 + q], hs[144 + q]);
+    std::fprintf(stderr, "\n[miqp_gpu stats] handed-over nodes with >= 480 general rows: %llu, mean %.0f, most %llu general rows", hs[7], (double)hs[6] / std::max(1ull, hs[7]), hs[5]);
     std::fprintf(stderr, "\n[miqp_gpu stats] rounding probes by iterations / 3 (0-2, 3-5, ..., 45+):");
     { const char* oc_n[4] = {"infeasible", "cut off", "not converged", "solved"};
       for (int o = 0; o < 4; ++o) { std::fprintf(stderr, " %s", oc_n[o]); for (int q = 0; q < 16; ++q) std::fprintf(stderr, " %llu", hs[192 + 16 * o + q]); std::fprintf(stderr, ";"); } }
     std::fprintf(stderr, "\n");
   }
+  if (round_log) { std::fprintf(stderr, "[rounds]"); for (int v : round_bc) std::fprintf(stderr, " %d", v); std::fprintf(stderr, "\n"); }
   double ms_ipm = 0;
   for (size_t e = 0; e + 1 < nev; e += 2) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, X.ipm_ev[e], X.ipm_ev[e + 1])); ms_ipm += ms; }
   double t_solve = wall_s() - t0;
