@@ -245,8 +245,11 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     if (__builtin_amdgcn_readfirstlane(sh_node) >= nbatch) break;
     const int node = __builtin_amdgcn_readfirstlane(BIG && B.ovf_mode == 1 ? B.ovf_list[sh_node] : sh_node);   // wave-uniform by construction: said so, everything derived from it
                                                                   // (instance tables, references) is then addressed from SGPRs
-    if (BIG && B.ovf_mode == 2 && !is_probe_word(B.batch_depth[node])) continue;   // (a concurrent launch for the rounding probes of a small batch)
-    if (!BIG && B.skip_probes && is_probe_word(B.batch_depth[node])) continue;   // solved by the concurrent memory-backed launch (every row of a probe is there: far beyond the on-chip capacity)
+    // the concurrent launch of the larger variant takes the nodes known to be large before the round: the rounding probes (their
+    // depth word says so) and the records marked by an earlier decode or inherited from a marked parent
+    const bool marked = is_probe_word(B.batch_depth[node]) || (B.pool_big && B.pool_big[B.batch_node[node]]);   // (root records start unmarked: cleared per call)
+    if (BIG && B.ovf_mode == 2 && !marked) continue;
+    if (!BIG && B.skip_probes && marked) continue;   // solved by the concurrent memory-backed launch (every row of a probe is there: far beyond the on-chip capacity)
     const int inst = __builtin_amdgcn_readfirstlane(B.batch_inst[node]);
     const double* D = B.inst_d + (size_t)inst * Y.dstride;
     const int* T = B.inst_i + (size_t)inst * Y.istride;
@@ -395,6 +398,10 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
       if (tid == 0) sstart[N + 1] += __popcll(mk);
       ncoef += tot;
       OC_WAVE_SYNC();
+    }
+    if (overflow && !BIG && B.bounce) {   // found too large here: marked and returned unsolved; the concurrent launch of the larger variant takes it next round
+      if (tid == 0) { B.batch_ok[node] = 5; B.pool_big[B.batch_node[node]] = 1; if (B.stats) { atomicAdd(&B.stats[3], 1ull); atomicAdd(&B.stats[8 + (ngen >= 512 ? 15 : ngen / 32)], 1ull); } }
+      continue;
     }
     if (overflow) {   // more general rows than fit on chip: the memory-backed kernel takes the node
       if (tid == 0) { const int q = atomicAdd(BIG ? B.ovf2_count : B.ovf_count, 1); (BIG ? B.ovf2_list : B.ovf_list)[q] = node; if (B.stats && !BIG) { atomicAdd(&B.stats[3], 1ull); atomicAdd(&B.stats[8 + (ngen >= 512 ? 15 : ngen / 32)], 1ull); if (ngen >= 480) { atomicMax(&B.stats[5], (unsigned long long)ngen); atomicAdd(&B.stats[6], (unsigned long long)ngen); atomicAdd(&B.stats[7], 1ull); } } }

@@ -156,6 +156,9 @@ struct DevBuf {
   unsigned long long* stat_rowiters;
   int* ovf_count; int* ovf_list;  // nodes the on-chip interior point kernel handed to the memory-backed one (more general rows than its LDS holds)
   int* ovf2_count; int* ovf2_list;   // nodes the larger variant of the on-chip kernel handed on in its turn
+  unsigned char* pool_big;       // per record: 1 = more general rows than the standard on-chip kernel holds (found by that kernel at its decode, inherited by the children)
+  int bounce;                    // 1: the standard on-chip kernel does not hand such a node on but marks it (pool_big) and returns it unsolved (batch_ok 5): eval_kernel
+                                 // puts it back on its list, and from the next round on the larger variant takes it in its concurrent launch
   int ovf_mode;                  // 1: ipm_kernel works through ovf_list instead of the whole batch; 2: through the batch, rounding probes only
   int skip_probes;               // on-chip kernel: the rounding probes of the batch (depth word: sibling preference 63) are solved by a concurrent launch of ipm_kernel (ovf_mode 2)
   unsigned long long* stats;     // [32] diagnostic counters of the on-chip kernel (MIQP_STATS=1), else null
@@ -1447,6 +1450,15 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   __syncthreads();
   const double viol = B.batch_viol[node];
   const int okq = B.batch_ok[node];
+  if (okq == 5) {   // returned unsolved by the standard on-chip kernel (too large for it, now marked): back on the list with the bound it came with
+    if (lane == 0) {
+      const int pos = atomicAdd(&B.open_count[inst], 1);
+      if (pos < B.open_cap) { const size_t oi = ((size_t)B.open_sel * B.n_slots + slot) * B.open_cap + pos; B.open_bound[oi] = B.batch_bound[node]; B.open_node[oi] = B.batch_node[node]; B.open_depth[oi] = B.batch_depth[node]; }
+      else { atomicOr(&B.inst_flags[inst], 1); unsigned int q_ = atomicAdd(B.free_tail, 1u); B.free_q[q_ % (unsigned int)B.pool_cap] = B.batch_node[node]; }
+    }
+    return;
+  }
+  const unsigned char big_parent = B.pool_big ? B.pool_big[B.batch_node[node]] : 0;
   if (B.stats && lane == 0) {   // diagnostic (MIQP_STATS): outcome of the node and the iterations it took
     const int oc_ = okq == 2 ? 1 : (viol > FEAS_TOL ? 0 : (okq != 1 ? 2 : 3));   // infeasible, cut off, not converged, solved
     atomicAdd(&B.stats[32 + oc_], 1ull); atomicAdd(&B.stats[36 + oc_], (unsigned long long)B.batch_it[node]);
@@ -2092,6 +2104,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         B.pool_origin[slots[q]] = (signed char)(kk == -2 ? 15 : 4 * chosen.kind + cls);
       }
     }
+    if (B.pool_big && lane < nk) B.pool_big[slots[lane]] = big_parent;   // (a child has the rows of its parent and more)
     if (B.pool_Z) {   // the children start their relaxation from this node's solution (see DevBuf::pool_Z)
       for (int q = 0; q < nk; ++q) { if (slots[q] >= B.z_cap) continue; double* zd = B.pool_Z + (size_t)slots[q] * N * NZ; for (int k = lane; k < N * NZ; k += 64) zd[k] = Z[k]; }
     }

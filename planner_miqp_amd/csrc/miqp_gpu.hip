@@ -243,6 +243,7 @@ struct DevCtx {
   hipEvent_t ev_mid = nullptr;   // MIQP_LAUNCH_TRACE
   int* work_counter2 = nullptr; double* rowstate2 = nullptr; double* rowcache2 = nullptr; double* kgain2 = nullptr; int probe_grid = 0;
   int oc_grid = 0;   // resident wavefronts of the on-chip interior point kernel (0: the shape does not qualify)
+  bool concurrent_big = true;   // MIQP_CONCURRENT_BIG=0: the sequential chain standard -> larger -> memory-backed
   int ocb_grid = 0;  // resident wavefronts of its larger variant (OC_GCAP_BIG general rows, one wavefront per SIMD; 0: not in use)
   DevBuf B{};
   std::vector<void*> allocs;
@@ -324,7 +325,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
       int perc = (int)std::min<size_t>(8, (160 * 1024) / lo);
       if (std::getenv("MIQP_OC_WAVES")) perc = std::max(1, std::min(perc, std::atoi(std::getenv("MIQP_OC_WAVES"))));   // (experiment: resident wavefronts of the on-chip kernel per CU)
       if (perc >= 1) X.oc_grid = cus * perc;
-      X.ocb_grid = 0;
+      X.ocb_grid = 0; X.concurrent_big = !(std::getenv("MIQP_CONCURRENT_BIG") && std::atoi(std::getenv("MIQP_CONCURRENT_BIG")) == 0);
       if (X.oc_grid > 0 && !(std::getenv("MIQP_OC_BIG") && std::atoi(std::getenv("MIQP_OC_BIG")) == 0)) {
         const size_t lb = (size_t)oc_lds_layout(Y.N, Y.fixlen, OC_GCAP_BIG).total + 16;
         const int pb = (int)std::min<size_t>(4, (160 * 1024) / lb);
@@ -439,6 +440,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   }
   if (!X.alloc(&B.ovf_count, 1)) return false;
   if (!X.alloc(&B.ovf_list, batch_alloc)) return false;
+  if (X.ocb_grid > 0) { if (!X.alloc(&B.pool_big, (size_t)X.pool_cap)) return false; HIP_OK(hipMemset(B.pool_big, 0, (size_t)X.pool_cap)); }
   if (!X.alloc(&B.ovf2_count, 1)) return false;
   if (!X.alloc(&B.ovf2_list, batch_alloc)) return false;
   HIP_OK(hipMemset(B.ovf2_count, 0, 4));
@@ -507,6 +509,27 @@ void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool o
     const bool ov = overlap && X.probe_grid > 0 && X.stream2 && bc <= 4096;   // (a full batch keeps the device busy on its own: measured no gain there, 5.4 against 5.1 s on a 2048-instance queue; single solves: median 6.0 instead of 7.0 ms)
     DevBuf Bc = B;
     if (big) (void)hipMemsetAsync(B.ovf2_count, 0, 4, st);
+    if (big && overlap && X.probe_grid > 0 && X.stream2 && X.concurrent_big) {
+      // Every round: the larger variant works beside the standard one, on its own stream, through the nodes known to be large
+      // (rounding probes, marked records); behind it, on that stream, the memory-backed kernel takes what even it cannot hold.
+      // Both kernels hand their nodes out dynamically, so the wavefronts of the standard launch that find no room at first start
+      // as the large nodes finish: the tail of the large nodes (40+ iterations) hides behind the standard launch instead of
+      // being a launch of its own.  A node the standard kernel finds too large at its decode is marked and returned unsolved
+      // (bounce): no second launch behind the standard one.
+      (void)hipEventRecord(X.ev_fork, st); (void)hipStreamWaitEvent(X.stream2, X.ev_fork, 0);
+      DevBuf Bp = B; Bp.ovf_mode = 2; Bp.work_counter = X.work_counter2; Bp.rowstate = X.rowstate2; Bp.rowcache = X.rowcache2; Bp.kgain = X.kgain2;
+      static const int big_grid_cap = std::getenv("MIQP_BIG_GRID") ? std::atoi(std::getenv("MIQP_BIG_GRID")) : 1 << 30;
+      const int gb = std::min(std::min(bc, big_grid_cap), std::min(X.probe_grid, X.ocb_grid));
+      if (Y.C == 1) launch_ipm_oc_big<1>(Bp, gb, l_ocb, X.stream2); else launch_ipm_oc_big<2>(Bp, gb, l_ocb, X.stream2);
+      DevBuf Bm = Bp; Bm.ovf_mode = 1; Bm.ovf_count = B.ovf2_count; Bm.ovf_list = B.ovf2_list;
+      launch_ipm_c(Y.C, Bm, std::min(bc, X.probe_grid), l_ipm, X.stream2);
+      (void)hipEventRecord(X.ev_join, X.stream2);
+      Bc.skip_probes = 1; Bc.bounce = 1;
+      if (Y.C == 1) launch_ipm_oc<1>(Bc, std::min(bc, X.oc_grid), l_oc, st); else launch_ipm_oc<2>(Bc, std::min(bc, X.oc_grid), l_oc, st);
+      if (X.ev_mid) (void)hipEventRecord(X.ev_mid, st);
+      (void)hipStreamWaitEvent(st, X.ev_join, 0);
+      return;
+    }
     if (ov) {
       (void)hipEventRecord(X.ev_fork, st); (void)hipStreamWaitEvent(X.stream2, X.ev_fork, 0);
       DevBuf Bp = B; Bp.ovf_mode = 2; Bp.work_counter = X.work_counter2; Bp.rowstate = X.rowstate2; Bp.rowcache = X.rowcache2; Bp.kgain = X.kgain2;
@@ -859,6 +882,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemcpyAsync((void*)B.inst_i, hT.data(), hT.size() * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(B.pool_fix, roots.data(), roots.size(), hipMemcpyHostToDevice, st));
   int pool0 = nrec;
+  if (B.pool_big && nrec > 0) HIP_OK(hipMemsetAsync(B.pool_big, 0, (size_t)nrec, st));   // the root records start unmarked (children are marked or cleared when they are written)
   HIP_OK(hipMemcpyAsync(B.pool_count, &pool0, 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemsetAsync(B.free_head, 0, 4, st)); HIP_OK(hipMemsetAsync(B.free_tail, 0, 4, st)); HIP_OK(hipMemsetAsync(B.free_limit, 0, 4, st));
   HIP_OK(hipMemcpyAsync((void*)B.root_node, on.data(), on.size() * 4, hipMemcpyHostToDevice, st));
