@@ -276,7 +276,7 @@ def main():
                                solve_latency_s_rank0=dict(p50=float(np.percentile(lat, 50)), p95=float(np.percentile(lat, 95)), max=float(max(lat))) if lat else None),
                    roofline=dict(bound="mfma", achieved=ach / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s", frac=ach / FP64_PEAK, traffic=traffic,
                                  traffic_note=traffic_note, peak_measured=FP64_PEAK_MEASURED / 1e12, frac_of_measured_peak=ach / FP64_PEAK_MEASURED,
-                                 kernel="ipm_onchip_kernel<2,10> followed by ipm_kernel<2,64> on the nodes it hands over (one pair per B&B round)" if a.config in ("cfg3", "cfg4") else "interior point kernels of the configuration (one launch pair per B&B round)",
+                                 kernel="the interior point launches of a B&B round: ipm_onchip_kernel<2,10,0,128> and, beside it on a second stream, its larger variant <2,10,0,320> (rounding probes, large nodes) and ipm_kernel<2,64> (what that one cannot hold); HIP events around the group on the solver stream" if a.config in ("cfg3", "cfg4") else "interior point kernels of the configuration (one launch pair per B&B round)",
                                  launches=int(launches), avg_launch_ms=1e3 * ipm_s / max(1, launches), flops_per_launch=flops / max(1, launches)))
         if not a.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(batches[a.warmup][0], a.gap, a.time_limit)

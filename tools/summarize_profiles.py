@@ -11,9 +11,9 @@ t = json.load(open(os.path.join(F, "traffic_raw.json")))
 def kern(sub):
     k = [v for n, v in t.items() if sub in n][0]
     return dict(fetch_bytes_raw=k["FETCH_SIZE"]["bytes_per_launch"], fetch_bytes_corrected=2.0 * k["FETCH_SIZE"]["bytes_per_launch"], write_bytes=k["WRITE_SIZE"]["bytes_per_launch"], launches=k["FETCH_SIZE"]["launches"])
-oc, ov = kern("ipm_onchip_kernel<2"), kern("ipm_kernel<2")
-out = dict(bytes_per_round_corrected=oc["fetch_bytes_corrected"] + oc["write_bytes"] + ov["fetch_bytes_corrected"] + ov["write_bytes"], onchip_kernel=oc, overflow_kernel=ov,
-           note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes, no tracing) of `python3 bench.py --steps 1 --warmup 0 --no-cpu --time-limit 3` (the bench configuration: cfg3, 1024 in flight, queue of 2048; the 3 s limit keeps the counter passes short); counters are KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; both count L2<->fabric requests (Infinity-Cache hits included), per launch averaged over all launches of the pass; one B&B round = one launch of ipm_onchip_kernel<2,10> + one of ipm_kernel<2,64> (the nodes handed over)",
+oc, ob, ov = kern("ipm_onchip_kernel<2, 10, 0, 128>"), kern("ipm_onchip_kernel<2, 10, 0, 320>"), kern("ipm_kernel<2")
+out = dict(bytes_per_round_corrected=sum(k["fetch_bytes_corrected"] + k["write_bytes"] for k in (oc, ob, ov)), onchip_kernel=oc, onchip_kernel_larger_variant=ob, overflow_kernel=ov,
+           note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes, no tracing) of `python3 bench.py --steps 1 --warmup 0 --no-cpu --time-limit 3` (the bench configuration: cfg3, 1024 in flight, queue of 2048; the 3 s limit keeps the counter passes short); counters are KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; both count L2<->fabric requests (Infinity-Cache hits included), per launch averaged over all launches of the pass; one B&B round = one launch of ipm_onchip_kernel<2,10,0,128>, beside it on a second stream one of its larger variant <2,10,0,320> (rounding probes, marked large nodes) and one of ipm_kernel<2,64> (what that one cannot hold)",
            source="profiles/%s_final_pmc_traffic.json (tools/final_profiles.sh, tools/pmc_traffic.py, tools/summarize_profiles.py)" % tag)
 json.dump(out, open(os.path.join(P, "%s_traffic.json" % tag), "w"), indent=1)
 if os.path.isdir(N):
