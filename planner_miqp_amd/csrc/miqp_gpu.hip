@@ -1061,7 +1061,10 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       for (int q = 0; q < oc; ++q) { const int k = ol[q]; if ((hdw[k] & 63) == 63 && (hdw[k] >> 6) >= 1) { np++; sp += hit[k]; mxp = std::max(mxp, hit[k]); } else { so += hit[k]; mxo = std::max(mxo, hit[k]); } }
       std::vector<char> isov(bc, 0); for (int q = 0; q < oc; ++q) isov[ol[q]] = 1;
       for (int k = 0; k < bc; ++k) if (!isov[k]) { sc += hit[k]; mxc = std::max(mxc, hit[k]); }
-      std::fprintf(stderr, "[launch] round %d nodes %d: on-chip %.2f ms (%d nodes, mean it %.1f, max %d); memory-backed %.2f ms: %d probes (mean it %.1f, max %d), %d others (mean it %.1f, max %d)\n",
+      // (with the concurrent launches of the large nodes - the default - the first time is the standard launch incl. its wait for room, the
+      // second the wait for the second stream after it, and the node split below is empty: nothing is handed on behind the standard launch;
+      // MIQP_CONCURRENT_BIG=0 MIQP_OC_BIG=0 gives the two launches of the first half of round 3 apart)
+      std::fprintf(stderr, "[launch] round %d nodes %d: on-chip %.2f ms (%d nodes, mean it %.1f, max %d); behind it %.2f ms: %d probes (mean it %.1f, max %d), %d others (mean it %.1f, max %d)\n",
                    rounds, bc, m1, bc - oc, (double)sc / std::max(1, bc - oc), mxc, m2, np, (double)sp / std::max(1, np), mxp, oc - np, (double)so / std::max(1, oc - np), mxo);
     }
     nev += 2;
