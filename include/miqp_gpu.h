@@ -76,7 +76,12 @@ int miqp_solver_solve_batch(miqp_solver_t* const* solvers, int n, int* statuses)
  * admission - hands its slot (open lists in HBM) to the next instance of the queue at the following branch-and-bound
  * round, so the device never idles behind the hardest instances of a batch.  SolutionProperties.time of an instance is the
  * time from its admission to its proof.  (No reference counterpart: MiqpPlanner issues one callCplex at a time,
- * src/miqp_planner.cpp:731; this is the entry a scenario-parallel caller binds to keep one GPU saturated.) */
+ * src/miqp_planner.cpp:731; this is the entry a scenario-parallel caller binds to keep one GPU saturated.)
+ * The device context (node pool, lists) is kept between calls of the same shape - slots, model dimensions - whose queue is no
+ * longer than the per-instance arrays of the context hold (64 x inflight at least); miqp_solver_last_setup says whether a call
+ * had to build it.  A single solve (miqp_solver_solve) returns the same result bit for bit when repeated, as CPLEX's default
+ * deterministic mode does; the instances of a queue influence each other's shares of a round, so their node counts move by a
+ * few nodes between runs (every reported bound and solution is valid either way). */
 int miqp_solver_solve_stream(miqp_solver_t* const* solvers, int n, int inflight, int* statuses);
 
 /* The same batch sharded over the first `gpus` HIP devices of this process (<= 0: all visible): instance b runs on
