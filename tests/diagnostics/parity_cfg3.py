@@ -1,7 +1,7 @@
 """One-off: full-size cfg3 instances that the CPU oracle can finish, device vs oracle at gap 1e-3 (GPU only)."""
 import os, sys, time
 from concurrent.futures import ThreadPoolExecutor
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import subprocess
 subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])

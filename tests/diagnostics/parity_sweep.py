@@ -1,6 +1,6 @@
 """One-off randomized parity sweep: device vs CPU oracle at a tight gap on many small multi-car instances (GPU only)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import subprocess
 subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
