@@ -1,7 +1,7 @@
 #!/bin/bash
 # headline against the number of instances in flight (GPU): one summary line per bench run -> profiles/r03_batch_sweep.json
 S=${STEPS:-4}
-for b in 128 256 512 1024 2048; do
+for b in 128 256 512 1024 1280 1536 2048; do
   python bench.py --batch $b --steps $S --warmup 1 --no-cpu 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); c=d['config']

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the round's profile artefacts on the GPU box into gpurun_out/final/ (copied to profiles/ afterwards):
-#   kernel trace + stats of one default bench step (1024 in flight, queue of 2048), three separate PMC passes (FETCH_SIZE, WRITE_SIZE, SQ counters;
+#   kernel trace + stats of one default bench step (1280 in flight, queue of 2560), three separate PMC passes (FETCH_SIZE, WRITE_SIZE, SQ counters;
 #   no tracing together with --pmc) on `bench.py --steps 1 --warmup 0 --no-cpu --time-limit 3` for the counters.
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/final; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
