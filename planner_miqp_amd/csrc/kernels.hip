@@ -1401,8 +1401,15 @@ __device__ inline double region_alt_lift_exact(const Layout& Y, const double* D,
 
 struct BranchDesc { int prio; int kind; int c; int o; int i; int pt; int cause; };  // kind: 0 region 1 env 2 obs 3 c2c; cause (diagnostic): what flagged a region disjunction - 0 its own rows, 1 / 2 / 3 an environment / obstacle / car-car row on a front point of a car whose region is undecided
 
+#ifndef MIQP_EVAL_WPE
+#define MIQP_EVAL_WPE 0   // wavefronts per SIMD eval_kernel is register-allocated for (0: the compiler's choice - 141 VGPRs, 3 per SIMD; measured against 2 and 4, tools/eval_wpe.sh)
+#endif
 template <int C>
+#if MIQP_EVAL_WPE > 0
+__global__ void __launch_bounds__(64, MIQP_EVAL_WPE) eval_kernel(DevBuf B) {
+#else
 __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
+#endif
   constexpr int NZ = 8 * C;
   const Layout& Y = B.Y;
   const int node = blockIdx.x, lane = threadIdx.x;
