@@ -131,6 +131,13 @@ int miqp_solver_lift_tables(const miqp_solver_t* s, double* out, int cap);
  * Fills the caller-allocated record (sizes must match the instance). */
 int miqp_solver_get_results(const miqp_solver_t* s, miqp_raw_results_c* out);
 
+/* collectRawResults for a whole batch                           src/cplex_wrapper.cpp:186 (collectRawResults() runs inside callCplex, before it returns)
+ * Builds the RawResults record of every handle that holds a solution, on `threads` host threads (0: all hardware threads), and
+ * keeps it inside the handle; miqp_solver_get_results then only copies.  The reference produces the record inside callCplex;
+ * the batch entry points leave it to this call so that a service can overlap it - bench.py calls it inside its timed region.
+ * Returns the number of records built, < 0 on error. */
+int miqp_solver_materialize_results(miqp_solver_t* const* solvers, int n, int threads);
+
 /* CplexWrapper::getSolutionProperties()                        src/cplex_wrapper.hpp:206-208, cpp:672-690 */
 int miqp_solver_get_properties(const miqp_solver_t* s, miqp_solution_properties_c* out);
 

@@ -7,4 +7,4 @@ solving requires the built library and a HIP device.
 """
 from .ctypes_types import ModelParameters, RawResults  # noqa: F401
 from .wrapper import (CplexWrapper, OptimizationStatus, SolutionProperties, WarmstartType, ParameterSource,  # noqa: F401
-                      solve_batch, prepare_batch, load_library, library_path, build_library)
+                      solve_batch, prepare_batch, materialize_results, load_library, library_path, build_library)

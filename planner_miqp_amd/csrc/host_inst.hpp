@@ -642,6 +642,7 @@ inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int*
   // step i that the reachable interval already satisfies is implied by the rows of the earlier steps and is not
   // generated (bit rr of i_boxskip: rows 0..6 of decode_row).
   std::vector<double> preach((size_t)C * N * 4, 0.0);   // reachable position box per car and step: x lo, x hi, y lo, y hi
+  double diam = 0.0;   // L1 diameter of the reachable set over all stage variables of the horizon (what a stationarity residual can add to a bound: kernels, batch_bound)
   for (int c = 0; c < C; ++c) {
     const int np = T[Y.i_nposs + c];
     double abox[4] = {I.amin, I.amax, I.amin, I.amax};     // lo_x, hi_x, lo_y, hi_y that every alternative respects
@@ -673,10 +674,12 @@ inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int*
         if (ax == 0 && whi <= I.vmax - pad) skip |= 1 << 2;
         alo[ax] = nlo; ahi[ax] = nhi;
         vlo[ax] = std::max(wlo, I.vmin); vhi[ax] = ax == 0 ? std::min(whi, I.vmax) : whi;
+        diam += (phi[ax] - plo[ax]) + (vhi[ax] - vlo[ax]) + (ahi[ax] - alo[ax]) + (jhi - jlo);
       }
       T[Y.i_boxskip + c * N + i] = skip;
     }
   }
+  D[Y.d_misc + 2] = std::max(1.0, diam);
   // Car/car alternatives that no reachable pair of positions can satisfy (exact): alternative a of group g at step i
   // asks  coord(A) - coord(B) <= -(separation) for a rear or front point of each car; front points lie within one wheel
   // base of the rear point.  Bit (4 g + a) of i_c2callow[pair][step] is set when the alternative is possible.

@@ -247,14 +247,17 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
                                                                   // (instance tables, references) is then addressed from SGPRs
     // the concurrent launch of the larger variant takes the nodes known to be large before the round: the rounding probes (their
     // depth word says so) and the records marked by an earlier decode or inherited from a marked parent
-    const bool marked = is_probe_word(B.batch_depth[node]) || (B.pool_big && B.pool_big[B.batch_node[node]]);   // (root records start unmarked: cleared per call)
-    if (BIG && B.ovf_mode == 2 && !marked) continue;
-    if (!BIG && B.skip_probes && marked) continue;   // solved by the concurrent memory-backed launch (every row of a probe is there: far beyond the on-chip capacity)
+    // (the split is select_kernel's snapshot batch_large: the mark the standard kernel sets when it returns a node is for the next round)
+    if ((BIG && B.ovf_mode == 2) || (!BIG && B.skip_probes)) {
+      const bool marked = B.batch_large ? B.batch_large[node] != 0 : is_probe_word(B.batch_depth[node]);
+      if (BIG ? !marked : marked) continue;   // the other launch of the round solves it
+    }
     const int inst = __builtin_amdgcn_readfirstlane(B.batch_inst[node]);
     const double* D = B.inst_d + (size_t)inst * Y.dstride;
     const int* T = B.inst_i + (size_t)inst * Y.istride;
     const double ts = D[Y.d_glob + 7];
     const double aqs = 2.0 * D[Y.d_misc + 0];               // quadratic weight of the soft car/car rows
+    const double zdiam = D[Y.d_misc + 2];                   // L1 diameter of the reachable set: the weight of a stationarity residual in a bound (see ipm_kernel)
     {
       const signed char* src = B.pool_fix + (size_t)B.batch_node[node] * Y.fixlen;
       for (int k = tid; k < Y.fixlen; k += 64) fix[k] = src[k];
@@ -482,7 +485,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
       // converged after probe_itcap iterations is abandoned: 1 % of the probes that leave slack front-point disjunctions undecided
       // ran to the iteration limit (80) and held the launch of the larger variant up
       if (BIG && B.probe_itcap > 0 && it > B.probe_itcap && B.ws_on != 2 && is_probe_word(B.batch_depth[node])) { ok = 2; break; }
-      if (it > 1 && resid_fac * R0 < 1e-5 * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp - resid_fac * R0 * 1.0e4 > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }   // (dual value minus the allowance for the stationarity residual still left, see batch_bound)
+      if (it > 1 && resid_fac * R0 < 1e-5 * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp - resid_fac * R0 * zdiam > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }   // (dual value minus the allowance for the stationarity residual still left, see batch_bound)
       }
       const double tau = sigma * comp;
       OCP_T(tp_r0);
@@ -940,7 +943,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     if (tid == 0) {
       const int itc = it > QP_MAXIT ? QP_MAXIT : it;
       B.batch_obj[node] = obj; B.batch_viol[node] = viol; B.batch_ok[node] = ok;
-      B.batch_bound[node] = (double)ncomp * comp + resid_fac * R0 * 1.0e4;   // (see ipm_kernel: complementarity + stationarity residual allowance)
+      B.batch_bound[node] = (double)ncomp * comp + resid_fac * R0 * zdiam;   // (see ipm_kernel: complementarity + stationarity residual allowance)
       B.batch_it[node] = itc;
       atomicAdd((unsigned long long*)&B.inst_iters[inst], (unsigned long long)itc);
       atomicAdd((unsigned long long*)&B.inst_nodes[inst], 1ull);

@@ -109,6 +109,7 @@ struct DevBuf {
   // per instance state
   unsigned long long* inc_key;   // orderable(objective), the low 20 bits replaced by a hash of the completed record (what wins a tie must not depend on batch slots)
   unsigned long long* batch_candkey;   // per batch slot: the key of the incumbent candidate evaluated there this round, ~0 otherwise
+  int* batch_candinst;           // ... and the instance it belongs to (batch_inst is being rewritten by other workgroups of select_kernel while one looks its winner up)
   int prev_bc;                   // batch slots of the round before (select_kernel looks the winner of the incumbent key up among them)
   unsigned long long* inc_seen;  // key whose solution has been copied to inc_fix / inc_Z
   double* inc_obj;               // objective of the stored incumbent
@@ -156,6 +157,9 @@ struct DevBuf {
   unsigned long long* stat_rowiters;
   int* ovf_count; int* ovf_list;  // nodes the on-chip interior point kernel handed to the memory-backed one (more general rows than its LDS holds)
   int* ovf2_count; int* ovf2_list;   // nodes the larger variant of the on-chip kernel handed on in its turn
+  unsigned char* batch_large;    // per batch slot, written by select_kernel: the node goes to the concurrent launch of the larger on-chip variant (rounding probe, or its record is
+                                 // marked).  A snapshot taken BEFORE the two launches fork: both read only this byte, so a node is never eligible for both in one round
+                                 // (a record the standard kernel marks at its decode is large from the NEXT round on)
   unsigned char* pool_big;       // per record: 1 = more general rows than the standard on-chip kernel holds (found by that kernel at its decode, inherited by the children)
   int bounce;                    // 1: the standard on-chip kernel does not hand such a node on but marks it (pool_big) and returns it unsolved (batch_ok 5): eval_kernel
                                  // puts it back on its list, and from the next round on the larger variant takes it in its concurrent launch
@@ -586,6 +590,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   const double* D = B.inst_d + (size_t)inst * Y.dstride;
   const int* T = B.inst_i + (size_t)inst * Y.istride;
   const double ts = D[Y.d_glob + 7];
+  const double zdiam = D[Y.d_misc + 2];   // L1 diameter of the instance's reachable set (host box presolve): the weight of a stationarity residual in a bound
   {
     const signed char* src = B.pool_fix + (size_t)B.batch_node[node] * Y.fixlen;
     for (int k = tid; k < Y.fixlen; k += NT) fix[k] = src[k];
@@ -713,7 +718,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
 #ifdef MIQP_PROFILE
     if (it > 1 && first_proxy == 0 && obj + RHO_EL * tsum - (double)ncomp * comp > cutoff + 1e-9 * fabs(cutoff)) first_proxy = it;
 #endif
-    if (!(MIQP_ABL) && it > 1 && resid_fac * R0 < 1e-5 * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp - resid_fac * R0 * 1.0e4 > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }   // (dual value minus the allowance for the stationarity residual still left, see batch_bound)
+    if (!(MIQP_ABL) && it > 1 && resid_fac * R0 < 1e-5 * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp - resid_fac * R0 * zdiam > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }   // (dual value minus the allowance for the stationarity residual still left, see batch_bound)
     const double tau = sigma * comp;
     // ================= backward sweep: Riccati recursion, the whole stage algebra stays in the registers of the wave.
     // Matrices live in the D layout of v_mfma_f64_16x16x4_f64 (lane l: g = l>>4, c = l&15, register r <-> M[g+4r][c]).
@@ -1227,9 +1232,9 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   if (tid == 0) {
     B.batch_obj[node] = obj; B.batch_viol[node] = viol; B.batch_ok[node] = ok;
     // primal - dual value of the final iterate: total complementarity, plus what a stationarity residual r of the iterate can
-    // add to the Lagrangian over the trajectories a child may reach (|r|_inf x |z' - z|_1, the latter below 1e4: positions
-    // within the road, 8 C N entries) - the dual value and the bound lifting built on it stay rigorous at loose tolerances
-    B.batch_bound[node] = (double)ncomp * comp + resid_fac * R0 * 1.0e4;
+    // add to the Lagrangian over the trajectories a child may reach (|r|_inf x |z' - z|_1, the latter bounded by the L1 diameter of the
+    // reachable set of the instance, host_inst.hpp: d_misc + 2) - the dual value and the bound lifting built on it stay rigorous at loose tolerances
+    B.batch_bound[node] = (double)ncomp * comp + resid_fac * R0 * zdiam;
     B.batch_it[node] = it > QP_MAXIT ? QP_MAXIT : it;
     atomicAdd((unsigned long long*)&B.inst_iters[inst], (unsigned long long)(it > QP_MAXIT ? QP_MAXIT : it));
     atomicAdd((unsigned long long*)&B.inst_nodes[inst], 1ull);
@@ -1759,7 +1764,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       // (slots are handed out in arrival order: the same solve would keep one or the other solution from run to run)
       unsigned long long key = (d2key(obj) & ~0xFFFFFull) | (unsigned long long)((unsigned int)hsh & 0xFFFFFu);
       B.batch_obj[node] = obj;
-      B.batch_candkey[node] = key;
+      B.batch_candkey[node] = key; B.batch_candinst[node] = inst;
       atomicMin(&B.inc_key[inst], key);
       atomicAdd(&B.inst_ninc[inst], 1);
     }
@@ -2192,12 +2197,12 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     // same record hash - the smallest full objective, then the smallest slot)
     const unsigned long long key = sh_thr;
     const int pbc = B.prev_bc < B.batch_cap ? B.prev_bc : B.batch_cap;
-    for (int k = tid; k < pbc; k += SEL_THREADS) if (B.batch_candkey[k] == key) atomicMin(&sh_fmin, d2key(B.batch_obj[k]));
+    for (int k = tid; k < pbc; k += SEL_THREADS) if (B.batch_candkey[k] == key && B.batch_candinst[k] == inst) atomicMin(&sh_fmin, d2key(B.batch_obj[k]));   // (this instance's slots only: two instances of a queue can reach the same key)
     __syncthreads();
     const unsigned long long bo = sh_fmin;
     if (tid == 0) sh_dkeep = 0x7FFFFFFF;
     __syncthreads();
-    if (bo != ~0ull) for (int k = tid; k < pbc; k += SEL_THREADS) if (B.batch_candkey[k] == key && d2key(B.batch_obj[k]) == bo) atomicMin(&sh_dkeep, k);
+    if (bo != ~0ull) for (int k = tid; k < pbc; k += SEL_THREADS) if (B.batch_candkey[k] == key && B.batch_candinst[k] == inst && d2key(B.batch_obj[k]) == bo) atomicMin(&sh_dkeep, k);
     __syncthreads();
     if (tid == 0 && sh_dkeep != 0x7FFFFFFF) { sh_take = sh_dkeep; B.inc_seen[inst] = key; }
   }
@@ -2527,7 +2532,8 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
       }
       if (pick) {
         int pos = atomicAdd(&sh_pick, 1);
-        if (pos < take) { B.batch_node[base + pos] = nd; B.batch_inst[base + pos] = inst; B.batch_bound[base + pos] = b; B.batch_depth[base + pos] = dp; }
+        if (pos < take) { B.batch_node[base + pos] = nd; B.batch_inst[base + pos] = inst; B.batch_bound[base + pos] = b; B.batch_depth[base + pos] = dp;
+                          if (B.batch_large) B.batch_large[base + pos] = (is_probe_word(dp) || (B.pool_big && B.pool_big[nd])) ? 1 : 0; }
         else pick = false;
       }
     }

@@ -60,6 +60,16 @@ struct OwnedResults {
                                f.slackvarsObstacle, f.slackvarsObstacle_front};
     for (int k = 0; k < 17; ++k) if (si[k]) std::copy(si[k], si[k] + i[k].size(), i[k].begin());
   }
+  // ... and the other way: this record into a caller's record of the same seven sizes (null arrays are skipped)
+  void copy_to(miqp_raw_results_c& f) const {
+    double* const sd[13] = {f.u_x, f.u_y, f.pos_x, f.vel_x, f.acc_x, f.pos_y, f.vel_y, f.acc_y, f.pos_x_front_UB, f.pos_x_front_LB, f.pos_y_front_UB, f.pos_y_front_LB, f.slackvars_real};
+    for (int k = 0; k < 13; ++k) if (sd[k]) std::copy(d[k].begin(), d[k].end(), sd[k]);
+    int* const si[17] = {f.notWithinEnvironmentRear, f.notWithinEnvironmentFrontUbUb, f.notWithinEnvironmentFrontLbUb, f.notWithinEnvironmentFrontUbLb, f.notWithinEnvironmentFrontLbLb,
+                         f.active_region, f.region_change_not_allowed_x_positive, f.region_change_not_allowed_y_positive, f.region_change_not_allowed_x_negative,
+                         f.region_change_not_allowed_y_negative, f.region_change_not_allowed_combined, f.deltacc, f.deltacc_front, f.car2car_collision, f.slackvars,
+                         f.slackvarsObstacle, f.slackvarsObstacle_front};
+    for (int k = 0; k < 17; ++k) if (si[k]) std::copy(i[k].begin(), i[k].end(), si[k]);
+  }
 };
 
 // the seven sizes of a RawResults record against the loaded instance (a record of another shape is never indexed)
@@ -82,6 +92,9 @@ struct miqp_solver {
   // Slot 0: receding-horizon start (addRecedingHorizonWarmstart), slot 1: last-solution start (.mst file); with
   // BOTH_WARMSTART_STRATEGIES the reference applies both (src/cplex_wrapper.cpp:124-138)
   std::unique_ptr<OwnedResults> ws[2];
+  // result record of the last solve, built by miqp_solver_materialize_results (host threads, inside a batch call's timing) and
+  // handed out by miqp_solver_get_results; dropped whenever the solution or the instance changes
+  std::unique_ptr<OwnedResults> rescache;
   std::string err;
 };
 
@@ -415,7 +428,11 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&B.batch_node, batch_alloc)) return false;
   if (!X.alloc(&B.batch_candkey, batch_alloc)) return false;
   HIP_OK(hipMemset(B.batch_candkey, 0xFF, (size_t)batch_alloc * 8));
+  if (!X.alloc(&B.batch_candinst, batch_alloc)) return false;
+  HIP_OK(hipMemset(B.batch_candinst, 0xFF, (size_t)batch_alloc * 4));
   if (!X.alloc(&B.batch_inst, batch_alloc)) return false;
+  if (!X.alloc(&B.batch_large, batch_alloc)) return false;
+  HIP_OK(hipMemset(B.batch_large, 0, (size_t)batch_alloc));
   if (!X.alloc(&B.batch_depth, batch_alloc)) return false;
   if (!X.alloc(&B.batch_Z, (size_t)batch_alloc * Y.N * Y.nz)) return false;
   if (!X.alloc(&B.batch_obj, batch_alloc)) return false;
@@ -825,7 +842,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   std::vector<std::vector<int>> inst_root_depth(n);
   std::vector<char> h_feas0(n, 0);
   auto prepare_one = [&](int k) {
-    miqp_solver* s = S[k]; s->lay = Y; s->has_sol = false;
+    miqp_solver* s = S[k]; s->lay = Y; s->has_sol = false; s->rescache.reset();
     compile_instance(s->inst, Y, &hD[(size_t)k * Y.dstride], &hT[(size_t)k * Y.istride]);
     HostGeo G{s->inst, Y, &hD[(size_t)k * Y.dstride], &hT[(size_t)k * Y.istride]};
     double cobj = 0; bool feas0 = step0_check(G, cobj);
@@ -933,6 +950,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   // ---- streaming admission (host side): which instance holds which slot, when it entered, who is next
   std::vector<int> h_slot_inst(NS, -1), h_kill(n, 0), h_pairs; std::vector<double> t_admit(n, 0.0);
   int next_q = 0, in_flight = 0;
+  bool abandoned = false, stuck_once = false;   // the round loop was left with instances still queued or in flight (reported, never silent)
   // frees the slots of proven / retired instances and fills them from the queue; `sel`: the list buffer the next select reads
   auto admit = [&](double now, int sel) -> bool {
     h_pairs.clear();
@@ -1020,11 +1038,21 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       if (any_kill) HIP_OK(hipMemcpyAsync(B.inst_kill, h_kill.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
       if (!admit(tnow, 1 - (rounds & 1))) return fail_all(nullptr);
       if (in_flight == 0 && next_q >= n) break;   // the queue is drained
-      if (tnow > tlim * (double)((n + NS - 1) / NS + 1) + 30.0) break;   // (safety net: no instance can outlive its limit by more than a round)
+      if (tnow > tlim * (double)((n + NS - 1) / NS + 1) + 30.0) { abandoned = true; break; }   // (safety net: no instance can outlive its limit by more than a round)
       if (bc <= 0) {   // a round may come up empty while a list tier is being reorganised, or right after admissions
-        if (++empty_rounds > 64) break;
+        // 64 empty rounds in a row: the instances in flight are stuck (none of them is done, none has an open node to offer).  They are
+        // retired like instances at their time limit - the slots go to the rest of the queue, which is NOT abandoned; a second such
+        // streak with nothing admitted in between ends the call with an error
+        if (++empty_rounds > 64) {
+          if (stuck_once) { abandoned = true; break; }
+          stuck_once = true; empty_rounds = 0;
+          for (int sl = 0; sl < NS; ++sl) { const int k = h_slot_inst[sl]; if (k >= 0 && !h_done_now[k]) h_kill[k] = 1; }
+          HIP_OK(hipMemcpyAsync(B.inst_kill, h_kill.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+          std::fprintf(stderr, "[miqp_gpu] %d instances in flight made no progress for 64 rounds: retired, the queue goes on\n", in_flight);
+        }
         rounds++; prev_bc = 0; continue;
       }
+      stuck_once = false;
       empty_rounds = 0;
     }
     if (bc > X.batch_cap) bc = X.batch_cap;
@@ -1262,6 +1290,11 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     miqp_solver* s = S[k];
     bool have = h_inc[k] < 1e299;
     bool unfinished = (h_flags[k] & 3) || h_oc[k] > 0 || !h_dn[k];   // bit 0: a list or the record pool overflowed, bit 1: retired at its time limit
+    if (!split && k >= next_q && !h_done[k]) {   // never admitted (the round loop was abandoned): the solver did not run on it - not a time-limit verdict
+      s->status = MIQP_STATUS_FAILED_SEG_FAULT; s->has_sol = false; s->props.objective = NAN; s->props.gap = NAN; s->props.best_bound = NAN; s->props.status = 0; s->props.time = 0.0;
+      s->err = "the queue was abandoned before this instance was admitted";
+      statuses[k] = s->status; continue;
+    }
     s->props.time = h_tdone[k] >= 0 ? h_tdone[k] : std::max(0.0, t_solve - t_admit[k]);   // from the instance's admission to its proof (or to the end of the call)
     s->props.NrIterations = (int)std::min<long long>(h_iters[k], 2147483647LL); s->props.nodes = h_nodes[k];
     s->props.NrSolutionPool = h_ninc[k];
@@ -1286,8 +1319,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     }
     statuses[k] = s->status;
   }
+  if (abandoned) std::fprintf(stderr, "[miqp_gpu] the round loop was abandoned with %d of %d instances never admitted: they report FAILED_SEG_FAULT, the call fails\n", n - next_q, n);
   if (std::getenv("MIQP_STATS")) std::fprintf(stderr, "[miqp_gpu stats] host: setup %.3f s (device context %.3f, instance tables and presolve %.3f, upload %.3f), rounds %.3f s (%d), results %.3f s\n", t_setup, t_ctx, t_tables, t_setup - t_ctx - t_tables, t_solve, rounds, wall_s() - t0 - t_solve);
-  return true;
+  return !abandoned;
 }
 
 }  // namespace
@@ -1311,6 +1345,7 @@ void miqp_solver_destroy(miqp_solver_t* s) { delete s; }
 int miqp_solver_set_params(miqp_solver_t* s, const miqp_model_params_c* p) {
   if (!s || !p) return -1;
   s->has_inst = inst_from_params(p, s->opts.precision - 2, s->inst, s->err);
+  s->rescache.reset();
   s->has_sol = false;   // MIP starts stay registered (the reference keeps them in the wrapper across resetParameters)
   if (!s->has_inst) std::fprintf(stderr, "[miqp_gpu] %s\n", s->err.c_str());
   return s->has_inst ? 0 : -2;
@@ -1319,7 +1354,7 @@ int miqp_solver_set_params(miqp_solver_t* s, const miqp_model_params_c* p) {
 int miqp_solver_load_dat(miqp_solver_t* s, const char* path) {
   if (!s || !path) return -1;
   s->has_inst = inst_from_dat(path, s->inst, s->err);
-  s->has_sol = false;
+  s->has_sol = false; s->rescache.reset();
   if (!s->has_inst) std::fprintf(stderr, "[miqp_gpu] %s\n", s->err.c_str());
   return s->has_inst ? 0 : -2;
 }
@@ -1551,10 +1586,34 @@ int miqp_solver_solve(miqp_solver_t* s, double timestamp) {
 int miqp_solver_get_results(const miqp_solver_t* s, miqp_raw_results_c* out) {
   if (!s || !out || !s->has_sol) return -1;
   if (!dims_match(*out, s->inst)) return -2;   // the caller's record must be sized for this instance
+  if (s->rescache) { out->N = s->rescache->r.N; out->NrEnvironments = s->rescache->r.NrEnvironments; out->NrRegions = s->rescache->r.NrRegions; out->NrObstacles = s->rescache->r.NrObstacles;
+                     out->MaxLinesObstacles = s->rescache->r.MaxLinesObstacles; out->NrCarToCarCollisions = s->rescache->r.NrCarToCarCollisions; out->NrCars = s->rescache->r.NrCars;
+                     s->rescache->copy_to(*out); return 0; }
   std::vector<double> D(s->lay.dstride); std::vector<int> T(s->lay.istride);
   compile_instance(s->inst, s->lay, D.data(), T.data());
   fill_results(s->inst, s->lay, D.data(), T.data(), s->comp.data(), s->Z.data(), out);
   return 0;
+}
+
+int miqp_solver_materialize_results(miqp_solver_t* const* solvers, int n, int threads) {
+  if (!solvers || n < 0) return -1;
+  int nth = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+  nth = std::max(1, std::min(nth, std::max(1, n / 4)));
+  std::atomic<int> next{0}, made{0};
+  auto work = [&] {
+    for (int k = next.fetch_add(1); k < n; k = next.fetch_add(1)) {
+      miqp_solver* s = solvers[k];
+      if (!s || !s->has_sol || s->rescache) continue;
+      std::unique_ptr<OwnedResults> R(new OwnedResults(s->inst));
+      std::vector<double> D(s->lay.dstride); std::vector<int> T(s->lay.istride);
+      compile_instance(s->inst, s->lay, D.data(), T.data());
+      fill_results(s->inst, s->lay, D.data(), T.data(), s->comp.data(), s->Z.data(), &R->r);
+      s->rescache = std::move(R); made.fetch_add(1);
+    }
+  };
+  if (nth <= 1) work();
+  else { std::vector<std::thread> th; for (int t = 0; t < nth; ++t) th.emplace_back(work); for (auto& t : th) t.join(); }
+  return made.load();
 }
 
 int miqp_solver_get_properties(const miqp_solver_t* s, miqp_solution_properties_c* out) {

@@ -69,6 +69,7 @@ def load_library():
     L.miqp_comm_finalize.restype = C.c_int; L.miqp_comm_finalize.argtypes = []
     L.miqp_comm_selftest.restype = C.c_int; L.miqp_comm_selftest.argtypes = [EXCHANGE_FN, vp, C.c_int, C.c_int]
     L.miqp_solver_get_results.restype = C.c_int; L.miqp_solver_get_results.argtypes = [vp, C.POINTER(RawResultsC)]
+    L.miqp_solver_materialize_results.restype = C.c_int; L.miqp_solver_materialize_results.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
     L.miqp_solver_get_properties.restype = C.c_int; L.miqp_solver_get_properties.argtypes = [vp, C.POINTER(SolutionPropertiesC)]
     L.miqp_solver_get_dims.restype = C.c_int; L.miqp_solver_get_dims.argtypes = [vp, C.POINTER(C.c_int)]
     L.miqp_solver_export_lp.restype = C.c_int; L.miqp_solver_export_lp.argtypes = [vp, C.c_char_p]
@@ -93,7 +94,7 @@ EXPORTED_SYMBOLS = ["miqp_solver_create", "miqp_solver_destroy", "miqp_solver_se
                     "miqp_calculate_possible_regions", "miqp_calculate_warmstart", "miqp_plan",
                     "miqp_solver_solve_batch_multi", "miqp_solver_raw_sizes", "miqp_solver_lift_tables", "miqp_reference_trajectory", "miqp_update_car", "miqp_fitting_polynomial_parameters",
                     "miqp_solver_solve_split", "miqp_solver_solve_split_rccl", "miqp_solver_split_roots", "miqp_comm_unique_id",
-                    "miqp_comm_init", "miqp_comm_finalize", "miqp_comm_selftest", "miqp_solver_solve_stream",
+                    "miqp_comm_init", "miqp_comm_finalize", "miqp_comm_selftest", "miqp_solver_solve_stream", "miqp_solver_materialize_results",
                     "miqp_initial_pose_check", "miqp_select_environment", "miqp_obstacle_intersects_environment", "miqp_environment_warmstart"]
 
 
@@ -405,6 +406,16 @@ def solve_batch(wrappers, gpus=None, inflight=None, prepared=False):
         rc = L.miqp_solver_solve_stream(hs, n, int(inflight), st)
     else:
         rc = L.miqp_solver_solve_batch(hs, n, st) if gpus is None else L.miqp_solver_solve_batch_multi(hs, n, int(gpus), st)
-    if rc != 0:
+    if rc not in (0, -2):
         return [OptimizationStatus.FAILED_SEG_FAULT] * n
+    # (-2: the call failed as a whole or in part - the library has set every status: FAILED_SEG_FAULT for the instances it did not run)
     return [w._collect(st[k], lazy=True) for k, w in enumerate(wrappers)]
+
+
+def materialize_results(wrappers, threads=0):
+    """builds the RawResults records of a solved batch on host threads inside the library (miqp_solver_materialize_results);
+    getRawResults() of each wrapper then only copies.  Returns the number of records built."""
+    L = load_library()
+    n = len(wrappers)
+    hs = (C.c_void_p * n)(*[w._h for w in wrappers])
+    return L.miqp_solver_materialize_results(hs, n, int(threads))

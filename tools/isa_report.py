@@ -17,7 +17,7 @@ def main():
     flags = ["--offload-arch=gfx950", "-O3", "-fno-math-errno", "-freciprocal-math", "-fno-signed-zeros", "-fno-trapping-math", "-std=c++17"]
     if not os.environ.get("ISA_REUSE"): subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-DMIQP_ISA_MARKS", "--cuda-device-only", "-S", "-o", tmp + "/k.s", SRC])
     txt = open(tmp + "/k.s").read()
-    sym = "_ZN4miqp17ipm_onchip_kernelILi2ELi10ELi0EEEvNS_6DevBufE"
+    sym = "_ZN4miqp17ipm_onchip_kernelILi2ELi10ELi0ELi128EEEvNS_6DevBufE"
     a = txt.index("\n" + sym + ":"); b = txt.index(".Lfunc_end", a)
     body = txt[a:b].split("\n")[2:]
     phase = "prologue"; order = [phase]
@@ -53,7 +53,7 @@ def main():
     for ph in order:
         out.append("%-22s" % names.get(ph, ph) + "".join("%11d" % cnt[ph][c] for c in cols))
     out.append("%-22s" % "total" + "".join("%11d" % sum(cnt[ph][c] for ph in order) for c in cols))
-    meta = re.search(r"\.amdhsa_kernel _ZN4miqp17ipm_onchip_kernelILi2ELi10ELi0EEEvNS_6DevBufE(.*?)\.end_amdhsa_kernel", txt, re.S).group(1)
+    meta = re.search(r"\.amdhsa_kernel _ZN4miqp17ipm_onchip_kernelILi2ELi10ELi0ELi128EEEvNS_6DevBufE(.*?)\.end_amdhsa_kernel", txt, re.S).group(1)
     for key in ("next_free_vgpr", "next_free_sgpr", "accum_offset", "private_segment_fixed_size", "group_segment_fixed_size"):
         mm = re.search(r"\.amdhsa_%s (\S+)" % key, meta)
         if mm: out.append("%s = %s" % (key, mm.group(1)))
