@@ -216,6 +216,8 @@ def main():
         return ps, ws
 
     batches = [make_batch(s) for s in range(a.warmup + a.steps)]
+    if os.environ.get("MIQP_BENCH_DUMP_SEEDS"):   # (tests: which seeds this rank solves in its timed steps)
+        print("[bench seeds] " + json.dumps(dict(rank=rank, timed=[sd for st_ in range(a.warmup, a.warmup + a.steps) for sd in seeds_of(st_)])), file=sys.stderr, flush=True)
     infl = None if a.no_stream else B
     lp_files = []
     if a.dump_lp and rank == 0:

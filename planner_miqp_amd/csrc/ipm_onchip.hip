@@ -184,13 +184,13 @@ __device__ inline bool slot_maybe(const Layout& Y, const signed char* fix, int i
 }
 
 // lambda + kappa and w of one row for the Newton system of the next iteration (see row_step)
-__device__ inline void row_weight(double s, double lam, double t, bool soft, double aq, double tau, double& w, double& lk) {
+__device__ inline void row_weight(double s, double lam, double t, bool soft, double aq, double tau, double& w, double& lk, double k1 = 1.0) {
   const double il = frcp(lam);
   double zz, r2mu = 0.0;
-  if (!soft) { const double mu = RHO_EL - lam, im = frcp(mu); zz = t * im; r2mu = (tau - t * mu) * im; }
+  if (!soft) { const double mu = RHO_EL - lam, im = frcp(mu); zz = t * im; r2mu = (tau - k1 * (t * mu)) * im; }
   else zz = frcp(aq);
   w = frcp(s * il + zz);
-  lk = lam + ((tau - s * lam) * il - r2mu) * w;
+  lk = lam + ((tau - k1 * (s * lam)) * il - r2mu) * w;
 }
 
 // ABL != 0 (diagnostic build -DMIQP_ABLATE, replayed on a batch the real kernel has solved): 15 iterations per node without
@@ -365,7 +365,8 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
       RowOut r; r.active = false; r.rhs = 0; r.aq = 0;
       int i = 0, nn = 0;
       const bool mine = tid < OC_SCR && c0 + tid < ngen;
-      if (mine) { const int pcode = cand[c0 + tid]; i = pcode / NSLOT; r = decode_row<C, true>(Y, D, T, fix, i, pcode - i * NSLOT, g); }
+      int slot_ = 0;
+      if (mine) { const int pcode = cand[c0 + tid]; i = pcode / NSLOT; slot_ = pcode - i * NSLOT; r = decode_row<C, true>(Y, D, T, fix, i, slot_, g); }
       unsigned long long map = 0ull; unsigned int cols = 0u;
       double v6[6];
 #pragma unroll
@@ -395,6 +396,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
         uint4 m4; m4.x = (unsigned int)map; m4.y = (unsigned int)(map >> 32);
         m4.z = (unsigned int)off | ((unsigned int)nn << 16) | ((unsigned int)i << 20) | (r.aq > 0.0 ? 0x80000000u : 0u); m4.w = cols;
         gmeta[idx] = m4; grhs[idx] = r.rhs;
+        cand[idx] = (unsigned short)(i * NSLOT + slot_);   // the row's identity (idx <= its position in the list: read above by every lane of this chunk)
         atomicAdd(&sstart[i + 1], 1);
       }
       OC_WAVE_SYNC();
@@ -415,7 +417,19 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     if (tid == 0) { int a = 0; for (int i = 0; i <= N; ++i) { const int n = sstart[i]; a += n; sstart[i] = a; } }   // sstart[i]: first general row of stage i (counts were stored at i + 1)
     OC_WAVE_SYNC();
 
-    // ---- initial row state (the interior point starts at the free rollout)
+    // ---- initial row state (the interior point starts at the free rollout, or at the parent's solution and multipliers)
+    const int rec_ = B.batch_node[node];
+    const unsigned char* const lgp = B.pool_Lgen ? B.pool_Lgen + (size_t)rec_ * LGEN_BYTES : nullptr;
+    const int npar = (warm && B.ws_dual && B.ws_on != 2 && lgp) ? __builtin_amdgcn_readfirstlane(*(const int*)lgp) : -1;   // general rows of the parent whose multipliers the record carries (-1: no multipliers)
+    const bool dual = npar >= 0;
+    const float* const lbp = dual ? B.pool_Lbox + (size_t)rec_ * lbox_floats(N) : nullptr;
+    unsigned short* const ppc = (unsigned short*)scr;                 // the parent's general rows, staged in the decode scratch: decode slots ...
+    float* const plm = (float*)(scr + (LGEN_CAP * 2 + 7) / 8);         // ... and multipliers
+    if (dual) {
+      const unsigned short* gpc = (const unsigned short*)(lgp + 4); const float* glm = (const float*)(lgp + 4 + LGEN_CAP * 2);
+      for (int k = tid; k < npar; k += 64) { ppc[k] = gpc[k]; plm[k] = glm[k]; }
+    }
+    OC_WAVE_SYNC();
     double bs[NSL], bl[NSL], bt[NSL];
     unsigned int bact = 0u;
     double csum = 0.0, tsum = 0.0; int cnt = 0;
@@ -428,7 +442,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
         if (key != ~0ull) {
           const double rh = key2d(key), c = rh - bsgn * Z[i * 16 + lc];
           double s, t, l0;
-          init_elastic(c, warm, B.ws_mu, B.ws_delta, s, l0, t);
+          init_elastic(c, warm, B.ws_mu, B.ws_delta, s, l0, t, dual ? (double)lbp[(i * 2 + side) * 16 + lc] : 0.0);
           bs[k] = s; bl[k] = l0; bt[k] = t; bact |= 1u << k;
           csum += s * l0 + t * (RHO_EL - l0); cnt += 2; tsum += t;
         }
@@ -447,17 +461,24 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
         double c = grhs[r];
 #pragma unroll
         for (int k = 0; k < 6; ++k) if (k < nn) c -= gcoef[off + k] * Z[i * 16 + ((m4.w >> (4 * k)) & 15u)];
+        double lam_p = 0.0;
+        if (dual) {   // the parent's multiplier of the row with this decode slot (both lists are in decode order)
+          const int pc = cand[r]; int lo = 0, hi = npar;
+          while (lo < hi) { const int md = (lo + hi) >> 1; if ((int)ppc[md] < pc) lo = md + 1; else hi = md; }
+          if (lo < npar && (int)ppc[lo] == pc) lam_p = (double)plm[lo];
+        }
         if (!(m4.z & 0x80000000u)) {
           double s, t, l0;
-          init_elastic(c, warm, B.ws_mu, B.ws_delta, s, l0, t);
+          init_elastic(c, warm, B.ws_mu, B.ws_delta, s, l0, t, lam_p);
           gs_[q] = s; gl_[q] = l0; gt_[q] = t;
           csum += s * l0 + t * (RHO_EL - l0); cnt += 2; tsum += t;
         } else {
-          const double lam = fmax(1.0, -2.0 * c * aqs + 1.0), s = c + lam / aqs;
+          const double lam = fmax(fmax(1.0, -2.0 * c * aqs + 1.0), lam_p), s = c + lam / aqs;
           gs_[q] = s; gl_[q] = lam; gt_[q] = 1.0; csum += s * lam; cnt += 1;   // t of a soft row is never used
         }
       }
     }
+    if (warm && B.ws_on != 2) gflag |= 0x40000000u;   // (a warm-started node relaxation: per-pair centring targets, see ws_theta)
     OC_WAVE_SYNC();   // the keys are consumed: their region becomes (sqrt(w), f)
     OCP_T(tp_d1); OCP_ACC(0, tp_d0, tp_d1);
     double comp = wave_sum(csum);
@@ -469,6 +490,8 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     const int NROWS = NM + nbox;
 
     int it = 0, ok = 0;
+    // centring targets of a start from the parent's multipliers: share wmix of the mean, the rest (k1 = 1 - sigma (1 - wmix), applied per pair
+    // below) proportional to the pair's own product, see row_step
     double resid_fac = 1.0, R0 = 0.0, obj = 0.0;
     double sigma = QP_SIGMA;
     unsigned long long rowiters = 0;
@@ -487,7 +510,12 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
       if (BIG && B.probe_itcap > 0 && it > B.probe_itcap && B.ws_on != 2 && is_probe_word(B.batch_depth[node])) { ok = 2; break; }
       if (it > 1 && resid_fac * R0 < 1e-5 * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp - resid_fac * R0 * zdiam > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }   // (dual value minus the allowance for the stationarity residual still left, see batch_bound)
       }
-      const double tau = sigma * comp;
+#ifdef MIQP_NO_K1
+      const double wmix = 1.0;
+#else
+      const double wmix = (gflag & 0x40000000u) ? B.ws_theta : 1.0;   // (bit 30 of the row flags: started from the parent's solution)
+#endif
+      const double tau = sigma * comp * wmix, k1 = 1.0 - sigma * (1.0 - wmix);   // target of a pair: sigma (wmix mean + (1 - wmix) own product); cold starts: wmix = 1, k1 = 1
       OCP_T(tp_r0);
       // ================= row pass 1: weights of every row for this iteration
       // box rows -> diagonal and gradient contribution per (stage, column): the two sides of a column sit in lanes l, l ^ 16
@@ -508,7 +536,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
           for (int k = k0; k < k0 + OC_GRP && k < NSL; ++k) {
             const int i = 2 * k + par1;
             const bool act = (bact >> k) & 1u;
-            double w, lk; row_weight(bs[k], bl[k], bt[k], false, 0.0, tau, w, lk);
+            double w, lk; row_weight(bs[k], bl[k], bt[k], false, 0.0, tau, w, lk, k1);
             w = act ? w : 0.0; lk = act ? lk * sg1 : 0.0;
             w = sum_xor16(w); lk = sum_xor16(lk);
             if (side0 && i < N) { dgp[k * 32] = w; gdp[k * 32] = lk; }   // row 2 k + par, column lc: one base, the slot as immediate offset
@@ -520,7 +548,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
       for (int q = 0; q < (((OC_ABL) & 4) ? 0 : OC_GSLOTS); ++q) {
         const int r = q * 64 + l1;
         const bool soft = ((gflag >> q) & 1u) != 0u;
-        double w, lk; row_weight(gs_[q], gl_[q], gt_[q], soft, aqs, tau, w, lk);
+        double w, lk; row_weight(gs_[q], gl_[q], gt_[q], soft, aqs, tau, w, lk, k1);
         const double isw = frsq(w);
         if (r < NM) {
           gswfs[2 * r] = w * isw;
@@ -835,7 +863,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
           for (int k = k0; k < k0 + OC_GRP && k < NSL; ++k) {
             const bool act = (bact >> k) & 1u;
             const double s = bs[k], lam = bl[k], t = bt[k], gd = act ? sg2 * dzp[k * 32] : 0.0;
-            double ds, dl, dt; row_step(s, lam, t, 0.0, gd, tau, ds, dl, dt);
+            double ds, dl, dt; row_step(s, lam, t, 0.0, gd, tau, ds, dl, dt, k1);
             const double mu = RHO_EL - lam;
             const double rr_ = fmax(fmax(-ds * __builtin_amdgcn_rcp(s), -dl * __builtin_amdgcn_rcp(lam)), fmax(-dt * __builtin_amdgcn_rcp(t), dl * __builtin_amdgcn_rcp(mu)));
             rinv = fmax(rinv, act ? rr_ : 0.0);
@@ -857,7 +885,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
         }
         ggd[q] = gd;
         const double s = gs_[q], lam = gl_[q], t = gt_[q];
-        double ds, dl, dt; row_step(s, lam, t, soft ? aqs : 0.0, gd, tau, ds, dl, dt);
+        double ds, dl, dt; row_step(s, lam, t, soft ? aqs : 0.0, gd, tau, ds, dl, dt, k1);
         const double mu = RHO_EL - lam;
         double rr_ = fmax(-ds * __builtin_amdgcn_rcp(s), -dl * __builtin_amdgcn_rcp(lam));
         const double r2_ = fmax(-dt * __builtin_amdgcn_rcp(t), dl * __builtin_amdgcn_rcp(mu));
@@ -892,7 +920,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
           for (int k = k0; k < k0 + OC_GRP && k < NSL; ++k) {
             const bool act = (bact >> k) & 1u;
             const double s = bs[k], lam = bl[k], t = bt[k], gd = act ? sg3 * dzq[k * 32] : 0.0;
-            double ds, dl, dt; row_step(s, lam, t, 0.0, gd, tau, ds, dl, dt);
+            double ds, dl, dt; row_step(s, lam, t, 0.0, gd, tau, ds, dl, dt, k1);
             const double al = act ? alpha : 0.0;
             bs[k] = s + al * ds; bl[k] = lam + al * dl; bt[k] = t + al * dt;
             tnew += act ? bt[k] : 0.0;
@@ -903,7 +931,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
       for (int q = 0; q < OC_GSLOTS; ++q) {
         const bool used = ((gflag >> (8 + q)) & 1u) != 0u, soft = ((gflag >> q) & 1u) != 0u;
         const double s = gs_[q], lam = gl_[q], t = gt_[q];
-        double ds, dl, dt; row_step(s, lam, t, soft ? aqs : 0.0, ggd[q], tau, ds, dl, dt);
+        double ds, dl, dt; row_step(s, lam, t, soft ? aqs : 0.0, ggd[q], tau, ds, dl, dt, k1);
         const double al = used ? alpha : 0.0;
         gs_[q] = s + al * ds; gl_[q] = lam + al * dl; gt_[q] = t + al * dt;
         tnew += (used && !soft) ? gt_[q] : 0.0;
@@ -940,6 +968,22 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     obj += scost;   // (obj is the quadratic objective of the final Z: recomputed by every update, and a node leaves the loop right after one or at its top)
     double* Zo = B.batch_Z + (size_t)node * N * NZ;
     for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) Zo[(k >> 4) * NZ + oc_lcol<C, CM>(q)] = Z[k]; }
+    if (B.batch_Lbox) {   // the multipliers, by row identity, for the children (DevBuf::pool_Lbox)
+      const int le = fresh_lane();   // (lane-dependent addresses from the execution mask: nothing of them is kept across the iteration loop)
+      float* lb = B.batch_Lbox + (size_t)node * lbox_floats(N) + ((le >> 5) * 2 + ((le >> 4) & 1)) * 16 + (le & 15);   // stage parity, side, column of this lane
+#pragma unroll
+      for (int k = 0; k < NSL; ++k) { if (2 * k + (le >> 5) < N) lb[k * 64] = ((bact >> k) & 1u) ? (float)bl[k] : 0.0f; }   // stage 2 k + parity: 2 x 32 floats on
+      unsigned char* lg = B.batch_Lgen + (size_t)node * LGEN_BYTES;
+      const int nm_ = sstart[N];   // (= NM: the general rows of the node)
+      const bool fits = nm_ <= LGEN_CAP;
+      if (le == 0) *(int*)lg = fits ? nm_ : -1;
+      if (fits) {
+        unsigned short* gpc = (unsigned short*)(lg + 4); float* glm = (float*)(lg + 4 + LGEN_CAP * 2);
+        const unsigned short* cd = (const unsigned short*)(L0 + oc_lds_layout(N, Y.fixlen, GCAP).cand);
+#pragma unroll
+        for (int q = 0; q < OC_GSLOTS; ++q) { const int r = q * 64 + le; if (r < nm_) { gpc[r] = cd[r]; glm[r] = (float)gl_[q]; } }
+      }
+    }
     if (tid == 0) {
       const int itc = it > QP_MAXIT ? QP_MAXIT : it;
       B.batch_obj[node] = obj; B.batch_viol[node] = viol; B.batch_ok[node] = ok;

@@ -173,7 +173,18 @@ struct DevBuf {
   // residual, multiplier ws_mu / s - instead of at the free rollout with the same multiplier on every row.
   double* pool_Z;                // [z_cap][N * nz] in the model's column order (null: cold starts only); records beyond z_cap start cold
   double ws_mu, ws_delta; int ws_on; int z_cap;
+  // ... and the parent's MULTIPLIERS (on-chip kernels).  Rows keep their identity from parent to child: a box row is its key (stage, side,
+  // column of the kernel's order), a general row its decode slot (stage x NSLOT + slot).  Per record: the multipliers of the box keys as
+  // floats, [N][2][16], 0 = no row; and {count, decode slots (u16), multipliers (f32)} of up to LGEN_CAP general rows in decode order
+  // (count -1: none stored - the node was solved by the memory-backed kernel, or had more rows).  The interior point of a child starts
+  // at (Z, lambda) of its parent: multiplier max(lambda_parent, ws_mu / s), which leaves only the rows the branching adds off the
+  // parent's stationarity.  eval_kernel copies the parent's batch record to every child (like pool_Z).
+  float* pool_Lbox; unsigned char* pool_Lgen; float* batch_Lbox; unsigned char* batch_Lgen; int ws_dual;
+  double ws_theta;               // share of the mean in a pair's centring target (1: the uniform target of a cold start), see row_step
 };
+constexpr int LGEN_CAP = 160;                                  // general-row multipliers carried per record
+constexpr int LGEN_BYTES = ((4 + LGEN_CAP * 6) + 15) & ~15;   // int count | u16 slot[LGEN_CAP] | f32 lambda[LGEN_CAP]
+__host__ __device__ inline int lbox_floats(int N) { return N * 32; }
 
 __device__ inline unsigned long long d2key(double v) {
   unsigned long long u = (unsigned long long)__double_as_longlong(v);
@@ -515,14 +526,15 @@ __device__ inline double frsq(double x) {
 // Cold (free rollout): the slack follows the residual, the same multiplier everywhere.  Warm (the parent's solution): the row is
 // put on the central path at mu0 - an inactive row (large residual) gets a small multiplier, an active or violated one a slack
 // of delta and the matching multiplier (capped well inside (0, rho)).
-__device__ inline void init_elastic(double c, bool warm, double mu0, double delta, double& s, double& lam, double& t) {
+// lam_p > 0: the multiplier the row had at the parent's solution - kept when it is the larger one.
+__device__ inline void init_elastic(double c, bool warm, double mu0, double delta, double& s, double& lam, double& t, double lam_p = 0.0) {
   if (!warm) {
     if (c > QP_T0) { t = QP_T0; s = c + QP_T0; } else { s = MIQP_S0 * QP_T0; t = s - c; }
     lam = MIQP_LAM0;
     return;
   }
   s = c > delta ? c : delta;
-  lam = mu0 / s; if (lam > 0.5 * RHO_EL) lam = 0.5 * RHO_EL;
+  lam = mu0 / s; if (lam < lam_p) lam = lam_p; if (lam > 0.5 * RHO_EL) lam = 0.5 * RHO_EL;
   double tt = mu0 / (RHO_EL - lam);          // central value of the elastic slack
   if (s - c > tt) tt = s - c;                // ... or what the violated row needs
   t = tt; s = c + tt;                        // (s - t = c exactly)
@@ -530,12 +542,15 @@ __device__ inline void init_elastic(double c, bool warm, double mu0, double delt
 
 // ------------------------------------------------------------------------------------------------
 //  Newton step of one row (elastic: aq == 0, quadratic-soft: aq > 0) given g.dz
-__device__ inline void row_step(double s, double lam, double t, double aq, double gd, double tau, double& ds, double& dl, double& dt) {
+// k1 < 1 (warm-started nodes, DevBuf::ws_theta): every complementarity pair follows its OWN target, tau + (1 - k1) x its product - the
+// uniform part tau = sigma theta mean, the rest proportional to where the pair stands; pairs the parent's solution has already
+// brought close to complementarity are not thrown back to the mean that the few violated rows of a child dominate
+__device__ inline void row_step(double s, double lam, double t, double aq, double gd, double tau, double& ds, double& dl, double& dt, double k1 = 1.0) {
   // three reciprocals per row: 1/lambda, 1/mu (or 1/aq), 1/D
   const double il = frcp(lam);
-  const double r1 = tau - s * lam;
+  const double r1 = tau - k1 * (s * lam);
   double zz, r2m = 0.0, im = 0.0, r2 = 0.0;
-  if (aq == 0.0) { const double mu = RHO_EL - lam; im = frcp(mu); zz = t * im; r2 = tau - t * mu; r2m = r2 * im; }
+  if (aq == 0.0) { const double mu = RHO_EL - lam; im = frcp(mu); zz = t * im; r2 = tau - k1 * (t * mu); r2m = r2 * im; }
   else zz = frcp(aq);
   const double w = frcp(s * il + zz);
   dl = (gd + r1 * il - r2m) * w;
@@ -1235,6 +1250,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     // add to the Lagrangian over the trajectories a child may reach (|r|_inf x |z' - z|_1, the latter bounded by the L1 diameter of the
     // reachable set of the instance, host_inst.hpp: d_misc + 2) - the dual value and the bound lifting built on it stay rigorous at loose tolerances
     B.batch_bound[node] = (double)ncomp * comp + resid_fac * R0 * zdiam;
+    if (B.batch_Lgen) *(int*)(B.batch_Lgen + (size_t)node * LGEN_BYTES) = -1;   // (this kernel does not hand multipliers on: the children start from Z alone)
     B.batch_it[node] = it > QP_MAXIT ? QP_MAXIT : it;
     atomicAdd((unsigned long long*)&B.inst_iters[inst], (unsigned long long)(it > QP_MAXIT ? QP_MAXIT : it));
     atomicAdd((unsigned long long*)&B.inst_nodes[inst], 1ull);
@@ -2119,6 +2135,16 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     if (B.pool_big && lane < nk) B.pool_big[slots[lane]] = big_parent;   // (a child has the rows of its parent and more)
     if (B.pool_Z) {   // the children start their relaxation from this node's solution (see DevBuf::pool_Z)
       for (int q = 0; q < nk; ++q) { if (slots[q] >= B.z_cap) continue; double* zd = B.pool_Z + (size_t)slots[q] * N * NZ; for (int k = lane; k < N * NZ; k += 64) zd[k] = Z[k]; }
+    }
+    if (B.pool_Lbox) {   // ... and from its multipliers (DevBuf::pool_Lbox): 16-byte copies of the batch record
+      const int nb4 = lbox_floats(N) / 4, ng4 = LGEN_BYTES / 16;
+      const float4* sb = (const float4*)(B.batch_Lbox + (size_t)node * lbox_floats(N)); const uint4* sg = (const uint4*)(B.batch_Lgen + (size_t)node * LGEN_BYTES);
+      for (int q = 0; q < nk; ++q) {
+        if (slots[q] >= B.z_cap) continue;
+        float4* db = (float4*)(B.pool_Lbox + (size_t)slots[q] * lbox_floats(N)); uint4* dg = (uint4*)(B.pool_Lgen + (size_t)slots[q] * LGEN_BYTES);
+        for (int k = lane; k < nb4; k += 64) db[k] = sb[k];
+        for (int k = lane; k < ng4; k += 64) dg[k] = sg[k];
+      }
     }
     if (lane < nk) {
       // depth word: (tree depth << 6) | preference among siblings (child_inf first) - used by the dive ordering

@@ -376,12 +376,24 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
     const size_t zb = (size_t)Y.N * Y.nz * 8;
     size_t zc = std::max<size_t>((size_t)2 << 20, (size_t)n_slots * 16384);
     zc = std::min(zc, std::min<size_t>((size_t)X.pool_cap, free_b / 8 / zb));
+    // the parents' multipliers beside them (on-chip kernels only): +N x 128 B for the box keys and LGEN_BYTES for the general rows per record
+    const bool ws_dual = X.oc_grid > 0 && !(std::getenv("MIQP_WS_DUAL") && std::atoi(std::getenv("MIQP_WS_DUAL")) == 0);
+    if (ws_dual) zc = std::min(zc, free_b / 5 / (zb + (size_t)lbox_floats(Y.N) * 4 + LGEN_BYTES));
     if (!X.alloc(&B.pool_Z, zc * (size_t)Y.N * Y.nz)) return false;
     B.z_cap = (int)zc;
+    if (ws_dual) {
+      if (!X.alloc(&B.pool_Lbox, zc * (size_t)lbox_floats(Y.N))) return false;
+      if (!X.alloc(&B.pool_Lgen, zc * (size_t)LGEN_BYTES)) return false;
+      if (!X.alloc(&B.batch_Lbox, (size_t)batch_alloc * lbox_floats(Y.N))) return false;
+      if (!X.alloc(&B.batch_Lgen, (size_t)batch_alloc * LGEN_BYTES)) return false;
+      HIP_OK(hipMemset(B.batch_Lgen, 0xFF, (size_t)batch_alloc * LGEN_BYTES));
+      B.ws_dual = 1;
+    }
   }
   B.ws_on = ws_on ? 1 : 0;
   B.ws_mu = std::getenv("MIQP_WS_MU") ? std::atof(std::getenv("MIQP_WS_MU")) : 1.0;
   B.ws_delta = std::getenv("MIQP_WS_DELTA") ? std::atof(std::getenv("MIQP_WS_DELTA")) : 1.0e-3;
+  B.ws_theta = std::getenv("MIQP_WS_THETA") ? std::min(1.0, std::max(0.0, std::atof(std::getenv("MIQP_WS_THETA")))) : 1.0;
   if (!X.alloc(&B.pool_count, 1)) return false;
   if (!X.alloc(&B.free_q, (size_t)X.pool_cap)) return false;
   if (!X.alloc(&B.free_head, 1)) return false;
@@ -1320,6 +1332,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     statuses[k] = s->status;
   }
   if (abandoned) std::fprintf(stderr, "[miqp_gpu] the round loop was abandoned with %d of %d instances never admitted: they report FAILED_SEG_FAULT, the call fails\n", n - next_q, n);
+  if (std::getenv("MIQP_STATS")) std::fprintf(stderr, "[miqp_gpu stats] reachable-set diameter (L1) of instance 0: %.1f\n", hD[Y.d_misc + 2]);
   if (std::getenv("MIQP_STATS")) std::fprintf(stderr, "[miqp_gpu stats] host: setup %.3f s (device context %.3f, instance tables and presolve %.3f, upload %.3f), rounds %.3f s (%d), results %.3f s\n", t_setup, t_ctx, t_tables, t_setup - t_ctx - t_tables, t_solve, rounds, wall_s() - t0 - t_solve);
   return !abandoned;
 }

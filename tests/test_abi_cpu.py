@@ -298,3 +298,28 @@ def test_bench_strong_scaling_mode_on_two_gloo_ranks():
     assert o["scaling"] == "strong" and o["n_gpus"] == 2 and o["steps"] == 2
     assert o["config"]["instances_attempted"] == 14 and [p["attempted"] for p in o["config"]["per_rank"]] == [8, 6]
     assert o["value"] == 0.0 and "no HIP device" in r.stderr
+
+
+def test_bench_weak_scaling_mode_on_two_gloo_ranks():
+    """`bench.py --gpus 2` (the metric's mode: a fixed queue per GPU, instance b of the job on rank b mod G, no data-path
+    collective): the two ranks draw DISJOINT seeds that together cover the job's seeds of every step, rank 0 prints one JSON line
+    with "scaling": "weak" whose `value` is the job's aggregate.  No GPU here: every solve ends in the loud no-device failure."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MIQP_BENCH_DUMP_SEEDS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "mini", "--batch", "3", "--queue-factor", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu", "--time-limit", "1"], capture_output=True, text=True, timeout=600, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    o = json.loads(lines[0])
+    assert o["scaling"] == "weak" and o["n_gpus"] == 2 and o["steps"] == 2
+    assert o["config"]["instances_attempted"] == 2 * 2 * 6 and [p["attempted"] for p in o["config"]["per_rank"]] == [12, 12]
+    assert o["config"]["marshalling_in_timed_region"] is False and o["config"]["result_records_in_timed_region"] is True
+    assert o["value"] == 0.0 and "no HIP device" in r.stderr
+    seeds = {}
+    for l in r.stderr.splitlines():
+        if l.startswith("[bench seeds] "):
+            d = json.loads(l[len("[bench seeds] "):]); seeds[d["rank"]] = d["timed"]
+    assert sorted(seeds) == [0, 1]
+    a, b = set(seeds[0]), set(seeds[1])
+    assert len(a) == len(seeds[0]) == 12 and len(b) == 12 and not (a & b)      # disjoint, no repeats
+    assert a | b == set(range(12, 36))                                          # warm-up step: seeds 0..11; the two timed steps: 12..35

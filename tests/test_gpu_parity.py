@@ -135,6 +135,115 @@ def test_synthetic_parity_tight_gap(oracle, cfg, seeds):
         oracle.free(h)
 
 
+LEAF_BINARIES = ["notWithinEnvironmentRear", "notWithinEnvironmentFrontUbUb", "deltacc", "deltacc_front", "car2car_collision",
+                 "region_change_not_allowed_combined", "region_change_not_allowed_x_positive"]
+
+
+def _oracle_many(oracle, ps, gap, limit, threads=48):
+    from concurrent.futures import ThreadPoolExecutor
+
+    def orc(p):
+        h = oracle.from_params(p, 10)
+        r = oracle.solve(h, oracle.dims(p), gap=gap, time_limit=limit)
+        oracle.free(h)
+        return r
+    with ThreadPoolExecutor(min(threads, os.cpu_count() or 8)) as ex:
+        return list(ex.map(orc, ps))
+
+
+@pytest.mark.parametrize("cfg,seeds,need", [("cfg3", range(700, 748), 16), ("cfg4", range(1000, 1032), 8)])
+def test_full_size_parity_at_a_tight_gap(oracle, cfg, seeds, need):
+    """the shape the bench times (2 cars x 20 steps x 32 regions; cfg4: + 4 moving obstacles) at gap 1e-7 on the seeds the CPU
+    oracle proves within 20 s: objective equal to 1e-6 relative, identical regions (up to ties on a sector border), canonical leaf
+    binaries equal, states within 1e-4, device result feasible for every raw big-M row - the bar of test/cplex_wrapper_test.cc:857-876
+    (exact sizes, objective 1e-5) and of north_star (identical assignments, states within 1e-4) at full size"""
+    ps = [synthetic.generate(cfg, s, gap=1e-7, max_time=60) for s in seeds]
+    ws = []
+    for p in ps:
+        w = P.CplexWrapper(); w.resetParameters(p); ws.append(w)
+    sts = P.solve_batch(ws)
+    res = _oracle_many(oracle, ps, 1e-7, 20)
+    compared = ties = sites = 0
+    for seed, p, w, st, (ost, ores, op) in zip(seeds, ps, ws, sts, res):
+        pr = w.getSolutionProperties()
+        if ost != 0 or op.status not in (101, 102):
+            if ost == 1 and op.status == 103:   # the oracle proves the instance infeasible: so must the device
+                assert st == P.OptimizationStatus.FAILED_NO_SOLUT and pr.status == 103, (cfg, seed, int(st), pr.status)
+            continue   # the oracle ran into its limit: no optimum to compare with
+        assert int(st) == 0 and pr.status in (101, 102) and pr.gap <= 1e-7 + 1e-12, (cfg, seed, int(st), pr.status, pr.gap)   # what the CPU proves in 20 s the device proves in 60
+        compared += 1
+        r = w.getRawResults()
+        assert abs(pr.objective - op.objective) <= 1e-6 * max(1.0, abs(op.objective)), (cfg, seed, pr.objective, op.objective)
+        assert_regions_canonical_equal(p, r, ores)
+        assert_states_close(r, ores, fields=CONT_FIELDS[:8])
+        # Where the velocity of a (car, step) lies exactly on the border of two sectors both labels describe the same state (checked
+        # above) and the two sides may each report either; the front axle point is DEFINED through the label's polynomial
+        # (cplexmodel/model_region_constraints.mod:56-69), so front points and the binaries on them are compared at the other steps
+        tie = r.active_region.argmax(-1) != ores.active_region.argmax(-1)          # [car, step]
+        ties += int(tie.sum()); sites += tie.size
+        for n in CONT_FIELDS[8:]:
+            d = np.abs(getattr(r, n) - getattr(ores, n))[~tie]
+            assert d.size == 0 or d.max() <= STATE_TOL, (cfg, seed, n, d.max())
+        anystep = tie.any(0)                                                         # [step]
+        for n in LEAF_BINARIES:
+            a, b = getattr(r, n), getattr(ores, n)
+            if n == "car2car_collision":
+                ok = np.array_equal(a[:, :, ~anystep], b[:, :, ~anystep])
+            elif a.ndim >= 3:                                                        # [car, piece | obstacle, step, ...]
+                m = np.broadcast_to(tie[:, None, :].reshape(tie.shape[0], 1, tie.shape[1], *([1] * (a.ndim - 3))), a.shape)
+                ok = np.array_equal(a[~m], b[~m])
+            else:
+                ok = np.array_equal(a[~tie], b[~tie])
+            assert ok, (cfg, seed, n)
+        h = oracle.from_params(p, 10)
+        v, obj, worst = oracle.raw_eval(h, r)
+        oracle.free(h)
+        assert v < 1e-5 and abs(obj - pr.objective) <= 1e-6 * max(1.0, abs(obj)), (cfg, seed, worst)
+    assert compared >= need, compared
+    assert ties <= 0.02 * sites, (ties, sites)   # ties are the exception: at most 2 % of the (car, step) sites
+
+
+def _translated(p, dx):
+    """the same scenario at another place of the map: everything that is a position along x moves by dx"""
+    import copy
+    q = copy.deepcopy(p)
+    q.IntitialState = np.array(p.IntitialState, float); q.IntitialState[:, 0] += dx
+    q.x_ref = np.array(p.x_ref, float) + dx
+    q.MultiEnvironmentConvexPolygon = [np.array(e, float) + np.array([dx, 0.0]) for e in p.MultiEnvironmentConvexPolygon]
+    q.ObstacleConvexPolygon = [[np.array(e, float) + np.array([dx, 0.0]) for e in o] for o in p.ObstacleConvexPolygon]
+    return q
+
+
+def test_translated_copies_in_one_queue_keep_their_own_solutions(oracle):
+    """two copies of a scenario, one moved 16 m along the road, in the same queue: same binaries, the same objective to the bits an
+    incumbent key holds - each instance must still return ITS trajectory (the incumbent's solution is looked up among the batch slots
+    of the instance, not among all slots with that key): feasible for its own raw model, and the pair exactly 16 m apart"""
+    DX = 16.0
+    ps = []
+    for s in range(24):
+        p = synthetic.generate("cfg3", s, gap=0.01, max_time=20)
+        ps += [p, _translated(p, DX)]
+    ws = []
+    for p in ps:
+        w = P.CplexWrapper(); w.resetParameters(p); ws.append(w)
+    sts = P.solve_batch(ws, inflight=len(ws))
+    same_key = 0
+    for k in range(0, len(ps), 2):
+        rr = []
+        for j in (k, k + 1):
+            assert int(sts[j]) == 0, (j, int(sts[j]))
+            pr = ws[j].getSolutionProperties(); r = ws[j].getRawResults()
+            h = oracle.from_params(ps[j], 10)
+            v, obj, worst = oracle.raw_eval(h, r)
+            oracle.free(h)
+            assert v < 1e-5 and abs(obj - pr.objective) <= 1e-6 * max(1.0, abs(obj)), (j, worst, obj, pr.objective)
+            rr.append((pr, r))
+        if abs(rr[0][0].objective - rr[1][0].objective) <= 1e-9 * abs(rr[0][0].objective):   # (the searches of the two may stop at different incumbents within the gap)
+            same_key += 1
+            assert np.abs(rr[1][1].pos_x - rr[0][1].pos_x - DX).max() <= 1e-5 and np.abs(rr[1][1].pos_y - rr[0][1].pos_y).max() <= 1e-5, k
+    assert same_key >= 12, same_key
+
+
 def test_cfg5s_four_cars_against_the_oracle(oracle):
     """cfg5s (4 cars x 10 steps x 32 regions: the largest 4-car shape the CPU oracle proves in seconds; the 4-car interior point
     kernel with the 2x2-tiled stage algebra): at gap 1e-3 both prove their gap, the objectives agree within the two gaps, each
@@ -492,6 +601,11 @@ def test_tree_split_over_rccl(tmp_path):
     n = max(1, min(2, torch.cuda.device_count()))
     res, out = _run_split(tmp_path, "rccl", n)
     assert res is not None, out.stdout[-2000:] + out.stderr[-2000:]
+    if torch.cuda.device_count() >= 2:
+        # with two devices in sight the exchange must really have run between two RCCL ranks - never the degenerate communicator
+        assert len(res) == 2, len(res)
+        for a, b in zip(res[0], res[1]):
+            assert a["status"] == b["status"] == 0 and a["objective"] == b["objective"] and a["px"] == b["px"], (a["cfg"], a["objective"], b["objective"])
     for rk in res:
         for a in rk:
             assert a["status"] == 0 and a["bound"] <= a["objective"] + 1e-9
@@ -652,7 +766,7 @@ def test_full_size_properties(oracle, cfg):
         assert v < 1e-5, (cfg, worst)
         assert abs(obj - pr.objective) <= 1e-6 * max(1.0, abs(obj))
         oracle.free(h)
-    assert nsolved >= 1
+    assert nsolved == len(ps), nsolved   # every one of these seeds is proven to the gap well inside the limit
 
 
 def test_cfg4_batch_of_256_with_dynamic_obstacles(oracle):
@@ -664,11 +778,18 @@ def test_cfg4_batch_of_256_with_dynamic_obstacles(oracle):
     for p in ps:
         w = P.CplexWrapper(); w.resetParameters(p); ws.append(w)
     sts = P.solve_batch(ws)
-    nsolved = nfeas = 0
+    nsolved = nfeas = ninfeasible = 0
     for p, w, st in zip(ps, ws, sts):
         pr = w.getSolutionProperties()
         if st != P.OptimizationStatus.SUCCESS:
-            assert st in (P.OptimizationStatus.FAILED_TIMEOUT, P.OptimizationStatus.FAILED_NO_SOLUT)
+            # the only failure this batch may show is a PROVEN infeasibility (an obstacle on a car's start position), and the CPU oracle
+            # must reach the same verdict
+            assert st == P.OptimizationStatus.FAILED_NO_SOLUT and pr.status == 103, (int(st), pr.status)
+            h = oracle.from_params(p, 10)
+            ost, _, op = oracle.solve(h, oracle.dims(p), gap=0.01, time_limit=20)
+            oracle.free(h)
+            assert ost == 1 and op.status == 103, (ost, op.status)
+            ninfeasible += 1
             continue
         nfeas += 1
         assert pr.best_bound <= pr.objective + 1e-9 and pr.status in (101, 102, 107) and (pr.status == 107 or pr.gap <= 0.01 + 1e-12)
@@ -678,7 +799,7 @@ def test_cfg4_batch_of_256_with_dynamic_obstacles(oracle):
         oracle.free(h)
         assert v < 1e-5, worst
         assert abs(obj - pr.objective) <= 1e-6 * max(1.0, abs(obj))
-    assert nfeas >= 200 and nsolved >= 128, (nfeas, nsolved)
+    assert nsolved + ninfeasible == 256 and ninfeasible <= 8, (nfeas, nsolved, ninfeasible)   # every instance decided inside its limit: proven to the gap, or proven infeasible
 
 
 def _many_alternatives_instance(seed, N=14, E=20, L=20):
@@ -768,14 +889,14 @@ def test_cfg5_four_cars_64_regions_with_warmstart(oracle):
     """BASELINE config 5 at its full size (4 cars x 30 steps x 64 regions; raw model 142 720 rows / 13 800 binaries):
     a time-limited solve returns a vector that is feasible for every raw big-M row; fed back as MIP start
     (variables_warmstart) the next solve starts from it and is not worse"""
-    p = synthetic.generate("cfg5", 0, gap=0.01, max_time=4.0)
+    p = synthetic.generate("cfg5", 0, gap=0.01, max_time=10.0)
     h = oracle.from_params(p, 10)
     assert oracle.sizes(h)["rows"] == 142720 and oracle.sizes(h)["bin"] == 13800
     w = P.CplexWrapper(); w.resetParameters(p)
     st = w.callCplex()
     assert int(st) == 0
     pr = w.getSolutionProperties(); res = w.getRawResults()
-    assert pr.status in (101, 102, 107) and pr.best_bound <= pr.objective + 1e-9 and pr.nodes > 1000
+    assert pr.status in (101, 102) and pr.gap <= 0.01 + 1e-12 and pr.best_bound <= pr.objective + 1e-9 and pr.nodes > 1000   # proven to the 1 % gap inside the reference's 10 s
     v, obj, worst = oracle.raw_eval(h, res)
     assert v < 1e-5 and abs(obj - pr.objective) <= 1e-6 * max(1.0, abs(obj)), worst
     w2 = P.CplexWrapper(); w2.resetParameters(p)
