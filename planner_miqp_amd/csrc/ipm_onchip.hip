@@ -18,6 +18,9 @@
 //     shifts and [A B]' T into sums over a lane's registers; the input block is eliminated by Gauss-Jordan on the four
 //     input rows of the tile (row_newbcast / permlane swaps), one MFMA forms the Schur complement and the next vector.
 // Nodes with more general rows than the on-chip capacity are queued for ipm_kernel (the general, memory-backed kernel).
+#ifndef MIQP_DUAL_START
+#define MIQP_DUAL_START 0   // 1: the experiment of round 4 - children start from the parent's MULTIPLIERS as well (DevBuf::pool_Lbox); measured: no fewer iterations, see DESIGN.md 3.2
+#endif
 namespace miqp {
 
 constexpr int OC_GCAP = 128;      // general rows kept on chip (2 register slots per lane)
@@ -257,7 +260,6 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     const int* T = B.inst_i + (size_t)inst * Y.istride;
     const double ts = D[Y.d_glob + 7];
     const double aqs = 2.0 * D[Y.d_misc + 0];               // quadratic weight of the soft car/car rows
-    const double zdiam = D[Y.d_misc + 2];                   // L1 diameter of the reachable set: the weight of a stationarity residual in a bound (see ipm_kernel)
     {
       const signed char* src = B.pool_fix + (size_t)B.batch_node[node] * Y.fixlen;
       for (int k = tid; k < Y.fixlen; k += 64) fix[k] = src[k];
@@ -396,7 +398,9 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
         uint4 m4; m4.x = (unsigned int)map; m4.y = (unsigned int)(map >> 32);
         m4.z = (unsigned int)off | ((unsigned int)nn << 16) | ((unsigned int)i << 20) | (r.aq > 0.0 ? 0x80000000u : 0u); m4.w = cols;
         gmeta[idx] = m4; grhs[idx] = r.rhs;
+#if MIQP_DUAL_START
         cand[idx] = (unsigned short)(i * NSLOT + slot_);   // the row's identity (idx <= its position in the list: read above by every lane of this chunk)
+#endif
         atomicAdd(&sstart[i + 1], 1);
       }
       OC_WAVE_SYNC();
@@ -418,6 +422,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     OC_WAVE_SYNC();
 
     // ---- initial row state (the interior point starts at the free rollout, or at the parent's solution and multipliers)
+#if MIQP_DUAL_START
     const int rec_ = B.batch_node[node];
     const unsigned char* const lgp = B.pool_Lgen ? B.pool_Lgen + (size_t)rec_ * LGEN_BYTES : nullptr;
     const int npar = (warm && B.ws_dual && B.ws_on != 2 && lgp) ? __builtin_amdgcn_readfirstlane(*(const int*)lgp) : -1;   // general rows of the parent whose multipliers the record carries (-1: no multipliers)
@@ -430,6 +435,9 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
       for (int k = tid; k < npar; k += 64) { ppc[k] = gpc[k]; plm[k] = glm[k]; }
     }
     OC_WAVE_SYNC();
+#else
+    constexpr bool dual = false; constexpr int npar = 0; const float* const lbp = nullptr; const unsigned short* const ppc = nullptr; const float* const plm = nullptr;
+#endif
     double bs[NSL], bl[NSL], bt[NSL];
     unsigned int bact = 0u;
     double csum = 0.0, tsum = 0.0; int cnt = 0;
@@ -508,9 +516,9 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
       // converged after probe_itcap iterations is abandoned: 1 % of the probes that leave slack front-point disjunctions undecided
       // ran to the iteration limit (80) and held the launch of the larger variant up
       if (BIG && B.probe_itcap > 0 && it > B.probe_itcap && B.ws_on != 2 && is_probe_word(B.batch_depth[node])) { ok = 2; break; }
-      if (it > 1 && resid_fac * R0 < 1e-5 * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp - resid_fac * R0 * zdiam > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }   // (dual value minus the allowance for the stationarity residual still left, see batch_bound)
+      if (it > 1 && resid_fac * R0 < 1e-5 * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp - resid_fac * R0 * D[Y.d_misc + 2] > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }   // (dual value minus the allowance for the stationarity residual still left, see batch_bound)
       }
-#ifdef MIQP_NO_K1
+#if !MIQP_DUAL_START
       const double wmix = 1.0;
 #else
       const double wmix = (gflag & 0x40000000u) ? B.ws_theta : 1.0;   // (bit 30 of the row flags: started from the parent's solution)
@@ -968,6 +976,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     obj += scost;   // (obj is the quadratic objective of the final Z: recomputed by every update, and a node leaves the loop right after one or at its top)
     double* Zo = B.batch_Z + (size_t)node * N * NZ;
     for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) Zo[(k >> 4) * NZ + oc_lcol<C, CM>(q)] = Z[k]; }
+#if MIQP_DUAL_START
     if (B.batch_Lbox) {   // the multipliers, by row identity, for the children (DevBuf::pool_Lbox)
       const int le = fresh_lane();   // (lane-dependent addresses from the execution mask: nothing of them is kept across the iteration loop)
       float* lb = B.batch_Lbox + (size_t)node * lbox_floats(N) + ((le >> 5) * 2 + ((le >> 4) & 1)) * 16 + (le & 15);   // stage parity, side, column of this lane
@@ -984,10 +993,11 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
         for (int q = 0; q < OC_GSLOTS; ++q) { const int r = q * 64 + le; if (r < nm_) { gpc[r] = cd[r]; glm[r] = (float)gl_[q]; } }
       }
     }
+#endif
     if (tid == 0) {
       const int itc = it > QP_MAXIT ? QP_MAXIT : it;
       B.batch_obj[node] = obj; B.batch_viol[node] = viol; B.batch_ok[node] = ok;
-      B.batch_bound[node] = (double)ncomp * comp + resid_fac * R0 * zdiam;   // (see ipm_kernel: complementarity + stationarity residual allowance)
+      B.batch_bound[node] = (double)ncomp * comp + resid_fac * R0 * D[Y.d_misc + 2];   // (see ipm_kernel: complementarity + stationarity residual allowance)
       B.batch_it[node] = itc;
       atomicAdd((unsigned long long*)&B.inst_iters[inst], (unsigned long long)itc);
       atomicAdd((unsigned long long*)&B.inst_nodes[inst], 1ull);

@@ -180,6 +180,9 @@ struct DevBuf {
   // at (Z, lambda) of its parent: multiplier max(lambda_parent, ws_mu / s), which leaves only the rows the branching adds off the
   // parent's stationarity.  eval_kernel copies the parent's batch record to every child (like pool_Z).
   float* pool_Lbox; unsigned char* pool_Lgen; float* batch_Lbox; unsigned char* batch_Lgen; int ws_dual;
+  // Local search around a new incumbent (lns_kernel): select_kernel raises inst_lns when it adopts a new incumbent; the neighbours of
+  // its region sequences join the batch of the same round
+  int* inst_lns; int lns_mode; int lns_min_nodes;   // (an instance gets its local search once it has cost lns_min_nodes node relaxations: the easy ones are done before)
   double ws_theta;               // share of the mean in a pair's centring target (1: the uniform target of a cold start), see row_step
 };
 constexpr int LGEN_CAP = 160;                                  // general-row multipliers carried per record
@@ -2239,7 +2242,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     for (int k = tid; k < Y.fixlen; k += SEL_THREADS) df[k] = cf[k];
     const double* zs = B.batch_Z + (size_t)bslot * Y.N * Y.nz; double* zd = B.inc_Z + (size_t)inst * Y.N * Y.nz;
     for (int k = tid; k < Y.N * Y.nz; k += SEL_THREADS) zd[k] = zs[k];
-    if (tid == 0) B.inc_obj[inst] = B.batch_obj[bslot];
+    if (tid == 0) { B.inc_obj[inst] = B.batch_obj[bslot]; if (B.inst_lns) B.inst_lns[inst] = 1; }
   }
   __syncthreads();
   if (B.inst_kill[inst]) {
@@ -2658,6 +2661,114 @@ __global__ void __launch_bounds__(1024) share_kernel(DevBuf B) {
   for (int k = tid; k < NSL; k += 1024) {
     long long r = (long long)B.slot_demand[k] - B.slot_take[k]; if (r > 8192 - B.slot_take[k]) r = 8192 - B.slot_take[k];
     if (r > 0) B.slot_take[k] += (int)(r < L ? r : L);
+  }
+}
+
+// Local search around a new incumbent - the device's answer to CPLEX's polishing heuristics (rinsheur, cplexmodel/cplexmodel.mod:8-21).
+// What separates the incumbents a search finds early from the optimum of the hard instances of this workload is rarely the
+// skeleton (who merges behind whom) but WHEN each car changes its region: the acceleration a car may use depends on the sector its
+// velocity lies in, and a change one step earlier or later is worth several per cent of the objective (measured: tools/skeleton.py).
+// The tree finds those one at a time, 10^5 nodes apart.  Here every new incumbent spawns its neighbours - each change of region of
+// a car moved one or two steps earlier or later, a short stay in a region removed - as LEAVES: the incumbent's completed record
+// with the changed region codes, every other disjunction as the incumbent has it.  They join the batch of the same round; a
+// feasible one that is better becomes the incumbent through the ordinary evaluation (which checks every disjunction at the leaf's
+// own solution) and spawns its own neighbours next round.  Heuristic nodes duplicate parts of the tree, they never replace it.
+constexpr int LNS_MAX = 512;
+__global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
+  const Layout& Y = B.Y;
+  const int slot = blockIdx.x, lane = threadIdx.x;
+  const int inst = B.slot_inst[slot];
+  if (inst < 0 || !B.inst_lns[inst]) return;
+  if (B.inst_nodes[inst] < (long long)B.lns_min_nodes) return;   // (the flag stays up: the search around its incumbent starts when the instance proves hard)
+  __shared__ int nb_c[LNS_MAX], nb_i[LNS_MAX], nb_n[LNS_MAX], nb_code[LNS_MAX];   // neighbour: first byte of the record, stride, number of entries, the value they take
+  __shared__ int sh_n, sh_base, sh_rec;
+  const int N = Y.N, C = Y.C;
+  const signed char* inc = B.inc_fix + (size_t)inst * Y.fixlen;
+  if (lane == 0) {
+    B.inst_lns[inst] = 0;
+    int n = 0;
+    auto push = [&](int first, int stride, int cnt, int val) { if (n < LNS_MAX) { nb_c[n] = first; nb_i[n] = stride; nb_n[n] = cnt; nb_code[n] = val; n++; } };
+    if (!B.inst_done[inst] && !B.inst_kill[inst]) {
+      // a sequence over the steps (the region codes of a car: stride 1; the alternatives of a car/car group: stride 4): every change
+      // between two steps moved one / two steps later and earlier, every short run between two changes given to its neighbours
+      auto moves = [&](int first, int stride, int mode) {
+        const signed char* q = inc + first;
+        auto at = [&](int i) { return (int)q[i * stride]; };
+        int run0 = 1;
+        for (int i = 2; i <= N; ++i) {
+          const bool brk = i == N || at(i) != at(i - 1);
+          if (!brk) continue;
+          if (i < N && at(i) >= 0 && at(i - 1) >= 0) {
+            push(first + i * stride, stride, 1, at(i - 1));
+            if ((mode & 2) && i + 1 < N) push(first + i * stride, stride, 2, at(i - 1));
+            push(first + (i - 1) * stride, stride, 1, at(i));
+            if ((mode & 2) && i - 2 >= 1) push(first + (i - 2) * stride, stride, 2, at(i));
+          }
+          const int len = i - run0;   // the run [run0, i)
+          if ((mode & 4) && run0 > 1 && i < N && len >= 3 && len <= 6 && at(run0 - 1) >= 0 && at(i) >= 0) {
+            push(first + run0 * stride, stride, len, at(run0 - 1));
+            if (at(i) != at(run0 - 1)) push(first + run0 * stride, stride, len, at(i));
+          }
+          run0 = i;
+        }
+      };
+      const int mode = B.lns_mode;
+      for (int c = 0; c < C; ++c) moves(Y.f_reg + c * N, 1, mode | 2);
+      if (mode & 8) for (int p = 0; p < Y.NP; ++p) for (int g = 0; g < 4; ++g) moves(Y.f_c2c + p * N * 4 + g, 4, mode & ~2);
+      if (mode & 16) {   // one (car, step) moved to a neighbouring sector (same kind of alternative): the excursions the moves above cannot make
+        const int* T = B.inst_i + (size_t)inst * Y.istride;
+        for (int c = 0; c < C; ++c) {
+          const int np = T[Y.i_nposs + c];
+          for (int i = 1; i < N; ++i) {
+            const int code = (int)inc[Y.f_reg + c * N + i];
+            if (code < 0 || (code & 3) == 3) continue;
+            const int j = T[Y.i_regj + c * Y.P + (code >> 2)];
+            for (int q = 0; q < np && q < Y.P; ++q) {
+              const int dj = (T[Y.i_regj + c * Y.P + q] - j + Y.R) % Y.R;
+              if (dj != 1 && dj != Y.R - 1) continue;
+              if ((i > 1 && (int)inc[Y.f_reg + c * N + i - 1] >> 2 == q) || (i + 1 < N && (int)inc[Y.f_reg + c * N + i + 1] >> 2 == q)) continue;   // (a shift: made above)
+              const int h = (code & 3) < T[Y.i_nhs + c * Y.P + q] ? (code & 3) : 0;
+              push(Y.f_reg + c * N + i, 1, 1, (q << 2) | h);
+            }
+          }
+        }
+      }
+    }
+    int base = 0, rec = 0;
+    if (n > 0) {
+      base = atomicAdd(B.batch_count, n);
+      if (base + n > B.batch_cap) { n = base < B.batch_cap ? B.batch_cap - base : 0; }
+      if (n > 0) { rec = atomicAdd(B.pool_count, n); if (rec + n > B.pool_cap) n = 0; }   // fresh records (the evaluation recycles them)
+    }
+    sh_n = n; sh_base = base; sh_rec = rec;
+  }
+  __syncthreads();
+  const int n = sh_n;
+  if (n <= 0) return;
+  const double lbq = B.lower_bound[inst] - B.inst_const[inst];
+  for (int q = 0; q < n; ++q) {
+    const int rec = sh_rec + q, bs = sh_base + q;
+    signed char* dst = B.pool_fix + (size_t)rec * Y.fixlen;
+    const int k0 = nb_c[q], st_ = nb_i[q], k1 = k0 + nb_n[q] * st_;
+    for (int k = lane; k < Y.fixlen; k += 64) {
+      signed char v = inc[k];
+      if (k >= k0 && k < k1 && (k - k0) % st_ == 0) v = (signed char)nb_code[q];
+      if (k >= Y.f_env && k < Y.f_c2c && (k - Y.f_env) % 5 != 0) v = (signed char)-1;   // front-point environment / obstacle disjunctions: undecided (their rows are most of a leaf's rows; the evaluation checks them at the leaf's solution)
+      if (k >= Y.f_c2n && k < Y.f_rmask) v = (signed char)-1;          // no exclusion rows
+      if (k >= Y.f_rmask && k < Y.f_rmask + C * N * 2) v = (signed char)-1;   // every region allowed (0xFF 0xFF)
+      dst[k] = v;
+    }
+    if (B.pool_Z && rec < B.z_cap) {
+      const double* zs = B.inc_Z + (size_t)inst * N * Y.nz; double* zd = B.pool_Z + (size_t)rec * N * Y.nz;
+      for (int k = lane; k < N * Y.nz; k += 64) zd[k] = zs[k];
+      if (B.pool_Lgen && lane == 0) *(int*)(B.pool_Lgen + (size_t)rec * LGEN_BYTES) = -1;
+    }
+    if (lane == 0) {
+      if (B.pool_big) B.pool_big[rec] = 1;
+      if (B.pool_origin) B.pool_origin[rec] = 14;
+      B.batch_node[bs] = rec; B.batch_inst[bs] = inst; B.batch_bound[bs] = lbq; B.batch_depth[bs] = (1 << 6) | 63;   // (the probe mark: a heuristic node - one that has not converged after probe_itcap iterations is abandoned)
+      if (B.batch_large) B.batch_large[bs] = 1;
+    }
   }
 }
 

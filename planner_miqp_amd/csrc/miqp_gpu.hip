@@ -377,7 +377,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
     size_t zc = std::max<size_t>((size_t)2 << 20, (size_t)n_slots * 16384);
     zc = std::min(zc, std::min<size_t>((size_t)X.pool_cap, free_b / 8 / zb));
     // the parents' multipliers beside them (on-chip kernels only): +N x 128 B for the box keys and LGEN_BYTES for the general rows per record
-    const bool ws_dual = X.oc_grid > 0 && !(std::getenv("MIQP_WS_DUAL") && std::atoi(std::getenv("MIQP_WS_DUAL")) == 0);
+    const bool ws_dual = MIQP_DUAL_START && X.oc_grid > 0 && !(std::getenv("MIQP_WS_DUAL") && std::atoi(std::getenv("MIQP_WS_DUAL")) == 0);   // (diagnostic build -DMIQP_DUAL_START=1 only)
     if (ws_dual) zc = std::min(zc, free_b / 5 / (zb + (size_t)lbox_floats(Y.N) * 4 + LGEN_BYTES));
     if (!X.alloc(&B.pool_Z, zc * (size_t)Y.N * Y.nz)) return false;
     B.z_cap = (int)zc;
@@ -436,6 +436,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&B.inst_nodes, n_inst)) return false;
   if (!X.alloc(&B.inst_iters, n_inst)) return false;
   if (!X.alloc(&B.inst_ninc, n_inst)) return false;
+  if (!X.alloc(&B.inst_lns, n_inst)) return false;
   if (!X.alloc(&B.batch_count, 1)) return false;
   if (!X.alloc(&B.batch_node, batch_alloc)) return false;
   if (!X.alloc(&B.batch_candkey, batch_alloc)) return false;
@@ -947,6 +948,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemsetAsync(B.inst_nodes, 0, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_iters, 0, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_ninc, 0, (size_t)n * 4, st));
+  HIP_OK(hipMemsetAsync(B.inst_lns, 0, (size_t)n * 4, st));
+  B.lns_mode = std::getenv("MIQP_LNS") ? std::atoi(std::getenv("MIQP_LNS")) : 13;
+  B.lns_min_nodes = std::getenv("MIQP_LNS_MIN") ? std::atoi(std::getenv("MIQP_LNS_MIN")) : 2000;
   HIP_OK(hipMemsetAsync(B.active_insts, 0, 4, st));   // admit_kernel counts the instances in as they enter
   HIP_OK(hipMemsetAsync(B.stat_rowiters, 0, 8, st));
   HIP_OK(hipStreamSynchronize(st));
@@ -1003,6 +1007,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     B.open_sel = rounds & 1;
     B.prev_bc = pipelined ? X.batch_cap : prev_bc;
     hipLaunchKernelGGL(select_kernel, dim3(NS), dim3(SEL_THREADS), 0, st, B, rounds);
+    if (B.lns_mode > 0) hipLaunchKernelGGL(lns_kernel, dim3(NS), dim3(64), 0, st, B);   // the neighbours of new incumbents join this round's batch
     if (std::getenv("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d select: %s\n", rounds, hipGetErrorString(e_)); }
     hipLaunchKernelGGL(roll_kernel, dim3(1), dim3(1), 0, st, B);
     hipLaunchKernelGGL(share_kernel, dim3(1), dim3(1024), 0, st, B);
