@@ -149,6 +149,7 @@ struct DevBuf {
   const int* root_cnt; const int* root_node; const int* root_depth; int root_stride;   // root records of every instance (uploaded once; admit_kernel writes them into the slot's list)
   double qp_tol;
   int use_cutoff;                // 0: solve every node to convergence (polish of the incumbent, solve_fixed)
+  double cut_gate;               // the early cutoff is tested once the stationarity residual is below cut_gate x (1 + |objective|) (what is left of it enters the test with the instance's diameter: rigorous at any value)
   int seq_kinds;                 // bit k set: first-deviation (time family) branching for disjunction kind k, else single step
   int abl;                       // ablation mask of the diagnostic build (0 otherwise)
   int opt2;                      // MIQP_OPT2: bit 0 rounding probe at every branched node; bits 4.. = K: probe at nodes where at most K lanes of the completion saw a violated disjunction (default 8; 0 = only until the first incumbent); bits 2..3 = s: only every 4^s-th such node (by a hash of its record number); bits 8.. = largest violation, in units of 0.05, a probed node may show; bit 1: dives prefer the sibling with the smallest lifted bound; bit 16: probes leave the front-point environment / obstacle disjunctions undecided (all measured: no gain)
@@ -736,7 +737,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
 #ifdef MIQP_PROFILE
     if (it > 1 && first_proxy == 0 && obj + RHO_EL * tsum - (double)ncomp * comp > cutoff + 1e-9 * fabs(cutoff)) first_proxy = it;
 #endif
-    if (!(MIQP_ABL) && it > 1 && resid_fac * R0 < 1e-5 * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp - resid_fac * R0 * zdiam > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }   // (dual value minus the allowance for the stationarity residual still left, see batch_bound)
+    if (!(MIQP_ABL) && it > 1 && resid_fac * R0 < B.cut_gate * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp - resid_fac * R0 * zdiam > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }   // (dual value minus the allowance for the stationarity residual still left, see batch_bound)
     const double tau = sigma * comp;
     // ================= backward sweep: Riccati recursion, the whole stage algebra stays in the registers of the wave.
     // Matrices live in the D layout of v_mfma_f64_16x16x4_f64 (lane l: g = l>>4, c = l&15, register r <-> M[g+4r][c]).

@@ -361,6 +361,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   X.pool_cap = (int)std::min<size_t>(std::min(want, maxrec), (size_t)0x7FFFFFF0);
   DevBuf& B = X.B; std::memset(&B, 0, sizeof(B));
   B.qp_tol = QP_TOL; B.use_cutoff = 1;
+  B.cut_gate = std::getenv("MIQP_CUT_GATE") ? std::atof(std::getenv("MIQP_CUT_GATE")) : 1.0e-5;
   B.opt2 = std::getenv("MIQP_OPT2") ? std::atoi(std::getenv("MIQP_OPT2")) : (8 << 4);   // rounding probe at nodes with at most 8 violated sites (eval_kernel)
   B.seq_kinds = std::getenv("MIQP_SEQ_KINDS") ? (int)std::strtoul(std::getenv("MIQP_SEQ_KINDS"), nullptr, 0) : (5 << 8);   // plain K-way children, branching order 5 (see eval_kernel)
   B.Y = Y; B.pool_cap = X.pool_cap; B.open_cap = open_cap; B.batch_cap = batch_cap; B.nodes_per_round = npr; B.n_inst = n_call; B.n_slots = n_slots; B.root_stride = roots_per_inst;
@@ -1018,7 +1019,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       HIP_OK(hipEventRecord(X.ev_sel, st));
       if (X.ipm_ev.size() < nev + 2) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); X.ipm_ev.push_back(a); X.ipm_ev.push_back(b); }
       HIP_OK(hipEventRecord(X.ipm_ev[nev], st));
-      launch_ipm_batch(X, B, X.batch_cap, st, false);
+      launch_ipm_batch(X, B, X.batch_cap, st, !std::getenv("MIQP_PIPELINE_SEQ"));   // (the concurrent launches of the large nodes, as in the unpipelined rounds)
       HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
       { DevBuf Be = B; Be.open_sel = 1 - (rounds & 1); launch_eval_c(Y.C, Be, X.batch_cap, l_eval, st); }
       HIP_OK(hipEventSynchronize(X.ev_sel));
