@@ -18,6 +18,9 @@
 //     shifts and [A B]' T into sums over a lane's registers; the input block is eliminated by Gauss-Jordan on the four
 //     input rows of the tile (row_newbcast / permlane swaps), one MFMA forms the Schur complement and the next vector.
 // Nodes with more general rows than the on-chip capacity are queued for ipm_kernel (the general, memory-backed kernel).
+#ifndef MIQP_PHI_BRANCH
+#define MIQP_PHI_BRANCH 1   // 1: the second group of four general rows of a stage only when the stage has more than four (a branch in the sweep)
+#endif
 #ifndef MIQP_DUAL_START
 #define MIQP_DUAL_START 0   // 1: the experiment of round 4 - children start from the parent's MULTIPLIERS as well (DevBuf::pool_Lbox); measured: no fewer iterations, see DESIGN.md 3.2
 #endif
@@ -225,7 +228,12 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
   double* const scr = Dg;                                   // decode: dense scratch rows
   unsigned long long* const bkey = (unsigned long long*)(L0 + LL.r);   // decode: orderable key of the tightest right-hand side per (stage, side, column)
   double* const gswfs = (double*)(L0 + LL.r);               // [OC_GCAP][2] sqrt(w) and f of the general rows
-  double* const KL0 = gswfs + 2 * OC_GCAP;                   // [OC_KL0][64] gains of the first stages (computed last, used first): they stay on chip
+#ifndef MIQP_KL0_PACK
+#define MIQP_KL0_PACK 1   // chain-major form: the row scalings are one double per row (the gradient goes straight into Gd), the other half of the table holds the gains of two (five) more stages
+#endif
+  constexpr int GS = (CM && MIQP_KL0_PACK) ? 1 : 2;          // doubles per general row in gswfs
+  constexpr int KL0N = OC_KL0 + (GS == 1 ? OC_GCAP / 64 : 0);   // stages whose gains stay in LDS
+  double* const KL0 = gswfs + GS * OC_GCAP;                  // [KL0N][64] gains of the first stages (computed last, used first): they stay on chip
   uint4* const gmeta = (uint4*)(L0 + LL.gmeta);             // x,y: column map (nibble c = 1 + index of the coefficient of column c), z: coefficient offset | nn << 16 | stage << 20 | soft << 31, w: columns (4 bits each)
   double* const gcoef = (double*)(L0 + LL.gcoef);
   double* const grhs = (double*)(L0 + LL.grhs);
@@ -559,7 +567,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
         double w, lk; row_weight(gs_[q], gl_[q], gt_[q], soft, aqs, tau, w, lk, k1);
         const double isw = frsq(w);
         if (r < NM) {
-          gswfs[2 * r] = w * isw;
+          gswfs[GS * r] = w * isw;
           if constexpr (CM) {   // gradient of the row straight into the stage's gradient vector (LDS atomics; the sweep then reads one array)
             const uint4 m4 = gmeta[r];
             const int off = (int)(m4.z & 0xFFFFu), nn = (int)((m4.z >> 16) & 7u), i = (int)((m4.z >> 20) & 0x7FFu);
@@ -600,20 +608,35 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
             if (r < re) {
               const uint4 m4 = gmeta[r];
               const unsigned int nib = lc < 8 ? (m4.x >> (4 * lc)) & 15u : (m4.y >> (4 * (lc - 8))) & 15u;
-              if (nib) a = gcoef[(m4.z & 0xFFFFu) + nib - 1u] * gswfs[2 * r];
+              if (nib) a = gcoef[(m4.z & 0xFFFFu) + nib - 1u] * gswfs[GS * r];
             }
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
           };
+#if MIQP_PHI_BRANCH
+          if (!((OC_ABL) & 8)) { kblock(rb); if (rb + 4 < re) { kblock(rb + 4);
+          for (int r0 = rb + 8; r0 < re; r0 += 4) kblock(r0); } }
+#else
           if (!((OC_ABL) & 8)) { kblock(rb); kblock(rb + 4);
           for (int r0 = rb + 8; r0 < re; r0 += 4) kblock(r0); }
+#endif
           const int lp = fresh_lane(), lcp = lp & 15, lgp = lp >> 4;
           const double dd = lcp < NZ ? 2.0 * Wd[lcp] + Dg[j * 16 + lcp] : 0.0;
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) if (lgp + 4 * rg == lcp) acc[rg] += dd;
         };
+#ifndef MIQP_BCAST_MFMA
+#define MIQP_BCAST_MFMA 0   // 1: the broadcast of a pivot row over the lane groups as one MFMA with a selector operand - measured 4 % SLOWER (the elimination is a dependent chain: the 64-cycle MFMA latency costs more than the 13 issue slots it frees)
+#endif
         auto bcast_group = [&](double v, int q) {   // the value of lane group q in every group
+#if MIQP_BCAST_MFMA
+          // on the matrix pipe: D = A B with B[k][c] = v of lane (k, c) and A[m][k] = [k == q] gives D[m][c] = v(q, c) in every row - exact
+          // (products with 1 and 0), one instruction instead of a select and two swap-and-add steps in the issue-bound elimination
+          const d4_t r = __builtin_amdgcn_mfma_f64_16x16x4f64(lg == q ? 1.0 : 0.0, v, d4_t{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+          return r[0];
+#else
           double t = lg == q ? v : 0.0;
           t = sum_xor16(t); return sum_xor32(t);
+#endif
         };
         d4_t accA;
         phiM(N - 1, accA);
@@ -666,7 +689,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
 #undef OC_PIVOT
           }
           OCP_T(tp_s4); OCP_ACC(5, tp_s2, tp_s4);
-          if (lc <= NX) { if (i < OC_KL0) KL0[i * 64 + lg * 16 + lc] = W3; else KG[i * 64 + lg * 16 + lc] = W3; }
+          if (lc <= NX) { if (i < KL0N) KL0[i * 64 + lg * 16 + lc] = W3; else KG[i * 64 + lg * 16 + lc] = W3; }
 #pragma unroll
           for (int k = 0; k < 3; ++k) acc[k] = lc == 12 ? sv[k] : acc[k];
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-own, lc <= NX ? W3 : 0.0, acc, 0, 0, 0);
@@ -800,7 +823,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
             double bop = 0.0, kop = 0.0;
 #pragma unroll
             for (int q = 0; q < NU; ++q) if (lg - GU0 == q) { bop = xk[q]; kop = kk[q]; }
-            if (urow && lc <= NX) { const double kv_ = lc < NX ? bop : kop; if (i < OC_KL0) KL0[i * 64 + (lg - GU0) * 16 + lc] = kv_; else KG[i * 64 + (lg - GU0) * 16 + lc] = kv_; }
+            if (urow && lc <= NX) { const double kv_ = lc < NX ? bop : kop; if (i < KL0N) KL0[i * 64 + (lg - GU0) * 16 + lc] = kv_; else KG[i * 64 + (lg - GU0) * 16 + lc] = kv_; }
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(urow ? -own : 0.0, urow ? bop : 0.0, acc, 0, 0, 0);
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) Pd[rg] = (lg + 4 * rg < NX && lc < NX) ? acc[rg] : 0.0;
@@ -826,7 +849,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
         auto kload = [&](int i) { const int ic = i < N - 2 ? i : N - 2; return KGs[ic * 64 + lf]; };
         double kring[OC_PF];
 #pragma unroll
-        for (int i = 0; i < OC_PF; ++i) kring[i] = kload(OC_KL0 + i);
+        for (int i = 0; i < OC_PF; ++i) kring[i] = kload(KL0N + i);
         if (lf < 16) dZ[lf] = 0.0;
         // [A B] row of this lane, rebuilt from a value of this iteration so that it is not kept in registers across the backward sweep
         const double tsl = fma(0.0, tau, ts);
@@ -840,8 +863,8 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
 #pragma unroll
         for (int i = 0; i < (((OC_ABL) & 128) ? 0 : 2 * NSL - 1); ++i) {
           double kq;
-          if (i < OC_KL0) kq = KL0[i * 64 + lf];
-          else { kq = kring[(i - OC_KL0) % OC_PF]; kring[(i - OC_KL0) % OC_PF] = kload(i + OC_PF); }
+          if (i < KL0N) kq = KL0[i * 64 + lf];
+          else { kq = kring[(i - KL0N) % OC_PF]; kring[(i - KL0N) % OC_PF] = kload(i + OC_PF); }
           const double xq = lcf < NX ? dZ[i * 16 + lcf] : 1.0;
           double pu = gownf ? -kq * xq : 0.0;   // (a select: the entries nobody owns were never written)
           pu += dpp_mov<0xB1>(pu); pu += dpp_mov<0x4E>(pu); pu += dpp_mov<0x141>(pu); pu += dpp_mov<0x140>(pu);   // sum over the row

@@ -2679,17 +2679,46 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
   const Layout& Y = B.Y;
   const int slot = blockIdx.x, lane = threadIdx.x;
   const int inst = B.slot_inst[slot];
-  if (inst < 0 || !B.inst_lns[inst]) return;
-  if (B.inst_nodes[inst] < (long long)B.lns_min_nodes) return;   // (the flag stays up: the search around its incumbent starts when the instance proves hard)
+  if (inst < 0) return;
+  const int flags = B.inst_lns[inst];   // bit 0: a new incumbent waits for its neighbours; bit 1: the skeleton roots of the instance have been tried
+  const bool want_skel = (B.lns_mode & 32) && !(flags & 2) && Y.NP > 0;
+  if (!(flags & 1) && !want_skel) return;
+  if (B.inst_nodes[inst] < (long long)B.lns_min_nodes) return;   // (the flags stay: the heuristics start when the instance proves hard)
   __shared__ int nb_c[LNS_MAX], nb_i[LNS_MAX], nb_n[LNS_MAX], nb_code[LNS_MAX];   // neighbour: first byte of the record, stride, number of entries, the value they take
-  __shared__ int sh_n, sh_base, sh_rec;
+  __shared__ int nb_c2[LNS_MAX], nb_n2[LNS_MAX], nb_code2[LNS_MAX];               // ... and a second stretch of the same stride (0 entries: none)
+  __shared__ int sh_n, sh_base, sh_rec, sh_skel;
   const int N = Y.N, C = Y.C;
   const signed char* inc = B.inc_fix + (size_t)inst * Y.fixlen;
   if (lane == 0) {
-    B.inst_lns[inst] = 0;
     int n = 0;
-    auto push = [&](int first, int stride, int cnt, int val) { if (n < LNS_MAX) { nb_c[n] = first; nb_i[n] = stride; nb_n[n] = cnt; nb_code[n] = val; n++; } };
-    if (!B.inst_done[inst] && !B.inst_kill[inst]) {
+    auto push = [&](int first, int stride, int cnt, int val) { if (n < LNS_MAX) { nb_c[n] = first; nb_i[n] = stride; nb_n[n] = cnt; nb_code[n] = val; nb_n2[n] = 0; n++; } };
+    const bool alive = !B.inst_done[inst] && !B.inst_kill[inst];
+    sh_skel = 0;
+    if (alive && want_skel) {
+      // Skeleton roots (once per hard instance): who drives beside, behind or ahead of whom is decided by the rear / rear car/car
+      // disjunction over the horizon, and the first dive of the tree commits to ONE such skeleton - the others are met again 10^5
+      // nodes later in best-bound order (measured: tools/skeleton.py).  For every pair of cars every sequence
+      // "alternative a throughout" and "a1 before step k, a2 from k on" (k = N/4, N/2, 3N/4) that the reachability presolve allows
+      // becomes a root of the MIP-start repair kind: its relaxation is solved, its completion rounded (one probe child), and a
+      // feasible rounding is an incumbent whose neighbourhood the local search then walks.  Never part of the tree.
+      sh_skel = 1;
+      const int* T = B.inst_i + (size_t)inst * Y.istride;
+      for (int p = 0; p < Y.NP; ++p) {
+        const int first = Y.f_c2c + p * N * 4;   // group 0 (rear / rear) of step i at first + 4 i
+        auto allowed = [&](int a, int i0, int i1) { for (int i = i0; i < i1; ++i) if (!((T[Y.i_c2callow + p * N + i] >> a) & 1)) return false; return true; };
+        for (int a = 0; a < 4; ++a) if (allowed(a, 1, N)) push(first + 4, 4, N - 1, a);
+        for (int kq = 1; kq <= 3; ++kq) {
+          const int k = (kq * N) / 4;
+          if (k < 2 || k >= N - 1) continue;
+          for (int a1 = 0; a1 < 4; ++a1) for (int a2 = 0; a2 < 4; ++a2) {
+            if (a1 == a2 || !allowed(a1, 1, k) || !allowed(a2, k, N) || n >= LNS_MAX) continue;
+            push(first + 4, 4, k - 1, a1); nb_c2[n - 1] = first + 4 * k; nb_n2[n - 1] = N - k; nb_code2[n - 1] = a2;
+          }
+        }
+      }
+      B.inst_lns[inst] = flags | 2;   // (a pending incumbent keeps its bit: its neighbours follow next round)
+    } else if (alive) {
+      B.inst_lns[inst] = flags & ~1;
       // a sequence over the steps (the region codes of a car: stride 1; the alternatives of a car/car group: stride 4): every change
       // between two steps moved one / two steps later and earlier, every short run between two changes given to its neighbours
       auto moves = [&](int first, int stride, int mode) {
@@ -2734,7 +2763,7 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
           }
         }
       }
-    }
+    } else B.inst_lns[inst] = flags & ~1;
     int base = 0, rec = 0;
     if (n > 0) {
       base = atomicAdd(B.batch_count, n);
@@ -2747,10 +2776,27 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
   const int n = sh_n;
   if (n <= 0) return;
   const double lbq = B.lower_bound[inst] - B.inst_const[inst];
+  const bool skel = sh_skel != 0;
   for (int q = 0; q < n; ++q) {
     const int rec = sh_rec + q, bs = sh_base + q;
     signed char* dst = B.pool_fix + (size_t)rec * Y.fixlen;
     const int k0 = nb_c[q], st_ = nb_i[q], k1 = k0 + nb_n[q] * st_;
+    if (skel) {   // a root record (everything undecided) with the sequence of one pair's rear / rear group
+      const int k2 = nb_c2[q], k3 = k2 + nb_n2[q] * st_;
+      for (int k = lane; k < Y.fixlen; k += 64) {
+        signed char v = (signed char)-1;
+        if (k >= k0 && k < k1 && (k - k0) % st_ == 0) v = (signed char)nb_code[q];
+        if (nb_n2[q] > 0 && k >= k2 && k < k3 && (k - k2) % st_ == 0) v = (signed char)nb_code2[q];
+        dst[k] = v;
+      }
+      if (lane == 0) {
+        if (B.pool_big) B.pool_big[rec] = 0;
+        if (B.pool_origin) B.pool_origin[rec] = 13;
+        B.batch_node[bs] = rec; B.batch_inst[bs] = inst; B.batch_bound[bs] = lbq; B.batch_depth[bs] = REPAIR_ROOT;
+        if (B.batch_large) B.batch_large[bs] = 0;
+      }
+      continue;
+    }
     for (int k = lane; k < Y.fixlen; k += 64) {
       signed char v = inc[k];
       if (k >= k0 && k < k1 && (k - k0) % st_ == 0) v = (signed char)nb_code[q];
@@ -2774,7 +2820,10 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
 }
 
 // makes the records freed so far available to the next eval launch
-__global__ void roll_kernel(DevBuf B) {
+// ... and zeroes the counter set of the NEXT round (`zero8`: eight ints, null = the host uses memsets)
+__global__ void roll_kernel(DevBuf B, int* zero8) {
+  if (zero8 && threadIdx.x < 8) zero8[threadIdx.x] = 0;
+  if (threadIdx.x != 0) return;
   unsigned int t = *B.free_tail, h = *B.free_head, l = *B.free_limit;
   if ((int)(h - l) > 0) h = l;   // pops that overshot the limit took fresh records instead
   *B.free_head = h; *B.free_limit = t;

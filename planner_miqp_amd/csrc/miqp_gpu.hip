@@ -256,6 +256,8 @@ struct DevCtx {
   hipEvent_t ev_mid = nullptr;   // MIQP_LAUNCH_TRACE
   int* work_counter2 = nullptr; double* rowstate2 = nullptr; double* rowcache2 = nullptr; double* kgain2 = nullptr; int probe_grid = 0;
   int oc_grid = 0;   // resident wavefronts of the on-chip interior point kernel (0: the shape does not qualify)
+  int kg_blocks = 0; // blocks the gain buffer holds
+  int* ctr = nullptr; // two parity sets of 8 counters for the launches of a round (batch count, work counters, hand-over counts): a round uses one set, roll_kernel zeroes the other
   bool concurrent_big = true;   // MIQP_CONCURRENT_BIG=0: the sequential chain standard -> larger -> memory-backed
   int ocb_grid = 0;  // resident wavefronts of its larger variant (OC_GCAP_BIG general rows, one wavefront per SIMD; 0: not in use)
   DevBuf B{};
@@ -346,6 +348,12 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
       }
     }
     if (X.oc_grid > X.ipm_grid_max) X.ipm_grid_max = X.oc_grid;   // the per-block buffers are sized for the larger grid
+    // Oversubscribed launches of the on-chip kernels (MIQP_OC_OVERSUB = F): F times the resident wavefronts, each working through 1 / F of the
+    // nodes - a wavefront slot comes free F times as often, so the short kernels of ANOTHER lane of the same device (MIQP_LANES: its
+    // evaluation and selection) are dispatched between them instead of waiting for the whole launch.  Only the gain buffer grows.
+    X.kg_blocks = X.ipm_grid_max;
+    if (const char* e = std::getenv("MIQP_OC_OVERSUB")) { const int f = std::max(1, std::min(64, std::atoi(e)));
+      X.oc_grid = std::min(batch_alloc, X.oc_grid * f); X.ocb_grid = std::min(batch_alloc, X.ocb_grid * f); X.kg_blocks = std::max(X.kg_blocks, std::max(X.oc_grid, X.ocb_grid)); }
   }
   // node pool: live nodes are bounded by the open lists plus one round of children; processed records are recycled
   size_t free_b = 0, total_b = 0; if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
@@ -457,8 +465,10 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&B.batch_comp, (size_t)batch_alloc * Y.fixlen)) return false;
   if (!X.alloc(&B.rowstate, (size_t)std::min(batch_alloc, X.ipm_grid_max) * NFIELD * Y.ROWCAP)) return false;
   if (!X.alloc(&B.rowcache, (size_t)std::min(batch_alloc, X.ipm_grid_max) * NCACHE * Y.ROWCAP)) return false;
-  if (!X.alloc(&B.kgain, (size_t)std::min(batch_alloc, X.ipm_grid_max) * std::max(Y.N * Y.nu * (Y.nx + 2), oc_gain_doubles(Y.N)))) return false;
+  if (!X.alloc(&B.kgain, (size_t)std::min(batch_alloc, X.kg_blocks) * std::max(Y.N * Y.nu * (Y.nx + 2), oc_gain_doubles(Y.N)))) return false;
   if (!X.alloc(&B.work_counter, 1)) return false;
+  if (!X.alloc(&X.ctr, 16)) return false;
+  HIP_OK(hipMemset(X.ctr, 0, 64));
   // buffers of the concurrent probe launch (two cars and fewer, on-chip kernel in use): 1024 resident blocks
   X.probe_grid = 0;
   if (X.oc_grid > 0 && !(std::getenv("MIQP_PROBE_OVERLAP") && std::atoi(std::getenv("MIQP_PROBE_OVERLAP")) == 0)) {
@@ -505,22 +515,23 @@ size_t eval_lds_bytes(const Layout& Y) {
          + (size_t)Y.fixlen + 16;                                  // ploose
 }
 
-template <int C> void launch_ipm(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { (void)hipMemsetAsync(B.work_counter, 0, 4, st); hipLaunchKernelGGL((ipm_kernel<C, IPM_NT>), dim3(nblocks), dim3(IPM_NT), lds, st, B); }
-template <int C> void launch_ipm_oc(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) {
-  (void)hipMemsetAsync(B.work_counter, 0, 4, st); (void)hipMemsetAsync(B.ovf_count, 0, 4, st);
+// `zero` false: the counters of the launch are the round's parity set, zeroed by roll_kernel one round ahead (no memset in the stream)
+template <int C> void launch_ipm(const DevBuf& B, int nblocks, size_t lds, hipStream_t st, bool zero = true) { if (zero) (void)hipMemsetAsync(B.work_counter, 0, 4, st); hipLaunchKernelGGL((ipm_kernel<C, IPM_NT>), dim3(nblocks), dim3(IPM_NT), lds, st, B); }
+template <int C> void launch_ipm_oc(const DevBuf& B, int nblocks, size_t lds, hipStream_t st, bool zero = true) {
+  if (zero) { (void)hipMemsetAsync(B.work_counter, 0, 4, st); (void)hipMemsetAsync(B.ovf_count, 0, 4, st); }
   hipLaunchKernelGGL((ipm_onchip_kernel<C, OC_NSL>), dim3(nblocks), dim3(64), lds, st, B);
 }
 // the larger variant: works through the list of the standard one (ovf_mode 1) or through the rounding probes of the batch (ovf_mode 2, on its
 // own stream with its own work counter); the caller has zeroed ovf2_count
-template <int C> void launch_ipm_oc_big(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) {
-  (void)hipMemsetAsync(B.work_counter, 0, 4, st);
+template <int C> void launch_ipm_oc_big(const DevBuf& B, int nblocks, size_t lds, hipStream_t st, bool zero = true) {
+  if (zero) (void)hipMemsetAsync(B.work_counter, 0, 4, st);
   hipLaunchKernelGGL((ipm_onchip_kernel<C, OC_NSL, 0, OC_GCAP_BIG>), dim3(nblocks), dim3(64), lds, st, B);
 }
 template <int C> void launch_eval(const DevBuf& B, int nblocks, size_t lds, hipStream_t st) { hipLaunchKernelGGL(eval_kernel<C>, dim3(nblocks), dim3(64), lds, st, B); }
 
-void launch_ipm_c(int C, const DevBuf& B, int nblocks, size_t lds, hipStream_t st) {
-  switch (C) { case 1: launch_ipm<1>(B, nblocks, lds, st); break; case 2: launch_ipm<2>(B, nblocks, lds, st); break;
-               case 3: launch_ipm<3>(B, nblocks, lds, st); break; default: launch_ipm<4>(B, nblocks, lds, st); }
+void launch_ipm_c(int C, const DevBuf& B, int nblocks, size_t lds, hipStream_t st, bool zero = true) {
+  switch (C) { case 1: launch_ipm<1>(B, nblocks, lds, st, zero); break; case 2: launch_ipm<2>(B, nblocks, lds, st, zero); break;
+               case 3: launch_ipm<3>(B, nblocks, lds, st, zero); break; default: launch_ipm<4>(B, nblocks, lds, st, zero); }
 }
 // interior point solves of the first `bc` batch entries: the on-chip kernel where the shape qualifies, followed by the
 // memory-backed kernel on the nodes it handed over (their count stays on the device: no host round trip); else the
@@ -530,7 +541,8 @@ void launch_ipm_c(int C, const DevBuf& B, int nblocks, size_t lds, hipStream_t s
 // beside the on-chip kernel: that kernel waits on memory for most of its cycles (58 % in s_waitcnt), the on-chip kernel is bound
 // by VALU issue, and the probes no longer cost a generation of their own behind it.  `overlap` false (the polish, solve_fixed): the
 // serial order of round 2.
-void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool overlap = false) {
+// `par` >= 0 (the rounds of a solve): the counters of this launch group are set `par` of X.ctr, zeroed one round ahead by roll_kernel
+void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool overlap = false, int par = -1) {
   const Layout& Y = X.Y;
   const size_t l_ipm = ipm_lds_bytes(Y);
   if (X.oc_grid > 0) {
@@ -539,7 +551,8 @@ void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool o
     const bool big = X.ocb_grid > 0;
     const bool ov = overlap && X.probe_grid > 0 && X.stream2 && bc <= 4096;   // (a full batch keeps the device busy on its own: measured no gain there, 5.4 against 5.1 s on a 2048-instance queue; single solves: median 6.0 instead of 7.0 ms)
     DevBuf Bc = B;
-    if (big) (void)hipMemsetAsync(B.ovf2_count, 0, 4, st);
+    const bool pc = par >= 0 && X.ctr && big && overlap && X.probe_grid > 0 && X.stream2 && X.concurrent_big;
+    if (big && !pc) (void)hipMemsetAsync(B.ovf2_count, 0, 4, st);
     if (big && overlap && X.probe_grid > 0 && X.stream2 && X.concurrent_big) {
       // Every round: the larger variant works beside the standard one, on its own stream, through the nodes known to be large
       // (rounding probes, marked records); behind it, on that stream, the memory-backed kernel takes what even it cannot hold.
@@ -548,15 +561,17 @@ void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool o
       // being a launch of its own.  A node the standard kernel finds too large at its decode is marked and returned unsolved
       // (bounce): no second launch behind the standard one.
       (void)hipEventRecord(X.ev_fork, st); (void)hipStreamWaitEvent(X.stream2, X.ev_fork, 0);
-      DevBuf Bp = B; Bp.ovf_mode = 2; Bp.work_counter = X.work_counter2; Bp.rowstate = X.rowstate2; Bp.rowcache = X.rowcache2; Bp.kgain = X.kgain2;
+      int* const cs = pc ? X.ctr + 8 * par : nullptr;   // [0] batch count, [1] standard launch, [2] its hand-over list, [3] the larger variant's list, [4] the larger variant, [5] the memory-backed launch behind it
+      if (pc) { Bc.work_counter = cs + 1; Bc.ovf_count = cs + 2; Bc.ovf2_count = cs + 3; }
+      DevBuf Bp = Bc; Bp.ovf_mode = 2; Bp.work_counter = pc ? cs + 4 : X.work_counter2; Bp.rowstate = X.rowstate2; Bp.rowcache = X.rowcache2; Bp.kgain = X.kgain2;
       static const int big_grid_cap = std::getenv("MIQP_BIG_GRID") ? std::atoi(std::getenv("MIQP_BIG_GRID")) : 1 << 30;
       const int gb = std::min(std::min(bc, big_grid_cap), std::min(X.probe_grid, X.ocb_grid));
-      if (Y.C == 1) launch_ipm_oc_big<1>(Bp, gb, l_ocb, X.stream2); else launch_ipm_oc_big<2>(Bp, gb, l_ocb, X.stream2);
-      DevBuf Bm = Bp; Bm.ovf_mode = 1; Bm.ovf_count = B.ovf2_count; Bm.ovf_list = B.ovf2_list;
-      launch_ipm_c(Y.C, Bm, std::min(bc, X.probe_grid), l_ipm, X.stream2);
+      if (Y.C == 1) launch_ipm_oc_big<1>(Bp, gb, l_ocb, X.stream2, !pc); else launch_ipm_oc_big<2>(Bp, gb, l_ocb, X.stream2, !pc);
+      DevBuf Bm = Bp; Bm.ovf_mode = 1; Bm.ovf_count = Bc.ovf2_count; Bm.ovf_list = B.ovf2_list; if (pc) Bm.work_counter = cs + 5;
+      launch_ipm_c(Y.C, Bm, std::min(bc, X.probe_grid), l_ipm, X.stream2, !pc);
       (void)hipEventRecord(X.ev_join, X.stream2);
       Bc.skip_probes = 1; Bc.bounce = 1;
-      if (Y.C == 1) launch_ipm_oc<1>(Bc, std::min(bc, X.oc_grid), l_oc, st); else launch_ipm_oc<2>(Bc, std::min(bc, X.oc_grid), l_oc, st);
+      if (Y.C == 1) launch_ipm_oc<1>(Bc, std::min(bc, X.oc_grid), l_oc, st, !pc); else launch_ipm_oc<2>(Bc, std::min(bc, X.oc_grid), l_oc, st, !pc);
       if (X.ev_mid) (void)hipEventRecord(X.ev_mid, st);
       (void)hipStreamWaitEvent(st, X.ev_join, 0);
       return;
@@ -816,6 +831,10 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   if (hipSetDevice(X.device) != hipSuccess) return fail_all("hipSetDevice failed");
   const int NS = (split || inflight <= 0 || inflight >= n) ? n : inflight;   // slots = instances in flight
   int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(16384, 32768 / (NS * lanes)));   // (the lanes of a call keep the round width of the undivided call)
+  // three and four cars: a node relaxation costs ~15 x that of two cars (memory-backed kernel, stage vector 24 / 32), a round of 32768 nodes
+  // lasts 0.13 s and an instance that shares the device gets 80 rounds in its 10 s - fewer than the levels of its first dive.  Rounds of
+  // 5120 nodes (0.035 s) give the tree its depth back at a quarter less node throughput: cfg5, 16 in flight, 7 -> 11 of 16 proven in 10 s
+  if (O0.nodes_per_round <= 0 && Y.C >= 3 && NS > 1) npr = std::max(16, std::min(npr, 5120 / NS));
   if (O0.nodes_per_round <= 0 && std::getenv("MIQP_NPR")) npr = std::max(1, std::atoi(std::getenv("MIQP_NPR")));  // tuning knob
   int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (std::getenv("MIQP_OPEN_CAP") ? std::atoi(std::getenv("MIQP_OPEN_CAP")) : std::max(1 << 17, std::min(1 << 20, (1 << 28) / NS)));   // near lists: 1 M entries per instance up to n = 256 (10 GB of list entries), 262144 at n = 1024; records are shared
   if (open_cap < 64) open_cap = 64;
@@ -950,7 +969,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemsetAsync(B.inst_iters, 0, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_ninc, 0, (size_t)n * 4, st));
   HIP_OK(hipMemsetAsync(B.inst_lns, 0, (size_t)n * 4, st));
-  B.lns_mode = std::getenv("MIQP_LNS") ? std::atoi(std::getenv("MIQP_LNS")) : 13;
+  B.lns_mode = std::getenv("MIQP_LNS") ? std::atoi(std::getenv("MIQP_LNS")) : 45;
   B.lns_min_nodes = std::getenv("MIQP_LNS_MIN") ? std::atoi(std::getenv("MIQP_LNS_MIN")) : 2000;
   HIP_OK(hipMemsetAsync(B.active_insts, 0, 4, st));   // admit_kernel counts the instances in as they enter
   HIP_OK(hipMemsetAsync(B.stat_rowiters, 0, 8, st));
@@ -1003,14 +1022,19 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   int prev_bc = 0;
   static const bool round_log = std::getenv("MIQP_ROUND_LOG") != nullptr;   // diagnostic: the batch sizes of the rounds, printed after the solve (no extra synchronisation)
   std::vector<int> round_bc;
+  // the counters of a round's launches (batch count, work counters, hand-over counts) come in two parity sets: a round uses one, its
+  // roll_kernel zeroes the other for the round after - six 4-byte memsets per round less in the stream (0.65 ms of the 1.4 ms round of a single solve)
+  const bool use_par = X.ctr && X.oc_grid > 0 && X.ocb_grid > 0 && X.concurrent_big && X.stream2 && X.probe_grid > 0 && !pipelined && !std::getenv("MIQP_MEMSETS");
+  if (use_par) HIP_OK(hipMemsetAsync(X.ctr, 0, 64, st));
   for (;;) {
-    HIP_OK(hipMemsetAsync(B.batch_count, 0, 4, st));
+    const int par = rounds & 1;
+    if (use_par) B.batch_count = X.ctr + 8 * par; else HIP_OK(hipMemsetAsync(B.batch_count, 0, 4, st));
     B.open_sel = rounds & 1;
     B.prev_bc = pipelined ? X.batch_cap : prev_bc;
     hipLaunchKernelGGL(select_kernel, dim3(NS), dim3(SEL_THREADS), 0, st, B, rounds);
     if (B.lns_mode > 0) hipLaunchKernelGGL(lns_kernel, dim3(NS), dim3(64), 0, st, B);   // the neighbours of new incumbents join this round's batch
     if (std::getenv("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d select: %s\n", rounds, hipGetErrorString(e_)); }
-    hipLaunchKernelGGL(roll_kernel, dim3(1), dim3(1), 0, st, B);
+    hipLaunchKernelGGL(roll_kernel, dim3(1), dim3(8), 0, st, B, use_par ? X.ctr + 8 * (par ^ 1) : (int*)nullptr);
     hipLaunchKernelGGL(share_kernel, dim3(1), dim3(1024), 0, st, B);
     int bc = 0;
     if (pipelined) {
@@ -1093,7 +1117,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     static const bool launch_trace = std::getenv("MIQP_LAUNCH_TRACE") != nullptr;
     if (launch_trace && !X.ev_mid) HIP_OK(hipEventCreate(&X.ev_mid));
     HIP_OK(hipEventRecord(X.ipm_ev[nev], st));
-    launch_ipm_batch(X, B, bc, st, true);
+    launch_ipm_batch(X, B, bc, st, true, use_par ? par : -1);
     HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
     if (launch_trace) {   // diagnostic: the two interior point launches of the round apart, and what the memory-backed one had to solve
       HIP_OK(hipStreamSynchronize(st));
@@ -1114,7 +1138,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
                    rounds, bc, m1, bc - oc, (double)sc / std::max(1, bc - oc), mxc, m2, np, (double)sp / std::max(1, np), mxp, oc - np, (double)so / std::max(1, oc - np), mxo);
     }
     nev += 2;
-    if (bc == X.batch_cap) {   // MIQP_REPLAY=k (diagnostic): the first full batch is solved k more times under a timer - the kernels
+    if (bc >= X.batch_cap / 2) {   // MIQP_REPLAY=k (diagnostic): the first batch that is at least half full is solved k more times under a timer - the kernels
       static int replay = std::getenv("MIQP_REPLAY") ? std::atoi(std::getenv("MIQP_REPLAY")) : 0;   // only read and write batch slots
       if (replay > 0) {
         hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
