@@ -294,14 +294,18 @@ def main():
         # Legs behind the timed region (rank 0, single GPU; they re-solve instances of the timed queues, results are discarded).
         # `value` depends on the instances in flight: with more in flight the hardest instances are starved until their own limit
         # ends them, which saves their work.  The knob-free figure is the rate at which EVERY instance is proven:
-        #  * all_proven: the head of the timed queue (up to 4096 instances) at the bench's own in-flight setting with the
-        #    per-instance limit lifted to 60 s - nothing is abandoned, the leg ends with its slowest instance;
+        #  * all_proven: the head of the timed queue (2048 instances) at 256 in flight with the per-instance limit lifted to
+        #    60 s - nothing is abandoned, the leg ends with its slowest instance; the same at the bench's own in-flight setting;
         #  * in_flight_sweep: the same queue at 256 / 512 in flight with the reference's 10 s limit;
         #  * one_batch_control: the semantics of rounds 1-2 with marshalling and result records inside the timer.
         pool = [w for _, ws in timed for w in ws]
-        qn = min(len(pool), 4096)
+        qn = min(len(pool), 2048)
+        # everything proven: 256 in flight (every instance gets a share of the batch that lets it finish), limit lifted to 60 s
+        ok_, n_, d_, nd_, mx_ = leg(pool[:qn], 256, limit=60.0)
+        ap_ = dict(in_flight=256, queue=n_, time_limit_s=60.0, solves_per_s=ok_ / d_, proven_share=ok_ / n_, seconds=d_, nodes_per_instance=nd_ / n_, slowest_instance_s=mx_)
+        # ... and what the same costs at the bench's own in-flight setting (the hardest instances are starved for most of their life: their trees grow)
         ok_, n_, d_, nd_, mx_ = leg(pool[:qn], B, limit=60.0)
-        ap_ = dict(in_flight=B, queue=n_, time_limit_s=60.0, solves_per_s=ok_ / d_, proven_share=ok_ / n_, seconds=d_, nodes_per_instance=nd_ / n_, slowest_instance_s=mx_)
+        aph_ = dict(in_flight=B, queue=n_, time_limit_s=60.0, solves_per_s=ok_ / d_, proven_share=ok_ / n_, seconds=d_, nodes_per_instance=nd_ / n_, slowest_instance_s=mx_)
         sweep = []
         for infl_ in (256, 512):
             if 4 * infl_ > len(pool):
@@ -310,7 +314,7 @@ def main():
             sweep.append(dict(in_flight=infl_, queue=n_, time_limit_s=a.time_limit, solves_per_s=ok_ / d_, proven_share=ok_ / n_, seconds=d_, nodes_per_instance=nd_ / n_, slowest_instance_s=mx_))
         nb_ = min(1024, len(pool))
         ok_, n_, d_, nd_, mx_ = leg(pool[:nb_], None, marshal=True)
-        extras = dict(in_flight_sweep=sweep, all_proven=ap_,
+        extras = dict(in_flight_sweep=sweep, all_proven=ap_, all_proven_at_bench_in_flight=aph_,
                       one_batch_control=dict(instances=n_, solves_per_s=ok_ / d_, proven_share=ok_ / n_, seconds=d_, slowest_instance_s=mx_,
                                              note="--no-stream semantics (one batch, all in flight, ends with its last instance); parameter marshalling, device upload and result records inside the timer"))
         for w in pool:
@@ -352,7 +356,7 @@ def main():
             # `value` depends on the instances in flight (more in flight = the hardest instances are abandoned at their limit sooner);
             # the knob-free figure is the rate at a setting that proves EVERY instance of its queue
             out["value_all_proven"] = extras["all_proven"]["solves_per_s"] if extras["all_proven"] and extras["all_proven"]["proven_share"] >= 1.0 else None
-            out["all_proven"] = extras["all_proven"]; out["in_flight_sweep"] = extras["in_flight_sweep"]; out["one_batch_control"] = extras["one_batch_control"]
+            out["all_proven"] = extras["all_proven"]; out["all_proven_at_bench_in_flight"] = extras["all_proven_at_bench_in_flight"]; out["in_flight_sweep"] = extras["in_flight_sweep"]; out["one_batch_control"] = extras["one_batch_control"]
         out["proven_share"] = tot_solved / max(1, tot_att)
         if not a.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(batches[a.warmup][0], a.gap, a.time_limit)
