@@ -2044,7 +2044,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         negm = 1 << (int)comp[base + ck[a] * stride];
         for (int a2 = 1; a2 < a; ++a2) if (ck[a2] == ck[a]) negm |= 1 << ca[a2];
       }
-      const bool tf = (cb - cst) > thr;
+      const bool tf = (cb - cst) > thr && B.batch_depth[node] != REPAIR_ROOT;   // (the rounding probe of a repair / skeleton root carries that root's LOW bound: it stays in the near list, where the next best-bound round takes it - parked in the far tier it held the instance's bound down until the next refill)
       k_ck[nk] = ck[a]; k_ca[nk] = ca[a]; k_neg[nk] = negm; k_ord[nk] = a; k_bnd[nk] = cb - cst;
       k_pos[nk] = tf ? (0x40000000 | nfar++) : nnear++;
       if (tf) fmin_ = fmin(fmin_, cb - cst);
@@ -2243,7 +2243,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     for (int k = tid; k < Y.fixlen; k += SEL_THREADS) df[k] = cf[k];
     const double* zs = B.batch_Z + (size_t)bslot * Y.N * Y.nz; double* zd = B.inc_Z + (size_t)inst * Y.N * Y.nz;
     for (int k = tid; k < Y.N * Y.nz; k += SEL_THREADS) zd[k] = zs[k];
-    if (tid == 0) { B.inc_obj[inst] = B.batch_obj[bslot]; if (B.inst_lns) B.inst_lns[inst] = 1; }
+    if (tid == 0) { B.inc_obj[inst] = B.batch_obj[bslot]; if (B.inst_lns) B.inst_lns[inst] |= 1; }   // (bit 1, "skeleton roots tried", stays)
   }
   __syncthreads();
   if (B.inst_kill[inst]) {
