@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     if (tid == 0) sh_node = atomicAdd(B.work_counter, 1);
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(sh_node) >= nbatch) break;
-    const int node = __builtin_amdgcn_readfirstlane(BIG && B.ovf_mode == 1 ? B.ovf_list[sh_node] : sh_node);   // wave-uniform by construction: said so, everything derived from it
+    const int node = __builtin_amdgcn_readfirstlane(BIG && B.ovf_mode == 1 ? B.ovf_list[sh_node] : ((!BIG && B.batch_order) ? B.batch_order[sh_node] : sh_node));   // wave-uniform by construction: said so, everything derived from it
                                                                   // (instance tables, references) is then addressed from SGPRs
     // the concurrent launch of the larger variant takes the nodes known to be large before the round: the rounding probes (their
     // depth word says so) and the records marked by an earlier decode or inherited from a marked parent

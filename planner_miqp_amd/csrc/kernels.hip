@@ -183,6 +183,7 @@ struct DevBuf {
   float* pool_Lbox; unsigned char* pool_Lgen; float* batch_Lbox; unsigned char* batch_Lgen; int ws_dual;
   // Local search around a new incumbent (lns_kernel): select_kernel raises inst_lns when it adopts a new incumbent; the neighbours of
   // its region sequences join the batch of the same round
+  const int* batch_order;        // diagnostic (MIQP_REPLAY_LPT): the order in which the standard on-chip launch hands the batch's nodes out (null: as they stand)
   int* inst_lns; int lns_mode; int lns_min_nodes;   // (an instance gets its local search once it has cost lns_min_nodes node relaxations: the easy ones are done before)
   double ws_theta;               // share of the mean in a pair's centring target (1: the uniform target of a cold start), see row_step
 };

@@ -1138,7 +1138,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
                    rounds, bc, m1, bc - oc, (double)sc / std::max(1, bc - oc), mxc, m2, np, (double)sp / std::max(1, np), mxp, oc - np, (double)so / std::max(1, oc - np), mxo);
     }
     nev += 2;
-    if (bc >= X.batch_cap / 2) {   // MIQP_REPLAY=k (diagnostic): the first batch that is at least half full is solved k more times under a timer - the kernels
+    static const int replay_round = std::getenv("MIQP_REPLAY_ROUND") ? std::atoi(std::getenv("MIQP_REPLAY_ROUND")) : 0;
+    if (bc >= X.batch_cap / 2 && rounds >= replay_round) {   // MIQP_REPLAY=k (diagnostic): the first batch that is at least half full is solved k more times under a timer - the kernels
       static int replay = std::getenv("MIQP_REPLAY") ? std::atoi(std::getenv("MIQP_REPLAY")) : 0;   // only read and write batch slots
       if (replay > 0) {
         hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
@@ -1149,6 +1150,25 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
         std::vector<int> its(bc); HIP_OK(hipMemcpy(its.data(), B.batch_it, (size_t)bc * 4, hipMemcpyDeviceToHost));
         long long tot = 0; for (int v : its) tot += v;
         std::fprintf(stderr, "[miqp_gpu replay] %d nodes, %lld node-iterations: %.3f ms per pass, %.1f ns per node-iteration\n", bc, tot, ms / replay, 1e6 * ms / replay / (double)tot);
+        if (std::getenv("MIQP_REPLAY_LPT")) {   // how much the order of the batch is worth: the same batch with its nodes handed out longest first (by the iterations just measured), and shortest first
+          int* d_ord = nullptr; HIP_OK(hipMalloc((void**)&d_ord, (size_t)bc * 4));
+          // (measured in round 4: longest first -3 ... -13 % of a steady-state round; the iterations of a node's PARENT predict its own with a correlation of 0.2-0.3 - ordering by them gains nothing)
+          for (int pass = 0; pass < 3; ++pass) {
+            std::vector<int> ord(bc); for (int k = 0; k < bc; ++k) ord[k] = k;
+            if (pass == 0) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return its[a] > its[b]; });
+            else if (pass == 1) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return its[a] < its[b]; });
+            else { unsigned int x = 12345u; for (int k = bc - 1; k > 0; --k) { x = x * 1664525u + 1013904223u; std::swap(ord[k], ord[(x >> 8) % (unsigned int)(k + 1)]); } }
+            HIP_OK(hipMemcpy(d_ord, ord.data(), (size_t)bc * 4, hipMemcpyHostToDevice));
+            DevBuf Bo = B; Bo.batch_order = d_ord;
+            HIP_OK(hipEventRecord(e0, st));
+            for (int r = 0; r < replay; ++r) launch_ipm_batch(X, Bo, bc, st);
+            HIP_OK(hipEventRecord(e1, st)); HIP_OK(hipStreamSynchronize(st));
+            float m2 = 0; HIP_OK(hipEventElapsedTime(&m2, e0, e1));
+            std::fprintf(stderr, "[miqp_gpu replay] %s: %.3f ms per pass\n", pass == 0 ? "longest first" : (pass == 1 ? "shortest first" : (pass == 2 ? "shuffled" : "?")), m2 / replay);
+          }
+          (void)hipFree(d_ord);
+          launch_ipm_batch(X, B, bc, st);
+        }
 #ifdef MIQP_ABLATE
         if (X.oc_grid > 0 && Y.C == 2) {   // cost map of the on-chip kernel: the same batch, 15 iterations per node, parts switched off
           const size_t l_oc = (size_t)oc_lds_layout(Y.N, Y.fixlen).total;
