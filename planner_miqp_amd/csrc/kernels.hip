@@ -140,7 +140,7 @@ struct DevBuf {
   // sharing the batch evenly all run into their max_solution_time (which counts from the admission) and their work is lost.
   // Earliest deadline first finishes what it starts; the cap (1024: narrow rounds waste the fewest nodes - every round prunes
   // with the incumbents of the one before) keeps a pathological instance to 3 % of the device.
-  int* slot_demand; int* slot_take; int share_cap; int base_take; int window_pct; double probe_room;
+  int* slot_demand; int* slot_take; int share_cap; int base_take; int floor_pct; int young_nodes; int window_pct; double probe_room;
   double probe_margin;           // > 0: the rounding probe leaves front-point environment / obstacle disjunctions undecided whose completed alternative holds with this much room
   int probe_itcap;               // iterations after which an unconverged rounding probe is abandoned (0: never)
   int probe_every;               // rounding probes are eligible every probe_every-th round (1: always)
@@ -2481,7 +2481,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     if (B.seq_kinds & 0x40000000) {   // (experiment switch, bit 30: the equal split and the endgame focus of round 2)
       w = (focus && !(B.seq_kinds & 0x10000000)) ? (B.batch_cap >> (rank + 1 < 30 ? rank + 1 : 30)) : B.batch_cap / act;
       if (w < B.nodes_per_round) w = B.nodes_per_round;
-    } else { w = B.slot_take[slot]; if (w < B.base_take) w = B.base_take; }
+    } else { w = B.slot_take[slot]; if (w < B.base_take && !(B.young_nodes > 0 && B.inst_nodes[inst] >= (long long)B.young_nodes)) w = B.base_take; }   // (an older instance may be told to wait: share 0)
     if (!(inc < 1e300) && w > 512) w = 512;   // no incumbent yet: a narrow dive (a wide one degenerates into breadth first)
     B.slot_demand[slot] = inc < 1e300 ? m_elig : (m < 512 ? m : 512);   // what this instance could use next round
     int take = m_elig < w ? m_elig : w;
@@ -2619,21 +2619,52 @@ __global__ void __launch_bounds__(1024) share_kernel(DevBuf B) {
     return red[0];
   };
   const long long target = (long long)B.batch_cap - (long long)B.batch_cap / 16;   // (demands are one round old: a little head room)
+  // The base share is a FLOOR that adapts to the load: the largest F in [base_take, share_cap] with sum_k min(demand_k, F) <= floor_pct % of
+  // the batch.  An instance that waits for its turn in the admission order must not crawl at a handful of nodes per round meanwhile - at 8 -
+  // 16 nodes per round the dives reach their leaves late, the local search (it starts after lns_min_nodes nodes) later still, and the wide
+  // rounds the instance gets afterwards wade through what a timely incumbent would have pruned: measured, two hard instances at the END of
+  // the admission order of 1280 cost 0.89 M and 1.20 M nodes against 0.24 M and 0.30 M at its head (tools/crowd_probe.py).
+  int base = B.base_take;
+  if (B.floor_pct > 0) {
+    if (tid == 0) { sh_lo = B.base_take; sh_hi = B.share_cap; }
+    __syncthreads();
+    const long long budget = target * B.floor_pct / 100;
+    for (int itn = 0; itn < 12; ++itn) {
+      const int lo = sh_lo, hi = sh_hi;
+      if (lo >= hi) break;
+      const int mid = lo + (hi - lo + 1) / 2;
+      long long a = 0;
+      for (int k = tid; k < NSL; k += 1024) { const int d = B.slot_demand[k]; a += d < mid ? d : mid; }
+      const long long tot = bsum(a);
+      if (tid == 0) { if (tot <= budget) sh_lo = mid; else sh_hi = mid - 1; }
+      __syncthreads();
+    }
+    base = sh_lo;
+    __syncthreads();
+  }
+  // ... and with young_nodes > 0 only instances that have cost fewer node relaxations than that have a base share at all (the easy ones finish on
+  // it within a few rounds); an older instance gets its share in the pass by admission order or WAITS - it keeps its tree as it is instead of
+  // growing it a handful of nodes at a time
+  auto base_of = [&](int k) -> int {
+    const int d = B.slot_demand[k], inst = B.slot_inst[k];
+    if (B.young_nodes > 0 && inst >= 0 && B.inst_nodes[inst] >= (long long)B.young_nodes) return 0;
+    return d < base ? d : base;
+  };
   long long ab = 0;
-  for (int k = tid; k < NSL; k += 1024) { const int d = B.slot_demand[k]; ab += d < B.base_take ? d : B.base_take; }
+  for (int k = tid; k < NSL; k += 1024) ab += base_of(k);
   const long long SB = bsum(ab);
   const long long rest = target - SB;
   const long long cap = B.share_cap;
   auto more_of = [&](int k) -> long long {   // what slot k may take beyond its base share in the pass by admission order
     const int d = B.slot_demand[k]; const long long c = d < cap ? d : cap;
-    const int b = d < B.base_take ? d : B.base_take;
+    const int b = base_of(k);
     return c > b ? c - b : 0;
   };
   // pass by admission order (earliest deadline first), every instance up to the cap
   long long at = 0;
   for (int k = tid; k < NSL; k += 1024) {
     const int d = B.slot_demand[k], inst = B.slot_inst[k];
-    int take = d < B.base_take ? d : B.base_take;
+    int take = base_of(k);
     const long long more = more_of(k);
     if (inst >= 0 && more > 0 && rest > 0) {
       long long before = 0;   // what the instances admitted earlier take from the rest

@@ -944,7 +944,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemsetAsync(B.slot_demand, 0, (size_t)NS * 4, st));
   { std::vector<int> t0_(NS, npr); HIP_OK(hipMemcpyAsync(B.slot_take, t0_.data(), (size_t)NS * 4, hipMemcpyHostToDevice, st)); HIP_OK(hipStreamSynchronize(st)); }
   B.base_take = std::max(1, std::min(npr, std::getenv("MIQP_BASE_TAKE") ? std::atoi(std::getenv("MIQP_BASE_TAKE")) : 8));
-  B.share_cap = std::max(1, std::getenv("MIQP_SHARE_CAP") ? std::atoi(std::getenv("MIQP_SHARE_CAP")) : 1024);
+  B.share_cap = std::max(1, std::getenv("MIQP_SHARE_CAP") ? std::atoi(std::getenv("MIQP_SHARE_CAP")) : 256);
+  B.floor_pct = std::max(0, std::min(100, std::getenv("MIQP_FLOOR_PCT") ? std::atoi(std::getenv("MIQP_FLOOR_PCT")) : 50));
+  B.young_nodes = std::max(0, std::getenv("MIQP_YOUNG_NODES") ? std::atoi(std::getenv("MIQP_YOUNG_NODES")) : 0);
   B.probe_room = std::getenv("MIQP_PROBE_ROOM") ? std::atof(std::getenv("MIQP_PROBE_ROOM")) : 0.0;
   B.live_inc = std::getenv("MIQP_LIVE_INC") ? std::atoi(std::getenv("MIQP_LIVE_INC")) : 0;
   B.probe_every = std::getenv("MIQP_PROBE_EVERY") ? std::atoi(std::getenv("MIQP_PROBE_EVERY")) : 1;

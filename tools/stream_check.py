@@ -16,10 +16,10 @@ ws = []
 for s in range(Q):
     w = P.CplexWrapper(); w.resetParameters(synthetic.generate(cfg, first + s, gap=gap, max_time=tl)); ws.append(w)
 P.prepare_batch(ws); t = time.time(); sts = P.solve_batch(ws, inflight=infl, prepared=True); dt = time.time() - t
-lat = []; nodes = 0; unsolved = []
+lat = []; nodes = 0; unsolved = []; un_nodes = 0; un_t = []
 for k, (w, st) in enumerate(zip(ws, sts)):
     pr = w.getSolutionProperties(); nodes += pr.nodes
     if int(st) == 0 and pr.status in (101, 102): lat.append(pr.time)
-    else: unsolved.append((first + k, int(st), pr.status, round(pr.gap, 4) if pr.gap == pr.gap else None, int(pr.nodes)))
+    else: unsolved.append((first + k, int(st), pr.status, round(pr.gap, 4) if pr.gap == pr.gap else None, int(pr.nodes))); un_nodes += pr.nodes
 print(json.dumps(dict(Q=Q, inflight=infl, seconds=round(dt, 3), solved=len(lat), solves_per_s=round(len(lat) / dt, 2), nodes=int(nodes), nodes_per_solved=round(nodes / max(1, len(lat))),
-                      latency={q: round(float(np.percentile(lat, q)), 4) for q in (50, 90, 95, 99, 100)}, timing=ws[0].lastTiming(), unsolved=unsolved[:12])))
+                      latency={q: round(float(np.percentile(lat, q)), 4) for q in (50, 90, 95, 99, 100)}, timing=ws[0].lastTiming(), unsolved_count=len(unsolved), unsolved_nodes=int(un_nodes), unsolved=unsolved[:12])))
