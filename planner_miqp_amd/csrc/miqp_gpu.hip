@@ -944,8 +944,15 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemsetAsync(B.slot_demand, 0, (size_t)NS * 4, st));
   { std::vector<int> t0_(NS, npr); HIP_OK(hipMemcpyAsync(B.slot_take, t0_.data(), (size_t)NS * 4, hipMemcpyHostToDevice, st)); HIP_OK(hipStreamSynchronize(st)); }
   B.base_take = std::max(1, std::min(npr, std::getenv("MIQP_BASE_TAKE") ? std::atoi(std::getenv("MIQP_BASE_TAKE")) : 8));
-  B.share_cap = std::max(1, std::getenv("MIQP_SHARE_CAP") ? std::atoi(std::getenv("MIQP_SHARE_CAP")) : 256);
-  B.floor_pct = std::max(0, std::min(100, std::getenv("MIQP_FLOOR_PCT") ? std::atoi(std::getenv("MIQP_FLOOR_PCT")) : 50));
+  // Batch shares (share_kernel).  A QUEUE (more instances than slots: admissions go on while the old instances run against their limits): half
+  // of the batch is shared evenly as a floor, the rest goes by admission order up to 256 nodes per instance - an instance that waits for its
+  // turn no longer crawls at 8 nodes per round (its tree then costs 3-4 x the nodes, tools/crowd_probe.py), and narrow shares cost the fewest
+  // nodes in all; measured on the 12-step bench stream: 1010 -> 1160 solves/s, 99.57 -> 99.39 % proven, p95 6.9 -> 4.5 s (the whole curve:
+  // profiles/r04_share_policy.txt).  ONE batch with every instance in flight from the start (cfg4's 256, cfg5's 16): all deadlines are the same and
+  // serving a few instances to their end frees the device for the others - admission order up to 1024 each, no floor (cfg5: 11 of 16 proven against 5).
+  const bool queue_mode = NS < n;
+  B.share_cap = std::max(1, std::getenv("MIQP_SHARE_CAP") ? std::atoi(std::getenv("MIQP_SHARE_CAP")) : (queue_mode ? 256 : 1024));
+  B.floor_pct = std::max(0, std::min(100, std::getenv("MIQP_FLOOR_PCT") ? std::atoi(std::getenv("MIQP_FLOOR_PCT")) : (queue_mode ? 50 : 0)));
   B.young_nodes = std::max(0, std::getenv("MIQP_YOUNG_NODES") ? std::atoi(std::getenv("MIQP_YOUNG_NODES")) : 0);
   B.probe_room = std::getenv("MIQP_PROBE_ROOM") ? std::atof(std::getenv("MIQP_PROBE_ROOM")) : 0.0;
   B.live_inc = std::getenv("MIQP_LIVE_INC") ? std::atoi(std::getenv("MIQP_LIVE_INC")) : 0;
