@@ -32,8 +32,14 @@ constexpr int OC_GCOEF = 432;     // their packed coefficients (with N = 20 and 
 constexpr int OC_SCR = 32;        // rows decoded per round through the dense scratch rows
 constexpr int OC_SSTR = 17;       // stride of a scratch row (conflict free)
 constexpr int OC_KL0 = 6;         // stages whose gains stay in LDS
-constexpr int OC_PF = 4;          // prefetch distance (stages) of the gains that come back from L2
-constexpr int OC_GRP = 2;         // box slots whose chains are interleaved in the row passes
+#ifndef MIQP_OC_PF
+#define MIQP_OC_PF 4
+#endif
+constexpr int OC_PF = MIQP_OC_PF;          // prefetch distance (stages) of the gains that come back from L2
+#ifndef MIQP_OC_GRP
+#define MIQP_OC_GRP 5   // (1: +9 %, 2: the value of rounds 2-3, 4 / 5 / 10: -2.1 / -3.0 / -0.9 % per pass of the replayed batch, profiles/r04_kernel_ab_replay.txt)
+#endif
+constexpr int OC_GRP = MIQP_OC_GRP;         // box slots whose chains are interleaved in the row passes
 constexpr int OC_NSL = 10;        // box-row slots per lane: horizons of up to 2 * OC_NSL steps
 
 struct OcLds { int z, u, r, gmeta, gcoef, grhs, wd, sstart, cand, fix, total; };   // byte offsets

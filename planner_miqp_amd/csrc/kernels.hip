@@ -184,6 +184,7 @@ struct DevBuf {
   // Local search around a new incumbent (lns_kernel): select_kernel raises inst_lns when it adopts a new incumbent; the neighbours of
   // its region sequences join the batch of the same round
   const int* batch_order;        // diagnostic (MIQP_REPLAY_LPT): the order in which the standard on-chip launch hands the batch's nodes out (null: as they stand)
+  double* inst_lns_obj; double lns_step;   // the local search runs again only when the incumbent has improved by lns_step (relative) since its last run: a hill climb in steps of 1e-5 re-evaluates the whole neighbourhood for nothing
   int* inst_lns; int lns_mode; int lns_min_nodes;   // (an instance gets its local search once it has cost lns_min_nodes node relaxations: the easy ones are done before)
   double ws_theta;               // share of the mean in a pair's centring target (1: the uniform target of a cold start), see row_step
 };
@@ -2716,6 +2717,10 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
   const bool want_skel = (B.lns_mode & 32) && !(flags & 2) && Y.NP > 0;
   if (!(flags & 1) && !want_skel) return;
   if (B.inst_nodes[inst] < (long long)B.lns_min_nodes) return;   // (the flags stay: the heuristics start when the instance proves hard)
+  if ((flags & 1) && !want_skel && B.lns_step > 0.0) {   // (the flag stays: a later, larger improvement runs the search)
+    const double io = B.inc_obj[inst] + B.inst_const[inst], last = B.inst_lns_obj[inst];
+    if (last < 1e299 && io > last - B.lns_step * fabs(last)) return;
+  }
   __shared__ int nb_c[LNS_MAX], nb_i[LNS_MAX], nb_n[LNS_MAX], nb_code[LNS_MAX];   // neighbour: first byte of the record, stride, number of entries, the value they take
   __shared__ int nb_c2[LNS_MAX], nb_n2[LNS_MAX], nb_code2[LNS_MAX];               // ... and a second stretch of the same stride (0 entries: none)
   __shared__ int sh_n, sh_base, sh_rec, sh_skel;
@@ -2750,7 +2755,7 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
       }
       B.inst_lns[inst] = flags | 2;   // (a pending incumbent keeps its bit: its neighbours follow next round)
     } else if (alive) {
-      B.inst_lns[inst] = flags & ~1;
+      B.inst_lns[inst] = flags & ~1; B.inst_lns_obj[inst] = B.inc_obj[inst] + B.inst_const[inst];
       // a sequence over the steps (the region codes of a car: stride 1; the alternatives of a car/car group: stride 4): every change
       // between two steps moved one / two steps later and earlier, every short run between two changes given to its neighbours
       auto moves = [&](int first, int stride, int mode) {

@@ -446,6 +446,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&B.inst_iters, n_inst)) return false;
   if (!X.alloc(&B.inst_ninc, n_inst)) return false;
   if (!X.alloc(&B.inst_lns, n_inst)) return false;
+  if (!X.alloc(&B.inst_lns_obj, n_inst)) return false;
   if (!X.alloc(&B.batch_count, 1)) return false;
   if (!X.alloc(&B.batch_node, batch_alloc)) return false;
   if (!X.alloc(&B.batch_candkey, batch_alloc)) return false;
@@ -978,6 +979,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemsetAsync(B.inst_iters, 0, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_ninc, 0, (size_t)n * 4, st));
   HIP_OK(hipMemsetAsync(B.inst_lns, 0, (size_t)n * 4, st));
+  { std::vector<double> big_(n, 1e300); HIP_OK(hipMemcpyAsync(B.inst_lns_obj, big_.data(), (size_t)n * 8, hipMemcpyHostToDevice, st)); HIP_OK(hipStreamSynchronize(st)); }
+  B.lns_step = std::getenv("MIQP_LNS_STEP") ? std::atof(std::getenv("MIQP_LNS_STEP")) : 0.0;
   B.lns_mode = std::getenv("MIQP_LNS") ? std::atoi(std::getenv("MIQP_LNS")) : 45;
   B.lns_min_nodes = std::getenv("MIQP_LNS_MIN") ? std::atoi(std::getenv("MIQP_LNS_MIN")) : 2000;
   HIP_OK(hipMemsetAsync(B.active_insts, 0, 4, st));   // admit_kernel counts the instances in as they enter

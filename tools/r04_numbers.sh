@@ -1,7 +1,7 @@
 #!/bin/bash
 # measurement campaign of round 4 (GPU): the default bench with its extra legs and the CPU baseline, the driver's command, the other BASELINE configurations, single solves
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; O=gpurun_out/r04_numbers; mkdir -p $O
-python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --long-extras > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-extras > $O/bench_driver_like.json 2> $O/bench_driver_like.err
 python bench.py --config cfg4 --total 256 --batch 256 --steps 1 --warmup 1 --no-cpu > $O/bench_cfg4_strong.json 2>/dev/null
 python tools/stream_check.py 256 256 0 10 cfg2 > $O/cfg2.json 2>/dev/null
