@@ -2753,6 +2753,13 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
           }
         }
       }
+      // three and four cars: also every ORDER of the cars along the road over the last quarter of the horizon (C! roots: the rear / rear
+      // alternative "the one behind the other in x" of every pair, wherever the presolve allows it) - the pairwise sequences above fix one
+      // pair at a time, an overtake that reorders three cars is not among them
+      if (C >= 3 && (B.lns_mode & 64)) {
+        int nperm = 1; for (int c = 2; c <= C; ++c) nperm *= c;
+        for (int pi = 0; pi < nperm && n < LNS_MAX; ++pi) { nb_c[n] = -1; nb_i[n] = 4; nb_n[n] = 0; nb_code[n] = pi; nb_n2[n] = 0; n++; }
+      }
       B.inst_lns[inst] = flags | 2;   // (a pending incumbent keeps its bit: its neighbours follow next round)
     } else if (alive) {
       B.inst_lns[inst] = flags & ~1; B.inst_lns_obj[inst] = B.inc_obj[inst] + B.inst_const[inst];
@@ -2818,12 +2825,30 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
     const int rec = sh_rec + q, bs = sh_base + q;
     signed char* dst = B.pool_fix + (size_t)rec * Y.fixlen;
     const int k0 = nb_c[q], st_ = nb_i[q], k1 = k0 + nb_n[q] * st_;
-    if (skel) {   // a root record (everything undecided) with the sequence of one pair's rear / rear group
+    if (skel) {   // a root record (everything undecided) with the sequence of one pair's rear / rear group, or with an order of all cars
       const int k2 = nb_c2[q], k3 = k2 + nb_n2[q] * st_;
+      int rank[4] = {0, 0, 0, 0};
+      if (k0 < 0) {   // the nb_code-th permutation of the cars (factorial number system): rank[c] = place of car c, 0 = rearmost
+        int code = nb_code[q], used = 0;
+        for (int place = 0; place < C; ++place) {
+          const int f = C - place; int pick = code % f; code /= f;
+          for (int c = 0; c < C; ++c) if (!((used >> c) & 1)) { if (pick == 0) { rank[c] = place; used |= 1 << c; break; } pick--; }
+        }
+      }
+      const int* Tq = B.inst_i + (size_t)inst * Y.istride;
       for (int k = lane; k < Y.fixlen; k += 64) {
         signed char v = (signed char)-1;
-        if (k >= k0 && k < k1 && (k - k0) % st_ == 0) v = (signed char)nb_code[q];
-        if (nb_n2[q] > 0 && k >= k2 && k < k3 && (k - k2) % st_ == 0) v = (signed char)nb_code2[q];
+        if (k0 >= 0) {
+          if (k >= k0 && k < k1 && (k - k0) % st_ == 0) v = (signed char)nb_code[q];
+          if (nb_n2[q] > 0 && k >= k2 && k < k3 && (k - k2) % st_ == 0) v = (signed char)nb_code2[q];
+        } else if (k >= Y.f_c2c && k < Y.f_c2c + Y.NP * N * 4 && ((k - Y.f_c2c) & 3) == 0) {
+          const int e = (k - Y.f_c2c) >> 2, pp = e / N, i = e - pp * N;
+          if (i >= N - N / 4) {
+            int c1, c2; pair_cars(pp, C, c1, c2);
+            const int alt = rank[c1] < rank[c2] ? 0 : 1;   // alternative 0: c1 behind c2 in x, 1: c2 behind c1 (decode_row)
+            if ((Tq[Y.i_c2callow + pp * N + i] >> alt) & 1) v = (signed char)alt;
+          }
+        }
         dst[k] = v;
       }
       if (lane == 0) {

@@ -958,7 +958,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   B.probe_room = std::getenv("MIQP_PROBE_ROOM") ? std::atof(std::getenv("MIQP_PROBE_ROOM")) : 0.0;
   B.live_inc = std::getenv("MIQP_LIVE_INC") ? std::atoi(std::getenv("MIQP_LIVE_INC")) : 0;
   B.probe_every = std::getenv("MIQP_PROBE_EVERY") ? std::atoi(std::getenv("MIQP_PROBE_EVERY")) : 1;
-  B.probe_itcap = std::getenv("MIQP_PROBE_ITCAP") ? std::atoi(std::getenv("MIQP_PROBE_ITCAP")) : 40;   // (0: never; solved probes take 9-24 iterations)
+  B.probe_itcap = std::getenv("MIQP_PROBE_ITCAP") ? std::atoi(std::getenv("MIQP_PROBE_ITCAP")) : 24;   // (0: never; solved probes take 9-24 iterations; 40 until round 4: the heuristic nodes - probes, local-search leaves - are the critical path of a single solve's round: p99 99 -> 80 ms at 24)
   B.probe_margin = std::getenv("MIQP_PROBE_MARGIN") ? std::atof(std::getenv("MIQP_PROBE_MARGIN")) : 0.25;   // (0: every disjunction of a probe fixed, as in round 2)
   B.det_ties = std::getenv("MIQP_DET_TIES") ? std::atoi(std::getenv("MIQP_DET_TIES")) : 1;
   B.window_pct = std::max(1, std::min(100, std::getenv("MIQP_WINDOW") ? std::atoi(std::getenv("MIQP_WINDOW")) : 100));
