@@ -941,7 +941,9 @@ def test_cfg5_four_cars_64_regions_with_warmstart(oracle):
     w2.addRecedingHorizonWarmstart(res)
     assert int(w2.callCplex()) == 0
     pr2 = w2.getSolutionProperties()
-    assert pr2.objective <= pr.objective * (1 + 1e-9) and pr2.NrSolutionPool >= 1
+    # (not worse up to the accuracy incumbents are compared at: the node relaxations are solved to 1e-6 relative - kernels.hip QP_TOL -, and the local
+    # search may hand back a neighbouring leaf that was better by less than that before the final polish)
+    assert pr2.objective <= pr.objective * (1 + 2e-6) and pr2.NrSolutionPool >= 1
     v2, obj2, worst2 = oracle.raw_eval(h, w2.getRawResults())
     assert v2 < 1e-5, worst2
     oracle.free(h)
