@@ -183,7 +183,7 @@ struct DevBuf {
   float* pool_Lbox; unsigned char* pool_Lgen; float* batch_Lbox; unsigned char* batch_Lgen; int ws_dual;
   // Local search around a new incumbent (lns_kernel): select_kernel raises inst_lns when it adopts a new incumbent; the neighbours of
   // its region sequences join the batch of the same round
-  const int* batch_order;        // diagnostic (MIQP_REPLAY_LPT): the order in which the standard on-chip launch hands the batch's nodes out (null: as they stand)
+  const int* batch_order;        // the order in which the standard on-chip launch hands the batch's nodes out (order_kernel; null: as they stand)
   double* inst_lns_obj; double lns_step;   // the local search runs again only when the incumbent has improved by lns_step (relative) since its last run: a hill climb in steps of 1e-5 re-evaluates the whole neighbourhood for nothing
   int* inst_lns; int lns_mode; int lns_min_nodes;   // (an instance gets its local search once it has cost lns_min_nodes node relaxations: the easy ones are done before)
   double ws_theta;               // share of the mean in a pair's centring target (1: the uniform target of a cold start), see row_step
@@ -2879,6 +2879,33 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
       if (B.batch_large) B.batch_large[bs] = 1;
     }
   }
+}
+
+// Order in which the standard on-chip launch hands the batch's nodes out: the ones that are expected to run longest first, so that the
+// launch does not end on a few late long nodes (its wavefronts take the nodes from a shared counter; with the true iteration counts as the order
+// a steady-state launch is 9-14 % shorter, tools: MIQP_REPLAY_LPT).  What is known before the launch: a root starts cold (16 iterations), and a
+// node whose list bound lies close to its instance's cutoff runs until its dual value crosses the cutoff (18.7 iterations on average against
+// 11.5) - a bucket sort by that distance gives 2-5 %.  The order touches nothing but the launch's schedule: every node is solved on its own.
+__global__ void __launch_bounds__(1024) order_kernel(DevBuf B, int* order) {
+  __shared__ int hist[64], base[64];
+  const int tid = threadIdx.x;
+  const int n = *B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap;
+  if (tid < 64) hist[tid] = 0;
+  __syncthreads();
+  auto bucket = [&](int k) -> int {
+    if ((B.batch_depth[k] >> 6) < 1) return 0;                       // a root: cold start
+    const int inst = B.batch_inst[k];
+    const double inc = B.inc_obj[inst];
+    if (!(inc < 1e299)) return 63;                                     // no incumbent, no cutoff
+    const double d = (inc - B.inst_gap[inst] * fabs(inc) - (B.batch_bound[k] + B.inst_const[inst])) / fmax(1e-9, fabs(inc));
+    const int b = 1 + (int)(d * 775.0);                                // 62 buckets over a distance of 8 % of the incumbent
+    return b < 1 ? 1 : (b > 62 ? 62 : b);
+  };
+  for (int k = tid; k < n; k += 1024) atomicAdd(&hist[bucket(k)], 1);
+  __syncthreads();
+  if (tid == 0) { int a = 0; for (int b = 0; b < 64; ++b) { base[b] = a; a += hist[b]; } }
+  __syncthreads();
+  for (int k = tid; k < n; k += 1024) order[atomicAdd(&base[bucket(k)], 1)] = k;
 }
 
 // makes the records freed so far available to the next eval launch

@@ -257,6 +257,7 @@ struct DevCtx {
   int* work_counter2 = nullptr; double* rowstate2 = nullptr; double* rowcache2 = nullptr; double* kgain2 = nullptr; int probe_grid = 0;
   int oc_grid = 0;   // resident wavefronts of the on-chip interior point kernel (0: the shape does not qualify)
   int kg_blocks = 0; // blocks the gain buffer holds
+  int* d_order = nullptr; // order of the batch for the standard on-chip launch (order_kernel)
   int* ctr = nullptr; // two parity sets of 8 counters for the launches of a round (batch count, work counters, hand-over counts): a round uses one set, roll_kernel zeroes the other
   bool concurrent_big = true;   // MIQP_CONCURRENT_BIG=0: the sequential chain standard -> larger -> memory-backed
   int ocb_grid = 0;  // resident wavefronts of its larger variant (OC_GCAP_BIG general rows, one wavefront per SIMD; 0: not in use)
@@ -469,6 +470,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&B.kgain, (size_t)std::min(batch_alloc, X.kg_blocks) * std::max(Y.N * Y.nu * (Y.nx + 2), oc_gain_doubles(Y.N)))) return false;
   if (!X.alloc(&B.work_counter, 1)) return false;
   if (!X.alloc(&X.ctr, 16)) return false;
+  if (X.oc_grid > 0) { if (!X.alloc(&X.d_order, batch_alloc)) return false; }
   HIP_OK(hipMemset(X.ctr, 0, 64));
   // buffers of the concurrent probe launch (two cars and fewer, on-chip kernel in use): 1024 resident blocks
   X.probe_grid = 0;
@@ -1036,6 +1038,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   std::vector<int> round_bc;
   // the counters of a round's launches (batch count, work counters, hand-over counts) come in two parity sets: a round uses one, its
   // roll_kernel zeroes the other for the round after - six 4-byte memsets per round less in the stream (0.65 ms of the 1.4 ms round of a single solve)
+  const bool use_order = X.oc_grid > 0 && NS >= 16 && !(std::getenv("MIQP_ORDER") && std::atoi(std::getenv("MIQP_ORDER")) == 0);   // (a handful of instances: the batches are small, nothing to schedule)
   const bool use_par = X.ctr && X.oc_grid > 0 && X.ocb_grid > 0 && X.concurrent_big && X.stream2 && X.probe_grid > 0 && !pipelined && !std::getenv("MIQP_MEMSETS");
   if (use_par) HIP_OK(hipMemsetAsync(X.ctr, 0, 64, st));
   for (;;) {
@@ -1129,6 +1132,11 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     static const bool launch_trace = std::getenv("MIQP_LAUNCH_TRACE") != nullptr;
     if (launch_trace && !X.ev_mid) HIP_OK(hipEventCreate(&X.ev_mid));
     HIP_OK(hipEventRecord(X.ipm_ev[nev], st));
+    static const bool lpt_diag = std::getenv("MIQP_REPLAY_LPT") != nullptr;
+    std::vector<double> pre_bound;   // (diagnostic: the list bounds of the batch before the interior point kernels overwrite them)
+    if (lpt_diag && bc >= X.batch_cap / 2) { pre_bound.resize(bc); HIP_OK(hipMemcpy(pre_bound.data(), B.batch_bound, (size_t)bc * 8, hipMemcpyDeviceToHost)); }
+    if (X.d_order && use_order) { hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, B, X.d_order); DevBuf Bo_ = B; Bo_.batch_order = X.d_order; launch_ipm_batch(X, Bo_, bc, st, true, use_par ? par : -1); }
+    else
     launch_ipm_batch(X, B, bc, st, true, use_par ? par : -1);
     HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
     if (launch_trace) {   // diagnostic: the two interior point launches of the round apart, and what the memory-backed one had to solve
@@ -1165,9 +1173,18 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
         if (std::getenv("MIQP_REPLAY_LPT")) {   // how much the order of the batch is worth: the same batch with its nodes handed out longest first (by the iterations just measured), and shortest first
           int* d_ord = nullptr; HIP_OK(hipMalloc((void**)&d_ord, (size_t)bc * 4));
           // (measured in round 4: longest first -3 ... -13 % of a steady-state round; the iterations of a node's PARENT predict its own with a correlation of 0.2-0.3 - ordering by them gains nothing)
-          for (int pass = 0; pass < 3; ++pass) {
+          // a predictor that is known before the launch: how close the node's list bound is to its instance's cutoff (nodes near the cutoff run until
+          // their dual value crosses it - 18.7 iterations on average against 11.5)
+          std::vector<double> close(bc, 1e300);
+          if ((int)pre_bound.size() == bc) {
+            std::vector<int> hinst(bc); std::vector<double> hio(n), hic(n);
+            HIP_OK(hipMemcpy(hinst.data(), B.batch_inst, (size_t)bc * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(hio.data(), B.inc_obj, (size_t)n * 8, hipMemcpyDeviceToHost));
+            for (int k = 0; k < bc; ++k) { const int ii = hinst[k]; const double inc_ = hio[ii]; if (inc_ < 1e299) close[k] = (inc_ - h_gap[ii] * std::fabs(inc_) - (pre_bound[k] + h_const[ii])) / std::max(1e-9, std::fabs(inc_)); }
+          }
+          for (int pass = 0; pass < 4; ++pass) {
             std::vector<int> ord(bc); for (int k = 0; k < bc; ++k) ord[k] = k;
-            if (pass == 0) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return its[a] > its[b]; });
+            if (pass == 3) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return close[a] < close[b]; });
+            else if (pass == 0) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return its[a] > its[b]; });
             else if (pass == 1) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return its[a] < its[b]; });
             else { unsigned int x = 12345u; for (int k = bc - 1; k > 0; --k) { x = x * 1664525u + 1013904223u; std::swap(ord[k], ord[(x >> 8) % (unsigned int)(k + 1)]); } }
             HIP_OK(hipMemcpy(d_ord, ord.data(), (size_t)bc * 4, hipMemcpyHostToDevice));
@@ -1176,7 +1193,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
             for (int r = 0; r < replay; ++r) launch_ipm_batch(X, Bo, bc, st);
             HIP_OK(hipEventRecord(e1, st)); HIP_OK(hipStreamSynchronize(st));
             float m2 = 0; HIP_OK(hipEventElapsedTime(&m2, e0, e1));
-            std::fprintf(stderr, "[miqp_gpu replay] %s: %.3f ms per pass\n", pass == 0 ? "longest first" : (pass == 1 ? "shortest first" : (pass == 2 ? "shuffled" : "?")), m2 / replay);
+            std::fprintf(stderr, "[miqp_gpu replay] %s: %.3f ms per pass\n", pass == 0 ? "longest first" : (pass == 1 ? "shortest first" : (pass == 2 ? "shuffled" : "closest to the cutoff first")), m2 / replay);
           }
           (void)hipFree(d_ord);
           launch_ipm_batch(X, B, bc, st);
