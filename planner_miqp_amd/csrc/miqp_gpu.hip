@@ -1181,9 +1181,14 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
             HIP_OK(hipMemcpy(hinst.data(), B.batch_inst, (size_t)bc * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(hio.data(), B.inc_obj, (size_t)n * 8, hipMemcpyDeviceToHost));
             for (int k = 0; k < bc; ++k) { const int ii = hinst[k]; const double inc_ = hio[ii]; if (inc_ < 1e299) close[k] = (inc_ - h_gap[ii] * std::fabs(inc_) - (pre_bound[k] + h_const[ii])) / std::max(1e-9, std::fabs(inc_)); }
           }
-          for (int pass = 0; pass < 4; ++pass) {
+          std::vector<int> hdep(bc); HIP_OK(hipMemcpy(hdep.data(), B.batch_depth, (size_t)bc * 4, hipMemcpyDeviceToHost));
+          auto dev = [&](int k) { return (hdep[k] & 63) < 62 ? 1 : 0; };   // a sibling that deviates from the reference alternative
+          for (int pass = 0; pass < 7; ++pass) {
             std::vector<int> ord(bc); for (int k = 0; k < bc; ++k) ord[k] = k;
             if (pass == 3) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return close[a] < close[b]; });
+            else if (pass == 4) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return dev(a) != dev(b) ? dev(a) > dev(b) : close[a] < close[b]; });
+            else if (pass == 5) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return close[a] - 0.02 * dev(a) < close[b] - 0.02 * dev(b); });
+            else if (pass == 6) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return (hdep[a] & 63) != (hdep[b] & 63) ? (hdep[a] & 63) < (hdep[b] & 63) : close[a] < close[b]; });
             else if (pass == 0) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return its[a] > its[b]; });
             else if (pass == 1) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return its[a] < its[b]; });
             else { unsigned int x = 12345u; for (int k = bc - 1; k > 0; --k) { x = x * 1664525u + 1013904223u; std::swap(ord[k], ord[(x >> 8) % (unsigned int)(k + 1)]); } }
@@ -1193,7 +1198,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
             for (int r = 0; r < replay; ++r) launch_ipm_batch(X, Bo, bc, st);
             HIP_OK(hipEventRecord(e1, st)); HIP_OK(hipStreamSynchronize(st));
             float m2 = 0; HIP_OK(hipEventElapsedTime(&m2, e0, e1));
-            std::fprintf(stderr, "[miqp_gpu replay] %s: %.3f ms per pass\n", pass == 0 ? "longest first" : (pass == 1 ? "shortest first" : (pass == 2 ? "shuffled" : "closest to the cutoff first")), m2 / replay);
+            std::fprintf(stderr, "[miqp_gpu replay] %s: %.3f ms per pass\n", pass == 0 ? "longest first" : (pass == 1 ? "shortest first" : (pass == 2 ? "shuffled" : (pass == 3 ? "closest to the cutoff first" : (pass == 4 ? "deviating siblings first, then closeness" : (pass == 5 ? "closeness - 0.02 x deviating" : "by sibling order, then closeness"))))), m2 / replay);
           }
           (void)hipFree(d_ord);
           launch_ipm_batch(X, B, bc, st);
