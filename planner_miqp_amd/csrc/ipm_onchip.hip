@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
         if (key != ~0ull) {
           const double rh = key2d(key), c = rh - bsgn * Z[i * 16 + lc];
           double s, t, l0;
-          init_elastic(c, warm, B.ws_mu, B.ws_delta, s, l0, t, dual ? (double)lbp[(i * 2 + side) * 16 + lc] : 0.0);
+          init_elastic(c, warm, B.ws_mu, B.ws_delta, s, l0, t, dual ? (double)lbp[(i * 2 + side) * 16 + lc] : 0.0, B.ws_svmin);
           bs[k] = s; bl[k] = l0; bt[k] = t; bact |= 1u << k;
           csum += s * l0 + t * (RHO_EL - l0); cnt += 2; tsum += t;
         }
@@ -491,7 +491,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
         }
         if (!(m4.z & 0x80000000u)) {
           double s, t, l0;
-          init_elastic(c, warm, B.ws_mu, B.ws_delta, s, l0, t, lam_p);
+          init_elastic(c, warm, B.ws_mu, B.ws_delta, s, l0, t, lam_p, B.ws_svmin);
           gs_[q] = s; gl_[q] = l0; gt_[q] = t;
           csum += s * l0 + t * (RHO_EL - l0); cnt += 2; tsum += t;
         } else {

@@ -173,7 +173,7 @@ struct DevBuf {
   // starts there with every row centred at complementarity ws_mu - slack s = max(residual, ws_delta), elastic slack t = s -
   // residual, multiplier ws_mu / s - instead of at the free rollout with the same multiplier on every row.
   double* pool_Z;                // [z_cap][N * nz] in the model's column order (null: cold starts only); records beyond z_cap start cold
-  double ws_mu, ws_delta; int ws_on; int z_cap;
+  double ws_mu, ws_delta, ws_svmin; int ws_on; int z_cap;
   // ... and the parent's MULTIPLIERS (on-chip kernels).  Rows keep their identity from parent to child: a box row is its key (stage, side,
   // column of the kernel's order), a general row its decode slot (stage x NSLOT + slot).  Per record: the multipliers of the box keys as
   // floats, [N][2][16], 0 = no row; and {count, decode slots (u16), multipliers (f32)} of up to LGEN_CAP general rows in decode order
@@ -533,13 +533,13 @@ __device__ inline double frsq(double x) {
 // put on the central path at mu0 - an inactive row (large residual) gets a small multiplier, an active or violated one a slack
 // of delta and the matching multiplier (capped well inside (0, rho)).
 // lam_p > 0: the multiplier the row had at the parent's solution - kept when it is the larger one.
-__device__ inline void init_elastic(double c, bool warm, double mu0, double delta, double& s, double& lam, double& t, double lam_p = 0.0) {
+__device__ inline void init_elastic(double c, bool warm, double mu0, double delta, double& s, double& lam, double& t, double lam_p = 0.0, double svmin = 0.0) {
   if (!warm) {
     if (c > QP_T0) { t = QP_T0; s = c + QP_T0; } else { s = MIQP_S0 * QP_T0; t = s - c; }
     lam = MIQP_LAM0;
     return;
   }
-  s = c > delta ? c : delta;
+  s = c > delta ? c : (delta > svmin ? delta : svmin);   // (svmin: a row that is violated or active at the parent's solution gets a slack the first step can shrink - with delta alone the first steps of a child are blocked at alpha = 0.05 ... 0.3, tools/ipm_lab.py)
   lam = mu0 / s; if (lam < lam_p) lam = lam_p; if (lam > 0.5 * RHO_EL) lam = 0.5 * RHO_EL;
   double tt = mu0 / (RHO_EL - lam);          // central value of the elastic slack
   if (s - c > tt) tt = s - c;                // ... or what the violated row needs
@@ -1469,7 +1469,8 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   double* mr_d = mr_v + LIFT_ROWS;                   // [LIFT_ROWS]
   double* mr_l = mr_d + LIFT_ROWS;                   // [LIFT_ROWS]
   double* mr_w = mr_l + LIFT_ROWS;                   // [NZ]
-  signed char* ploose = (signed char*)(mr_w + NZ);   // [fixlen] 1: the completed alternative of this undecided front-point disjunction holds with room to spare (probe_margin)
+  // (the multi-row buffers exist only when that experiment is switched on - 6.8 KB for two cars, the difference between 6 and 8 workgroups per CU of a kernel that waits on memory for 60 % of its cycles)
+  signed char* ploose = (B.seq_kinds & 0x80000000u) ? (signed char*)(mr_w + NZ) : (signed char*)mr_g;   // [fixlen] 1: the completed alternative of this undecided front-point disjunction holds with room to spare (probe_margin)
   __shared__ BranchDesc chosen;
   __shared__ int sh_base[4];
   __shared__ int slots[64];

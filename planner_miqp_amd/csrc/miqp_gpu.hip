@@ -403,6 +403,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   B.ws_on = ws_on ? 1 : 0;
   B.ws_mu = std::getenv("MIQP_WS_MU") ? std::atof(std::getenv("MIQP_WS_MU")) : 1.0;
   B.ws_delta = std::getenv("MIQP_WS_DELTA") ? std::atof(std::getenv("MIQP_WS_DELTA")) : 1.0e-3;
+  B.ws_svmin = std::getenv("MIQP_WS_SVMIN") ? std::atof(std::getenv("MIQP_WS_SVMIN")) : 0.0;
   B.ws_theta = std::getenv("MIQP_WS_THETA") ? std::min(1.0, std::max(0.0, std::atof(std::getenv("MIQP_WS_THETA")))) : 1.0;
   if (!X.alloc(&B.pool_count, 1)) return false;
   if (!X.alloc(&B.free_q, (size_t)X.pool_cap)) return false;
@@ -511,10 +512,11 @@ size_t ipm_lds_bytes(const Layout& Y) {
   size_t d = (size_t)N * NZ + (size_t)ipm_scratch_doubles(N, Y.C) + NZ + 8 + 32 + 2 * ((N + 6) / 2 + 1);
   return d * 8 + (size_t)Y.fixlen + 16;
 }
+bool multi_row_lifting_on() { const char* e = std::getenv("MIQP_SEQ_KINDS"); return e && (std::strtoul(e, nullptr, 0) & 0x80000000ul) != 0ul; }
 size_t eval_lds_bytes(const Layout& Y) {
   size_t d = (size_t)Y.N * Y.nz + (size_t)Y.C * Y.N * Y.P + 2 * (size_t)Y.C * Y.N;
   return d * 8 + (size_t)(2 * Y.C * Y.N + 64) * 4 + 64 * 8 + 3 * (size_t)Y.fixlen + (size_t)64 * (Y.nz + 1) * 8 + 64
-         + (size_t)(LIFT_ROWS * (2 * Y.nz + 3) + Y.nz) * 8 + 64   // rows of the multi-row lifting
+         + (multi_row_lifting_on() ? (size_t)(LIFT_ROWS * (2 * Y.nz + 3) + Y.nz) * 8 : 0) + 64   // rows of the multi-row lifting (an experiment: MIQP_SEQ_KINDS bit 31)
          + (size_t)Y.fixlen + 16;                                  // ploose
 }
 
@@ -545,7 +547,9 @@ void launch_ipm_c(int C, const DevBuf& B, int nblocks, size_t lds, hipStream_t s
 // by VALU issue, and the probes no longer cost a generation of their own behind it.  `overlap` false (the polish, solve_fixed): the
 // serial order of round 2.
 // `par` >= 0 (the rounds of a solve): the counters of this launch group are set `par` of X.ctr, zeroed one round ahead by roll_kernel
-void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool overlap = false, int par = -1) {
+// `order_buf`: the standard launch takes its nodes in the order order_kernel writes there - launched on `st` BEHIND the fork, so that the large-node
+// launches of the second stream get their wavefronts resident while it runs (they need 34 KB of LDS each; started behind the standard launch they wait for its end)
+void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool overlap = false, int par = -1, int* order_buf = nullptr) {
   const Layout& Y = X.Y;
   const size_t l_ipm = ipm_lds_bytes(Y);
   if (X.oc_grid > 0) {
@@ -574,6 +578,7 @@ void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool o
       launch_ipm_c(Y.C, Bm, std::min(bc, X.probe_grid), l_ipm, X.stream2, !pc);
       (void)hipEventRecord(X.ev_join, X.stream2);
       Bc.skip_probes = 1; Bc.bounce = 1;
+      if (order_buf) { hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, Bc, order_buf); Bc.batch_order = order_buf; }
       if (Y.C == 1) launch_ipm_oc<1>(Bc, std::min(bc, X.oc_grid), l_oc, st, !pc); else launch_ipm_oc<2>(Bc, std::min(bc, X.oc_grid), l_oc, st, !pc);
       if (X.ev_mid) (void)hipEventRecord(X.ev_mid, st);
       (void)hipStreamWaitEvent(st, X.ev_join, 0);
@@ -1038,7 +1043,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   std::vector<int> round_bc;
   // the counters of a round's launches (batch count, work counters, hand-over counts) come in two parity sets: a round uses one, its
   // roll_kernel zeroes the other for the round after - six 4-byte memsets per round less in the stream (0.65 ms of the 1.4 ms round of a single solve)
-  const bool use_order = X.oc_grid > 0 && NS >= 16 && !(std::getenv("MIQP_ORDER") && std::atoi(std::getenv("MIQP_ORDER")) == 0);   // (a handful of instances: the batches are small, nothing to schedule)
+  // (OFF by default: the standard launch alone is 2-6 % shorter with it, the round is not - launched before the fork it lets the standard launch take the
+  // CUs ahead of the large-node launches, which then run behind it (8.2 ms instead of 2.8), launched behind the fork its one workgroup starves beside them (1.3 ms))
+  const bool use_order = X.oc_grid > 0 && NS >= 16 && std::getenv("MIQP_ORDER") && std::atoi(std::getenv("MIQP_ORDER")) == 1;
   const bool use_par = X.ctr && X.oc_grid > 0 && X.ocb_grid > 0 && X.concurrent_big && X.stream2 && X.probe_grid > 0 && !pipelined && !std::getenv("MIQP_MEMSETS");
   if (use_par) HIP_OK(hipMemsetAsync(X.ctr, 0, 64, st));
   for (;;) {
@@ -1135,9 +1142,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     static const bool lpt_diag = std::getenv("MIQP_REPLAY_LPT") != nullptr;
     std::vector<double> pre_bound;   // (diagnostic: the list bounds of the batch before the interior point kernels overwrite them)
     if (lpt_diag && bc >= X.batch_cap / 2) { pre_bound.resize(bc); HIP_OK(hipMemcpy(pre_bound.data(), B.batch_bound, (size_t)bc * 8, hipMemcpyDeviceToHost)); }
-    if (X.d_order && use_order) { hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, B, X.d_order); DevBuf Bo_ = B; Bo_.batch_order = X.d_order; launch_ipm_batch(X, Bo_, bc, st, true, use_par ? par : -1); }
-    else
-    launch_ipm_batch(X, B, bc, st, true, use_par ? par : -1);
+    launch_ipm_batch(X, B, bc, st, true, use_par ? par : -1, (X.d_order && use_order) ? X.d_order : nullptr);
     HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
     if (launch_trace) {   // diagnostic: the two interior point launches of the round apart, and what the memory-backed one had to solve
       HIP_OK(hipStreamSynchronize(st));
