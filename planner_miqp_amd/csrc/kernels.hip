@@ -2724,6 +2724,7 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
   }
   __shared__ int nb_c[LNS_MAX], nb_i[LNS_MAX], nb_n[LNS_MAX], nb_code[LNS_MAX];   // neighbour: first byte of the record, stride, number of entries, the value they take
   __shared__ int nb_c2[LNS_MAX], nb_n2[LNS_MAX], nb_code2[LNS_MAX];               // ... and a second stretch of the same stride (0 entries: none)
+  __shared__ int nb_rec[LNS_MAX];                                                  // the node record of every neighbour
   __shared__ int sh_n, sh_base, sh_rec, sh_skel;
   const int N = Y.N, C = Y.C;
   const signed char* inc = B.inc_fix + (size_t)inst * Y.fixlen;
@@ -2813,7 +2814,11 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
     if (n > 0) {
       base = atomicAdd(B.batch_count, n);
       if (base + n > B.batch_cap) { n = base < B.batch_cap ? B.batch_cap - base : 0; }
-      if (n > 0) { rec = atomicAdd(B.pool_count, n); if (rec + n > B.pool_cap) n = 0; }   // fresh records (the evaluation recycles them)
+      if (n > 0) {   // node records: recycled ones first (as eval_kernel takes them), fresh ones otherwise; the evaluation of the round frees them again
+        const unsigned int h = atomicAdd(B.free_head, (unsigned int)n);
+        if ((int)(*B.free_limit - h) >= n) { for (int q = 0; q < n; ++q) nb_rec[q] = B.free_q[(h + q) % (unsigned int)B.pool_cap]; }
+        else { rec = atomicAdd(B.pool_count, n); if (rec + n > B.pool_cap) n = 0; for (int q = 0; q < n; ++q) nb_rec[q] = rec + q; }
+      }
     }
     sh_n = n; sh_base = base; sh_rec = rec;
   }
@@ -2823,7 +2828,7 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
   const double lbq = B.lower_bound[inst] - B.inst_const[inst];
   const bool skel = sh_skel != 0;
   for (int q = 0; q < n; ++q) {
-    const int rec = sh_rec + q, bs = sh_base + q;
+    const int rec = nb_rec[q], bs = sh_base + q;
     signed char* dst = B.pool_fix + (size_t)rec * Y.fixlen;
     const int k0 = nb_c[q], st_ = nb_i[q], k1 = k0 + nb_n[q] * st_;
     if (skel) {   // a root record (everything undecided) with the sequence of one pair's rear / rear group, or with an order of all cars
