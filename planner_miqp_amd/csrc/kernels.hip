@@ -140,8 +140,9 @@ struct DevBuf {
   // sharing the batch evenly all run into their max_solution_time (which counts from the admission) and their work is lost.
   // Earliest deadline first finishes what it starts; the cap (1024: narrow rounds waste the fewest nodes - every round prunes
   // with the incumbents of the one before) keeps a pathological instance to 3 % of the device.
-  int* slot_demand; int* slot_take; int share_cap; int base_take; int floor_pct; int young_nodes; int window_pct; double probe_room;
+  int* slot_demand; int* slot_take; int share_cap; int base_take; int floor_pct; int young_nodes; int pump_max; int window_pct; double probe_room;
   double probe_margin;           // > 0: the rounding probe leaves front-point environment / obstacle disjunctions undecided whose completed alternative holds with this much room
+  int probe_itcap0;              // the same while the instance has no incumbent
   int probe_itcap;               // iterations after which an unconverged rounding probe is abandoned (0: never)
   int probe_every;               // rounding probes are eligible every probe_every-th round (1: always)
   int det_ties;                  // 1: ties of the node selection are broken by the nodes' own low key bits and sibling preference (reproducible), 0: by arrival
@@ -734,7 +735,8 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     // A rounding probe is a heuristic (it lies inside the first child, the children stay exhaustive without it): one that has
     // not converged after probe_itcap iterations - nearly always an infeasible rounding, 27 iterations to prove - is abandoned.
     // The launch of this kernel lasts as long as its slowest node.
-    if (B.probe_itcap > 0 && it > B.probe_itcap && B.ws_on != 2 && is_probe_word(B.batch_depth[node])) { ok = 2; break; }
+    { const int pcap = cutoff < 1e299 ? B.probe_itcap : B.probe_itcap0;   // (without an incumbent the probes are given longer: the re-rounding needs the converged solution of an infeasible one)
+      if (pcap > 0 && it > pcap && B.ws_on != 2 && is_probe_word(B.batch_depth[node])) { ok = 2; break; } }
     // dual bound of the penalised problem: primal value - total complementarity (valid once the iterate is dual feasible)
 #ifdef MIQP_PROFILE
     if (it > 1 && first_proxy == 0 && obj + RHO_EL * tsum - (double)ncomp * comp > cutoff + 1e-9 * fabs(cutoff)) first_proxy = it;
@@ -1499,7 +1501,19 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     atomicAdd(&B.stats[32 + oc_], 1ull); atomicAdd(&B.stats[36 + oc_], (unsigned long long)B.batch_it[node]);
     if (B.pool_origin) { const int og_ = (int)B.pool_origin[B.batch_node[node]] & 15; atomicAdd(&B.stats[80 + og_], 1ull); atomicAdd(&B.stats[96 + 16 * oc_ + og_], 1ull); if (og_ == 15) { const int ib_ = B.batch_it[node] / 3; atomicAdd(&B.stats[192 + 16 * oc_ + (ib_ > 15 ? 15 : ib_)], 1ull); } }   // the same by the branching that created the node
   }
-  if (viol > FEAS_TOL || okq != 1) { FREE_NODE(); return; }  // infeasible relaxation, or abandoned at the incumbent cutoff
+  // Re-rounding (the step of a feasibility pump): a rounding probe whose relaxation is infeasible - the alternatives its parent's solution
+  // completed to cannot hold together - has, through its elastic rows, a solution of least violation.  While the instance has no incumbent,
+  // that solution is completed afresh (EVERY disjunction undecided again) and the completion becomes the next probe: its one child, as for a
+  // repair root.  At most pump_max generations (the high nibble of the record's size mark counts them).
+  bool pumped = false;
+  if (viol > FEAS_TOL && okq == 1 && B.pump_max > 0 && B.pool_big && is_probe_word(B.batch_depth[node]) && (int)(big_parent >> 4) < B.pump_max
+      && !(fmin(B.live_inc ? inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]) : B.inc_obj[inst], B.inc_ext[inst]) < 1e300)) pumped = true;
+  if (!pumped && (viol > FEAS_TOL || okq != 1)) { FREE_NODE(); return; }  // infeasible relaxation, or abandoned at the incumbent cutoff
+  if (pumped) {
+    for (int k = lane; k < Y.f_rmask + C * N * 2 && k < Y.fixlen; k += 64) { fix[k] = (signed char)-1; comp[k] = (signed char)-1; }
+    __syncthreads();
+    if (B.stats && lane == 0) atomicAdd(&B.stats[62], 1ull);
+  }
   // soft obstacles that this node ignores cost WEIGHTS_SLACK_OBSTACLE each (obstacle_environment_constraints.mod:85-91)
   int nign = 0;
   for (int k = lane; k < C * Y.O * N * 5; k += 64) nign += fix[Y.f_obs + k] >= Y.L ? 1 : 0;
@@ -1507,7 +1521,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   const double obj = B.batch_obj[node] + B.inst_const[inst] + nign * D[Y.d_misc + 1];   // primal value: what an incumbent costs
   // what the node proves: the dual value of its relaxation (the primal value of an interior point iterate lies above the
   // optimum of the relaxation by the remaining complementarity)
-  const double objlb = obj - fmax(0.0, B.batch_bound[node]);
+  const double objlb = pumped ? B.lower_bound[inst] : obj - fmax(0.0, B.batch_bound[node]);   // (a re-rounded probe proves nothing: its child carries the instance's bound)
   // own incumbent or the one another rank of a tree split found.  The incumbent of the START of the round (select_kernel
   // copied it): nodes of one round are evaluated in no fixed order, and pruning with an incumbent another node of the same
   // round has just found would make the tree - and with it the returned solution within the gap - differ from run to run.
@@ -1774,7 +1788,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   int best = mine.prio;
   for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
   __syncthreads();
-  if (best == 0x7FFFFFFF) {
+  if (best == 0x7FFFFFFF && !pumped) {   // (the solution of a re-rounded probe violates rows of its own: only its completion, solved as the next probe, can be an incumbent)
     if (B.stats && lane == 0) atomicAdd(&B.stats[42], 1ull);
     // integer feasible: candidate incumbent.  The winner of the 64-bit atomicMin owns the low 20 bits (batch slot).
     signed char* dst = B.batch_comp + (size_t)node * Y.fixlen;
@@ -1798,7 +1812,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   const double vmax_all = wave_max(myvmax);
   unsigned long long bal = __ballot(mine.prio == best);
   int winner = __ffsll((long long)bal) - 1;
-  if (lane == winner) chosen = mine;
+  if (lane == winner) { chosen = mine; if (best == 0x7FFFFFFF) chosen.i = 1; }   // (no violated disjunction: a re-rounded probe - any valid step serves, it has no children but the probe)
   __syncthreads();
   // ---------------- first-deviation branching over the time family of the chosen disjunction.
   // The same kind of decision exists at every step j (family: same car / obstacle / point / group).  With the completed
@@ -1888,7 +1902,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     // REGION binaries of a start (depth word REPAIR_ROOT) is not part of the tree - the tree's own root covers it.  When the
     // completion of its relaxation is not integer feasible it gets one child, the rounding probe (every undecided disjunction
     // fixed to its completed value: feasible -> incumbent), and nothing else.
-    const bool repair_root = B.batch_depth[node] == REPAIR_ROOT;
+    const bool repair_root = B.batch_depth[node] == REPAIR_ROOT || pumped;
     if (repair_root) nalt = 0;
     else {
     ck[0] = N; ca[0] = 0; nalt = 1;                       // child_inf
@@ -2139,7 +2153,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         B.pool_origin[slots[q]] = (signed char)(kk == -2 ? 15 : 4 * chosen.kind + cls);
       }
     }
-    if (B.pool_big && lane < nk) B.pool_big[slots[lane]] = big_parent;   // (a child has the rows of its parent and more)
+    if (B.pool_big && lane < nk) B.pool_big[slots[lane]] = pumped ? (unsigned char)((((big_parent >> 4) + 1) << 4) | 1) : big_parent;   // (a child has the rows of its parent and more)
     if (B.pool_Z) {   // the children start their relaxation from this node's solution (see DevBuf::pool_Z)
       for (int q = 0; q < nk; ++q) { if (slots[q] >= B.z_cap) continue; double* zd = B.pool_Z + (size_t)slots[q] * N * NZ; for (int k = lane; k < N * NZ; k += 64) zd[k] = Z[k]; }
     }
@@ -2809,6 +2823,13 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
           }
         }
       }
+      // Neighbourhoods solved as sub-problems (the RINS idea of cplexmodel.mod's rinsheur, with the incumbent alone defining the fixings): the incumbent's
+      // record with EVERY disjunction of one car (its regions, environment pieces, obstacle sides and the pairs it belongs to: bit 7), or of all cars
+      // within a window of a third of the horizon (bit 8), undecided again.  Such a record is an ordinary node - it is solved, branched and its
+      // children join the instance's lists - whose subtree holds the incumbent and every solution that differs from it inside the
+      // neighbourhood only: changes of several sequences at once, which the single moves above cannot make.  It duplicates a part of the tree.
+      if (mode & 128) for (int c = 0; c < C && n < LNS_MAX; ++c) { nb_c[n] = -2; nb_i[n] = 1; nb_n[n] = 0; nb_code[n] = c; nb_n2[n] = 0; n++; }
+      if (mode & 256) { const int W = N / 3, st = W / 2 > 0 ? W / 2 : 1; for (int i0 = 1; i0 + W <= N && n < LNS_MAX; i0 += st) { nb_c[n] = -3; nb_i[n] = 1; nb_n[n] = 0; nb_code[n] = i0 | (W << 8); nb_n2[n] = 0; n++; } }
     } else B.inst_lns[inst] = flags & ~1;
     int base = 0, rec = 0;
     if (n > 0) {
@@ -2865,9 +2886,19 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
       }
       continue;
     }
+    const bool sub = k0 <= -2;   // a neighbourhood root: car nb_code (k0 == -2) or the steps [i0, i0 + W) (k0 == -3)
+    const int fc = nb_code[q], wi0 = nb_code[q] & 255, wi1 = wi0 + (nb_code[q] >> 8);
     for (int k = lane; k < Y.fixlen; k += 64) {
       signed char v = inc[k];
-      if (k >= k0 && k < k1 && (k - k0) % st_ == 0) v = (signed char)nb_code[q];
+      if (!sub) { if (k >= k0 && k < k1 && (k - k0) % st_ == 0) v = (signed char)nb_code[q]; }
+      else if (k < Y.f_c2n) {
+        int car = -1, car2 = -1, step;
+        if (k < Y.f_env) { car = k / N; step = k - car * N; }
+        else if (k < Y.f_obs) { const int e = (k - Y.f_env) / 5; car = e / N; step = e - car * N; }
+        else if (k < Y.f_c2c) { const int e = (k - Y.f_obs) / 5; step = e % N; car = e / (N * Y.O); }
+        else { const int e = (k - Y.f_c2c) >> 2, pp = e / N; step = e - pp * N; pair_cars(pp, C, car, car2); }
+        if (k0 == -2 ? (car == fc || car2 == fc) : (step >= wi0 && step < wi1)) v = (signed char)-1;
+      }
       if (k >= Y.f_env && k < Y.f_c2c && (k - Y.f_env) % 5 != 0) v = (signed char)-1;   // front-point environment / obstacle disjunctions: undecided (their rows are most of a leaf's rows; the evaluation checks them at the leaf's solution)
       if (k >= Y.f_c2n && k < Y.f_rmask) v = (signed char)-1;          // no exclusion rows
       if (k >= Y.f_rmask && k < Y.f_rmask + C * N * 2) v = (signed char)-1;   // every region allowed (0xFF 0xFF)
@@ -2881,7 +2912,7 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
     if (lane == 0) {
       if (B.pool_big) B.pool_big[rec] = 1;
       if (B.pool_origin) B.pool_origin[rec] = 14;
-      B.batch_node[bs] = rec; B.batch_inst[bs] = inst; B.batch_bound[bs] = lbq; B.batch_depth[bs] = (1 << 6) | 63;   // (the probe mark: a heuristic node - one that has not converged after probe_itcap iterations is abandoned)
+      B.batch_node[bs] = rec; B.batch_inst[bs] = inst; B.batch_bound[bs] = lbq; B.batch_depth[bs] = sub ? ((B.lns_mode & 512) ? (1 << 6) : REPAIR_ROOT) : ((1 << 6) | 63);   // (the probe mark: a heuristic node - one that has not converged after probe_itcap iterations is abandoned; a neighbourhood root is an ordinary node)
       if (B.batch_large) B.batch_large[bs] = 1;
     }
   }

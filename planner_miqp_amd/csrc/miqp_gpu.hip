@@ -485,7 +485,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   }
   if (!X.alloc(&B.ovf_count, 1)) return false;
   if (!X.alloc(&B.ovf_list, batch_alloc)) return false;
-  if (X.ocb_grid > 0) { if (!X.alloc(&B.pool_big, (size_t)X.pool_cap)) return false; HIP_OK(hipMemset(B.pool_big, 0, (size_t)X.pool_cap)); }
+  { if (!X.alloc(&B.pool_big, (size_t)X.pool_cap)) return false; HIP_OK(hipMemset(B.pool_big, 0, (size_t)X.pool_cap)); }   // (size mark of the on-chip variants; its high nibble counts the re-roundings of a probe, for every kernel)
   if (!X.alloc(&B.ovf2_count, 1)) return false;
   if (!X.alloc(&B.ovf2_list, batch_alloc)) return false;
   HIP_OK(hipMemset(B.ovf2_count, 0, 4));
@@ -961,11 +961,13 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   const bool queue_mode = NS < n;
   B.share_cap = std::max(1, std::getenv("MIQP_SHARE_CAP") ? std::atoi(std::getenv("MIQP_SHARE_CAP")) : (queue_mode ? 256 : 1024));
   B.floor_pct = std::max(0, std::min(100, std::getenv("MIQP_FLOOR_PCT") ? std::atoi(std::getenv("MIQP_FLOOR_PCT")) : (queue_mode ? 50 : 0)));
+  B.probe_itcap0 = std::getenv("MIQP_PROBE_ITCAP0") ? std::atoi(std::getenv("MIQP_PROBE_ITCAP0")) : (Y.C >= 3 ? 0 : 40);   // (the cap while the instance has no incumbent)
+  B.pump_max = std::max(0, std::min(15, std::getenv("MIQP_PUMP") ? std::atoi(std::getenv("MIQP_PUMP")) : 6));   // re-rounding of infeasible rounding probes (eval_kernel)
   B.young_nodes = std::max(0, std::getenv("MIQP_YOUNG_NODES") ? std::atoi(std::getenv("MIQP_YOUNG_NODES")) : 0);
   B.probe_room = std::getenv("MIQP_PROBE_ROOM") ? std::atof(std::getenv("MIQP_PROBE_ROOM")) : 0.0;
   B.live_inc = std::getenv("MIQP_LIVE_INC") ? std::atoi(std::getenv("MIQP_LIVE_INC")) : 0;
   B.probe_every = std::getenv("MIQP_PROBE_EVERY") ? std::atoi(std::getenv("MIQP_PROBE_EVERY")) : 1;
-  B.probe_itcap = std::getenv("MIQP_PROBE_ITCAP") ? std::atoi(std::getenv("MIQP_PROBE_ITCAP")) : 24;   // (0: never; solved probes take 9-24 iterations; 40 until round 4: the heuristic nodes - probes, local-search leaves - are the critical path of a single solve's round: p99 99 -> 80 ms at 24)
+  B.probe_itcap = std::getenv("MIQP_PROBE_ITCAP") ? std::atoi(std::getenv("MIQP_PROBE_ITCAP")) : (Y.C >= 3 ? 0 : 24);   // (three and four cars: no cap - EVERY probe of the phase without incumbent hit it there, at 25 iterations: infeasible roundings take 36-48, and it is their least-violation solution that the re-rounding needs)   // (0: never; solved probes take 9-24 iterations; 40 until round 4: the heuristic nodes - probes, local-search leaves - are the critical path of a single solve's round: p99 99 -> 80 ms at 24)
   B.probe_margin = std::getenv("MIQP_PROBE_MARGIN") ? std::atof(std::getenv("MIQP_PROBE_MARGIN")) : 0.25;   // (0: every disjunction of a probe fixed, as in round 2)
   B.det_ties = std::getenv("MIQP_DET_TIES") ? std::atoi(std::getenv("MIQP_DET_TIES")) : 1;
   B.window_pct = std::max(1, std::min(100, std::getenv("MIQP_WINDOW") ? std::atoi(std::getenv("MIQP_WINDOW")) : 100));
@@ -1334,6 +1336,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     std::fprintf(stderr, "\n[miqp_gpu stats] node outcomes by origin (processed: infeasible / cut off / not converged / solved):");
     const char* on_[16] = {"root|reg-ref", "reg-adjacent", "reg-other", "reg-slow", "env-ref", "env-other", "-", "-", "obs-ref", "obs-other", "-", "-", "c2c-ref", "c2c-other", "-", "probe"};
     for (int q = 0; q < 16; ++q) if (hs[80 + q]) std::fprintf(stderr, " %s %llu: %llu / %llu / %llu / %llu;", on_[q], hs[80 + q], hs[96 + q], hs[112 + q], hs[128 + q], hs[144 + q]);
+    std::fprintf(stderr, "\n[miqp_gpu stats] infeasible rounding probes re-rounded: %llu", hs[62]);
     std::fprintf(stderr, "\n[miqp_gpu stats] handed-over nodes with >= 480 general rows: %llu, mean %.0f, most %llu general rows", hs[7], (double)hs[6] / std::max(1ull, hs[7]), hs[5]);
     std::fprintf(stderr, "\n[miqp_gpu stats] rounding probes by iterations / 3 (0-2, 3-5, ..., 45+):");
     { const char* oc_n[4] = {"infeasible", "cut off", "not converged", "solved"};
