@@ -186,7 +186,7 @@ struct DevBuf {
   // its region sequences join the batch of the same round
   const int* batch_order;        // the order in which the standard on-chip launch hands the batch's nodes out (order_kernel; null: as they stand)
   double* inst_lns_obj; double lns_step;   // the local search runs again only when the incumbent has improved by lns_step (relative) since its last run: a hill climb in steps of 1e-5 re-evaluates the whole neighbourhood for nothing
-  int* inst_lns; int lns_mode; int lns_min_nodes;   // (an instance gets its local search once it has cost lns_min_nodes node relaxations: the easy ones are done before)
+  int* inst_lns; int lns_mode; int lns_min_nodes; int lns_narrow;   // (an instance gets its local search once it has cost lns_min_nodes node relaxations: the easy ones are done before)
   double ws_theta;               // share of the mean in a pair's centring target (1: the uniform target of a cold start), see row_step
 };
 constexpr int LGEN_CAP = 160;                                  // general-row multipliers carried per record
@@ -2499,6 +2499,9 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
       if (w < B.nodes_per_round) w = B.nodes_per_round;
     } else { w = B.slot_take[slot]; if (w < B.base_take && !(B.young_nodes > 0 && B.inst_nodes[inst] >= (long long)B.young_nodes)) w = B.base_take; }   // (an older instance may be told to wait: share 0)
     if (!(inc < 1e300) && w > 512) w = 512;   // no incumbent yet: a narrow dive (a wide one degenerates into breadth first)
+    // a round that carries the neighbours of a new incumbent is kept narrow: the local search is a chain - a better neighbour, ITS neighbours the
+    // round after - and what the tree would solve beside it in a wide round is mostly what the next incumbent of the chain prunes
+    if (B.lns_narrow > 0 && B.inst_lns && (B.inst_lns[inst] & 1) && inc < 1e300 && B.inst_nodes[inst] >= (long long)B.lns_min_nodes && w > B.lns_narrow) w = B.lns_narrow;
     B.slot_demand[slot] = inc < 1e300 ? m_elig : (m < 512 ? m : 512);   // what this instance could use next round
     int take = m_elig < w ? m_elig : w;
     const int maxch = B.far_cap > 0 ? 8 : 64;     // children of one node: at most 63 (eval_kernel); with a far tier behind the list an overflow is absorbed there

@@ -263,7 +263,8 @@ def test_local_search_changes_the_order_not_the_answer(monkeypatch):
         assert ba <= ob + tol and bb <= oa + tol, (seed, oa, ba, ob, bb)
         g = 1e-4 if seed == 20 else 1e-2
         assert abs(oa - ob) <= g * max(abs(oa), abs(ob)) + tol, (seed, oa, ob)
-    assert out[("45", 1913)][2] < 0.5 * out[("0", 1913)][2], (out[("0", 1913)][2], out[("45", 1913)][2])   # measured: 2.4 M -> 0.16 M nodes
+    # measured: 2.4 M -> 0.16 M nodes before the re-rounding of infeasible probes found this instance's incumbents early in either mode, 215 k -> 135 k with it
+    assert out[("45", 1913)][2] < 0.8 * out[("0", 1913)][2], (out[("0", 1913)][2], out[("45", 1913)][2])
 
 
 def test_result_records_built_in_a_batch_equal_the_lazy_ones():
