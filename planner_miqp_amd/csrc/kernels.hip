@@ -140,7 +140,7 @@ struct DevBuf {
   // sharing the batch evenly all run into their max_solution_time (which counts from the admission) and their work is lost.
   // Earliest deadline first finishes what it starts; the cap (1024: narrow rounds waste the fewest nodes - every round prunes
   // with the incumbents of the one before) keeps a pathological instance to 3 % of the device.
-  int* slot_demand; int* slot_take; int share_cap; int base_take; int floor_pct; int young_nodes; int pump_max; int window_pct; double probe_room;
+  int* slot_demand; int* slot_take; int share_cap; int base_take; int floor_pct; int young_nodes; int pump_max; int pump_inc; int window_pct; double probe_room;
   double probe_margin;           // > 0: the rounding probe leaves front-point environment / obstacle disjunctions undecided whose completed alternative holds with this much room
   int probe_itcap0;              // the same while the instance has no incumbent
   int probe_itcap;               // iterations after which an unconverged rounding probe is abandoned (0: never)
@@ -735,13 +735,14 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     // A rounding probe is a heuristic (it lies inside the first child, the children stay exhaustive without it): one that has
     // not converged after probe_itcap iterations - nearly always an infeasible rounding, 27 iterations to prove - is abandoned.
     // The launch of this kernel lasts as long as its slowest node.
-    { const int pcap = cutoff < 1e299 ? B.probe_itcap : B.probe_itcap0;   // (without an incumbent the probes are given longer: the re-rounding needs the converged solution of an infeasible one)
+    const bool pump_probe = B.pump_inc && B.pump_max > 0 && is_probe_word(B.batch_depth[node]);   // (re-rounding with an incumbent, pump_inc: a probe is then only cut off by its objective, not by the penalty of its violated rows - an infeasible one converges to its least-violation point and is re-rounded by eval_kernel)
+    { const int pcap = (cutoff < 1e299 && !pump_probe) ? B.probe_itcap : B.probe_itcap0;   // (without an incumbent the probes are given longer: the re-rounding needs the converged solution of an infeasible one)
       if (pcap > 0 && it > pcap && B.ws_on != 2 && is_probe_word(B.batch_depth[node])) { ok = 2; break; } }
     // dual bound of the penalised problem: primal value - total complementarity (valid once the iterate is dual feasible)
 #ifdef MIQP_PROFILE
     if (it > 1 && first_proxy == 0 && obj + RHO_EL * tsum - (double)ncomp * comp > cutoff + 1e-9 * fabs(cutoff)) first_proxy = it;
 #endif
-    if (!(MIQP_ABL) && it > 1 && resid_fac * R0 < B.cut_gate * (1.0 + fabs(obj)) && obj + RHO_EL * tsum - (double)ncomp * comp - resid_fac * R0 * zdiam > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }   // (dual value minus the allowance for the stationarity residual still left, see batch_bound)
+    if (!(MIQP_ABL) && it > 1 && resid_fac * R0 < B.cut_gate * (1.0 + fabs(obj)) && obj + (pump_probe ? 0.0 : RHO_EL * tsum) - (double)ncomp * comp - resid_fac * R0 * zdiam > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }   // (dual value minus the allowance for the stationarity residual still left, see batch_bound)
     const double tau = sigma * comp;
     // ================= backward sweep: Riccati recursion, the whole stage algebra stays in the registers of the wave.
     // Matrices live in the D layout of v_mfma_f64_16x16x4_f64 (lane l: g = l>>4, c = l&15, register r <-> M[g+4r][c]).
@@ -1507,7 +1508,8 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   // repair root.  At most pump_max generations (the high nibble of the record's size mark counts them).
   bool pumped = false;
   if (viol > FEAS_TOL && okq == 1 && B.pump_max > 0 && B.pool_big && is_probe_word(B.batch_depth[node]) && (int)(big_parent >> 4) < B.pump_max
-      && !(fmin(B.live_inc ? inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]) : B.inc_obj[inst], B.inc_ext[inst]) < 1e300)) pumped = true;
+      && (!(fmin(B.live_inc ? inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]) : B.inc_obj[inst], B.inc_ext[inst]) < 1e300)
+          || (B.pump_inc && B.batch_obj[node] + B.inst_const[inst] < fmin(B.inc_obj[inst], B.inc_ext[inst])))) pumped = true;
   if (!pumped && (viol > FEAS_TOL || okq != 1)) { FREE_NODE(); return; }  // infeasible relaxation, or abandoned at the incumbent cutoff
   if (pumped) {
     for (int k = lane; k < Y.f_rmask + C * N * 2 && k < Y.fixlen; k += 64) { fix[k] = (signed char)-1; comp[k] = (signed char)-1; }
