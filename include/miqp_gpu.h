@@ -234,6 +234,13 @@ int miqp_select_environment(const double* pieces_xy, const int* piece_off, int n
 /* MiqpPlanner::ObstacleIntersectsEnvironment (src/miqp_planner.cpp:1248-1306, without the region of interest): 1 when the obstacle
  * (n_steps x 4 vertices) intersects a piece - checked at step 0 only when it is static; an empty environment admits every obstacle */
 int miqp_obstacle_intersects_environment(const double* pieces_xy, const int* piece_off, int n_pieces, const double* obstacle_xy, int n_steps, int is_static);
+/* MiqpPlanner::UpdateObstaclesROI (src/miqp_planner.cpp:1308-1335): the region of interest around the ego car as 4 vertices (x, y pairs:
+ * front upper, front lower, rear lower, rear upper), computed exactly as the reference writes it */
+int miqp_obstacles_roi(double x, double y, double theta, double behind_distance, double front_distance, double side_distance, double* roi_xy);
+/* MiqpPlanner::ObstacleIntersectsEnvironment with its region-of-interest filter (src/miqp_planner.cpp:1278-1288; settings
+ * obstacle_roi_filter, src/miqp_planner_settings.h:74-77): as above, but a step at which the obstacle does not intersect roi_xy (4 vertices;
+ * NULL = no filter) is skipped - a static obstacle is then irrelevant (0), a moving one is checked at its next step */
+int miqp_obstacle_intersects_environment_roi(const double* pieces_xy, const int* piece_off, int n_pieces, const double* obstacle_xy, int n_steps, int is_static, const double* roi_xy);
 /* MiqpPlanner::EnvironmentWarmstart (src/miqp_planner.cpp:1053-1115): the five environment arrays of `last` ([C][n_old][N]) re-indexed
  * into `out` ([C][n_new][N]) by piece id; new pieces and the last step start as 1 */
 int miqp_environment_warmstart(const miqp_raw_results_c* last, miqp_raw_results_c* out, const int* ids_old, int n_old, const int* ids_new, int n_new);

@@ -1816,6 +1816,15 @@ int miqp_obstacle_intersects_environment(const double* pieces_xy, const int* pie
   if (n_pieces < 0 || n_steps < 1 || !obstacle_xy || (n_pieces > 0 && (!pieces_xy || !piece_off))) return -1;
   return miqp::obstacle_intersects_environment(pieces_xy, piece_off, n_pieces, obstacle_xy, n_steps, is_static != 0) ? 1 : 0;
 }
+int miqp_obstacles_roi(double x, double y, double theta, double behind_distance, double front_distance, double side_distance, double* roi_xy) {
+  if (!roi_xy) return -1;
+  miqp::obstacles_roi(x, y, theta, behind_distance, front_distance, side_distance, roi_xy);
+  return 0;
+}
+int miqp_obstacle_intersects_environment_roi(const double* pieces_xy, const int* piece_off, int n_pieces, const double* obstacle_xy, int n_steps, int is_static, const double* roi_xy) {
+  if (n_pieces < 0 || n_steps < 1 || !obstacle_xy || (n_pieces > 0 && (!pieces_xy || !piece_off))) return -1;
+  return miqp::obstacle_intersects_environment(pieces_xy, piece_off, n_pieces, obstacle_xy, n_steps, is_static != 0, roi_xy) ? 1 : 0;
+}
 int miqp_environment_warmstart(const miqp_raw_results_c* last, miqp_raw_results_c* out, const int* ids_old, int n_old, const int* ids_new, int n_new) {
   if (!last || !out || n_old < 0 || n_new < 0 || last->NrEnvironments != n_old || out->NrEnvironments != n_new || last->N != out->N || last->NrCars != out->NrCars) return -1;
   const int* const in[5] = {last->notWithinEnvironmentRear, last->notWithinEnvironmentFrontUbUb, last->notWithinEnvironmentFrontLbUb, last->notWithinEnvironmentFrontUbLb, last->notWithinEnvironmentFrontLbLb};

@@ -349,11 +349,27 @@ inline int initial_pose_check(const miqp_model_params_c& p) {
   return -1;
 }
 
-// MiqpPlanner::ObstacleIntersectsEnvironment (src/miqp_planner.cpp:1248-1306) without the region of interest: does the
-// obstacle (T time steps of 4 vertices) intersect one of the pieces - at step 0 only when it is static
-inline bool obstacle_intersects_environment(const double* pieces, const int* off, int n_pieces, const double* obstacle, int T, bool is_static) {
+// MiqpPlanner::UpdateObstaclesROI (src/miqp_planner.cpp:1308-1335): the region of interest around the ego car, four vertices
+// (front upper, front lower, rear lower, rear upper).  As in the reference the side offset is +-(sin theta, cos theta) * side - a
+// parallelogram whose sides are only perpendicular to the heading at theta = 0 or pi / 2; restated as written, not "corrected".
+inline void obstacles_roi(double x, double y, double theta, double behind, double front, double side, double* roi8) {
+  const double c = std::cos(theta), s = std::sin(theta);
+  const double fx = x + c * front, fy = y + s * front;
+  const double rx = x + std::cos(theta + M_PI) * behind, ry = y + std::sin(theta + M_PI) * behind;
+  roi8[0] = fx + s * side; roi8[1] = fy + c * side;
+  roi8[2] = fx - s * side; roi8[3] = fy - c * side;
+  roi8[4] = rx - s * side; roi8[5] = ry - c * side;
+  roi8[6] = rx + s * side; roi8[7] = ry + c * side;
+}
+
+// MiqpPlanner::ObstacleIntersectsEnvironment (src/miqp_planner.cpp:1248-1306): does the obstacle (T time steps of 4 vertices)
+// intersect one of the pieces - at step 0 only when it is static.  With a region of interest (roi: 4 vertices, or nullptr for the
+// reference's empty polygon) a step at which the obstacle lies outside it does not count: a static obstacle is then irrelevant,
+// a moving one is looked at again at its next step (:1278-1288).
+inline bool obstacle_intersects_environment(const double* pieces, const int* off, int n_pieces, const double* obstacle, int T, bool is_static, const double* roi = nullptr) {
   if (n_pieces == 0) return true;   // empty environment: every obstacle is added
   for (int t = 0; t < T; ++t) {
+    if (roi && !convex_polygons_intersect(roi, 4, obstacle + (size_t)t * 8, 4)) { if (is_static) return false; continue; }
     for (int e = 0; e < n_pieces; ++e)
       if (convex_polygons_intersect(pieces + 2 * off[e], off[e + 1] - off[e], obstacle + (size_t)t * 8, 4)) return true;
     if (is_static) return false;

@@ -31,6 +31,8 @@ def _lib():
         L.miqp_initial_pose_check.restype = C.c_int; L.miqp_initial_pose_check.argtypes = [C.POINTER(ModelParamsC)]
         L.miqp_select_environment.restype = C.c_int; L.miqp_select_environment.argtypes = [dp, ip, C.c_int, dp, ip, C.c_int, ip]
         L.miqp_obstacle_intersects_environment.restype = C.c_int; L.miqp_obstacle_intersects_environment.argtypes = [dp, ip, C.c_int, dp, C.c_int, C.c_int]
+        L.miqp_obstacle_intersects_environment_roi.restype = C.c_int; L.miqp_obstacle_intersects_environment_roi.argtypes = [dp, ip, C.c_int, dp, C.c_int, C.c_int, dp]
+        L.miqp_obstacles_roi.restype = C.c_int; L.miqp_obstacles_roi.argtypes = [C.c_double] * 6 + [dp]
         L.miqp_environment_warmstart.restype = C.c_int
         L.miqp_environment_warmstart.argtypes = [C.POINTER(RawResultsC), C.POINTER(RawResultsC), ip, C.c_int, ip, C.c_int]
         _PROTO = True
@@ -165,11 +167,23 @@ def select_environment(pieces, trajectories):
     return np.nonzero(sel)[0].tolist()
 
 
-def obstacle_intersects_environment(pieces, dynamic_obstacle, is_static):
-    """MiqpPlanner::ObstacleIntersectsEnvironment (src/miqp_planner.cpp:1248-1306) without the region of interest"""
+def obstacles_roi(x, y, theta, behind_distance, front_distance, side_distance):
+    """MiqpPlanner::UpdateObstaclesROI (src/miqp_planner.cpp:1308-1335): the four vertices of the region of interest around the ego car"""
+    roi = np.zeros((4, 2))
+    if _lib().miqp_obstacles_roi(float(x), float(y), float(theta), float(behind_distance), float(front_distance), float(side_distance), _d(roi)) != 0:
+        raise ValueError("invalid region of interest")
+    return roi
+
+
+def obstacle_intersects_environment(pieces, dynamic_obstacle, is_static, roi=None):
+    """MiqpPlanner::ObstacleIntersectsEnvironment (src/miqp_planner.cpp:1248-1306); roi: the region of interest (4 vertices, see
+    obstacles_roi) of the reference's obstacle_roi_filter, None = the empty polygon the planner starts with"""
     pxy, poff = _flat_polys(pieces)
     ob = np.ascontiguousarray(np.asarray(dynamic_obstacle, dtype=np.float64).reshape(-1, 4, 2))
-    return _lib().miqp_obstacle_intersects_environment(_d(pxy), _i(poff), len(pieces), _d(ob), ob.shape[0], int(bool(is_static))) == 1
+    if roi is None:
+        return _lib().miqp_obstacle_intersects_environment(_d(pxy), _i(poff), len(pieces), _d(ob), ob.shape[0], int(bool(is_static))) == 1
+    r = np.ascontiguousarray(np.asarray(roi, dtype=np.float64).reshape(4, 2))
+    return _lib().miqp_obstacle_intersects_environment_roi(_d(pxy), _i(poff), len(pieces), _d(ob), ob.shape[0], int(bool(is_static)), _d(r)) == 1
 
 
 def environment_warmstart(last: RawResults, ids_old, ids_new):
@@ -234,7 +248,8 @@ def DefaultSettings():
                 constant_agent_safety_distance_slack=3.0, minimum_region_change_speed=2.0, lambda_=0.5, wheelBase=2.8, collisionRadius=1.0,
                 slackWeight=30.0, slackWeightObstacle=2000.0, jerkWeight=1.0, positionWeight=2.0, velocityWeight=0.0, acclerationWeight=0.0,
                 accLonMaxLimit=2.0, accLonMinLimit=-4.0, jerkLonMaxLimit=3.0, accLatMinMaxLimit=1.6, jerkLatMinMaxLimit=1.4, refLineInterpInc=0.2,
-                additionalStepsForReferenceLongerHorizon=4, max_velocity_fitting=20.0, parallelMode=1, warmstartType=WarmstartType.NO_WARMSTART)
+                additionalStepsForReferenceLongerHorizon=4, max_velocity_fitting=20.0, parallelMode=1, warmstartType=WarmstartType.NO_WARMSTART,
+                obstacle_roi_filter=False, obstacle_roi_behind_distance=5.0, obstacle_roi_front_distance=30.0, obstacle_roi_side_distance=15.0)
 
 
 class MiqpPlanner:
@@ -275,6 +290,7 @@ class MiqpPlanner:
         p.initial_region = np.zeros(0, dtype=np.int32); p.possible_region = np.zeros((0, R), dtype=np.int32)
         self.parameters = p
         self.egoCarIdx = 0
+        self._obstacles_roi = None   # MiqpPlanner::obstacles_roi_: empty until the ego car is updated with obstacle_roi_filter set
         self._refs = []          # per car: (reference line, desired velocity, delta s)
         self.wrapper = CplexWrapper("cplexmodel.mod", precision=S["precision"], **wrapper_args)
         self.status = None
@@ -343,6 +359,8 @@ class MiqpPlanner:
         p.possible_region[idx] = poss
         for k, nm in enumerate(("WEIGHTS_POS_X", "WEIGHTS_VEL_X", "WEIGHTS_ACC_X", "WEIGHTS_POS_Y", "WEIGHTS_VEL_Y", "WEIGHTS_ACC_Y", "WEIGHTS_JERK_X", "WEIGHTS_JERK_Y")):
             getattr(p, nm)[idx] = w8[k]
+        if S["obstacle_roi_filter"] and idx == self.egoCarIdx:   # far-away obstacles are filtered out around the ego car (src/miqp_planner.cpp:380-387)
+            self._obstacles_roi = obstacles_roi(st[0], st[3], np.arctan2(st[4], st[1]), S["obstacle_roi_behind_distance"], S["obstacle_roi_front_distance"], S["obstacle_roi_side_distance"])
         return rc == 0
 
     def Plan(self, timestamp=0.0):
@@ -409,7 +427,7 @@ class MiqpPlanner:
         ob = [np.asarray(q, dtype=np.float64).reshape(4, 2).copy() for q in dynamic_obstacle]
         assert len(ob) == p.NumSteps
         env = list(p.MultiEnvironmentConvexPolygon) if p.nr_environments > 0 else list(self._map)
-        if not obstacle_intersects_environment(env, ob, is_static):
+        if not obstacle_intersects_environment(env, ob, is_static, getattr(self, "_obstacles_roi", None)):
             return -1
         p.ObstacleConvexPolygon = list(p.ObstacleConvexPolygon) + [ob]
         p.obstacle_is_soft = list(p.obstacle_is_soft) + [int(bool(is_soft))]

@@ -284,3 +284,47 @@ def test_add_car_fills_the_model_like_update_car():
     assert p.WEIGHTS_POS_X[0] == 1.0 and p.WEIGHTS_JERK_X[0] == 0.5 and p.WEIGHTS_VEL_X[0] == 0.0      # lambda 0.5 x (2, 1, 0)
     assert abs(p.total_max_jerk - (max(p.max_jerk_x.max(), p.max_jerk_y.max()) + 1e-6)) < 1e-12
     assert p.WheelBase[0] == 2.8 and p.CollisionRadius[0] == 1.0
+
+
+def test_obstacle_region_of_interest_filter():
+    """the obstacle_roi_filter of MiqpPlanner (src/miqp_planner.cpp:380-387 UpdateCar, :1278-1288 ObstacleIntersectsEnvironment,
+    :1308-1335 UpdateObstaclesROI; settings src/miqp_planner_settings.h:74-77, the values of test/miqp_planner_test.cc:65-68):
+    the region around the ego car exactly as the reference computes it, and what it filters"""
+    # the vertices as written in the reference: side offsets +-(sin theta, cos theta) * side
+    x, y, th, behind, front, side = 3.0, -2.0, 0.3, 10.0, 100.0, 15.0
+    roi = K.obstacles_roi(x, y, th, behind, front, side)
+    fx, fy = x + np.cos(th) * front, y + np.sin(th) * front
+    rx, ry = x + np.cos(th + np.pi) * behind, y + np.sin(th + np.pi) * behind
+    want = [[fx + np.sin(th) * side, fy + np.cos(th) * side], [fx - np.sin(th) * side, fy - np.cos(th) * side],
+            [rx - np.sin(th) * side, ry - np.cos(th) * side], [rx + np.sin(th) * side, ry + np.cos(th) * side]]
+    np.testing.assert_allclose(roi, want, rtol=0, atol=1e-12)
+    # heading along x: the rectangle [x - behind, x + front] x [y - side, y + side]
+    roi0 = K.obstacles_roi(0.0, 0.0, 0.0, 10.0, 100.0, 15.0)
+    np.testing.assert_allclose(roi0, [[100, 15], [100, -15], [-10, -15], [-10, 15]], atol=1e-9)
+    road = [[-200, -4], [400, -4], [400, 4], [-200, 4]]
+    box = lambda cx: np.array([[cx, -0.5], [cx + 1, -0.5], [cx + 1, 0.5], [cx, 0.5]], float)
+    near, behind_far, ahead_far = [box(50.0)] * 20, [box(-60.0)] * 20, [box(150.0)] * 20
+    approaching = [box(150.0 - 5.0 * i) for i in range(20)]                     # enters the region at step 10
+    assert K.obstacle_intersects_environment([road], near, True, roi0)
+    assert not K.obstacle_intersects_environment([road], behind_far, True, roi0) and K.obstacle_intersects_environment([road], behind_far, True)
+    assert not K.obstacle_intersects_environment([road], ahead_far, False, roi0)   # never inside the region
+    assert K.obstacle_intersects_environment([road], approaching, False, roi0)     # a moving obstacle is looked at step by step
+    assert not K.obstacle_intersects_environment([road], approaching, True, roi0)  # a static one at step 0 only
+    assert K.obstacle_intersects_environment([], behind_far, True, roi0)           # the empty environment admits everything, region or not
+    touching = [box(100.0)] * 20                                                  # shares the edge x = 100 with the region: intersects (boost: touching counts)
+    assert K.obstacle_intersects_environment([road], touching, True, roi0)
+
+    # the planner: the region follows the ego car's update; other cars do not move it; without the setting nothing is filtered
+    S = dict(obstacle_roi_filter=True, obstacle_roi_behind_distance=10.0, obstacle_roi_front_distance=100.0, obstacle_roi_side_distance=15.0)
+    pl = K.MiqpPlanner(settings=S, mapPieces=[road])
+    assert pl._obstacles_roi is None
+    pl.AddCar([0, 5, 0, 0, 0.0, 0], [[0, 0], [300, 0]], 5, 1, 0.0, True)
+    np.testing.assert_allclose(pl._obstacles_roi, roi0, atol=1e-9)
+    assert pl.AddObstacle(behind_far, False, True) == -1 and pl.AddObstacle(ahead_far, False, False) == -1
+    assert pl.AddObstacle(near, False, True) == 0 and pl.AddObstacle(approaching, False, False) == 1
+    pl.AddCar([40, 5, 0, 0, 0.0, 0], [[0, 0], [300, 0]], 5, 1, 0.0, True)          # a second car: not the ego car
+    np.testing.assert_allclose(pl._obstacles_roi, roi0, atol=1e-9)
+    pl.UpdateCar(0, [100, 5, 0, 0, 0.0, 0], [[0, 0], [300, 0]], 0.0, True)         # the ego car has moved on: the far obstacle is now relevant
+    assert pl.AddObstacle(ahead_far, False, True) == 2
+    pl2 = K.MiqpPlanner(mapPieces=[road]); pl2.AddCar([0, 5, 0, 0, 0.0, 0], [[0, 0], [300, 0]], 5, 1, 0.0, True)
+    assert pl2._obstacles_roi is None and pl2.AddObstacle(behind_far, False, True) == 0
