@@ -234,6 +234,10 @@ int miqp_select_environment(const double* pieces_xy, const int* piece_off, int n
 /* MiqpPlanner::ObstacleIntersectsEnvironment (src/miqp_planner.cpp:1248-1306, without the region of interest): 1 when the obstacle
  * (n_steps x 4 vertices) intersects a piece - checked at step 0 only when it is static; an empty environment admits every obstacle */
 int miqp_obstacle_intersects_environment(const double* pieces_xy, const int* piece_off, int n_pieces, const double* obstacle_xy, int n_steps, int is_static);
+/* MiqpPlanner::GetBarkTrajectory (src/miqp_planner.cpp:1132-1170) on plain arrays: out_rows5 receives up to N rows (time, x, y, theta, v)
+ * - bark's StateDefinition order - of car `car`; the trajectory is cut off at the first step whose |vx| and |vy| are both <= min_speed
+ * (IsVxVyValid :1184-1187; the planner uses 0.7, :53-54).  Returns the number of rows, -1 on invalid arguments */
+int miqp_bark_trajectory(const miqp_raw_results_c* results, int car, double start_time, double ts, double min_speed, double* out_rows5);
 /* MiqpPlanner::UpdateObstaclesROI (src/miqp_planner.cpp:1308-1335): the region of interest around the ego car as 4 vertices (x, y pairs:
  * front upper, front lower, rear lower, rear upper), computed exactly as the reference writes it */
 int miqp_obstacles_roi(double x, double y, double theta, double behind_distance, double front_distance, double side_distance, double* roi_xy);

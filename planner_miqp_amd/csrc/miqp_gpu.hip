@@ -1816,6 +1816,10 @@ int miqp_obstacle_intersects_environment(const double* pieces_xy, const int* pie
   if (n_pieces < 0 || n_steps < 1 || !obstacle_xy || (n_pieces > 0 && (!pieces_xy || !piece_off))) return -1;
   return miqp::obstacle_intersects_environment(pieces_xy, piece_off, n_pieces, obstacle_xy, n_steps, is_static != 0) ? 1 : 0;
 }
+int miqp_bark_trajectory(const miqp_raw_results_c* results, int car, double start_time, double ts, double min_speed, double* out_rows5) {
+  if (!results || !out_rows5 || car < 0 || car >= results->NrCars || results->N < 0 || !results->vel_x || !results->vel_y || !results->pos_x || !results->pos_y) return -1;
+  return miqp::bark_trajectory(*results, car, start_time, ts, min_speed, out_rows5);
+}
 int miqp_obstacles_roi(double x, double y, double theta, double behind_distance, double front_distance, double side_distance, double* roi_xy) {
   if (!roi_xy) return -1;
   miqp::obstacles_roi(x, y, theta, behind_distance, front_distance, side_distance, roi_xy);

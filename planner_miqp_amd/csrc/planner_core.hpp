@@ -377,6 +377,21 @@ inline bool obstacle_intersects_environment(const double* pieces, const int* off
   return false;
 }
 
+// MiqpPlanner::GetBarkTrajectory (src/miqp_planner.cpp:1132-1170) on plain arrays: rows (time, x, y, theta, v) - bark's StateDefinition
+// order TIME, X, Y, THETA, VEL - of car `car`, cut off at the first step whose velocity components are both at most `min_speed` in
+// magnitude (IsVxVyValid :1184-1187; the planner's minimum_valid_speed_vx_vy_ is 0.7, :53-54: the heading atan2(vy, vx) means nothing there).
+// Returns the number of rows written.
+inline int bark_trajectory(const miqp_raw_results_c& r, int car, double start_time, double ts, double min_speed, double* out5) {
+  const int N = r.N; int n = 0;
+  for (int i = 0; i < N; ++i) {
+    const double vx = r.vel_x[car * N + i], vy = r.vel_y[car * N + i];
+    if (!(std::fabs(vx) > min_speed || std::fabs(vy) > min_speed)) break;
+    double* o = out5 + 5 * n++;
+    o[0] = start_time + i * ts; o[1] = r.pos_x[car * N + i]; o[2] = r.pos_y[car * N + i]; o[3] = std::atan2(vy, vx); o[4] = std::sqrt(vx * vx + vy * vy);
+  }
+  return n;
+}
+
 // MiqpPlanner::EnvironmentWarmstart (src/miqp_planner.cpp:1053-1115): the environment binaries of the warm start follow the
 // piece ids - pieces that stay keep their columns (steps 0 .. N-2: the reference copies an extent of NumSteps - 1), new pieces
 // and the last step start as 1 ("not within").  in / out are the five [C][E][N] arrays with E_old / E_new pieces.

@@ -32,6 +32,7 @@ def _lib():
         L.miqp_select_environment.restype = C.c_int; L.miqp_select_environment.argtypes = [dp, ip, C.c_int, dp, ip, C.c_int, ip]
         L.miqp_obstacle_intersects_environment.restype = C.c_int; L.miqp_obstacle_intersects_environment.argtypes = [dp, ip, C.c_int, dp, C.c_int, C.c_int]
         L.miqp_obstacle_intersects_environment_roi.restype = C.c_int; L.miqp_obstacle_intersects_environment_roi.argtypes = [dp, ip, C.c_int, dp, C.c_int, C.c_int, dp]
+        L.miqp_bark_trajectory.restype = C.c_int; L.miqp_bark_trajectory.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, dp]
         L.miqp_obstacles_roi.restype = C.c_int; L.miqp_obstacles_roi.argtypes = [C.c_double] * 6 + [dp]
         L.miqp_environment_warmstart.restype = C.c_int
         L.miqp_environment_warmstart.argtypes = [C.POINTER(RawResultsC), C.POINTER(RawResultsC), ip, C.c_int, ip, C.c_int]
@@ -467,6 +468,33 @@ class MiqpPlanner:
         for k, nm in enumerate(("pos_x", "pos_y", "vel_x", "vel_y", "acc_x", "acc_y", "u_x", "u_y")):
             out[:, 1 + k] = getattr(r, nm)[carIdx]
         return out
+
+
+    MINIMUM_VALID_SPEED_VX_VY = 0.7   # MiqpPlanner::minimum_valid_speed_vx_vy_ (src/miqp_planner.cpp:53-54)
+
+    def GetBarkTrajectory(self, carIdx, start_time=0.0):
+        """MiqpPlanner::GetBarkTrajectory (src/miqp_planner.cpp:1132-1170) as a plain array: rows (time, x, y, theta, v) in bark's
+        StateDefinition order, cut off at the first step whose velocity components are both below the valid speed"""
+        r = self.GetSolution()
+        if not 0 <= carIdx < r.NrCars:
+            raise IndexError("car %d of %d" % (carIdx, r.NrCars))
+        out = np.zeros((r.N, 5)); c = r.to_c()
+        n = _lib().miqp_bark_trajectory(C.byref(c), int(carIdx), float(start_time), float(self.parameters.ts), self.MINIMUM_VALID_SPEED_VX_VY, _d(out))
+        if n < 0:
+            raise ValueError("invalid trajectory request")
+        return out[:n].copy()
+
+    def Get2ndOrderStateFromSolution(self, timeIdx, carIdx):
+        """(x, vx, ax, y, vy, ay) of a car at a step of the last solution (src/miqp_planner.cpp:1117-1130)"""
+        r = self.GetSolution()
+        return np.array([[getattr(r, nm)[carIdx, timeIdx] for nm in ("pos_x", "vel_x", "acc_x", "pos_y", "vel_y", "acc_y")]])
+
+    @staticmethod
+    def CarStateToMiqpState(x, y, theta, v, a):
+        """(x, vx, ax, y, vy, ay) of a car state given as pose, speed and acceleration along the heading (src/miqp_planner.cpp:1189-1200;
+        the reference takes its arguments as float: they are rounded to single precision first)"""
+        x, y, theta, v, a = (float(np.float32(q)) for q in (x, y, theta, v, a))
+        return np.array([[x, np.cos(theta) * v, np.cos(theta) * a, y, np.sin(theta) * v, np.sin(theta) * a]])
 
 
 ModelParameters_MAT_CN = ["x_ref", "vx_ref", "y_ref", "vy_ref"]

@@ -95,7 +95,7 @@ EXPORTED_SYMBOLS = ["miqp_solver_create", "miqp_solver_destroy", "miqp_solver_se
                     "miqp_solver_solve_batch_multi", "miqp_solver_raw_sizes", "miqp_solver_lift_tables", "miqp_reference_trajectory", "miqp_update_car", "miqp_fitting_polynomial_parameters",
                     "miqp_solver_solve_split", "miqp_solver_solve_split_rccl", "miqp_solver_split_roots", "miqp_comm_unique_id",
                     "miqp_comm_init", "miqp_comm_finalize", "miqp_comm_selftest", "miqp_solver_solve_stream", "miqp_solver_materialize_results",
-                    "miqp_initial_pose_check", "miqp_select_environment", "miqp_obstacle_intersects_environment", "miqp_obstacles_roi", "miqp_obstacle_intersects_environment_roi", "miqp_environment_warmstart"]
+                    "miqp_initial_pose_check", "miqp_select_environment", "miqp_obstacle_intersects_environment", "miqp_obstacles_roi", "miqp_bark_trajectory", "miqp_obstacle_intersects_environment_roi", "miqp_environment_warmstart"]
 
 
 class OptimizationStatus(enum.IntEnum):  # src/cplex_wrapper.hpp:54-59

@@ -1136,3 +1136,34 @@ def test_planner_mirror_receding_horizon_two_cars():
         last = trajs
         for c, t in zip(cars, trajs):
             pl.UpdateCar(c, [t[1, 1], t[1, 3], t[1, 5], t[1, 2], t[1, 4], t[1, 6]], lanes[c], (step + 1) * ts)
+
+
+def test_receding_horizon_through_the_bark_trajectory():
+    """TEST(miqp_planner, receding_horizon) (test/miqp_planner_test.cc:310-360): a 100 x 100 m free square, one car at (0, 1) with
+    velocity (4, -0.1) and a reference along y = 0 at 10 m/s; eight times: Plan, read the plan as GetBarkTrajectory (time, x, y,
+    theta, v), move the car to its second row through CarStateToMiqpState with a = (v1 - v0) / dt, UpdateCar.  Expected as in the
+    reference: every Plan succeeds, x grows, y falls towards the reference line, v grows.  DefaultTestSettings = the mirror's
+    defaults with the obstacle region of interest switched on (test/miqp_planner_test.cc:65-68)."""
+    from planner_miqp_amd import planner_core as K
+    S = dict(K.DefaultSettings(), obstacle_roi_filter=True, obstacle_roi_behind_distance=10.0, obstacle_roi_front_distance=100.0, obstacle_roi_side_distance=15.0)
+    pl = K.MiqpPlanner(S, mapPieces=[[[-50, -50], [50, -50], [50, 50], [-50, 50]]])
+    ref = [[0, 0], [1000, 0]]
+    st = np.array([0, 4, 0, 1, -0.1, 0], float)
+    idx = pl.AddCar(st, ref, 10, 1)
+    dt = pl.GetTs()
+    x, y, v = [st[0]], [st[3]], [float(np.hypot(st[1], st[4]))]
+    t = 0.0
+    while t < 2.0:
+        assert pl.Plan(), (t, pl.status)
+        tr = pl.GetBarkTrajectory(idx, t)
+        assert tr.shape[1] == 5 and tr.shape[0] == pl.GetN()              # the car is never slower than 0.7 m/s: nothing is cut off
+        assert tr[0, 0] == np.float64(np.float32(t)) or abs(tr[0, 0] - t) < 1e-6
+        raw = pl.GetRawCMiqpTrajectory(idx, t)
+        np.testing.assert_allclose(tr[:, 1:3], raw[:, 1:3], atol=0)        # x, y of the raw read-out
+        np.testing.assert_allclose(tr[:, 3], np.arctan2(raw[:, 4], raw[:, 3]), atol=1e-15)
+        np.testing.assert_allclose(tr[:, 4], np.hypot(raw[:, 3], raw[:, 4]), atol=1e-12)
+        x.append(tr[1, 1]); y.append(tr[1, 2]); v.append(tr[1, 4])
+        a = (tr[1, 4] - tr[0, 4]) / dt
+        pl.UpdateCar(idx, K.MiqpPlanner.CarStateToMiqpState(tr[1, 1], tr[1, 2], tr[1, 3], tr[1, 4], a).reshape(6), ref)
+        t = float(np.float32(t) + np.float32(dt))                          # (the reference counts in float)
+    assert x[0] < x[-1] and y[0] > y[-1] and v[0] < v[-1], (x, y, v)

@@ -328,3 +328,24 @@ def test_obstacle_region_of_interest_filter():
     assert pl.AddObstacle(ahead_far, False, True) == 2
     pl2 = K.MiqpPlanner(mapPieces=[road]); pl2.AddCar([0, 5, 0, 0, 0.0, 0], [[0, 0], [300, 0]], 5, 1, 0.0, True)
     assert pl2._obstacles_roi is None and pl2.AddObstacle(behind_far, False, True) == 0
+
+
+def test_bark_trajectory_read_out_is_cut_at_the_first_invalid_velocity():
+    """miqp_bark_trajectory = MiqpPlanner::GetBarkTrajectory (src/miqp_planner.cpp:1132-1170) on a hand-made result record: rows
+    (time, x, y, atan2(vy, vx), |v|), cut off at the first step with |vx| <= 0.7 and |vy| <= 0.7 (IsVxVyValid :1184-1187)"""
+    import ctypes as C
+    from planner_miqp_amd.ctypes_types import RawResults
+    r = RawResults(2, 6, 4, 0, 0, 0)
+    r.pos_x[1] = [0, 1, 2, 3, 4, 5]; r.pos_y[1] = [0, .1, .2, .3, .4, .5]
+    r.vel_x[1] = [4, 3, 0.5, 0.7, 0.2, 5]; r.vel_y[1] = [0, -1, 0.71, -0.7, 0.1, 5]
+    out = np.zeros((6, 5)); c = r.to_c(); L = K._lib()
+    K.reference_trajectory([[0, 0], [1, 0]], [0, 0, 0, 0, 1], 1.0, 2, 1.0, 1.0, 0.0, 1.0)   # (declares the prototypes)
+    n = L.miqp_bark_trajectory(C.byref(c), 1, 2.0, 0.25, 0.7, out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert n == 3                                                   # step 2 is valid through vy = 0.71, step 3 (0.7, -0.7) is not: strict inequality
+    np.testing.assert_allclose(out[:3, 0], [2.0, 2.25, 2.5]); np.testing.assert_allclose(out[:3, 1], [0, 1, 2]); np.testing.assert_allclose(out[:3, 2], [0, .1, .2])
+    np.testing.assert_allclose(out[:3, 3], np.arctan2([0, -1, 0.71], [4, 3, 0.5])); np.testing.assert_allclose(out[:3, 4], np.hypot([4, 3, 0.5], [0, -1, 0.71]))
+    assert L.miqp_bark_trajectory(C.byref(c), 2, 0.0, 0.25, 0.7, out.ctypes.data_as(C.POINTER(C.c_double))) == -1    # no such car
+    r.vel_x[0] = 0.1; r.vel_y[0] = 0.0
+    assert L.miqp_bark_trajectory(C.byref(c), 0, 0.0, 0.25, 0.7, out.ctypes.data_as(C.POINTER(C.c_double))) == 0     # standing from the start: empty
+    s = K.MiqpPlanner.CarStateToMiqpState(1.0, 2.0, 0.5, 3.0, -1.0)
+    np.testing.assert_allclose(s, [[1.0, np.cos(0.5) * 3, np.cos(0.5) * -1, 2.0, np.sin(0.5) * 3, np.sin(0.5) * -1]], rtol=1e-7)
