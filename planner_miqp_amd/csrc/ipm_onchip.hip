@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
       // converged after probe_itcap iterations is abandoned: 1 % of the probes that leave slack front-point disjunctions undecided
       // ran to the iteration limit (80) and held the launch of the larger variant up
       const bool pump_probe = BIG && B.pump_inc && B.pump_max > 0 && is_probe_word(B.batch_depth[node]);
-      if (BIG) { const int pcap = (cutoff < 1e299 && !pump_probe) ? B.probe_itcap : B.probe_itcap0; if (pcap > 0 && it > pcap && B.ws_on != 2 && is_probe_word(B.batch_depth[node])) { ok = 2; break; } }
+      if (BIG) { const int pcap = (cutoff < 1e299 && (!pump_probe || (B.pump_inc & 2))) ? B.probe_itcap : B.probe_itcap0; if (pcap > 0 && it > pcap && B.ws_on != 2 && is_probe_word(B.batch_depth[node])) { ok = 2; break; } }
       if (it > 1 && resid_fac * R0 < B.cut_gate * (1.0 + fabs(obj)) && obj + (pump_probe ? 0.0 : RHO_EL * tsum) - (double)ncomp * comp - resid_fac * R0 * D[Y.d_misc + 2] > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }   // (dual value minus the allowance for the stationarity residual still left, see batch_bound)
       }
 #if !MIQP_DUAL_START
