@@ -841,8 +841,10 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(16384, 32768 / (NS * lanes)));   // (the lanes of a call keep the round width of the undivided call)
   // three and four cars: a node relaxation costs ~15 x that of two cars (memory-backed kernel, stage vector 24 / 32), a round of 32768 nodes
   // lasts 0.13 s and an instance that shares the device gets 80 rounds in its 10 s - fewer than the levels of its first dive.  Rounds of
-  // 5120 nodes (0.035 s) give the tree its depth back at a quarter less node throughput: cfg5, 16 in flight, 7 -> 11 of 16 proven in 10 s
-  if (O0.nodes_per_round <= 0 && Y.C >= 3 && NS > 1) npr = std::max(16, std::min(npr, 5120 / NS));
+  // 5120 nodes (0.035 s) give the tree its depth back at a quarter less node throughput: cfg5, 16 in flight, 7 -> 11 of 16 proven in 10 s.
+  // Since the re-rounding finds the first incumbents within a few rounds the depth matters less and the throughput more: 8192 nodes
+  // (3072 / 5120 / 8192 / 10240 / 12288 / 16384: 14 / 14 / 15 / 14 / 14 / 14 of 16, the open gaps smallest at 8192 - 12288; profiles/r04b_heuristics_ab.txt)
+  if (O0.nodes_per_round <= 0 && Y.C >= 3 && NS > 1) npr = std::max(16, std::min(npr, 8192 / NS));
   if (O0.nodes_per_round <= 0 && std::getenv("MIQP_NPR")) npr = std::max(1, std::atoi(std::getenv("MIQP_NPR")));  // tuning knob
   int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (std::getenv("MIQP_OPEN_CAP") ? std::atoi(std::getenv("MIQP_OPEN_CAP")) : std::max(1 << 17, std::min(1 << 20, (1 << 28) / NS)));   // near lists: 1 M entries per instance up to n = 256 (10 GB of list entries), 262144 at n = 1024; records are shared
   if (open_cap < 64) open_cap = 64;
