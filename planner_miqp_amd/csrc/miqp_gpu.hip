@@ -845,6 +845,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   // Since the re-rounding finds the first incumbents within a few rounds the depth matters less and the throughput more: 8192 nodes
   // (3072 / 5120 / 8192 / 10240 / 12288 / 16384: 14 / 14 / 15 / 14 / 14 / 14 of 16, the open gaps smallest at 8192 - 12288; profiles/r04b_heuristics_ab.txt)
   if (O0.nodes_per_round <= 0 && Y.C >= 3 && NS > 1) npr = std::max(16, std::min(npr, 8192 / NS));
+  // ... and a single solve of three or four cars takes 2048 nodes per round (16384 / 8192 / 4096 / 2048: the sixteen cfg5 seeds in 35.1 / 34.3 / 29.5 / 25.3 s, 15 proven each time;
+  // seed 15 8.5 -> 4.5 s): its rounds are as long as their slowest node whatever their width (~25 ms), so what a narrower round gives up is node throughput it could not use for the proof anyway
+  if (O0.nodes_per_round <= 0 && Y.C >= 3 && NS == 1) npr = std::min(npr, 2048);
   if (O0.nodes_per_round <= 0 && std::getenv("MIQP_NPR")) npr = std::max(1, std::atoi(std::getenv("MIQP_NPR")));  // tuning knob
   int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (std::getenv("MIQP_OPEN_CAP") ? std::atoi(std::getenv("MIQP_OPEN_CAP")) : std::max(1 << 17, std::min(1 << 20, (1 << 28) / NS)));   // near lists: 1 M entries per instance up to n = 256 (10 GB of list entries), 262144 at n = 1024; records are shared
   if (open_cap < 64) open_cap = 64;
