@@ -736,7 +736,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     // not converged after probe_itcap iterations - nearly always an infeasible rounding, 27 iterations to prove - is abandoned.
     // The launch of this kernel lasts as long as its slowest node.
     const bool pump_probe = B.pump_inc && B.pump_max > 0 && is_probe_word(B.batch_depth[node]);   // (re-rounding with an incumbent, pump_inc: a probe is then only cut off by its objective, not by the penalty of its violated rows - an infeasible one converges to its least-violation point and is re-rounded by eval_kernel)
-    { const int pcap = (cutoff < 1e299 && (!pump_probe || (B.pump_inc & 2))) ? B.probe_itcap : B.probe_itcap0;   // (pump_inc bit 1: the cap of the phase with an incumbent stays)   // (without an incumbent the probes are given longer: the re-rounding needs the converged solution of an infeasible one)
+    { const int pcap = (cutoff < 1e299 && (!pump_probe || (B.pump_inc & 2))) ? B.probe_itcap : B.probe_itcap0;   // (without an incumbent the probes are given longer: the re-rounding needs the converged solution of an infeasible one; pump_inc bit 1: the cap of the phase with an incumbent stays)
       if (pcap > 0 && it > pcap && B.ws_on != 2 && is_probe_word(B.batch_depth[node])) { ok = 2; break; } }
     // dual bound of the penalised problem: primal value - total complementarity (valid once the iterate is dual feasible)
 #ifdef MIQP_PROFILE
