@@ -56,8 +56,11 @@ def pack(M, rows):
     return keys, G, h, av
 
 
-def ipm(M, keys, G, h, av, start=None, tol=1e-6, maxit=80, theta=1.0, trace=False, mu0=1.0, delta=1e-3, mode="primal", lamfloor=None, sviol=0.0, svmin=0.0, muv=None):
-    """start: None (cold) or dict(U=, lam={key: lambda}); mode: how the parent's multipliers are used"""
+def ipm(M, keys, G, h, av, start=None, tol=1e-6, maxit=80, theta=1.0, trace=False, mu0=1.0, delta=1e-3, mode="primal", lamfloor=None, sviol=0.0, svmin=0.0, muv=None, pc=0, sig_hi=None):
+    """start: None (cold) or dict(U=, lam={key: lambda}); mode: how the parent's multipliers are used;
+    pc: 0 the device's centring rule (sigma = 1 - alpha of the previous step), 1 sigma from an affine predictor step ((mu_aff / mu)^3, Mehrotra's
+    heuristic) without the second-order term, 2 with it (the full predictor-corrector); both cost a second solve with the same factorisation.
+    Returns it = iterations and solves = linear solves (1 or 2 per iteration)"""
     H, g = M.H, M.g
     el = av == 0
     m = len(h); ncomp = int(el.sum()) * 2 + int((~el).sum())
@@ -97,7 +100,7 @@ def ipm(M, keys, G, h, av, start=None, tol=1e-6, maxit=80, theta=1.0, trace=Fals
                 t[k] = tt; s[k] = c[k] + tt; lam[k] = lk
         else:
             lam[k] = max(1.0, -2 * c[k] * av[k] + 1.0, lp[k]); s[k] = c[k] + lam[k] / av[k]
-    sigma = SIG0; resid_fac = 1.0; R0 = None; ok = False
+    sigma = SIG0; resid_fac = 1.0; R0 = None; ok = False; nsolves = 0
     wmix = theta if warm else 1.0
     it = 0
     for it in range(1, maxit + 1):
@@ -112,14 +115,27 @@ def ipm(M, keys, G, h, av, start=None, tol=1e-6, maxit=80, theta=1.0, trace=Fals
         if comp < tol * max(1.0, abs(obj)) and resid_fac * R0 < 1e-7:
             ok = True
             break
-        tau = sigma * comp * wmix; k1 = 1.0 - sigma * (1.0 - wmix)
-        r1 = tau - k1 * s * lam
-        r2 = np.where(el, tau - k1 * t * mu, 0.0)
         zz = np.where(el, t / mu, 1.0 / np.where(el, 1.0, av))
         w = 1.0 / (s / lam + zz)
-        kap = (r1 / lam - np.where(el, r2 / mu, 0.0)) * w
         K = H + G.T @ (w[:, None] * G)
-        dU = np.linalg.solve(K, -rd - G.T @ kap)
+        so1 = 0.0; so2 = 0.0
+        if pc:
+            r1a = -s * lam; r2a = np.where(el, -t * mu, 0.0)
+            kapa = (r1a / lam - np.where(el, r2a / mu, 0.0)) * w
+            dUa = np.linalg.solve(K, -rd - G.T @ kapa); nsolves += 1
+            dla = w * (G @ dUa) + kapa; dsa = (r1a - s * dla) / lam; dta = np.where(el, (r2a + t * dla) / mu, 0.0)
+            ra = [np.where(dsa < 0, -s / np.where(dsa < 0, dsa, -1), np.inf), np.where(dla < 0, -lam / np.where(dla < 0, dla, -1), np.inf),
+                  np.where(el & (dta < 0), -t / np.where(dta < 0, dta, -1), np.inf), np.where(el & (dla > 0), mu / np.where(dla > 0, dla, 1), np.inf)]
+            aa = min(1.0, min(float(r.min()) for r in ra))
+            mua = ((s + aa * dsa) @ (lam + aa * dla) + ((t + aa * dta) * (mu - aa * dla))[el].sum()) / max(1, ncomp)
+            sigma = min(sig_hi if sig_hi is not None else SIG_HI, max(SIG_LO if pc < 3 else 1e-4, (mua / comp) ** 3))
+            if pc == 2:
+                so1 = dsa * dla; so2 = np.where(el, -dta * dla, 0.0)
+        tau = sigma * comp * wmix; k1 = 1.0 - sigma * (1.0 - wmix)
+        r1 = tau - k1 * s * lam - so1
+        r2 = np.where(el, tau - k1 * t * mu - so2, 0.0)
+        kap = (r1 / lam - np.where(el, r2 / mu, 0.0)) * w
+        dU = np.linalg.solve(K, -rd - G.T @ kap); nsolves += 1
         gd = G @ dU
         dl = w * gd + kap
         ds = (r1 - s * dl) / lam
@@ -134,7 +150,8 @@ def ipm(M, keys, G, h, av, start=None, tol=1e-6, maxit=80, theta=1.0, trace=Fals
         alpha = min(1.0, STEPFRAC * amax)
         U = U + alpha * dU; s = s + alpha * ds; lam = lam + alpha * dl; t = t + alpha * dt
         resid_fac *= (1.0 - alpha)
-        sigma = min(SIG_HI, max(SIG_LO, 1.0 - alpha))
+        if not pc:
+            sigma = min(SIG_HI, max(SIG_LO, 1.0 - alpha))
         if trace:
             print("        alpha %.4f sigma_next %.3f" % (alpha, sigma))
         if alpha < 1e-12:
@@ -143,7 +160,7 @@ def ipm(M, keys, G, h, av, start=None, tol=1e-6, maxit=80, theta=1.0, trace=Fals
     viol = float(np.maximum(-c, 0)[el].max()) if el.any() else 0.0
     sc = float((0.5 * av[~el] * (lam[~el] / av[~el]) ** 2).sum()) if (~el).any() else 0.0
     obj = float(0.5 * U @ H @ U + g @ U + M.k0) + sc
-    return dict(U=U, Z=M.Z0 + M.ZU @ U, obj=obj, viol=viol, it=it, ok=ok, lam={k: float(v) for k, v in zip(keys, lam)})
+    return dict(U=U, Z=M.Z0 + M.ZU @ U, obj=obj, viol=viol, it=it, ok=ok, solves=nsolves, lam={k: float(v) for k, v in zip(keys, lam)})
 
 
 def main():
@@ -179,7 +196,19 @@ def main():
         "parent_s mu.01 th.3": dict(mode="parent_s", mu0=0.01, theta=0.3),
         "parent_s mu.001": dict(mode="parent_s", mu0=0.001),
     }
-    its = {k: [] for k in variants}; fails = {k: 0 for k in variants}
+    if len(sys.argv) > 4 and sys.argv[4] == "pc":   # the centring rules against each other, product start (parent's solution, mu0 = 1, delta = 1e-3)
+        variants = {
+            "cold": dict(start=False),
+            "cold pc1": dict(start=False, pc=1),
+            "cold pc2": dict(start=False, pc=2),
+            "primal (device rule)": dict(mode="primal"),
+            "primal pc1": dict(mode="primal", pc=1),
+            "primal pc1 hi1": dict(mode="primal", pc=1, sig_hi=1.0),
+            "primal pc1 lo1e-4": dict(mode="primal", pc=3),
+            "primal pc2": dict(mode="primal", pc=2),
+            "primal pc2 hi1": dict(mode="primal", pc=2, sig_hi=1.0),
+        }
+    its = {k: [] for k in variants}; fails = {k: 0 for k in variants}; sol = {k: [] for k in variants}
     heap = [(-math.inf, 0, {}, None)]
     cnt = itertools.count(1)
     inc = math.inf; nodes = 0
@@ -194,7 +223,7 @@ def main():
             for name, kw in variants.items():
                 kw = dict(kw); st = par if kw.pop("start", True) else None
                 r = ipm(M, keys, G, h, av, start=st, **kw)
-                its[name].append(r["it"])
+                its[name].append(r["it"]); sol[name].append(r["solves"])
                 if not r["ok"] or abs(r["obj"] - ref["obj"]) > 1e-4 * max(1.0, abs(ref["obj"])):
                     fails[name] += 1
         obj = ref["obj"] + B.const_cost(fix)
@@ -211,7 +240,7 @@ def main():
     print("%s seed %d: %d nodes, incumbent %s, rows of the last node %d" % (cfg, seed, nodes, inc, len(keys)))
     for name in variants:
         a = np.array(its[name])
-        print("  %-22s mean %5.2f  median %4.1f  p90 %4.1f  max %3d  (%d children, %d not converged / other optimum)" % (name, a.mean(), np.median(a), np.percentile(a, 90), a.max(), len(a), fails[name]))
+        print("  %-22s mean %5.2f  median %4.1f  p90 %4.1f  max %3d  solves %5.2f  (%d children, %d not converged / other optimum)" % (name, a.mean(), np.median(a), np.percentile(a, 90), a.max(), np.mean(sol[name]), len(a), fails[name]))
 
 
 if __name__ == "__main__":
