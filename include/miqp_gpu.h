@@ -181,6 +181,14 @@ int miqp_solver_last_timing(const miqp_solver_t* s, double* out6);
  * instances than its per-instance arrays hold), out[2] = 1 when the context was built or rebuilt by that call, else 0 */
 int miqp_solver_last_setup(const miqp_solver_t* s, double* out3);
 
+/* why the last solve of this handle did not run or did not finish, as text ("" when there is nothing to say; the pointer is valid
+ * until the next call on the handle).  The reference logs such conditions with LOG(ERROR) inside callCplex
+ * (src/cplex_wrapper.cpp:97-109, 162-180); here the status code says WHAT (the four OptimizationStatus values), this says WHY:
+ * malformed parameters, the queue abandoned before the instance was admitted, an instance retired because it made no progress
+ * for 64 branch-and-bound rounds (it then reports FAILED_SEG_FAULT without an incumbent, SUCCESS / time-limit-feasible with one -
+ * never the time-limit verdict of an instance that really used up max_solution_time). */
+const char* miqp_solver_last_error(const miqp_solver_t* s);
+
 /* ---- planner core: the host logic directly above the solve ---- */
 
 /* ParameterPreparer::CalculateFractionParameters             common/parameter/parameter_preparer.cpp:37-52; out[R*4] */

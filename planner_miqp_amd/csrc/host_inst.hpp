@@ -18,6 +18,16 @@
 
 #include "../../include/miqp_types.h"
 
+// Environment switches of the library.  KNOB_P: read by the shipped library - the list, with defaults, is INTEGRATION.md section "Environment
+// switches" (tests/test_abi_cpu.py compares the two).  KNOB_T: an experiment or a tuning sweep of an earlier round; live only in a tuning build
+// (-DMIQP_TUNING=1, tools/build_variants.sh), in the product build the name is not even in the binary and the documented default applies.
+#define KNOB_P(name) std::getenv(name)
+#ifdef MIQP_TUNING
+#define KNOB_T(name) std::getenv(name)
+#else
+#define KNOB_T(name) ((const char*)nullptr)
+#endif
+
 namespace miqp {
 
 constexpr int MAXC = 4;          // cars supported by the device kernels (stage vector of at most 32 entries)
@@ -271,7 +281,7 @@ inline Layout make_layout(int C, int N, int R, int P, int E, int EL, int O, int 
   // (OFF by default; MIQP_RELAX_FRONT=1 switches the relaxed rows on.  Measured on the bench instances: deciding a car/car group
   // on a front point BEFORE the region of its car - with the front-point offset bounded over the region set - doubles the nodes,
   // 23 M against 10.9 M on a 2048-instance queue: the exact row is still violated afterwards, the region is branched anyway)
-  { const char* e = std::getenv("MIQP_RELAX_FRONT"); Y.relax_front_off = (e && std::atoi(e) == 1) ? 0 : 1; }
+  { const char* e = KNOB_T("MIQP_RELAX_FRONT"); Y.relax_front_off = (e && std::atoi(e) == 1) ? 0 : 1; }
   Y.SC = 16 + 5 * EL + 5 * O; Y.NSLOT = C * Y.SC + Y.NP * 24; Y.ROWCAP = N * Y.NSLOT;
   int o = 0;
   Y.d_x0 = o; o += C * 6; Y.d_wd = o; o += Y.nz; Y.d_ref = o; o += N * Y.nz; Y.d_glob = o; o += 8; Y.d_u0box = o; o += C * 4;
@@ -547,7 +557,7 @@ inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int*
       // flagged by a sector row, and those are settled by the branching itself), but two more general rows per undecided
       // (car, step) push two thirds of the nodes over the on-chip kernel's 128 general rows into the memory-backed kernel
       // (+25 % interior point time).  The boxes are box rows of the kernels: free.
-      { static const bool cone = std::getenv("MIQP_HULL_CONE") != nullptr && std::atoi(std::getenv("MIQP_HULL_CONE")) != 0; if (!cone) continue; }
+      { static const bool cone = KNOB_T("MIQP_HULL_CONE") != nullptr && std::atoi(KNOB_T("MIQP_HULL_CONE")) != 0; if (!cone) continue; }
       // the cone around all sectors = complement of the widest angular gap between them
       std::vector<int> ord(cones.size()); for (size_t k = 0; k < ord.size(); ++k) ord[k] = (int)k;
       std::sort(ord.begin(), ord.end(), [&](int a, int b) { return cones[a][0] < cones[b][0]; });
@@ -679,7 +689,10 @@ inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int*
       T[Y.i_boxskip + c * N + i] = skip;
     }
   }
-  D[Y.d_misc + 2] = std::max(1.0, diam);
+  // (twice the diameter: |z' - z|_1 is taken between the interior point ITERATE z and a point z' of the box, and the iterate may lie outside the box
+  // by the elastic slack of its velocity / acceleration / jerk rows - those are penalised, not hard - while its distance to the box never exceeds
+  // the box's own size once the penalty term is what the cutoff test carries anyway; the inputs of step 0 are counted through jhi - jlo of step 1)
+  D[Y.d_misc + 2] = std::max(1.0, 2.0 * diam);
   // Car/car alternatives that no reachable pair of positions can satisfy (exact): alternative a of group g at step i
   // asks  coord(A) - coord(B) <= -(separation) for a rear or front point of each car; front points lie within one wheel
   // base of the rear point.  Bit (4 g + a) of i_c2callow[pair][step] is set when the alternative is possible.

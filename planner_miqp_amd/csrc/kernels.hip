@@ -2838,12 +2838,21 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
     } else B.inst_lns[inst] = flags & ~1;
     int base = 0, rec = 0;
     if (n > 0) {
-      base = atomicAdd(B.batch_count, n);
-      if (base + n > B.batch_cap) { n = base < B.batch_cap ? B.batch_cap - base : 0; }
-      if (n > 0) {   // node records: recycled ones first (as eval_kernel takes them), fresh ones otherwise; the evaluation of the round frees them again
-        const unsigned int h = atomicAdd(B.free_head, (unsigned int)n);
-        if ((int)(*B.free_limit - h) >= n) { for (int q = 0; q < n; ++q) nb_rec[q] = B.free_q[(h + q) % (unsigned int)B.pool_cap]; }
-        else { rec = atomicAdd(B.pool_count, n); if (rec + n > B.pool_cap) n = 0; for (int q = 0; q < n; ++q) nb_rec[q] = rec + q; }
+      // node records FIRST: recycled ones (as eval_kernel takes them), fresh ones otherwise; the evaluation of the round frees them again.  Batch
+      // slots are reserved only for records that exist - a reserved slot that is never written would keep the node of the round before, and the
+      // interior point and evaluation kernels would process a record that has been freed or reused since (advisor finding, round 4)
+      const unsigned int h = atomicAdd(B.free_head, (unsigned int)n);
+      if ((int)(*B.free_limit - h) >= n) { for (int q = 0; q < n; ++q) nb_rec[q] = B.free_q[(h + q) % (unsigned int)B.pool_cap]; }
+      else {
+        rec = atomicAdd(B.pool_count, n);
+        if (rec + n > B.pool_cap) { atomicSub(B.pool_count, n); n = 0; }   // the pool is exhausted: no neighbours this time (heuristic nodes - the tree is not affected), the count is put back
+        for (int q = 0; q < n; ++q) nb_rec[q] = rec + q;
+      }
+      if (n > 0) {
+        base = atomicAdd(B.batch_count, n);
+        const int fit = base + n > B.batch_cap ? (base < B.batch_cap ? B.batch_cap - base : 0) : n;
+        for (int q = fit; q < n; ++q) { const unsigned int t_ = atomicAdd(B.free_tail, 1u); B.free_q[t_ % (unsigned int)B.pool_cap] = nb_rec[q]; }   // records without a batch slot go back to the pool
+        n = fit;
       }
     }
     sh_n = n; sh_base = base; sh_rec = rec;

@@ -336,13 +336,13 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
     X.oc_grid = 0;
     const OcLds ol = oc_lds_layout(Y.N, Y.fixlen);
     const size_t bitmap_b = (size_t)((Y.N * Y.NSLOT + 63) / 64) * 10 + 16;   // decode bitmap + prefix inside the scratch region
-    if (Y.C <= 2 && Y.N <= 2 * OC_NSL && bitmap_b + 1024 <= (size_t)(ol.r - ol.u) && !std::getenv("MIQP_IPM_V1")) {
+    if (Y.C <= 2 && Y.N <= 2 * OC_NSL && bitmap_b + 1024 <= (size_t)(ol.r - ol.u) && !KNOB_T("MIQP_IPM_V1")) {
       size_t lo = (size_t)ol.total + 16;
       int perc = (int)std::min<size_t>(8, (160 * 1024) / lo);
-      if (std::getenv("MIQP_OC_WAVES")) perc = std::max(1, std::min(perc, std::atoi(std::getenv("MIQP_OC_WAVES"))));   // (experiment: resident wavefronts of the on-chip kernel per CU)
+      if (KNOB_T("MIQP_OC_WAVES")) perc = std::max(1, std::min(perc, std::atoi(KNOB_T("MIQP_OC_WAVES"))));   // (experiment: resident wavefronts of the on-chip kernel per CU)
       if (perc >= 1) X.oc_grid = cus * perc;
-      X.ocb_grid = 0; X.concurrent_big = !(std::getenv("MIQP_CONCURRENT_BIG") && std::atoi(std::getenv("MIQP_CONCURRENT_BIG")) == 0);
-      if (X.oc_grid > 0 && !(std::getenv("MIQP_OC_BIG") && std::atoi(std::getenv("MIQP_OC_BIG")) == 0)) {
+      X.ocb_grid = 0; X.concurrent_big = !(KNOB_T("MIQP_CONCURRENT_BIG") && std::atoi(KNOB_T("MIQP_CONCURRENT_BIG")) == 0);
+      if (X.oc_grid > 0 && !(KNOB_T("MIQP_OC_BIG") && std::atoi(KNOB_T("MIQP_OC_BIG")) == 0)) {
         const size_t lb = (size_t)oc_lds_layout(Y.N, Y.fixlen, OC_GCAP_BIG).total + 16;
         const int pb = (int)std::min<size_t>(4, (160 * 1024) / lb);
         if (pb >= 1) X.ocb_grid = cus * pb;
@@ -353,7 +353,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
     // nodes - a wavefront slot comes free F times as often, so the short kernels of ANOTHER lane of the same device (MIQP_LANES: its
     // evaluation and selection) are dispatched between them instead of waiting for the whole launch.  Only the gain buffer grows.
     X.kg_blocks = X.ipm_grid_max;
-    if (const char* e = std::getenv("MIQP_OC_OVERSUB")) { const int f = std::max(1, std::min(64, std::atoi(e)));
+    if (const char* e = KNOB_T("MIQP_OC_OVERSUB")) { const int f = std::max(1, std::min(64, std::atoi(e)));
       X.oc_grid = std::min(batch_alloc, X.oc_grid * f); X.ocb_grid = std::min(batch_alloc, X.ocb_grid * f); X.kg_blocks = std::max(X.kg_blocks, std::max(X.oc_grid, X.ocb_grid)); }
   }
   // node pool: live nodes are bounded by the open lists plus one round of children; processed records are recycled
@@ -362,17 +362,17 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   // far tier of the open lists (16 B per entry): up to 2^24 entries per instance within a tenth of the free memory
   // (256 instances: 4 M entries each, 16 GB); MIQP_FAR_CAP overrides, 0 switches the tier off
   { size_t fc = std::min<size_t>((size_t)1 << 24, free_b / 10 / 16 / (size_t)n_slots);
-    if (const char* e = std::getenv("MIQP_FAR_CAP")) fc = (size_t)std::max(0LL, std::atoll(e));
+    if (const char* e = KNOB_P("MIQP_FAR_CAP")) fc = (size_t)std::max(0LL, std::atoll(e));
     X.far_cap = fc < 4096 ? 0 : (int)fc; }
   size_t want = (size_t)n_slots * ((size_t)open_cap + (size_t)X.far_cap + (size_t)npr * 64 + 64) + (size_t)n_inst * roots_per_inst;
-  const bool ws_on = !(std::getenv("MIQP_WARM") && std::atoi(std::getenv("MIQP_WARM")) == 0);   // warm start of the node relaxations (MIQP_WARM=0: cold)
+  const bool ws_on = !(KNOB_T("MIQP_WARM") && std::atoi(KNOB_T("MIQP_WARM")) == 0);   // warm start of the node relaxations (MIQP_WARM=0: cold)
   size_t maxrec = std::min<size_t>((size_t)64 << 30, free_b / 4) / (size_t)Y.fixlen;   // node records: up to 64 GB of the 288 GB, at most a quarter of what is free
   X.pool_cap = (int)std::min<size_t>(std::min(want, maxrec), (size_t)0x7FFFFFF0);
   DevBuf& B = X.B; std::memset(&B, 0, sizeof(B));
   B.qp_tol = QP_TOL; B.use_cutoff = 1;
-  B.cut_gate = std::getenv("MIQP_CUT_GATE") ? std::atof(std::getenv("MIQP_CUT_GATE")) : 1.0e-5;
-  B.opt2 = std::getenv("MIQP_OPT2") ? std::atoi(std::getenv("MIQP_OPT2")) : (8 << 4);   // rounding probe at nodes with at most 8 violated sites (eval_kernel)
-  B.seq_kinds = std::getenv("MIQP_SEQ_KINDS") ? (int)std::strtoul(std::getenv("MIQP_SEQ_KINDS"), nullptr, 0) : (5 << 8);   // plain K-way children, branching order 5 (see eval_kernel)
+  B.cut_gate = KNOB_P("MIQP_CUT_GATE") ? std::atof(KNOB_P("MIQP_CUT_GATE")) : 1.0e-5;
+  B.opt2 = KNOB_T("MIQP_OPT2") ? std::atoi(KNOB_T("MIQP_OPT2")) : (8 << 4);   // rounding probe at nodes with at most 8 violated sites (eval_kernel)
+  B.seq_kinds = KNOB_P("MIQP_SEQ_KINDS") ? (int)std::strtoul(KNOB_P("MIQP_SEQ_KINDS"), nullptr, 0) : (5 << 8);   // plain K-way children, branching order 5 (see eval_kernel)
   B.Y = Y; B.pool_cap = X.pool_cap; B.open_cap = open_cap; B.batch_cap = batch_cap; B.nodes_per_round = npr; B.n_inst = n_call; B.n_slots = n_slots; B.root_stride = roots_per_inst;
   double* dd; int* ii;
   if (!X.alloc(&dd, (size_t)n_inst * Y.dstride)) return false; B.inst_d = dd;
@@ -387,7 +387,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
     size_t zc = std::max<size_t>((size_t)2 << 20, (size_t)n_slots * 16384);
     zc = std::min(zc, std::min<size_t>((size_t)X.pool_cap, free_b / 8 / zb));
     // the parents' multipliers beside them (on-chip kernels only): +N x 128 B for the box keys and LGEN_BYTES for the general rows per record
-    const bool ws_dual = MIQP_DUAL_START && X.oc_grid > 0 && !(std::getenv("MIQP_WS_DUAL") && std::atoi(std::getenv("MIQP_WS_DUAL")) == 0);   // (diagnostic build -DMIQP_DUAL_START=1 only)
+    const bool ws_dual = MIQP_DUAL_START && X.oc_grid > 0 && !(KNOB_T("MIQP_WS_DUAL") && std::atoi(KNOB_T("MIQP_WS_DUAL")) == 0);   // (diagnostic build -DMIQP_DUAL_START=1 only)
     if (ws_dual) zc = std::min(zc, free_b / 5 / (zb + (size_t)lbox_floats(Y.N) * 4 + LGEN_BYTES));
     if (!X.alloc(&B.pool_Z, zc * (size_t)Y.N * Y.nz)) return false;
     B.z_cap = (int)zc;
@@ -401,10 +401,10 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
     }
   }
   B.ws_on = ws_on ? 1 : 0;
-  B.ws_mu = std::getenv("MIQP_WS_MU") ? std::atof(std::getenv("MIQP_WS_MU")) : 1.0;
-  B.ws_delta = std::getenv("MIQP_WS_DELTA") ? std::atof(std::getenv("MIQP_WS_DELTA")) : 1.0e-3;
-  B.ws_svmin = std::getenv("MIQP_WS_SVMIN") ? std::atof(std::getenv("MIQP_WS_SVMIN")) : 0.0;
-  B.ws_theta = std::getenv("MIQP_WS_THETA") ? std::min(1.0, std::max(0.0, std::atof(std::getenv("MIQP_WS_THETA")))) : 1.0;
+  B.ws_mu = KNOB_T("MIQP_WS_MU") ? std::atof(KNOB_T("MIQP_WS_MU")) : 1.0;
+  B.ws_delta = KNOB_T("MIQP_WS_DELTA") ? std::atof(KNOB_T("MIQP_WS_DELTA")) : 1.0e-3;
+  B.ws_svmin = KNOB_T("MIQP_WS_SVMIN") ? std::atof(KNOB_T("MIQP_WS_SVMIN")) : 0.0;
+  B.ws_theta = KNOB_T("MIQP_WS_THETA") ? std::min(1.0, std::max(0.0, std::atof(KNOB_T("MIQP_WS_THETA")))) : 1.0;
   if (!X.alloc(&B.pool_count, 1)) return false;
   if (!X.alloc(&B.free_q, (size_t)X.pool_cap)) return false;
   if (!X.alloc(&B.free_head, 1)) return false;
@@ -475,7 +475,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   HIP_OK(hipMemset(X.ctr, 0, 64));
   // buffers of the concurrent probe launch (two cars and fewer, on-chip kernel in use): 1024 resident blocks
   X.probe_grid = 0;
-  if (X.oc_grid > 0 && !(std::getenv("MIQP_PROBE_OVERLAP") && std::atoi(std::getenv("MIQP_PROBE_OVERLAP")) == 0)) {
+  if (X.oc_grid > 0 && !(KNOB_T("MIQP_PROBE_OVERLAP") && std::atoi(KNOB_T("MIQP_PROBE_OVERLAP")) == 0)) {
     X.probe_grid = std::min(batch_alloc, 1536);
     if (!X.alloc(&X.work_counter2, 1)) return false;
     if (!X.alloc(&X.rowstate2, (size_t)X.probe_grid * NFIELD * Y.ROWCAP)) return false;
@@ -490,11 +490,11 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&B.ovf2_list, batch_alloc)) return false;
   HIP_OK(hipMemset(B.ovf2_count, 0, 4));
   HIP_OK(hipMemset(B.ovf_count, 0, 4));
-  if (std::getenv("MIQP_STATS")) {
+  if (KNOB_P("MIQP_STATS")) {
     if (!X.alloc(&B.stats, 256)) return false; HIP_OK(hipMemset(B.stats, 0, 256 * 8));
     if (!X.alloc(&B.pool_origin, (size_t)X.pool_cap)) return false; HIP_OK(hipMemset(B.pool_origin, 0, (size_t)X.pool_cap));
   }
-  if (std::getenv("MIQP_NOCUT")) B.use_cutoff = 0;   // diagnostic: every node relaxation runs to convergence (tells infeasible children from expensive ones)
+  if (KNOB_T("MIQP_NOCUT")) B.use_cutoff = 0;   // diagnostic: every node relaxation runs to convergence (tells infeasible children from expensive ones)
   if (!X.alloc(&B.prof, 128)) return false;
   (void)hipMemset(B.prof, 0, 128 * 8);
   if (!X.alloc(&B.active_insts, 1)) return false;
@@ -512,7 +512,7 @@ size_t ipm_lds_bytes(const Layout& Y) {
   size_t d = (size_t)N * NZ + (size_t)ipm_scratch_doubles(N, Y.C) + NZ + 8 + 32 + 2 * ((N + 6) / 2 + 1);
   return d * 8 + (size_t)Y.fixlen + 16;
 }
-bool multi_row_lifting_on() { const char* e = std::getenv("MIQP_SEQ_KINDS"); return e && (std::strtoul(e, nullptr, 0) & 0x80000000ul) != 0ul; }
+bool multi_row_lifting_on() { const char* e = KNOB_P("MIQP_SEQ_KINDS"); return e && (std::strtoul(e, nullptr, 0) & 0x80000000ul) != 0ul; }
 size_t eval_lds_bytes(const Layout& Y) {
   size_t d = (size_t)Y.N * Y.nz + (size_t)Y.C * Y.N * Y.P + 2 * (size_t)Y.C * Y.N;
   return d * 8 + (size_t)(2 * Y.C * Y.N + 64) * 4 + 64 * 8 + 3 * (size_t)Y.fixlen + (size_t)64 * (Y.nz + 1) * 8 + 64
@@ -571,7 +571,7 @@ void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool o
       int* const cs = pc ? X.ctr + 8 * par : nullptr;   // [0] batch count, [1] standard launch, [2] its hand-over list, [3] the larger variant's list, [4] the larger variant, [5] the memory-backed launch behind it
       if (pc) { Bc.work_counter = cs + 1; Bc.ovf_count = cs + 2; Bc.ovf2_count = cs + 3; }
       DevBuf Bp = Bc; Bp.ovf_mode = 2; Bp.work_counter = pc ? cs + 4 : X.work_counter2; Bp.rowstate = X.rowstate2; Bp.rowcache = X.rowcache2; Bp.kgain = X.kgain2;
-      static const int big_grid_cap = std::getenv("MIQP_BIG_GRID") ? std::atoi(std::getenv("MIQP_BIG_GRID")) : 1 << 30;
+      static const int big_grid_cap = KNOB_T("MIQP_BIG_GRID") ? std::atoi(KNOB_T("MIQP_BIG_GRID")) : 1 << 30;
       const int gb = std::min(std::min(bc, big_grid_cap), std::min(X.probe_grid, X.ocb_grid));
       if (Y.C == 1) launch_ipm_oc_big<1>(Bp, gb, l_ocb, X.stream2, !pc); else launch_ipm_oc_big<2>(Bp, gb, l_ocb, X.stream2, !pc);
       DevBuf Bm = Bp; Bm.ovf_mode = 1; Bm.ovf_count = Bc.ovf2_count; Bm.ovf_list = B.ovf2_list; if (pc) Bm.work_counter = cs + 5;
@@ -824,7 +824,10 @@ void split_roots(const Layout& Y, const int* T, std::vector<std::vector<std::pai
 // hands its slot to the next one at the following round.
 // `lane` / `lanes`: this call is one of `lanes` concurrent calls that share the device, each with its own context (miqp_solver_solve_stream)
 bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const SplitCtx* split = nullptr, int inflight = 0, int lane = 0, int lanes = 1) {
-  if (split && n != 1) { for (int k = 0; k < n; ++k) statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; return false; }
+  // every way out of this function that is not the result loop at its end (a failed HIP call, a failed exchange) leaves "the solver
+  // could not run" behind: a caller's zero-filled status array would otherwise read as SUCCESS for instances that were never solved
+  for (int k = 0; k < n; ++k) { statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; if (S[k]) { S[k]->status = MIQP_STATUS_FAILED_SEG_FAULT; S[k]->has_sol = false; S[k]->rescache.reset(); } }
+  if (split && n != 1) return false;
   BatchShape bs = batch_layout(S, n);
   if (!bs.ok) { for (int k = 0; k < n; ++k) { if (S[k]) S[k]->err = bs.err; statuses[k] = MIQP_STATUS_FAILED_SEG_FAULT; } std::fprintf(stderr, "[miqp_gpu] %s\n", bs.err.c_str()); return false; }
   const Layout& Y = bs.Y;
@@ -848,8 +851,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   // ... and a single solve of three or four cars takes 2048 nodes per round (16384 / 8192 / 4096 / 2048: the sixteen cfg5 seeds in 35.1 / 34.3 / 29.5 / 25.3 s, 15 proven each time;
   // seed 15 8.5 -> 4.5 s): its rounds are as long as their slowest node whatever their width (~25 ms), so what a narrower round gives up is node throughput it could not use for the proof anyway
   if (O0.nodes_per_round <= 0 && Y.C >= 3 && NS == 1) npr = std::min(npr, 2048);
-  if (O0.nodes_per_round <= 0 && std::getenv("MIQP_NPR")) npr = std::max(1, std::atoi(std::getenv("MIQP_NPR")));  // tuning knob
-  int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (std::getenv("MIQP_OPEN_CAP") ? std::atoi(std::getenv("MIQP_OPEN_CAP")) : std::max(1 << 17, std::min(1 << 20, (1 << 28) / NS)));   // near lists: 1 M entries per instance up to n = 256 (10 GB of list entries), 262144 at n = 1024; records are shared
+  if (O0.nodes_per_round <= 0 && KNOB_P("MIQP_NPR")) npr = std::max(1, std::atoi(KNOB_P("MIQP_NPR")));  // tuning knob
+  int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (KNOB_P("MIQP_OPEN_CAP") ? std::atoi(KNOB_P("MIQP_OPEN_CAP")) : std::max(1 << 17, std::min(1 << 20, (1 << 28) / NS)));   // near lists: 1 M entries per instance up to n = 256 (10 GB of list entries), 262144 at n = 1024; records are shared
   if (open_cap < 64) open_cap = 64;
   if (split && open_cap < SPLIT_MAXROOTS + 4 + 64) open_cap = SPLIT_MAXROOTS + 4 + 64;   // the root records of a tree split are the head of the list
   // (list entries - 40 B per open node - must fit an eighth of the free device memory: ctx_prepare cuts the capacity when it builds the context)
@@ -937,8 +940,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   }
   const double t_tables = wall_s() - t_enter - t_ctx;
   { double gmin = 1.0; for (int k = 0; k < n; ++k) gmin = std::min(gmin, h_gap[k]);
-    const double ftol = std::getenv("MIQP_QPTOL_F") ? std::atof(std::getenv("MIQP_QPTOL_F")) : 1e-4;   // (tuning knob)
-    const double tolcap = std::getenv("MIQP_QPTOL") ? std::atof(std::getenv("MIQP_QPTOL")) : QP_TOL;
+    const double ftol = KNOB_T("MIQP_QPTOL_F") ? std::atof(KNOB_T("MIQP_QPTOL_F")) : 1e-4;   // (tuning knob)
+    const double tolcap = KNOB_T("MIQP_QPTOL") ? std::atof(KNOB_T("MIQP_QPTOL")) : QP_TOL;
     B.qp_tol = std::min(tolcap, std::max(1e-12, ftol * gmin)); }  // node relaxations: accurate to a small fraction of the MIP gap
   hipStream_t st = X.stream;
   HIP_OK(hipMemcpyAsync((void*)B.inst_d, hD.data(), hD.size() * 8, hipMemcpyHostToDevice, st));
@@ -956,7 +959,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemsetAsync(B.inst_kill, 0, (size_t)n * 4, st));
   HIP_OK(hipMemsetAsync(B.slot_demand, 0, (size_t)NS * 4, st));
   { std::vector<int> t0_(NS, npr); HIP_OK(hipMemcpyAsync(B.slot_take, t0_.data(), (size_t)NS * 4, hipMemcpyHostToDevice, st)); HIP_OK(hipStreamSynchronize(st)); }
-  B.base_take = std::max(1, std::min(npr, std::getenv("MIQP_BASE_TAKE") ? std::atoi(std::getenv("MIQP_BASE_TAKE")) : 8));
+  B.base_take = std::max(1, std::min(npr, KNOB_T("MIQP_BASE_TAKE") ? std::atoi(KNOB_T("MIQP_BASE_TAKE")) : 8));
   // Batch shares (share_kernel).  A QUEUE (more instances than slots: admissions go on while the old instances run against their limits): half
   // of the batch is shared evenly as a floor, the rest goes by admission order up to 256 nodes per instance - an instance that waits for its
   // turn no longer crawls at 8 nodes per round (its tree then costs 3-4 x the nodes, tools/crowd_probe.py), and narrow shares cost the fewest
@@ -964,20 +967,20 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   // profiles/r04_share_policy.txt).  ONE batch with every instance in flight from the start (cfg4's 256, cfg5's 16): all deadlines are the same and
   // serving a few instances to their end frees the device for the others - admission order up to 1024 each, no floor (cfg5: 11 of 16 proven against 5).
   const bool queue_mode = NS < n;
-  B.share_cap = std::max(1, std::getenv("MIQP_SHARE_CAP") ? std::atoi(std::getenv("MIQP_SHARE_CAP")) : (queue_mode ? 256 : 1024));
-  B.floor_pct = std::max(0, std::min(100, std::getenv("MIQP_FLOOR_PCT") ? std::atoi(std::getenv("MIQP_FLOOR_PCT")) : (queue_mode ? 50 : 0)));
-  B.lns_narrow = std::max(0, std::getenv("MIQP_LNS_NARROW") ? std::atoi(std::getenv("MIQP_LNS_NARROW")) : 512);   // width of a round that carries local-search leaves (0: as wide as any)
-  B.probe_itcap0 = std::getenv("MIQP_PROBE_ITCAP0") ? std::atoi(std::getenv("MIQP_PROBE_ITCAP0")) : (Y.C >= 3 ? 0 : 40);   // (the cap while the instance has no incumbent)
-  B.pump_max = std::max(0, std::min(15, std::getenv("MIQP_PUMP") ? std::atoi(std::getenv("MIQP_PUMP")) : 6));   // re-rounding of infeasible rounding probes (eval_kernel)
-  B.pump_inc = std::getenv("MIQP_PUMP_INC") ? std::atoi(std::getenv("MIQP_PUMP_INC")) : (Y.C >= 3 ? 1 : 0);   // re-rounding also with an incumbent (probes whose OBJECTIVE is below it): three and four cars - cfg5 seed 15 proven in 8 s, the gaps of the two seeds left at 10 s with 16 in flight 0.38 / 0.32 -> 0.09 / 0.03; two cars: the probes it lets converge are the critical path of a round (single-solve p99 62 -> 72 ms, queue -1 %)
-  B.young_nodes = std::max(0, std::getenv("MIQP_YOUNG_NODES") ? std::atoi(std::getenv("MIQP_YOUNG_NODES")) : 0);
-  B.probe_room = std::getenv("MIQP_PROBE_ROOM") ? std::atof(std::getenv("MIQP_PROBE_ROOM")) : 0.0;
-  B.live_inc = std::getenv("MIQP_LIVE_INC") ? std::atoi(std::getenv("MIQP_LIVE_INC")) : 0;
-  B.probe_every = std::getenv("MIQP_PROBE_EVERY") ? std::atoi(std::getenv("MIQP_PROBE_EVERY")) : 1;
-  B.probe_itcap = std::getenv("MIQP_PROBE_ITCAP") ? std::atoi(std::getenv("MIQP_PROBE_ITCAP")) : (Y.C >= 3 ? 0 : 24);   // (three and four cars: no cap - EVERY probe of the phase without incumbent hit it there, at 25 iterations: infeasible roundings take 36-48, and it is their least-violation solution that the re-rounding needs)   // (0: never; solved probes take 9-24 iterations; 40 until round 4: the heuristic nodes - probes, local-search leaves - are the critical path of a single solve's round: p99 99 -> 80 ms at 24)
-  B.probe_margin = std::getenv("MIQP_PROBE_MARGIN") ? std::atof(std::getenv("MIQP_PROBE_MARGIN")) : 0.25;   // (0: every disjunction of a probe fixed, as in round 2)
-  B.det_ties = std::getenv("MIQP_DET_TIES") ? std::atoi(std::getenv("MIQP_DET_TIES")) : 1;
-  B.window_pct = std::max(1, std::min(100, std::getenv("MIQP_WINDOW") ? std::atoi(std::getenv("MIQP_WINDOW")) : 100));
+  B.share_cap = std::max(1, KNOB_T("MIQP_SHARE_CAP") ? std::atoi(KNOB_T("MIQP_SHARE_CAP")) : (queue_mode ? 256 : 1024));
+  B.floor_pct = std::max(0, std::min(100, KNOB_T("MIQP_FLOOR_PCT") ? std::atoi(KNOB_T("MIQP_FLOOR_PCT")) : (queue_mode ? 50 : 0)));
+  B.lns_narrow = std::max(0, KNOB_T("MIQP_LNS_NARROW") ? std::atoi(KNOB_T("MIQP_LNS_NARROW")) : 512);   // width of a round that carries local-search leaves (0: as wide as any)
+  B.probe_itcap0 = KNOB_T("MIQP_PROBE_ITCAP0") ? std::atoi(KNOB_T("MIQP_PROBE_ITCAP0")) : (Y.C >= 3 ? 0 : 40);   // (the cap while the instance has no incumbent)
+  B.pump_max = std::max(0, std::min(15, KNOB_P("MIQP_PUMP") ? std::atoi(KNOB_P("MIQP_PUMP")) : 6));   // re-rounding of infeasible rounding probes (eval_kernel)
+  B.pump_inc = KNOB_T("MIQP_PUMP_INC") ? std::atoi(KNOB_T("MIQP_PUMP_INC")) : (Y.C >= 3 ? 1 : 0);   // re-rounding also with an incumbent (probes whose OBJECTIVE is below it): three and four cars - cfg5 seed 15 proven in 8 s, the gaps of the two seeds left at 10 s with 16 in flight 0.38 / 0.32 -> 0.09 / 0.03; two cars: the probes it lets converge are the critical path of a round (single-solve p99 62 -> 72 ms, queue -1 %)
+  B.young_nodes = std::max(0, KNOB_T("MIQP_YOUNG_NODES") ? std::atoi(KNOB_T("MIQP_YOUNG_NODES")) : 0);
+  B.probe_room = KNOB_T("MIQP_PROBE_ROOM") ? std::atof(KNOB_T("MIQP_PROBE_ROOM")) : 0.0;
+  B.live_inc = KNOB_T("MIQP_LIVE_INC") ? std::atoi(KNOB_T("MIQP_LIVE_INC")) : 0;
+  B.probe_every = KNOB_T("MIQP_PROBE_EVERY") ? std::atoi(KNOB_T("MIQP_PROBE_EVERY")) : 1;
+  B.probe_itcap = KNOB_T("MIQP_PROBE_ITCAP") ? std::atoi(KNOB_T("MIQP_PROBE_ITCAP")) : (Y.C >= 3 ? 0 : 24);   // (three and four cars: no cap - EVERY probe of the phase without incumbent hit it there, at 25 iterations: infeasible roundings take 36-48, and it is their least-violation solution that the re-rounding needs)   // (0: never; solved probes take 9-24 iterations; 40 until round 4: the heuristic nodes - probes, local-search leaves - are the critical path of a single solve's round: p99 99 -> 80 ms at 24)
+  B.probe_margin = KNOB_T("MIQP_PROBE_MARGIN") ? std::atof(KNOB_T("MIQP_PROBE_MARGIN")) : 0.25;   // (0: every disjunction of a probe fixed, as in round 2)
+  B.det_ties = KNOB_T("MIQP_DET_TIES") ? std::atoi(KNOB_T("MIQP_DET_TIES")) : 1;
+  B.window_pct = std::max(1, std::min(100, KNOB_T("MIQP_WINDOW") ? std::atoi(KNOB_T("MIQP_WINDOW")) : 100));
   HIP_OK(hipMemsetAsync(B.far_count, 0, (size_t)n * 4, st)); HIP_OK(hipMemsetAsync(B.far_minkey, 0xFF, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_mode, 0, (size_t)n * 4, st));
 
@@ -996,9 +999,15 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemsetAsync(B.inst_ninc, 0, (size_t)n * 4, st));
   HIP_OK(hipMemsetAsync(B.inst_lns, 0, (size_t)n * 4, st));
   { std::vector<double> big_(n, 1e300); HIP_OK(hipMemcpyAsync(B.inst_lns_obj, big_.data(), (size_t)n * 8, hipMemcpyHostToDevice, st)); HIP_OK(hipStreamSynchronize(st)); }
-  B.lns_step = std::getenv("MIQP_LNS_STEP") ? std::atof(std::getenv("MIQP_LNS_STEP")) : 0.0;
-  B.lns_mode = std::getenv("MIQP_LNS") ? std::atoi(std::getenv("MIQP_LNS")) : 45;
-  B.lns_min_nodes = std::getenv("MIQP_LNS_MIN") ? std::atoi(std::getenv("MIQP_LNS_MIN")) : (NS == 1 ? 500 : 2000);   // (a single solve: sooner - 90 % quantile of seeds 0-95 24 -> 19 ms; a queue at 500: 1 % slower)
+  B.lns_step = KNOB_T("MIQP_LNS_STEP") ? std::atof(KNOB_T("MIQP_LNS_STEP")) : 0.0;
+  // (read per call, not only when the device context is built: a context is reused by every later call of the same shape)
+  B.cut_gate = KNOB_P("MIQP_CUT_GATE") ? std::atof(KNOB_P("MIQP_CUT_GATE")) : 1.0e-5;
+  B.seq_kinds = KNOB_P("MIQP_SEQ_KINDS") ? (int)std::strtoul(KNOB_P("MIQP_SEQ_KINDS"), nullptr, 0) : (5 << 8);
+  B.lns_mode = KNOB_P("MIQP_LNS") ? std::atoi(KNOB_P("MIQP_LNS")) : 45;
+#ifndef MIQP_TUNING
+  B.lns_mode &= 127;   // (bits 7-9: the neighbourhood sub-problems of round 4 - measured without effect, DESIGN.md 2b - exist in a tuning build only)
+#endif
+  B.lns_min_nodes = KNOB_T("MIQP_LNS_MIN") ? std::atoi(KNOB_T("MIQP_LNS_MIN")) : (NS == 1 ? 500 : 2000);   // (a single solve: sooner - 90 % quantile of seeds 0-95 24 -> 19 ms; a queue at 500: 1 % slower)
   HIP_OK(hipMemsetAsync(B.active_insts, 0, 4, st));   // admit_kernel counts the instances in as they enter
   HIP_OK(hipMemsetAsync(B.stat_rowiters, 0, 8, st));
   HIP_OK(hipStreamSynchronize(st));
@@ -1013,6 +1022,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   double sp_inc = 1e300, sp_lb = -1e300; int sp_owner = 0; bool sp_timeup = false, sp_finished = false;   // state of a tree split
   // ---- streaming admission (host side): which instance holds which slot, when it entered, who is next
   std::vector<int> h_slot_inst(NS, -1), h_kill(n, 0), h_pairs; std::vector<double> t_admit(n, 0.0);
+  std::vector<char> h_stalled(n, 0);   // retired because it made no progress (not because its time was up)
   int next_q = 0, in_flight = 0;
   bool abandoned = false, stuck_once = false;   // the round loop was left with instances still queued or in flight (reported, never silent)
   // frees the slots of proven / retired instances and fills them from the queue; `sel`: the list buffer the next select reads
@@ -1042,20 +1052,20 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   // idles while the host does its per-round bookkeeping.
   // (Measured: no gain - 10.56 s with and without on a 4096-instance queue at 1024 in flight; the time between the interior point
   // launches is the selection and evaluation kernels, not the host.  Kept behind MIQP_PIPELINE=1.)
-  const bool pipelined = !split && NS >= 16 && !std::getenv("MIQP_DEBUG_SYNC") && !std::getenv("MIQP_REPLAY") && std::getenv("MIQP_PIPELINE") && std::atoi(std::getenv("MIQP_PIPELINE")) == 1;
+  const bool pipelined = !split && NS >= 16 && !KNOB_P("MIQP_DEBUG_SYNC") && !KNOB_T("MIQP_REPLAY") && KNOB_T("MIQP_PIPELINE") && std::atoi(KNOB_T("MIQP_PIPELINE")) == 1;
   if (pipelined) {
     if (X.h_pin_n < (size_t)n + 16) { if (X.h_pin) (void)hipHostFree(X.h_pin); X.h_pin = nullptr; X.h_pin_n = 0; HIP_OK(hipHostMalloc((void**)&X.h_pin, ((size_t)n + 16) * 4, hipHostMallocDefault)); X.h_pin_n = (size_t)n + 16; }
     if (!X.ev_sel) HIP_OK(hipEventCreate(&X.ev_sel));
   }
   int prev_bc = 0;
-  static const bool round_log = std::getenv("MIQP_ROUND_LOG") != nullptr;   // diagnostic: the batch sizes of the rounds, printed after the solve (no extra synchronisation)
+  static const bool round_log = KNOB_P("MIQP_ROUND_LOG") != nullptr;   // diagnostic: the batch sizes of the rounds, printed after the solve (no extra synchronisation)
   std::vector<int> round_bc;
   // the counters of a round's launches (batch count, work counters, hand-over counts) come in two parity sets: a round uses one, its
   // roll_kernel zeroes the other for the round after - six 4-byte memsets per round less in the stream (0.65 ms of the 1.4 ms round of a single solve)
   // (OFF by default: the standard launch alone is 2-6 % shorter with it, the round is not - launched before the fork it lets the standard launch take the
   // CUs ahead of the large-node launches, which then run behind it (8.2 ms instead of 2.8), launched behind the fork its one workgroup starves beside them (1.3 ms))
-  const bool use_order = X.oc_grid > 0 && NS >= 16 && std::getenv("MIQP_ORDER") && std::atoi(std::getenv("MIQP_ORDER")) == 1;
-  const bool use_par = X.ctr && X.oc_grid > 0 && X.ocb_grid > 0 && X.concurrent_big && X.stream2 && X.probe_grid > 0 && !pipelined && !std::getenv("MIQP_MEMSETS");
+  const bool use_order = X.oc_grid > 0 && NS >= 16 && KNOB_T("MIQP_ORDER") && std::atoi(KNOB_T("MIQP_ORDER")) == 1;
+  const bool use_par = X.ctr && X.oc_grid > 0 && X.ocb_grid > 0 && X.concurrent_big && X.stream2 && X.probe_grid > 0 && !pipelined && !KNOB_T("MIQP_MEMSETS");
   if (use_par) HIP_OK(hipMemsetAsync(X.ctr, 0, 64, st));
   for (;;) {
     const int par = rounds & 1;
@@ -1064,7 +1074,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     B.prev_bc = pipelined ? X.batch_cap : prev_bc;
     hipLaunchKernelGGL(select_kernel, dim3(NS), dim3(SEL_THREADS), 0, st, B, rounds);
     if (B.lns_mode > 0) hipLaunchKernelGGL(lns_kernel, dim3(NS), dim3(64), 0, st, B);   // the neighbours of new incumbents join this round's batch
-    if (std::getenv("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d select: %s\n", rounds, hipGetErrorString(e_)); }
+    if (KNOB_P("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d select: %s\n", rounds, hipGetErrorString(e_)); }
     hipLaunchKernelGGL(roll_kernel, dim3(1), dim3(8), 0, st, B, use_par ? X.ctr + 8 * (par ^ 1) : (int*)nullptr);
     hipLaunchKernelGGL(share_kernel, dim3(1), dim3(1024), 0, st, B);
     int bc = 0;
@@ -1074,7 +1084,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       HIP_OK(hipEventRecord(X.ev_sel, st));
       if (X.ipm_ev.size() < nev + 2) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); X.ipm_ev.push_back(a); X.ipm_ev.push_back(b); }
       HIP_OK(hipEventRecord(X.ipm_ev[nev], st));
-      launch_ipm_batch(X, B, X.batch_cap, st, !std::getenv("MIQP_PIPELINE_SEQ"));   // (the concurrent launches of the large nodes, as in the unpipelined rounds)
+      launch_ipm_batch(X, B, X.batch_cap, st, !KNOB_T("MIQP_PIPELINE_SEQ"));   // (the concurrent launches of the large nodes, as in the unpipelined rounds)
       HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
       { DevBuf Be = B; Be.open_sel = 1 - (rounds & 1); launch_eval_c(Y.C, Be, X.batch_cap, l_eval, st); }
       HIP_OK(hipEventSynchronize(X.ev_sel));
@@ -1119,7 +1129,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
         if (++empty_rounds > 64) {
           if (stuck_once) { abandoned = true; break; }
           stuck_once = true; empty_rounds = 0;
-          for (int sl = 0; sl < NS; ++sl) { const int k = h_slot_inst[sl]; if (k >= 0 && !h_done_now[k]) h_kill[k] = 1; }
+          for (int sl = 0; sl < NS; ++sl) { const int k = h_slot_inst[sl]; if (k >= 0 && !h_done_now[k]) { h_kill[k] = 1; h_stalled[k] = 1; } }
           HIP_OK(hipMemcpyAsync(B.inst_kill, h_kill.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
           std::fprintf(stderr, "[miqp_gpu] %d instances in flight made no progress for 64 rounds: retired, the queue goes on\n", in_flight);
         }
@@ -1129,7 +1139,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       empty_rounds = 0;
     }
     if (bc > X.batch_cap) bc = X.batch_cap;
-    if (std::getenv("MIQP_TRACE") && bc > 0 && bc <= 256) {   // diagnostic: what the selection picked (list bound, depth word), the incumbent it pruned with, its mode
+    if (KNOB_P("MIQP_TRACE") && bc > 0 && bc <= 256) {   // diagnostic: what the selection picked (list bound, depth word), the incumbent it pruned with, its mode
       std::vector<double> sb(bc); std::vector<int> sd(bc); double io_ = 0; int md_ = 0;
       HIP_OK(hipMemcpy(sb.data(), B.batch_bound, (size_t)bc * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(sd.data(), B.batch_depth, (size_t)bc * 4, hipMemcpyDeviceToHost));
       HIP_OK(hipMemcpy(&io_, B.inc_obj, 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(&md_, B.inst_mode, 4, hipMemcpyDeviceToHost));
@@ -1145,10 +1155,10 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       continue;
     }
     if (X.ipm_ev.size() < nev + 2) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); X.ipm_ev.push_back(a); X.ipm_ev.push_back(b); }
-    static const bool launch_trace = std::getenv("MIQP_LAUNCH_TRACE") != nullptr;
+    static const bool launch_trace = KNOB_T("MIQP_LAUNCH_TRACE") != nullptr;
     if (launch_trace && !X.ev_mid) HIP_OK(hipEventCreate(&X.ev_mid));
     HIP_OK(hipEventRecord(X.ipm_ev[nev], st));
-    static const bool lpt_diag = std::getenv("MIQP_REPLAY_LPT") != nullptr;
+    static const bool lpt_diag = KNOB_T("MIQP_REPLAY_LPT") != nullptr;
     std::vector<double> pre_bound;   // (diagnostic: the list bounds of the batch before the interior point kernels overwrite them)
     if (lpt_diag && bc >= X.batch_cap / 2) { pre_bound.resize(bc); HIP_OK(hipMemcpy(pre_bound.data(), B.batch_bound, (size_t)bc * 8, hipMemcpyDeviceToHost)); }
     launch_ipm_batch(X, B, bc, st, true, use_par ? par : -1, (X.d_order && use_order) ? X.d_order : nullptr);
@@ -1172,9 +1182,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
                    rounds, bc, m1, bc - oc, (double)sc / std::max(1, bc - oc), mxc, m2, np, (double)sp / std::max(1, np), mxp, oc - np, (double)so / std::max(1, oc - np), mxo);
     }
     nev += 2;
-    static const int replay_round = std::getenv("MIQP_REPLAY_ROUND") ? std::atoi(std::getenv("MIQP_REPLAY_ROUND")) : 0;
+    static const int replay_round = KNOB_T("MIQP_REPLAY_ROUND") ? std::atoi(KNOB_T("MIQP_REPLAY_ROUND")) : 0;
     if (bc >= X.batch_cap / 2 && rounds >= replay_round) {   // MIQP_REPLAY=k (diagnostic): the first batch that is at least half full is solved k more times under a timer - the kernels
-      static int replay = std::getenv("MIQP_REPLAY") ? std::atoi(std::getenv("MIQP_REPLAY")) : 0;   // only read and write batch slots
+      static int replay = KNOB_T("MIQP_REPLAY") ? std::atoi(KNOB_T("MIQP_REPLAY")) : 0;   // only read and write batch slots
       if (replay > 0) {
         hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
         HIP_OK(hipEventRecord(e0, st));
@@ -1184,7 +1194,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
         std::vector<int> its(bc); HIP_OK(hipMemcpy(its.data(), B.batch_it, (size_t)bc * 4, hipMemcpyDeviceToHost));
         long long tot = 0; for (int v : its) tot += v;
         std::fprintf(stderr, "[miqp_gpu replay] %d nodes, %lld node-iterations: %.3f ms per pass, %.1f ns per node-iteration\n", bc, tot, ms / replay, 1e6 * ms / replay / (double)tot);
-        if (std::getenv("MIQP_REPLAY_LPT")) {   // how much the order of the batch is worth: the same batch with its nodes handed out longest first (by the iterations just measured), and shortest first
+        if (KNOB_T("MIQP_REPLAY_LPT")) {   // how much the order of the batch is worth: the same batch with its nodes handed out longest first (by the iterations just measured), and shortest first
           int* d_ord = nullptr; HIP_OK(hipMalloc((void**)&d_ord, (size_t)bc * 4));
           // (measured in round 4: longest first -3 ... -13 % of a steady-state round; the iterations of a node's PARENT predict its own with a correlation of 0.2-0.3 - ordering by them gains nothing)
           // a predictor that is known before the launch: how close the node's list bound is to its instance's cutoff (nodes near the cutoff run until
@@ -1238,8 +1248,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
         replay = 0;
       }
     }
-    if (std::getenv("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d ipm (%d nodes): %s\n", rounds, bc, hipGetErrorString(e_)); }
-    if (std::getenv("MIQP_TRACE")) {   // diagnostic: the solved batch of the round in an order that does not depend on the batch slots, for diffing two runs
+    if (KNOB_P("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d ipm (%d nodes): %s\n", rounds, bc, hipGetErrorString(e_)); }
+    if (KNOB_P("MIQP_TRACE")) {   // diagnostic: the solved batch of the round in an order that does not depend on the batch slots, for diffing two runs
       HIP_OK(hipStreamSynchronize(st));
       if (X.stream2) HIP_OK(hipStreamSynchronize(X.stream2));
       std::vector<int> hd(bc), hi(bc), hk(bc); std::vector<double> ho(bc), hb(bc), hv(bc);
@@ -1255,7 +1265,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       for (int k : ord) std::fprintf(stderr, "[trace] r%d depth %d.%d ok %d it %d obj %a bound %a viol %.3e\n", rounds, hd[k] >> 6, hd[k] & 63, hk[k], hi[k], ho[k], hb[k], hv[k]);
     }
     { DevBuf Be = B; Be.open_sel = 1 - (rounds & 1); launch_eval_c(Y.C, Be, bc, l_eval, st); }
-    if (std::getenv("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d eval: %s\n", rounds, hipGetErrorString(e_)); }
+    if (KNOB_P("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d eval: %s\n", rounds, hipGetErrorString(e_)); }
     launched_nodes += bc; rounds++; prev_bc = bc;
     if (round_log) round_bc.push_back(bc);
     if (O0.verbose > 1) std::fprintf(stderr, "[miqp_gpu] round %d: %d nodes\n", rounds, bc);
@@ -1268,7 +1278,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       std::fprintf(stderr, "[miqp_gpu] t %.2f s round %d nodes %lld: instance 0 bound %.4f incumbent %.4f open %d + %d\n", wall_s() - t0, rounds, launched_nodes, lb0, k0 >= 0xFFF0000000000000ull ? INFINITY : io0 + h_const[0], oc0, fc0);
     }
   }
-  if (const char* dp = std::getenv("MIQP_DUMP_OPEN")) {   // diagnostic: open list of instance 0 (bound, depth, fix record of the 400 lowest)
+  if (const char* dp = KNOB_T("MIQP_DUMP_OPEN")) {   // diagnostic: open list of instance 0 (bound, depth, fix record of the 400 lowest)
     int oc0 = 0; HIP_OK(hipMemcpy(&oc0, B.open_count, 4, hipMemcpyDeviceToHost)); oc0 = std::min(oc0, open_cap);
     const size_t src = ((size_t)(rounds & 1) * NS + 0) * open_cap;
     std::vector<double> hb(oc0); std::vector<int> hn(oc0), hd(oc0);
@@ -1299,7 +1309,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     DevBuf Bp = B; Bp.qp_tol = QP_TOL_FINAL; Bp.use_cutoff = 0; Bp.batch_cap = X.batch_alloc;
     // the polish starts at the incumbent's own solution (integer feasible: every row of the completed record holds there), centred
     // at a small complementarity - a third of the iterations of a cold solve to 1e-13 (the last thing a single solve waits for)
-    Bp.ws_on = (B.ws_on && !std::getenv("MIQP_POLISH_COLD")) ? 2 : 0; Bp.ws_mu = std::getenv("MIQP_POLISH_MU") ? std::atof(std::getenv("MIQP_POLISH_MU")) : 1.0e-2; Bp.ws_delta = std::getenv("MIQP_POLISH_DELTA") ? std::atof(std::getenv("MIQP_POLISH_DELTA")) : 1.0e-4;
+    Bp.ws_on = (B.ws_on && !KNOB_T("MIQP_POLISH_COLD")) ? 2 : 0; Bp.ws_mu = KNOB_T("MIQP_POLISH_MU") ? std::atof(KNOB_T("MIQP_POLISH_MU")) : 1.0e-2; Bp.ws_delta = KNOB_T("MIQP_POLISH_DELTA") ? std::atof(KNOB_T("MIQP_POLISH_DELTA")) : 1.0e-4;
     int nb = std::min(n, X.batch_alloc);
     launch_ipm_batch(X, Bp, nb, st);
     HIP_OK(hipMemcpyAsync(h_pobj.data(), B.batch_obj, nb * 8, hipMemcpyDeviceToHost, st));
@@ -1412,6 +1422,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     s->timing[0] = ms_all * 1e-3; s->timing[1] = ms_ipm * 1e-3; s->timing[2] = (double)(nev / 2); s->timing[3] = (double)launched_nodes;
     s->timing[4] = (double)tot_iters; s->timing[5] = (double)rowiters;
     s->setup[0] = t_setup; s->setup[1] = t_ctx; s->setup[2] = ctx_built ? 1.0 : 0.0;
+    s->err.clear();
+    if (h_stalled[k] && unfinished) s->err = "retired without a proof: no progress for 64 branch-and-bound rounds (not a time-limit verdict)";
     if (have) {
       s->status = MIQP_STATUS_SUCCESS; s->has_sol = true;
       s->props.objective = h_inc[k];
@@ -1424,15 +1436,15 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       s->Z.assign(h_Z.begin() + (size_t)k * Y.N * Y.nz, h_Z.begin() + (size_t)(k + 1) * Y.N * Y.nz);
       s->comp.assign(h_fix.begin() + (size_t)k * Y.fixlen, h_fix.begin() + (size_t)(k + 1) * Y.fixlen);
     } else {
-      s->status = unfinished ? MIQP_STATUS_FAILED_TIMEOUT : MIQP_STATUS_FAILED_NO_SOLUT;
+      s->status = unfinished ? (h_stalled[k] ? MIQP_STATUS_FAILED_SEG_FAULT : MIQP_STATUS_FAILED_TIMEOUT) : MIQP_STATUS_FAILED_NO_SOLUT;   // (a stalled instance did not run out of time: the solver could not go on)
       s->props.objective = NAN; s->props.gap = NAN; s->props.best_bound = h_lb[k];
       s->props.status = unfinished ? MIQP_CPX_STAT_TIME_LIM_INFEAS : MIQP_CPX_STAT_INFEASIBLE;
     }
     statuses[k] = s->status;
   }
   if (abandoned) std::fprintf(stderr, "[miqp_gpu] the round loop was abandoned with %d of %d instances never admitted: they report FAILED_SEG_FAULT, the call fails\n", n - next_q, n);
-  if (std::getenv("MIQP_STATS")) std::fprintf(stderr, "[miqp_gpu stats] reachable-set diameter (L1) of instance 0: %.1f\n", hD[Y.d_misc + 2]);
-  if (std::getenv("MIQP_STATS")) std::fprintf(stderr, "[miqp_gpu stats] host: setup %.3f s (device context %.3f, instance tables and presolve %.3f, upload %.3f), rounds %.3f s (%d), results %.3f s\n", t_setup, t_ctx, t_tables, t_setup - t_ctx - t_tables, t_solve, rounds, wall_s() - t0 - t_solve);
+  if (KNOB_P("MIQP_STATS")) std::fprintf(stderr, "[miqp_gpu stats] reachable-set diameter (L1) of instance 0: %.1f\n", hD[Y.d_misc + 2]);
+  if (KNOB_P("MIQP_STATS")) std::fprintf(stderr, "[miqp_gpu stats] host: setup %.3f s (device context %.3f, instance tables and presolve %.3f, upload %.3f), rounds %.3f s (%d), results %.3f s\n", t_setup, t_ctx, t_tables, t_setup - t_ctx - t_tables, t_solve, rounds, wall_s() - t0 - t_solve);
   return !abandoned;
 }
 
@@ -1513,7 +1525,7 @@ int miqp_solver_solve_batch(miqp_solver_t* const* solvers, int n, int* statuses)
 // longer than the slots.
 int miqp_solver_solve_stream(miqp_solver_t* const* solvers, int n, int inflight, int* statuses) {
   if (!solvers || n < 1 || !statuses) return -1;
-  int lanes = std::getenv("MIQP_LANES") ? std::atoi(std::getenv("MIQP_LANES")) : 1;
+  int lanes = KNOB_P("MIQP_LANES") ? std::atoi(KNOB_P("MIQP_LANES")) : 1;
   if (lanes > 8) lanes = 8;
   while (lanes > 1 && (inflight <= 0 || inflight >= n || inflight / lanes < 128)) lanes--;
   if (lanes <= 1) return solve_batch_impl(solvers, n, statuses, nullptr, inflight) ? 0 : -2;
@@ -1694,6 +1706,8 @@ int miqp_solver_solve(miqp_solver_t* s, double timestamp) {
   if (!solve_batch_impl(one, 1, &st)) return MIQP_STATUS_FAILED_SEG_FAULT;
   return st;
 }
+
+const char* miqp_solver_last_error(const miqp_solver_t* s) { return s ? s->err.c_str() : "null handle"; }
 
 int miqp_solver_get_results(const miqp_solver_t* s, miqp_raw_results_c* out) {
   if (!s || !out || !s->has_sol) return -1;

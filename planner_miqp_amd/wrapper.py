@@ -79,6 +79,7 @@ def load_library():
     L.miqp_solver_solve_fixed.argtypes = [vp, C.POINTER(RawResultsC), C.POINTER(RawResultsC), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.miqp_solver_last_timing.restype = C.c_int; L.miqp_solver_last_timing.argtypes = [vp, C.POINTER(C.c_double)]
     L.miqp_solver_last_setup.restype = C.c_int; L.miqp_solver_last_setup.argtypes = [vp, C.POINTER(C.c_double)]
+    L.miqp_solver_last_error.restype = C.c_char_p; L.miqp_solver_last_error.argtypes = [vp]
     L.miqp_gpu_version.restype = C.c_char_p
     _LIB = L
     return L
@@ -88,7 +89,7 @@ EXPORTED_SYMBOLS = ["miqp_solver_create", "miqp_solver_destroy", "miqp_solver_se
                     "miqp_solver_override_settings", "miqp_solver_set_warmstart", "miqp_solver_solve",
                     "miqp_solver_solve_batch", "miqp_solver_get_results", "miqp_solver_get_properties",
                     "miqp_solver_get_dims", "miqp_solver_export_lp", "miqp_solver_solve_fixed",
-                    "miqp_solver_last_timing", "miqp_solver_last_setup", "miqp_gpu_version", "miqp_solver_write_dat", "miqp_solver_write_solution",
+                    "miqp_solver_last_timing", "miqp_solver_last_setup", "miqp_solver_last_error", "miqp_gpu_version", "miqp_solver_write_dat", "miqp_solver_write_solution",
                     "miqp_solver_write_mst", "miqp_solver_read_mst", "miqp_fraction_parameters", "miqp_mean_angles",
                     "miqp_limits_per_region", "miqp_calculate_region_idx", "miqp_reserve_neighbor_regions",
                     "miqp_calculate_possible_regions", "miqp_calculate_warmstart", "miqp_plan",
@@ -277,7 +278,8 @@ class CplexWrapper:
             self._L.miqp_solver_get_dims(self._h, d)
             res = RawResults(*list(d))
             rc = res.to_c()
-            self._L.miqp_solver_get_results(self._h, C.byref(rc))
+            if self._L.miqp_solver_get_results(self._h, C.byref(rc)) != 0:
+                raise RuntimeError("miqp_solver_get_results failed: the library holds no solution for this handle")
             self._results = res
             self._last = res
             self._stale = False
@@ -374,6 +376,10 @@ class CplexWrapper:
             return None
         return dict(rows=o[0], bin=o[1], cont=o[2], nnz=o[3])
 
+    def lastError(self):
+        """why the last solve of this wrapper did not run or did not finish ("" when there is nothing to say)"""
+        return (self._L.miqp_solver_last_error(self._h) or b"").decode()
+
     def lastTiming(self):
         t = (C.c_double * 6)()
         self._L.miqp_solver_last_timing(self._h, t)
@@ -401,7 +407,7 @@ def solve_batch(wrappers, gpus=None, inflight=None, prepared=False):
         prepare_batch(wrappers)
     n = len(wrappers)
     hs = (C.c_void_p * n)(*[w._h for w in wrappers])
-    st = (C.c_int * n)()
+    st = (C.c_int * n)(*([int(OptimizationStatus.FAILED_SEG_FAULT)] * n))   # (a status the library does not write must not read as SUCCESS = 0)
     if inflight is not None and gpus is None:
         rc = L.miqp_solver_solve_stream(hs, n, int(inflight), st)
     else:

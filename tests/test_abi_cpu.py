@@ -323,3 +323,27 @@ def test_bench_weak_scaling_mode_on_two_gloo_ranks():
     a, b = set(seeds[0]), set(seeds[1])
     assert len(a) == len(seeds[0]) == 12 and len(b) == 12 and not (a & b)      # disjoint, no repeats
     assert a | b == set(range(12, 36))                                          # warm-up step: seeds 0..11; the two timed steps: 12..35
+
+
+def test_environment_switches_of_the_shipped_library_are_the_documented_ones():
+    """the library reads its environment only through KNOB_P (product) and KNOB_T (tuning builds only), host_inst.hpp: the KNOB_P names
+    in the sources == the table of INTEGRATION.md section 5 == the MIQP_* strings of the built .so; no raw getenv("MIQP_...") is left,
+    and no KNOB_T name is in the product binary"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = ""
+    for f in sorted(os.listdir(os.path.join(root, "planner_miqp_amd", "csrc"))):
+        src += open(os.path.join(root, "planner_miqp_amd", "csrc", f)).read()
+    assert not re.findall(r'getenv\("MIQP_', src), "raw getenv of a MIQP_ switch in the product sources"
+    prod = set(re.findall(r'KNOB_P\("(MIQP_[A-Z0-9_]+)"\)', src)); tune = set(re.findall(r'KNOB_T\("(MIQP_[A-Z0-9_]+)"\)', src))
+    assert prod and not (prod & tune), prod & tune
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## 5. Environment switches"):]
+    table = set(re.findall(r"^\| `(MIQP_[A-Z0-9_]+)` \|", sec, re.M))
+    assert table == prod, (sorted(table - prod), sorted(prod - table))
+    lib = P.library_path()
+    if os.path.exists(lib):
+        blob = open(lib, "rb").read()
+        inbin = set(m.decode() for m in re.findall(rb"MIQP_[A-Z0-9_]+", blob))
+        assert prod <= inbin, sorted(prod - inbin)
+        assert not (tune & inbin), sorted(tune & inbin)
