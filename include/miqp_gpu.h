@@ -181,6 +181,11 @@ int miqp_solver_last_timing(const miqp_solver_t* s, double* out6);
  * instances than its per-instance arrays hold), out[2] = 1 when the context was built or rebuilt by that call, else 0 */
 int miqp_solver_last_setup(const miqp_solver_t* s, double* out3);
 
+/* out[0] = when the last batch / stream call admitted this instance to a slot, in seconds after the call's first branch-and-bound round started
+ * (0 for a single solve and for the instances in flight from the start).  Together with SolutionProperties.time (admission to proof) it places
+ * every instance of a drained queue on the call's time axis - bench.py derives the drain rate of the queue while it still had a backlog from it. */
+int miqp_solver_last_admission(const miqp_solver_t* s, double* out1);
+
 /* why the last solve of this handle did not run or did not finish, as text ("" when there is nothing to say; the pointer is valid
  * until the next call on the handle).  The reference logs such conditions with LOG(ERROR) inside callCplex
  * (src/cplex_wrapper.cpp:97-109, 162-180); here the status code says WHAT (the four OptimizationStatus values), this says WHY:

@@ -88,6 +88,7 @@ struct miqp_solver {
   Layout lay{};
   double timing[6] = {0, 0, 0, 0, 0, 0};
   double setup[3] = {0, 0, 0};   // host set-up of the last call: seconds, of which the device context, 1 when the context was (re)built
+  double admit_s = 0.0;          // when the last batch / stream call admitted this instance, in seconds after the first round of that call started
   // MIP starts (each tried as an additional root: binaries fixed, QP solved, accepted as incumbent when feasible).
   // Slot 0: receding-horizon start (addRecedingHorizonWarmstart), slot 1: last-solution start (.mst file); with
   // BOTH_WARMSTART_STRATEGIES the reference applies both (src/cplex_wrapper.cpp:124-138)
@@ -851,6 +852,11 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   // ... and a single solve of three or four cars takes 2048 nodes per round (16384 / 8192 / 4096 / 2048: the sixteen cfg5 seeds in 35.1 / 34.3 / 29.5 / 25.3 s, 15 proven each time;
   // seed 15 8.5 -> 4.5 s): its rounds are as long as their slowest node whatever their width (~25 ms), so what a narrower round gives up is node throughput it could not use for the proof anyway
   if (O0.nodes_per_round <= 0 && Y.C >= 3 && NS == 1) npr = std::min(npr, 2048);
+  // ... and so does a single solve of one or two cars (round 5): 2048 nodes are one per resident wavefront of the standard on-chip launch (256 CUs x 8) - a
+  // wider round lasts longer (several nodes per wavefront) and solves nodes that the incumbents of a narrower round would have pruned.  Measured on seeds 0-95
+  // (tools/single_latency.py, profiles/r05_single_latency.txt), 16384 -> 2048 nodes per round: p99 58 -> 47 ms at gap 0.1 (seed 62: 55 k -> 26 k node
+  // relaxations), 92 -> 75 ms at 0.01; p50 / p90 unchanged (5 / 18 ms); 1024: 51 / 76 ms (too narrow: more rounds), 4096: 51 / 86, 8192: 58 / 90
+  if (O0.nodes_per_round <= 0 && Y.C <= 2 && NS == 1) npr = std::min(npr, 2048);
   if (O0.nodes_per_round <= 0 && KNOB_P("MIQP_NPR")) npr = std::max(1, std::atoi(KNOB_P("MIQP_NPR")));  // tuning knob
   int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (KNOB_P("MIQP_OPEN_CAP") ? std::atoi(KNOB_P("MIQP_OPEN_CAP")) : std::max(1 << 17, std::min(1 << 20, (1 << 28) / NS)));   // near lists: 1 M entries per instance up to n = 256 (10 GB of list entries), 262144 at n = 1024; records are shared
   if (open_cap < 64) open_cap = 64;
@@ -1052,7 +1058,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   // idles while the host does its per-round bookkeeping.
   // (Measured: no gain - 10.56 s with and without on a 4096-instance queue at 1024 in flight; the time between the interior point
   // launches is the selection and evaluation kernels, not the host.  Kept behind MIQP_PIPELINE=1.)
-  const bool pipelined = !split && NS >= 16 && !KNOB_P("MIQP_DEBUG_SYNC") && !KNOB_T("MIQP_REPLAY") && KNOB_T("MIQP_PIPELINE") && std::atoi(KNOB_T("MIQP_PIPELINE")) == 1;
+  const int pipe_knob = KNOB_T("MIQP_PIPELINE") ? std::atoi(KNOB_T("MIQP_PIPELINE")) : 0;   // (tuning builds: 1 = queues of >= 16 in flight, 2 = single solves as well)
+  const bool pipelined = !split && (NS >= 16 || (pipe_knob == 2 && NS == 1)) && !KNOB_P("MIQP_DEBUG_SYNC") && !KNOB_T("MIQP_REPLAY") && pipe_knob >= 1;
   if (pipelined) {
     if (X.h_pin_n < (size_t)n + 16) { if (X.h_pin) (void)hipHostFree(X.h_pin); X.h_pin = nullptr; X.h_pin_n = 0; HIP_OK(hipHostMalloc((void**)&X.h_pin, ((size_t)n + 16) * 4, hipHostMallocDefault)); X.h_pin_n = (size_t)n + 16; }
     if (!X.ev_sel) HIP_OK(hipEventCreate(&X.ev_sel));
@@ -1417,6 +1424,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       statuses[k] = s->status; continue;
     }
     s->props.time = h_tdone[k] >= 0 ? h_tdone[k] : std::max(0.0, t_solve - t_admit[k]);   // from the instance's admission to its proof (or to the end of the call)
+    s->admit_s = t_admit[k];
     s->props.NrIterations = (int)std::min<long long>(h_iters[k], 2147483647LL); s->props.nodes = h_nodes[k];
     s->props.NrSolutionPool = h_ninc[k];
     s->timing[0] = ms_all * 1e-3; s->timing[1] = ms_ipm * 1e-3; s->timing[2] = (double)(nev / 2); s->timing[3] = (double)launched_nodes;
@@ -1706,6 +1714,8 @@ int miqp_solver_solve(miqp_solver_t* s, double timestamp) {
   if (!solve_batch_impl(one, 1, &st)) return MIQP_STATUS_FAILED_SEG_FAULT;
   return st;
 }
+
+int miqp_solver_last_admission(const miqp_solver_t* s, double* out1) { if (!s || !out1) return -1; out1[0] = s->admit_s; return 0; }
 
 const char* miqp_solver_last_error(const miqp_solver_t* s) { return s ? s->err.c_str() : "null handle"; }
 

@@ -80,6 +80,7 @@ def load_library():
     L.miqp_solver_last_timing.restype = C.c_int; L.miqp_solver_last_timing.argtypes = [vp, C.POINTER(C.c_double)]
     L.miqp_solver_last_setup.restype = C.c_int; L.miqp_solver_last_setup.argtypes = [vp, C.POINTER(C.c_double)]
     L.miqp_solver_last_error.restype = C.c_char_p; L.miqp_solver_last_error.argtypes = [vp]
+    L.miqp_solver_last_admission.restype = C.c_int; L.miqp_solver_last_admission.argtypes = [vp, C.POINTER(C.c_double)]
     L.miqp_gpu_version.restype = C.c_char_p
     _LIB = L
     return L
@@ -89,7 +90,7 @@ EXPORTED_SYMBOLS = ["miqp_solver_create", "miqp_solver_destroy", "miqp_solver_se
                     "miqp_solver_override_settings", "miqp_solver_set_warmstart", "miqp_solver_solve",
                     "miqp_solver_solve_batch", "miqp_solver_get_results", "miqp_solver_get_properties",
                     "miqp_solver_get_dims", "miqp_solver_export_lp", "miqp_solver_solve_fixed",
-                    "miqp_solver_last_timing", "miqp_solver_last_setup", "miqp_solver_last_error", "miqp_gpu_version", "miqp_solver_write_dat", "miqp_solver_write_solution",
+                    "miqp_solver_last_timing", "miqp_solver_last_setup", "miqp_solver_last_error", "miqp_solver_last_admission", "miqp_gpu_version", "miqp_solver_write_dat", "miqp_solver_write_solution",
                     "miqp_solver_write_mst", "miqp_solver_read_mst", "miqp_fraction_parameters", "miqp_mean_angles",
                     "miqp_limits_per_region", "miqp_calculate_region_idx", "miqp_reserve_neighbor_regions",
                     "miqp_calculate_possible_regions", "miqp_calculate_warmstart", "miqp_plan",
@@ -375,6 +376,12 @@ class CplexWrapper:
         if self._L.miqp_solver_raw_sizes(self._h, o) != 0:
             return None
         return dict(rows=o[0], bin=o[1], cont=o[2], nnz=o[3])
+
+    def lastAdmission(self):
+        """seconds after the start of the last batch / stream call at which this instance was admitted to a slot"""
+        o = (C.c_double * 1)()
+        self._L.miqp_solver_last_admission(self._h, o)
+        return o[0]
 
     def lastError(self):
         """why the last solve of this wrapper did not run or did not finish ("" when there is nothing to say)"""

@@ -1,6 +1,7 @@
 """Parity of the HIP solver (through the C ABI) with the CPU oracle and the reference's known answers.
 All tests here need a real MI355X: run with  python -m pytest tests -m gpu."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -151,7 +152,7 @@ def _oracle_many(oracle, ps, gap, limit, threads=48):
         return list(ex.map(orc, ps))
 
 
-@pytest.mark.parametrize("cfg,seeds,need,gap,olimit", [("cfg3", range(700, 748), 16, 1e-7, 20), ("cfg4", range(1000, 1032), 8, 1e-7, 20),
+@pytest.mark.parametrize("cfg,seeds,need,gap,olimit", [("cfg3", range(700, 748), 30, 1e-7, 20), ("cfg4", range(1000, 1032), 14, 1e-7, 20),
                                                        ("cfg5s", [0, 1, 2, 3, 4, 5, 7, 9, 10, 12], 10, 1e-6, 60)])
 def test_full_size_parity_at_a_tight_gap(oracle, cfg, seeds, need, gap, olimit):
     """the shape the bench times (2 cars x 20 steps x 32 regions; cfg4: + 4 moving obstacles) at gap 1e-7 on the seeds the CPU
@@ -246,7 +247,7 @@ def test_translated_copies_in_one_queue_keep_their_own_solutions(oracle):
             same_key += 1
             assert np.abs(rr[1][1].pos_x - rr[0][1].pos_x - DX).max() <= 1e-5 and np.abs(rr[1][1].pos_y - rr[0][1].pos_y).max() <= 1e-5, k
     print("[count] translated_copies same_key", same_key)
-    assert same_key >= 12, same_key
+    assert same_key >= 22, same_key   # (24 of 24 in every run so far; two may stop at different incumbents within the gap)
 
 
 def test_local_search_changes_the_order_not_the_answer(monkeypatch):
@@ -563,7 +564,9 @@ def test_bounds_at_the_bench_tolerance_are_valid(oracle):
         assert pr.best_bound <= op.objective + tol, (k, pr.best_bound, op.objective)
         assert op.objective * (1 - 1e-6) - tol <= pr.objective <= op.objective * (1 + 1e-2) + tol, (k, pr.objective, op.objective)
     print("[count] bounds_at_the_bench_tolerance checked", checked, seen)
-    assert checked >= 24
+    # the seeds the oracle proves at 1e-6 within 5 s on eight cores (31 within its 20 s there, 35 on the GPU box's host) must all have been compared
+    must = {702, 703, 704, 705, 706, 707, 708, 709, 710, 713, 714, 717, 719, 720, 726, 728, 729, 731, 733, 734, 735, 736, 737, 741, 744, 745, 746}
+    assert must <= set(seen) and checked >= 30, (checked, sorted(must - set(seen)))
 
 
 def test_batch_multi_shards_over_the_visible_devices():
@@ -872,7 +875,7 @@ def test_cfg4_batch_of_256_with_dynamic_obstacles(oracle):
         assert v < 1e-5, worst
         assert abs(obj - pr.objective) <= 1e-6 * max(1.0, abs(obj))
     print("[count] cfg4 nsolved", nsolved, "ninfeasible", ninfeasible)
-    assert nsolved + ninfeasible == 256 and ninfeasible <= 8, (nfeas, nsolved, ninfeasible)   # every instance decided inside its limit: proven to the gap, or proven infeasible
+    assert nsolved == 251 and ninfeasible == 5, (nfeas, nsolved, ninfeasible)   # every instance decided inside its limit: proven to the gap, or proven infeasible
 
 
 def _many_alternatives_instance(seed, N=14, E=20, L=20):
@@ -958,7 +961,9 @@ def test_full_size_bounds_are_mutually_valid(oracle):
         assert pr.objective >= op.best_bound - tol and op.objective >= pr.best_bound - tol, (k, pr.objective, pr.best_bound, op.objective, op.best_bound)
         assert abs(pr.objective - op.objective) <= 2 * G * max(1.0, abs(op.objective))
     print("[count] full_size_bounds_are_mutually_valid both", both, seen, "device proven", len(dev_ok), dev_ok)
-    assert both >= 10
+    assert len(dev_ok) == 48, len(dev_ok)   # the device proves every one of the 48 at 1e-3 inside 12 s
+    must = {300, 301, 302, 303, 304, 305, 306, 309, 310, 312, 314, 317, 318, 322, 324, 326, 331, 332, 333, 334, 335, 338, 339, 340, 341, 342, 346, 347}   # the oracle: within 5 s on eight cores
+    assert must <= set(seen) and both >= 30, (both, sorted(must - set(seen)))
 
 
 def test_cfg5_four_cars_64_regions_with_warmstart(oracle):
@@ -1013,11 +1018,28 @@ def test_cfg5_all_sixteen_seeds_one_at_a_time(oracle):
     assert proven >= 15, (proven, left)
 
 
+def test_single_solve_latency_of_the_planners_call_pattern():
+    """one callCplex per instance on one reused wrapper, the way MiqpPlanner::Plan calls the path (src/miqp_planner.cpp:731), cfg3 seeds 0..95 at the
+    reference's default gap 0.1: every solve proven, median <= 8 ms, 99 % quantile <= 55 ms, the slowest <= 75 ms (profiles/r05_single_latency.txt:
+    4.9 / 46.6 / 58.4 ms on one MI355X; the reference's own tolerance is limit + 0.1 s, test/miqp_planner_test.cc:725)"""
+    w = P.CplexWrapper(); lat = []
+    for s in range(96):
+        w.resetParameters(synthetic.generate("cfg3", s, gap=0.1, max_time=10.0))
+        t = time.time(); st = w.callCplex(); dt = time.time() - t
+        pr = w.getSolutionProperties()
+        assert int(st) == 0 and pr.status in (101, 102), (s, int(st), pr.status)
+        if s > 0:   # (the first call builds the device context)
+            lat.append(dt)
+    p50, p99, mx = (1e3 * float(np.percentile(lat, q)) for q in (50, 99, 100))
+    print("[count] single solve latency ms p50 %.1f p99 %.1f max %.1f" % (p50, p99, mx))
+    assert p50 <= 8.0 and p99 <= 55.0 and mx <= 75.0, (p50, p99, mx)
+
+
 def test_queue_node_counts_vary_little_between_runs():
     """a queue is not reproducible bit for bit (the order in which concurrent workgroups reserve batch slots and records moves the batch
     shares by a node or two: include/miqp_gpu.h) - but the spread is small and every verdict is the same: the same
     256-instance queue at 64 in flight three times: every instance proven each time, objectives within the gap of each other, total node
-    relaxations within 5 % of each other"""
+    relaxations within 2 % of each other"""
     ps = [synthetic.generate("cfg3", s, gap=0.01, max_time=20) for s in range(2000, 2256)]
     totals = []; objs = []
     for rep in range(3):
@@ -1029,7 +1051,7 @@ def test_queue_node_counts_vary_little_between_runs():
         assert all(int(st) == 0 and pr.status in (101, 102) for st, pr in zip(sts, prs)), rep
         totals.append(sum(int(pr.nodes) for pr in prs)); objs.append([pr.objective for pr in prs])
     print("[count] queue node totals of three runs", totals)
-    assert max(totals) <= 1.05 * min(totals), totals
+    assert max(totals) <= 1.02 * min(totals), totals   # (identical totals in the runs so far: at 64 in flight every instance gets its whole share)
     for a, b in zip(objs[0], objs[2]):
         assert abs(a - b) <= 0.0101 * max(abs(a), abs(b)), (a, b)
 
