@@ -314,6 +314,7 @@ def test_bench_weak_scaling_mode_on_two_gloo_ranks():
     assert o["scaling"] == "weak" and o["n_gpus"] == 2 and o["steps"] == 2
     assert o["config"]["instances_attempted"] == 2 * 2 * 6 and [p["attempted"] for p in o["config"]["per_rank"]] == [12, 12]
     assert o["config"]["marshalling_in_timed_region"] is False and o["config"]["result_records_in_timed_region"] is True
+    assert o["config"]["collective_backend"] == "gloo" and o["config"]["ranks_seen"] == 2   # what the backend itself saw (an all-reduce of ones); "nccl" = RCCL when every rank has a device
     assert o["value"] == 0.0 and "no HIP device" in r.stderr
     seeds = {}
     for l in r.stderr.splitlines():
