@@ -21,9 +21,6 @@
 #ifndef MIQP_PHI_BRANCH
 #define MIQP_PHI_BRANCH 1   // 1: the second group of four general rows of a stage only when the stage has more than four (a branch in the sweep)
 #endif
-#ifndef MIQP_DUAL_START
-#define MIQP_DUAL_START 0   // 1: the experiment of round 4 - children start from the parent's MULTIPLIERS as well (DevBuf::pool_Lbox); measured: no fewer iterations, see DESIGN.md 3.2
-#endif
 namespace miqp {
 
 constexpr int OC_GCAP = 128;      // general rows kept on chip (2 register slots per lane)
@@ -196,13 +193,13 @@ __device__ inline bool slot_maybe(const Layout& Y, const signed char* fix, int i
 }
 
 // lambda + kappa and w of one row for the Newton system of the next iteration (see row_step)
-__device__ inline void row_weight(double s, double lam, double t, bool soft, double aq, double tau, double& w, double& lk, double k1 = 1.0) {
+__device__ inline void row_weight(double s, double lam, double t, bool soft, double aq, double tau, double& w, double& lk) {
   const double il = frcp(lam);
   double zz, r2mu = 0.0;
-  if (!soft) { const double mu = RHO_EL - lam, im = frcp(mu); zz = t * im; r2mu = (tau - k1 * (t * mu)) * im; }
+  if (!soft) { const double mu = RHO_EL - lam, im = frcp(mu); zz = t * im; r2mu = (tau - t * mu) * im; }
   else zz = frcp(aq);
   w = frcp(s * il + zz);
-  lk = lam + ((tau - k1 * (s * lam)) * il - r2mu) * w;
+  lk = lam + ((tau - s * lam) * il - r2mu) * w;
 }
 
 // ABL != 0 (diagnostic build -DMIQP_ABLATE, replayed on a batch the real kernel has solved): 15 iterations per node without
@@ -260,7 +257,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     if (tid == 0) sh_node = atomicAdd(B.work_counter, 1);
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(sh_node) >= nbatch) break;
-    const int node = __builtin_amdgcn_readfirstlane(BIG && B.ovf_mode == 1 ? B.ovf_list[sh_node] : ((!BIG && B.batch_order) ? B.batch_order[sh_node] : sh_node));   // wave-uniform by construction: said so, everything derived from it
+    const int node = __builtin_amdgcn_readfirstlane(BIG && B.ovf_mode == 1 ? B.ovf_list[sh_node] : sh_node);   // wave-uniform by construction: said so, everything derived from it
                                                                   // (instance tables, references) is then addressed from SGPRs
     // the concurrent launch of the larger variant takes the nodes known to be large before the round: the rounding probes (their
     // depth word says so) and the records marked by an earlier decode or inherited from a marked parent
@@ -412,9 +409,6 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
         uint4 m4; m4.x = (unsigned int)map; m4.y = (unsigned int)(map >> 32);
         m4.z = (unsigned int)off | ((unsigned int)nn << 16) | ((unsigned int)i << 20) | (r.aq > 0.0 ? 0x80000000u : 0u); m4.w = cols;
         gmeta[idx] = m4; grhs[idx] = r.rhs;
-#if MIQP_DUAL_START
-        cand[idx] = (unsigned short)(i * NSLOT + slot_);   // the row's identity (idx <= its position in the list: read above by every lane of this chunk)
-#endif
         atomicAdd(&sstart[i + 1], 1);
       }
       OC_WAVE_SYNC();
@@ -435,23 +429,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     if (tid == 0) { int a = 0; for (int i = 0; i <= N; ++i) { const int n = sstart[i]; a += n; sstart[i] = a; } }   // sstart[i]: first general row of stage i (counts were stored at i + 1)
     OC_WAVE_SYNC();
 
-    // ---- initial row state (the interior point starts at the free rollout, or at the parent's solution and multipliers)
-#if MIQP_DUAL_START
-    const int rec_ = B.batch_node[node];
-    const unsigned char* const lgp = B.pool_Lgen ? B.pool_Lgen + (size_t)rec_ * LGEN_BYTES : nullptr;
-    const int npar = (warm && B.ws_dual && B.ws_on != 2 && lgp) ? __builtin_amdgcn_readfirstlane(*(const int*)lgp) : -1;   // general rows of the parent whose multipliers the record carries (-1: no multipliers)
-    const bool dual = npar >= 0;
-    const float* const lbp = dual ? B.pool_Lbox + (size_t)rec_ * lbox_floats(N) : nullptr;
-    unsigned short* const ppc = (unsigned short*)scr;                 // the parent's general rows, staged in the decode scratch: decode slots ...
-    float* const plm = (float*)(scr + (LGEN_CAP * 2 + 7) / 8);         // ... and multipliers
-    if (dual) {
-      const unsigned short* gpc = (const unsigned short*)(lgp + 4); const float* glm = (const float*)(lgp + 4 + LGEN_CAP * 2);
-      for (int k = tid; k < npar; k += 64) { ppc[k] = gpc[k]; plm[k] = glm[k]; }
-    }
-    OC_WAVE_SYNC();
-#else
-    constexpr bool dual = false; constexpr int npar = 0; const float* const lbp = nullptr; const unsigned short* const ppc = nullptr; const float* const plm = nullptr;
-#endif
+    // ---- initial row state (the interior point starts at the free rollout, or at the parent's solution: DevBuf::pool_Z)
     double bs[NSL], bl[NSL], bt[NSL];
     unsigned int bact = 0u;
     double csum = 0.0, tsum = 0.0; int cnt = 0;
@@ -464,7 +442,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
         if (key != ~0ull) {
           const double rh = key2d(key), c = rh - bsgn * Z[i * 16 + lc];
           double s, t, l0;
-          init_elastic(c, warm, B.ws_mu, B.ws_delta, s, l0, t, dual ? (double)lbp[(i * 2 + side) * 16 + lc] : 0.0, B.ws_svmin);
+          init_elastic(c, warm, B.ws_mu, B.ws_delta, s, l0, t);
           bs[k] = s; bl[k] = l0; bt[k] = t; bact |= 1u << k;
           csum += s * l0 + t * (RHO_EL - l0); cnt += 2; tsum += t;
         }
@@ -483,24 +461,17 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
         double c = grhs[r];
 #pragma unroll
         for (int k = 0; k < 6; ++k) if (k < nn) c -= gcoef[off + k] * Z[i * 16 + ((m4.w >> (4 * k)) & 15u)];
-        double lam_p = 0.0;
-        if (dual) {   // the parent's multiplier of the row with this decode slot (both lists are in decode order)
-          const int pc = cand[r]; int lo = 0, hi = npar;
-          while (lo < hi) { const int md = (lo + hi) >> 1; if ((int)ppc[md] < pc) lo = md + 1; else hi = md; }
-          if (lo < npar && (int)ppc[lo] == pc) lam_p = (double)plm[lo];
-        }
         if (!(m4.z & 0x80000000u)) {
           double s, t, l0;
-          init_elastic(c, warm, B.ws_mu, B.ws_delta, s, l0, t, lam_p, B.ws_svmin);
+          init_elastic(c, warm, B.ws_mu, B.ws_delta, s, l0, t);
           gs_[q] = s; gl_[q] = l0; gt_[q] = t;
           csum += s * l0 + t * (RHO_EL - l0); cnt += 2; tsum += t;
         } else {
-          const double lam = fmax(fmax(1.0, -2.0 * c * aqs + 1.0), lam_p), s = c + lam / aqs;
+          const double lam = fmax(1.0, -2.0 * c * aqs + 1.0), s = c + lam / aqs;
           gs_[q] = s; gl_[q] = lam; gt_[q] = 1.0; csum += s * lam; cnt += 1;   // t of a soft row is never used
         }
       }
     }
-    if (warm && B.ws_on != 2) gflag |= 0x40000000u;   // (a warm-started node relaxation: per-pair centring targets, see ws_theta)
     OC_WAVE_SYNC();   // the keys are consumed: their region becomes (sqrt(w), f)
     OCP_T(tp_d1); OCP_ACC(0, tp_d0, tp_d1);
     double comp = wave_sum(csum);
@@ -512,8 +483,6 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     const int NROWS = NM + nbox;
 
     int it = 0, ok = 0;
-    // centring targets of a start from the parent's multipliers: share wmix of the mean, the rest (k1 = 1 - sigma (1 - wmix), applied per pair
-    // below) proportional to the pair's own product, see row_step
     double resid_fac = 1.0, R0 = 0.0, obj = 0.0;
     double sigma = QP_SIGMA;
     unsigned long long rowiters = 0;
@@ -533,12 +502,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
       if (BIG) { const int pcap = (cutoff < 1e299 && (!pump_probe || (B.pump_inc & 2))) ? B.probe_itcap : B.probe_itcap0; if (pcap > 0 && it > pcap && B.ws_on != 2 && is_probe_word(B.batch_depth[node])) { ok = 2; break; } }
       if (it > 1 && resid_fac * R0 < B.cut_gate * (1.0 + fabs(obj)) && obj + (pump_probe ? 0.0 : RHO_EL * tsum) - (double)ncomp * comp - resid_fac * R0 * D[Y.d_misc + 2] > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }   // (dual value minus the allowance for the stationarity residual still left, see batch_bound)
       }
-#if !MIQP_DUAL_START
-      const double wmix = 1.0;
-#else
-      const double wmix = (gflag & 0x40000000u) ? B.ws_theta : 1.0;   // (bit 30 of the row flags: started from the parent's solution)
-#endif
-      const double tau = sigma * comp * wmix, k1 = 1.0 - sigma * (1.0 - wmix);   // target of a pair: sigma (wmix mean + (1 - wmix) own product); cold starts: wmix = 1, k1 = 1
+      const double tau = sigma * comp;   // the common centring target of every complementarity pair
       OCP_T(tp_r0);
       // ================= row pass 1: weights of every row for this iteration
       // box rows -> diagonal and gradient contribution per (stage, column): the two sides of a column sit in lanes l, l ^ 16
@@ -559,7 +523,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
           for (int k = k0; k < k0 + OC_GRP && k < NSL; ++k) {
             const int i = 2 * k + par1;
             const bool act = (bact >> k) & 1u;
-            double w, lk; row_weight(bs[k], bl[k], bt[k], false, 0.0, tau, w, lk, k1);
+            double w, lk; row_weight(bs[k], bl[k], bt[k], false, 0.0, tau, w, lk);
             w = act ? w : 0.0; lk = act ? lk * sg1 : 0.0;
             w = sum_xor16(w); lk = sum_xor16(lk);
             if (side0 && i < N) { dgp[k * 32] = w; gdp[k * 32] = lk; }   // row 2 k + par, column lc: one base, the slot as immediate offset
@@ -571,7 +535,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
       for (int q = 0; q < (((OC_ABL) & 4) ? 0 : OC_GSLOTS); ++q) {
         const int r = q * 64 + l1;
         const bool soft = ((gflag >> q) & 1u) != 0u;
-        double w, lk; row_weight(gs_[q], gl_[q], gt_[q], soft, aqs, tau, w, lk, k1);
+        double w, lk; row_weight(gs_[q], gl_[q], gt_[q], soft, aqs, tau, w, lk);
         const double isw = frsq(w);
         if (r < NM) {
           gswfs[GS * r] = w * isw;
@@ -631,19 +595,10 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) if (lgp + 4 * rg == lcp) acc[rg] += dd;
         };
-#ifndef MIQP_BCAST_MFMA
-#define MIQP_BCAST_MFMA 0   // 1: the broadcast of a pivot row over the lane groups as one MFMA with a selector operand - measured 4 % SLOWER (the elimination is a dependent chain: the 64-cycle MFMA latency costs more than the 13 issue slots it frees)
-#endif
         auto bcast_group = [&](double v, int q) {   // the value of lane group q in every group
-#if MIQP_BCAST_MFMA
-          // on the matrix pipe: D = A B with B[k][c] = v of lane (k, c) and A[m][k] = [k == q] gives D[m][c] = v(q, c) in every row - exact
-          // (products with 1 and 0), one instruction instead of a select and two swap-and-add steps in the issue-bound elimination
-          const d4_t r = __builtin_amdgcn_mfma_f64_16x16x4f64(lg == q ? 1.0 : 0.0, v, d4_t{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
-          return r[0];
-#else
+          // (as ONE MFMA with a selector operand this was 4 % slower in round 4: the elimination is a dependent chain, the 64-cycle latency costs more than the 13 issue slots it frees)
           double t = lg == q ? v : 0.0;
           t = sum_xor16(t); return sum_xor32(t);
-#endif
         };
         d4_t accA;
         phiM(N - 1, accA);
@@ -901,7 +856,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
           for (int k = k0; k < k0 + OC_GRP && k < NSL; ++k) {
             const bool act = (bact >> k) & 1u;
             const double s = bs[k], lam = bl[k], t = bt[k], gd = act ? sg2 * dzp[k * 32] : 0.0;
-            double ds, dl, dt; row_step(s, lam, t, 0.0, gd, tau, ds, dl, dt, k1);
+            double ds, dl, dt; row_step(s, lam, t, 0.0, gd, tau, ds, dl, dt);
             const double mu = RHO_EL - lam;
             const double rr_ = fmax(fmax(-ds * __builtin_amdgcn_rcp(s), -dl * __builtin_amdgcn_rcp(lam)), fmax(-dt * __builtin_amdgcn_rcp(t), dl * __builtin_amdgcn_rcp(mu)));
             rinv = fmax(rinv, act ? rr_ : 0.0);
@@ -923,7 +878,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
         }
         ggd[q] = gd;
         const double s = gs_[q], lam = gl_[q], t = gt_[q];
-        double ds, dl, dt; row_step(s, lam, t, soft ? aqs : 0.0, gd, tau, ds, dl, dt, k1);
+        double ds, dl, dt; row_step(s, lam, t, soft ? aqs : 0.0, gd, tau, ds, dl, dt);
         const double mu = RHO_EL - lam;
         double rr_ = fmax(-ds * __builtin_amdgcn_rcp(s), -dl * __builtin_amdgcn_rcp(lam));
         const double r2_ = fmax(-dt * __builtin_amdgcn_rcp(t), dl * __builtin_amdgcn_rcp(mu));
@@ -958,7 +913,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
           for (int k = k0; k < k0 + OC_GRP && k < NSL; ++k) {
             const bool act = (bact >> k) & 1u;
             const double s = bs[k], lam = bl[k], t = bt[k], gd = act ? sg3 * dzq[k * 32] : 0.0;
-            double ds, dl, dt; row_step(s, lam, t, 0.0, gd, tau, ds, dl, dt, k1);
+            double ds, dl, dt; row_step(s, lam, t, 0.0, gd, tau, ds, dl, dt);
             const double al = act ? alpha : 0.0;
             bs[k] = s + al * ds; bl[k] = lam + al * dl; bt[k] = t + al * dt;
             tnew += act ? bt[k] : 0.0;
@@ -969,7 +924,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
       for (int q = 0; q < OC_GSLOTS; ++q) {
         const bool used = ((gflag >> (8 + q)) & 1u) != 0u, soft = ((gflag >> q) & 1u) != 0u;
         const double s = gs_[q], lam = gl_[q], t = gt_[q];
-        double ds, dl, dt; row_step(s, lam, t, soft ? aqs : 0.0, ggd[q], tau, ds, dl, dt, k1);
+        double ds, dl, dt; row_step(s, lam, t, soft ? aqs : 0.0, ggd[q], tau, ds, dl, dt);
         const double al = used ? alpha : 0.0;
         gs_[q] = s + al * ds; gl_[q] = lam + al * dl; gt_[q] = t + al * dt;
         tnew += (used && !soft) ? gt_[q] : 0.0;
@@ -1006,24 +961,6 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     obj += scost;   // (obj is the quadratic objective of the final Z: recomputed by every update, and a node leaves the loop right after one or at its top)
     double* Zo = B.batch_Z + (size_t)node * N * NZ;
     for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) Zo[(k >> 4) * NZ + oc_lcol<C, CM>(q)] = Z[k]; }
-#if MIQP_DUAL_START
-    if (B.batch_Lbox) {   // the multipliers, by row identity, for the children (DevBuf::pool_Lbox)
-      const int le = fresh_lane();   // (lane-dependent addresses from the execution mask: nothing of them is kept across the iteration loop)
-      float* lb = B.batch_Lbox + (size_t)node * lbox_floats(N) + ((le >> 5) * 2 + ((le >> 4) & 1)) * 16 + (le & 15);   // stage parity, side, column of this lane
-#pragma unroll
-      for (int k = 0; k < NSL; ++k) { if (2 * k + (le >> 5) < N) lb[k * 64] = ((bact >> k) & 1u) ? (float)bl[k] : 0.0f; }   // stage 2 k + parity: 2 x 32 floats on
-      unsigned char* lg = B.batch_Lgen + (size_t)node * LGEN_BYTES;
-      const int nm_ = sstart[N];   // (= NM: the general rows of the node)
-      const bool fits = nm_ <= LGEN_CAP;
-      if (le == 0) *(int*)lg = fits ? nm_ : -1;
-      if (fits) {
-        unsigned short* gpc = (unsigned short*)(lg + 4); float* glm = (float*)(lg + 4 + LGEN_CAP * 2);
-        const unsigned short* cd = (const unsigned short*)(L0 + oc_lds_layout(N, Y.fixlen, GCAP).cand);
-#pragma unroll
-        for (int q = 0; q < OC_GSLOTS; ++q) { const int r = q * 64 + le; if (r < nm_) { gpc[r] = cd[r]; glm[r] = (float)gl_[q]; } }
-      }
-    }
-#endif
     if (tid == 0) {
       const int itc = it > QP_MAXIT ? QP_MAXIT : it;
       B.batch_obj[node] = obj; B.batch_viol[node] = viol; B.batch_ok[node] = ok;

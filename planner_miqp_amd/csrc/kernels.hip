@@ -174,24 +174,12 @@ struct DevBuf {
   // starts there with every row centred at complementarity ws_mu - slack s = max(residual, ws_delta), elastic slack t = s -
   // residual, multiplier ws_mu / s - instead of at the free rollout with the same multiplier on every row.
   double* pool_Z;                // [z_cap][N * nz] in the model's column order (null: cold starts only); records beyond z_cap start cold
-  double ws_mu, ws_delta, ws_svmin; int ws_on; int z_cap;
-  // ... and the parent's MULTIPLIERS (on-chip kernels).  Rows keep their identity from parent to child: a box row is its key (stage, side,
-  // column of the kernel's order), a general row its decode slot (stage x NSLOT + slot).  Per record: the multipliers of the box keys as
-  // floats, [N][2][16], 0 = no row; and {count, decode slots (u16), multipliers (f32)} of up to LGEN_CAP general rows in decode order
-  // (count -1: none stored - the node was solved by the memory-backed kernel, or had more rows).  The interior point of a child starts
-  // at (Z, lambda) of its parent: multiplier max(lambda_parent, ws_mu / s), which leaves only the rows the branching adds off the
-  // parent's stationarity.  eval_kernel copies the parent's batch record to every child (like pool_Z).
-  float* pool_Lbox; unsigned char* pool_Lgen; float* batch_Lbox; unsigned char* batch_Lgen; int ws_dual;
+  double ws_mu, ws_delta; int ws_on; int z_cap;
   // Local search around a new incumbent (lns_kernel): select_kernel raises inst_lns when it adopts a new incumbent; the neighbours of
   // its region sequences join the batch of the same round
-  const int* batch_order;        // the order in which the standard on-chip launch hands the batch's nodes out (order_kernel; null: as they stand)
   double* inst_lns_obj; double lns_step;   // the local search runs again only when the incumbent has improved by lns_step (relative) since its last run: a hill climb in steps of 1e-5 re-evaluates the whole neighbourhood for nothing
   int* inst_lns; int lns_mode; int lns_min_nodes; int lns_narrow;   // (an instance gets its local search once it has cost lns_min_nodes node relaxations: the easy ones are done before)
-  double ws_theta;               // share of the mean in a pair's centring target (1: the uniform target of a cold start), see row_step
 };
-constexpr int LGEN_CAP = 160;                                  // general-row multipliers carried per record
-constexpr int LGEN_BYTES = ((4 + LGEN_CAP * 6) + 15) & ~15;   // int count | u16 slot[LGEN_CAP] | f32 lambda[LGEN_CAP]
-__host__ __device__ inline int lbox_floats(int N) { return N * 32; }
 
 __device__ inline unsigned long long d2key(double v) {
   unsigned long long u = (unsigned long long)__double_as_longlong(v);
@@ -533,15 +521,14 @@ __device__ inline double frsq(double x) {
 // Cold (free rollout): the slack follows the residual, the same multiplier everywhere.  Warm (the parent's solution): the row is
 // put on the central path at mu0 - an inactive row (large residual) gets a small multiplier, an active or violated one a slack
 // of delta and the matching multiplier (capped well inside (0, rho)).
-// lam_p > 0: the multiplier the row had at the parent's solution - kept when it is the larger one.
-__device__ inline void init_elastic(double c, bool warm, double mu0, double delta, double& s, double& lam, double& t, double lam_p = 0.0, double svmin = 0.0) {
+__device__ inline void init_elastic(double c, bool warm, double mu0, double delta, double& s, double& lam, double& t) {
   if (!warm) {
     if (c > QP_T0) { t = QP_T0; s = c + QP_T0; } else { s = MIQP_S0 * QP_T0; t = s - c; }
     lam = MIQP_LAM0;
     return;
   }
-  s = c > delta ? c : (delta > svmin ? delta : svmin);   // (svmin: a row that is violated or active at the parent's solution gets a slack the first step can shrink - with delta alone the first steps of a child are blocked at alpha = 0.05 ... 0.3, tools/ipm_lab.py)
-  lam = mu0 / s; if (lam < lam_p) lam = lam_p; if (lam > 0.5 * RHO_EL) lam = 0.5 * RHO_EL;
+  s = c > delta ? c : delta;   // (a larger floor for the rows the branching violates, and the parent's multipliers as the start, were tried in round 4: DESIGN.md 3.2 - no fewer iterations)
+  lam = mu0 / s; if (lam > 0.5 * RHO_EL) lam = 0.5 * RHO_EL;
   double tt = mu0 / (RHO_EL - lam);          // central value of the elastic slack
   if (s - c > tt) tt = s - c;                // ... or what the violated row needs
   t = tt; s = c + tt;                        // (s - t = c exactly)
@@ -549,15 +536,12 @@ __device__ inline void init_elastic(double c, bool warm, double mu0, double delt
 
 // ------------------------------------------------------------------------------------------------
 //  Newton step of one row (elastic: aq == 0, quadratic-soft: aq > 0) given g.dz
-// k1 < 1 (warm-started nodes, DevBuf::ws_theta): every complementarity pair follows its OWN target, tau + (1 - k1) x its product - the
-// uniform part tau = sigma theta mean, the rest proportional to where the pair stands; pairs the parent's solution has already
-// brought close to complementarity are not thrown back to the mean that the few violated rows of a child dominate
-__device__ inline void row_step(double s, double lam, double t, double aq, double gd, double tau, double& ds, double& dl, double& dt, double k1 = 1.0) {
+__device__ inline void row_step(double s, double lam, double t, double aq, double gd, double tau, double& ds, double& dl, double& dt) {
   // three reciprocals per row: 1/lambda, 1/mu (or 1/aq), 1/D
   const double il = frcp(lam);
-  const double r1 = tau - k1 * (s * lam);
+  const double r1 = tau - s * lam;
   double zz, r2m = 0.0, im = 0.0, r2 = 0.0;
-  if (aq == 0.0) { const double mu = RHO_EL - lam; im = frcp(mu); zz = t * im; r2 = tau - k1 * (t * mu); r2m = r2 * im; }
+  if (aq == 0.0) { const double mu = RHO_EL - lam; im = frcp(mu); zz = t * im; r2 = tau - t * mu; r2m = r2 * im; }
   else zz = frcp(aq);
   const double w = frcp(s * il + zz);
   dl = (gd + r1 * il - r2m) * w;
@@ -1259,7 +1243,6 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     // add to the Lagrangian over the trajectories a child may reach (|r|_inf x |z' - z|_1, the latter bounded by the L1 diameter of the
     // reachable set of the instance, host_inst.hpp: d_misc + 2) - the dual value and the bound lifting built on it stay rigorous at loose tolerances
     B.batch_bound[node] = (double)ncomp * comp + resid_fac * R0 * zdiam;
-    if (B.batch_Lgen) *(int*)(B.batch_Lgen + (size_t)node * LGEN_BYTES) = -1;   // (this kernel does not hand multipliers on: the children start from Z alone)
     B.batch_it[node] = it > QP_MAXIT ? QP_MAXIT : it;
     atomicAdd((unsigned long long*)&B.inst_iters[inst], (unsigned long long)(it > QP_MAXIT ? QP_MAXIT : it));
     atomicAdd((unsigned long long*)&B.inst_nodes[inst], 1ull);
@@ -2159,16 +2142,6 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     if (B.pool_Z) {   // the children start their relaxation from this node's solution (see DevBuf::pool_Z)
       for (int q = 0; q < nk; ++q) { if (slots[q] >= B.z_cap) continue; double* zd = B.pool_Z + (size_t)slots[q] * N * NZ; for (int k = lane; k < N * NZ; k += 64) zd[k] = Z[k]; }
     }
-    if (B.pool_Lbox) {   // ... and from its multipliers (DevBuf::pool_Lbox): 16-byte copies of the batch record
-      const int nb4 = lbox_floats(N) / 4, ng4 = LGEN_BYTES / 16;
-      const float4* sb = (const float4*)(B.batch_Lbox + (size_t)node * lbox_floats(N)); const uint4* sg = (const uint4*)(B.batch_Lgen + (size_t)node * LGEN_BYTES);
-      for (int q = 0; q < nk; ++q) {
-        if (slots[q] >= B.z_cap) continue;
-        float4* db = (float4*)(B.pool_Lbox + (size_t)slots[q] * lbox_floats(N)); uint4* dg = (uint4*)(B.pool_Lgen + (size_t)slots[q] * LGEN_BYTES);
-        for (int k = lane; k < nb4; k += 64) db[k] = sb[k];
-        for (int k = lane; k < ng4; k += 64) dg[k] = sg[k];
-      }
-    }
     if (lane < nk) {
       // depth word: (tree depth << 6) | preference among siblings (child_inf first) - used by the dive ordering
       int pd = B.batch_depth[node] >> 6;
@@ -2828,13 +2801,6 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
           }
         }
       }
-      // Neighbourhoods solved as sub-problems (the RINS idea of cplexmodel.mod's rinsheur, with the incumbent alone defining the fixings): the incumbent's
-      // record with EVERY disjunction of one car (its regions, environment pieces, obstacle sides and the pairs it belongs to: bit 7), or of all cars
-      // within a window of a third of the horizon (bit 8), undecided again.  Such a record is an ordinary node - it is solved, branched and its
-      // children join the instance's lists - whose subtree holds the incumbent and every solution that differs from it inside the
-      // neighbourhood only: changes of several sequences at once, which the single moves above cannot make.  It duplicates a part of the tree.
-      if (mode & 128) for (int c = 0; c < C && n < LNS_MAX; ++c) { nb_c[n] = -2; nb_i[n] = 1; nb_n[n] = 0; nb_code[n] = c; nb_n2[n] = 0; n++; }
-      if (mode & 256) { const int W = N / 3, st = W / 2 > 0 ? W / 2 : 1; for (int i0 = 1; i0 + W <= N && n < LNS_MAX; i0 += st) { nb_c[n] = -3; nb_i[n] = 1; nb_n[n] = 0; nb_code[n] = i0 | (W << 8); nb_n2[n] = 0; n++; } }
     } else B.inst_lns[inst] = flags & ~1;
     int base = 0, rec = 0;
     if (n > 0) {
@@ -2900,19 +2866,9 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
       }
       continue;
     }
-    const bool sub = k0 <= -2;   // a neighbourhood root: car nb_code (k0 == -2) or the steps [i0, i0 + W) (k0 == -3)
-    const int fc = nb_code[q], wi0 = nb_code[q] & 255, wi1 = wi0 + (nb_code[q] >> 8);
     for (int k = lane; k < Y.fixlen; k += 64) {
       signed char v = inc[k];
-      if (!sub) { if (k >= k0 && k < k1 && (k - k0) % st_ == 0) v = (signed char)nb_code[q]; }
-      else if (k < Y.f_c2n) {
-        int car = -1, car2 = -1, step;
-        if (k < Y.f_env) { car = k / N; step = k - car * N; }
-        else if (k < Y.f_obs) { const int e = (k - Y.f_env) / 5; car = e / N; step = e - car * N; }
-        else if (k < Y.f_c2c) { const int e = (k - Y.f_obs) / 5; step = e % N; car = e / (N * Y.O); }
-        else { const int e = (k - Y.f_c2c) >> 2, pp = e / N; step = e - pp * N; pair_cars(pp, C, car, car2); }
-        if (k0 == -2 ? (car == fc || car2 == fc) : (step >= wi0 && step < wi1)) v = (signed char)-1;
-      }
+      if (k >= k0 && k < k1 && (k - k0) % st_ == 0) v = (signed char)nb_code[q];
       if (k >= Y.f_env && k < Y.f_c2c && (k - Y.f_env) % 5 != 0) v = (signed char)-1;   // front-point environment / obstacle disjunctions: undecided (their rows are most of a leaf's rows; the evaluation checks them at the leaf's solution)
       if (k >= Y.f_c2n && k < Y.f_rmask) v = (signed char)-1;          // no exclusion rows
       if (k >= Y.f_rmask && k < Y.f_rmask + C * N * 2) v = (signed char)-1;   // every region allowed (0xFF 0xFF)
@@ -2921,50 +2877,14 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
     if (B.pool_Z && rec < B.z_cap) {
       const double* zs = B.inc_Z + (size_t)inst * N * Y.nz; double* zd = B.pool_Z + (size_t)rec * N * Y.nz;
       for (int k = lane; k < N * Y.nz; k += 64) zd[k] = zs[k];
-      if (B.pool_Lgen && lane == 0) *(int*)(B.pool_Lgen + (size_t)rec * LGEN_BYTES) = -1;
     }
     if (lane == 0) {
       if (B.pool_big) B.pool_big[rec] = 1;
       if (B.pool_origin) B.pool_origin[rec] = 14;
-      B.batch_node[bs] = rec; B.batch_inst[bs] = inst; B.batch_bound[bs] = lbq; B.batch_depth[bs] = sub ? ((B.lns_mode & 512) ? (1 << 6) : REPAIR_ROOT) : ((1 << 6) | 63);   // (the probe mark: a heuristic node - one that has not converged after probe_itcap iterations is abandoned; a neighbourhood root is an ordinary node)
+      B.batch_node[bs] = rec; B.batch_inst[bs] = inst; B.batch_bound[bs] = lbq; B.batch_depth[bs] = (1 << 6) | 63;   // (the probe mark: a heuristic node - one that has not converged after probe_itcap iterations is abandoned)
       if (B.batch_large) B.batch_large[bs] = 1;
     }
   }
-}
-
-// Order in which the standard on-chip launch hands the batch's nodes out: the ones that are expected to run longest first, so that the
-// launch does not end on a few late long nodes (its wavefronts take the nodes from a shared counter; with the true iteration counts as the order
-// a steady-state launch is 9-14 % shorter, tools: MIQP_REPLAY_LPT).  What is known before the launch: a root starts cold (16 iterations), and a
-// node whose list bound lies close to its instance's cutoff runs until its dual value crosses the cutoff (18.7 iterations on average against
-// 11.5) - a bucket sort by sibling order and that distance gives 4-6 % (by the distance alone 2-5 %).  The order touches nothing but the launch's schedule: every node is solved on its own.
-__global__ void __launch_bounds__(1024) order_kernel(DevBuf B, int* order) {
-  __shared__ int hist[1024], base[1024];
-  const int tid = threadIdx.x;
-  const int n = *B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap;
-  hist[tid] = 0;
-  __syncthreads();
-  // primary: the sibling preference of the node's depth word - the later a sibling, the more it deviates from the completed alternative of its
-  // parent and the likelier it is cut off or infeasible (63 % of the "other region" children against 3 % of the reference car/car children,
-  // MIQP_STATS) -; secondary: the distance of its list bound to the cutoff in 16 steps over 8 % of the incumbent
-  auto bucket = [&](int k) -> int {
-    const int dw = B.batch_depth[k];
-    if ((dw >> 6) < 1) return 0;                                       // a root: cold start
-    const int pref = dw & 63;                                          // 62: first child, 61, 60, ...: later siblings; 63: a heuristic node (the larger variant takes it)
-    const int inst = B.batch_inst[k];
-    const double inc = B.inc_obj[inst];
-    int cb = 15;
-    if (inc < 1e299) {
-      const double d = (inc - B.inst_gap[inst] * fabs(inc) - (B.batch_bound[k] + B.inst_const[inst])) / fmax(1e-9, fabs(inc));
-      cb = (int)(d * 200.0); cb = cb < 0 ? 0 : (cb > 15 ? 15 : cb);
-    }
-    const int b = (pref > 63 ? 63 : pref) * 16 + cb;
-    return b < 1 ? 1 : b;
-  };
-  for (int k = tid; k < n; k += 1024) atomicAdd(&hist[bucket(k)], 1);
-  __syncthreads();
-  if (tid == 0) { int a = 0; for (int b = 0; b < 1024; ++b) { base[b] = a; a += hist[b]; } }
-  __syncthreads();
-  for (int k = tid; k < n; k += 1024) order[atomicAdd(&base[bucket(k)], 1)] = k;
 }
 
 // makes the records freed so far available to the next eval launch

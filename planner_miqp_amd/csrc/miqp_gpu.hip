@@ -249,8 +249,6 @@ struct DevCtx {
   int mem_div = 1;         // contexts that share the device (lanes of one stream call): each sizes its pools for its share of the free memory
   int lane = 0;
   int* d_pairs = nullptr;   // admissions of one round: (slot, instance) pairs
-  int* h_pin = nullptr; size_t h_pin_n = 0;   // pinned host buffer for the per-round read-back (batch count + done flags)
-  hipEvent_t ev_sel = nullptr;
   // concurrent launch of the memory-backed kernel on the rounding probes of a batch (second stream, its own work counter and
   // per-block buffers): see launch_ipm_batch
   hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -258,7 +256,6 @@ struct DevCtx {
   int* work_counter2 = nullptr; double* rowstate2 = nullptr; double* rowcache2 = nullptr; double* kgain2 = nullptr; int probe_grid = 0;
   int oc_grid = 0;   // resident wavefronts of the on-chip interior point kernel (0: the shape does not qualify)
   int kg_blocks = 0; // blocks the gain buffer holds
-  int* d_order = nullptr; // order of the batch for the standard on-chip launch (order_kernel)
   int* ctr = nullptr; // two parity sets of 8 counters for the launches of a round (batch count, work counters, hand-over counts): a round uses one set, roll_kernel zeroes the other
   bool concurrent_big = true;   // MIQP_CONCURRENT_BIG=0: the sequential chain standard -> larger -> memory-backed
   int ocb_grid = 0;  // resident wavefronts of its larger variant (OC_GCAP_BIG general rows, one wavefront per SIMD; 0: not in use)
@@ -276,7 +273,6 @@ struct DevCtx {
     allocs.clear();
     for (auto e : ipm_ev) (void)hipEventDestroy(e);
     ipm_ev.clear();
-    if (h_pin) { (void)hipHostFree(h_pin); h_pin = nullptr; h_pin_n = 0; }
     ready = false;
   }
 };
@@ -387,25 +383,12 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
     const size_t zb = (size_t)Y.N * Y.nz * 8;
     size_t zc = std::max<size_t>((size_t)2 << 20, (size_t)n_slots * 16384);
     zc = std::min(zc, std::min<size_t>((size_t)X.pool_cap, free_b / 8 / zb));
-    // the parents' multipliers beside them (on-chip kernels only): +N x 128 B for the box keys and LGEN_BYTES for the general rows per record
-    const bool ws_dual = MIQP_DUAL_START && X.oc_grid > 0 && !(KNOB_T("MIQP_WS_DUAL") && std::atoi(KNOB_T("MIQP_WS_DUAL")) == 0);   // (diagnostic build -DMIQP_DUAL_START=1 only)
-    if (ws_dual) zc = std::min(zc, free_b / 5 / (zb + (size_t)lbox_floats(Y.N) * 4 + LGEN_BYTES));
     if (!X.alloc(&B.pool_Z, zc * (size_t)Y.N * Y.nz)) return false;
     B.z_cap = (int)zc;
-    if (ws_dual) {
-      if (!X.alloc(&B.pool_Lbox, zc * (size_t)lbox_floats(Y.N))) return false;
-      if (!X.alloc(&B.pool_Lgen, zc * (size_t)LGEN_BYTES)) return false;
-      if (!X.alloc(&B.batch_Lbox, (size_t)batch_alloc * lbox_floats(Y.N))) return false;
-      if (!X.alloc(&B.batch_Lgen, (size_t)batch_alloc * LGEN_BYTES)) return false;
-      HIP_OK(hipMemset(B.batch_Lgen, 0xFF, (size_t)batch_alloc * LGEN_BYTES));
-      B.ws_dual = 1;
-    }
   }
   B.ws_on = ws_on ? 1 : 0;
   B.ws_mu = KNOB_T("MIQP_WS_MU") ? std::atof(KNOB_T("MIQP_WS_MU")) : 1.0;
   B.ws_delta = KNOB_T("MIQP_WS_DELTA") ? std::atof(KNOB_T("MIQP_WS_DELTA")) : 1.0e-3;
-  B.ws_svmin = KNOB_T("MIQP_WS_SVMIN") ? std::atof(KNOB_T("MIQP_WS_SVMIN")) : 0.0;
-  B.ws_theta = KNOB_T("MIQP_WS_THETA") ? std::min(1.0, std::max(0.0, std::atof(KNOB_T("MIQP_WS_THETA")))) : 1.0;
   if (!X.alloc(&B.pool_count, 1)) return false;
   if (!X.alloc(&B.free_q, (size_t)X.pool_cap)) return false;
   if (!X.alloc(&B.free_head, 1)) return false;
@@ -472,7 +455,6 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&B.kgain, (size_t)std::min(batch_alloc, X.kg_blocks) * std::max(Y.N * Y.nu * (Y.nx + 2), oc_gain_doubles(Y.N)))) return false;
   if (!X.alloc(&B.work_counter, 1)) return false;
   if (!X.alloc(&X.ctr, 16)) return false;
-  if (X.oc_grid > 0) { if (!X.alloc(&X.d_order, batch_alloc)) return false; }
   HIP_OK(hipMemset(X.ctr, 0, 64));
   // buffers of the concurrent probe launch (two cars and fewer, on-chip kernel in use): 1024 resident blocks
   X.probe_grid = 0;
@@ -548,9 +530,7 @@ void launch_ipm_c(int C, const DevBuf& B, int nblocks, size_t lds, hipStream_t s
 // by VALU issue, and the probes no longer cost a generation of their own behind it.  `overlap` false (the polish, solve_fixed): the
 // serial order of round 2.
 // `par` >= 0 (the rounds of a solve): the counters of this launch group are set `par` of X.ctr, zeroed one round ahead by roll_kernel
-// `order_buf`: the standard launch takes its nodes in the order order_kernel writes there - launched on `st` BEHIND the fork, so that the large-node
-// launches of the second stream get their wavefronts resident while it runs (they need 34 KB of LDS each; started behind the standard launch they wait for its end)
-void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool overlap = false, int par = -1, int* order_buf = nullptr) {
+void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool overlap = false, int par = -1) {
   const Layout& Y = X.Y;
   const size_t l_ipm = ipm_lds_bytes(Y);
   if (X.oc_grid > 0) {
@@ -579,7 +559,6 @@ void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool o
       launch_ipm_c(Y.C, Bm, std::min(bc, X.probe_grid), l_ipm, X.stream2, !pc);
       (void)hipEventRecord(X.ev_join, X.stream2);
       Bc.skip_probes = 1; Bc.bounce = 1;
-      if (order_buf) { hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, Bc, order_buf); Bc.batch_order = order_buf; }
       if (Y.C == 1) launch_ipm_oc<1>(Bc, std::min(bc, X.oc_grid), l_oc, st, !pc); else launch_ipm_oc<2>(Bc, std::min(bc, X.oc_grid), l_oc, st, !pc);
       if (X.ev_mid) (void)hipEventRecord(X.ev_mid, st);
       (void)hipStreamWaitEvent(st, X.ev_join, 0);
@@ -1051,56 +1030,30 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     return true;
   };
   if (!admit(0.0, 0)) return fail_all(nullptr);
-  // Pipelined rounds (queues with many instances in flight): the interior point and evaluation launches of a round are enqueued
-  // right behind its selection, sized for a full batch (blocks without a node leave at once), and the host reads the selection's
-  // results - batch count, done flags: through pinned memory, waiting on an event recorded behind the selection only - WHILE the
-  // device solves the round.  Admissions and retirements take effect with the next selection either way; the device no longer
-  // idles while the host does its per-round bookkeeping.
-  // (Measured: no gain - 10.56 s with and without on a 4096-instance queue at 1024 in flight; the time between the interior point
-  // launches is the selection and evaluation kernels, not the host.  Kept behind MIQP_PIPELINE=1.)
-  const int pipe_knob = KNOB_T("MIQP_PIPELINE") ? std::atoi(KNOB_T("MIQP_PIPELINE")) : 0;   // (tuning builds: 1 = queues of >= 16 in flight, 2 = single solves as well)
-  const bool pipelined = !split && (NS >= 16 || (pipe_knob == 2 && NS == 1)) && !KNOB_P("MIQP_DEBUG_SYNC") && !KNOB_T("MIQP_REPLAY") && pipe_knob >= 1;
-  if (pipelined) {
-    if (X.h_pin_n < (size_t)n + 16) { if (X.h_pin) (void)hipHostFree(X.h_pin); X.h_pin = nullptr; X.h_pin_n = 0; HIP_OK(hipHostMalloc((void**)&X.h_pin, ((size_t)n + 16) * 4, hipHostMallocDefault)); X.h_pin_n = (size_t)n + 16; }
-    if (!X.ev_sel) HIP_OK(hipEventCreate(&X.ev_sel));
-  }
+  // (Enqueueing the launches of a round before the host has read the selection's counters - "pipelined rounds" - was measured twice and
+  // removed in round 5: no gain on queues (round 3: the time between the interior point launches is the selection and evaluation kernels, not
+  // the host) and none on single solves (round 5: p99 58.3 -> 59.6 ms, profiles/r05_single_latency.txt))
   int prev_bc = 0;
   static const bool round_log = KNOB_P("MIQP_ROUND_LOG") != nullptr;   // diagnostic: the batch sizes of the rounds, printed after the solve (no extra synchronisation)
   std::vector<int> round_bc;
   // the counters of a round's launches (batch count, work counters, hand-over counts) come in two parity sets: a round uses one, its
   // roll_kernel zeroes the other for the round after - six 4-byte memsets per round less in the stream (0.65 ms of the 1.4 ms round of a single solve)
-  // (OFF by default: the standard launch alone is 2-6 % shorter with it, the round is not - launched before the fork it lets the standard launch take the
-  // CUs ahead of the large-node launches, which then run behind it (8.2 ms instead of 2.8), launched behind the fork its one workgroup starves beside them (1.3 ms))
-  const bool use_order = X.oc_grid > 0 && NS >= 16 && KNOB_T("MIQP_ORDER") && std::atoi(KNOB_T("MIQP_ORDER")) == 1;
-  const bool use_par = X.ctr && X.oc_grid > 0 && X.ocb_grid > 0 && X.concurrent_big && X.stream2 && X.probe_grid > 0 && !pipelined && !KNOB_T("MIQP_MEMSETS");
+  const bool use_par = X.ctr && X.oc_grid > 0 && X.ocb_grid > 0 && X.concurrent_big && X.stream2 && X.probe_grid > 0 && !KNOB_T("MIQP_MEMSETS");
   if (use_par) HIP_OK(hipMemsetAsync(X.ctr, 0, 64, st));
   for (;;) {
     const int par = rounds & 1;
     if (use_par) B.batch_count = X.ctr + 8 * par; else HIP_OK(hipMemsetAsync(B.batch_count, 0, 4, st));
     B.open_sel = rounds & 1;
-    B.prev_bc = pipelined ? X.batch_cap : prev_bc;
+    B.prev_bc = prev_bc;
     hipLaunchKernelGGL(select_kernel, dim3(NS), dim3(SEL_THREADS), 0, st, B, rounds);
     if (B.lns_mode > 0) hipLaunchKernelGGL(lns_kernel, dim3(NS), dim3(64), 0, st, B);   // the neighbours of new incumbents join this round's batch
     if (KNOB_P("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d select: %s\n", rounds, hipGetErrorString(e_)); }
     hipLaunchKernelGGL(roll_kernel, dim3(1), dim3(8), 0, st, B, use_par ? X.ctr + 8 * (par ^ 1) : (int*)nullptr);
     hipLaunchKernelGGL(share_kernel, dim3(1), dim3(1024), 0, st, B);
     int bc = 0;
-    if (pipelined) {
-      HIP_OK(hipMemcpyAsync(X.h_pin, B.batch_count, 4, hipMemcpyDeviceToHost, st));
-      HIP_OK(hipMemcpyAsync(X.h_pin + 16, B.inst_done, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-      HIP_OK(hipEventRecord(X.ev_sel, st));
-      if (X.ipm_ev.size() < nev + 2) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); X.ipm_ev.push_back(a); X.ipm_ev.push_back(b); }
-      HIP_OK(hipEventRecord(X.ipm_ev[nev], st));
-      launch_ipm_batch(X, B, X.batch_cap, st, !KNOB_T("MIQP_PIPELINE_SEQ"));   // (the concurrent launches of the large nodes, as in the unpipelined rounds)
-      HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
-      { DevBuf Be = B; Be.open_sel = 1 - (rounds & 1); launch_eval_c(Y.C, Be, X.batch_cap, l_eval, st); }
-      HIP_OK(hipEventSynchronize(X.ev_sel));
-      bc = X.h_pin[0]; std::memcpy(h_done_now.data(), X.h_pin + 16, (size_t)n * 4);
-    } else {
     HIP_OK(hipMemcpyAsync(&bc, B.batch_count, 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(h_done_now.data(), B.inst_done, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    }
     const double tnow = wall_s() - t0;
     for (int sl = 0; sl < NS; ++sl) { const int k = h_slot_inst[sl]; if (k >= 0 && h_done_now[k] && h_tdone[k] < 0) h_tdone[k] = tnow - t_admit[k]; }   // time from admission to proof
     if (split) {   // once per round: the ranks agree on incumbent, bound and whether to go on (identical decisions everywhere)
@@ -1156,19 +1109,11 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       for (int k : ord) std::fprintf(stderr, " %d.%d/%a", sd[k] >> 6, sd[k] & 63, sb[k]);
       std::fprintf(stderr, "\n");
     }
-    if (pipelined) {   // (the launches of this round are already in the stream)
-      nev += 2; launched_nodes += bc; rounds++;
-      if (O0.verbose > 1) std::fprintf(stderr, "[miqp_gpu] round %d: %d nodes\n", rounds, bc);
-      continue;
-    }
     if (X.ipm_ev.size() < nev + 2) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); X.ipm_ev.push_back(a); X.ipm_ev.push_back(b); }
     static const bool launch_trace = KNOB_T("MIQP_LAUNCH_TRACE") != nullptr;
     if (launch_trace && !X.ev_mid) HIP_OK(hipEventCreate(&X.ev_mid));
     HIP_OK(hipEventRecord(X.ipm_ev[nev], st));
-    static const bool lpt_diag = KNOB_T("MIQP_REPLAY_LPT") != nullptr;
-    std::vector<double> pre_bound;   // (diagnostic: the list bounds of the batch before the interior point kernels overwrite them)
-    if (lpt_diag && bc >= X.batch_cap / 2) { pre_bound.resize(bc); HIP_OK(hipMemcpy(pre_bound.data(), B.batch_bound, (size_t)bc * 8, hipMemcpyDeviceToHost)); }
-    launch_ipm_batch(X, B, bc, st, true, use_par ? par : -1, (X.d_order && use_order) ? X.d_order : nullptr);
+    launch_ipm_batch(X, B, bc, st, true, use_par ? par : -1);
     HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
     if (launch_trace) {   // diagnostic: the two interior point launches of the round apart, and what the memory-backed one had to solve
       HIP_OK(hipStreamSynchronize(st));
@@ -1201,39 +1146,6 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
         std::vector<int> its(bc); HIP_OK(hipMemcpy(its.data(), B.batch_it, (size_t)bc * 4, hipMemcpyDeviceToHost));
         long long tot = 0; for (int v : its) tot += v;
         std::fprintf(stderr, "[miqp_gpu replay] %d nodes, %lld node-iterations: %.3f ms per pass, %.1f ns per node-iteration\n", bc, tot, ms / replay, 1e6 * ms / replay / (double)tot);
-        if (KNOB_T("MIQP_REPLAY_LPT")) {   // how much the order of the batch is worth: the same batch with its nodes handed out longest first (by the iterations just measured), and shortest first
-          int* d_ord = nullptr; HIP_OK(hipMalloc((void**)&d_ord, (size_t)bc * 4));
-          // (measured in round 4: longest first -3 ... -13 % of a steady-state round; the iterations of a node's PARENT predict its own with a correlation of 0.2-0.3 - ordering by them gains nothing)
-          // a predictor that is known before the launch: how close the node's list bound is to its instance's cutoff (nodes near the cutoff run until
-          // their dual value crosses it - 18.7 iterations on average against 11.5)
-          std::vector<double> close(bc, 1e300);
-          if ((int)pre_bound.size() == bc) {
-            std::vector<int> hinst(bc); std::vector<double> hio(n), hic(n);
-            HIP_OK(hipMemcpy(hinst.data(), B.batch_inst, (size_t)bc * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(hio.data(), B.inc_obj, (size_t)n * 8, hipMemcpyDeviceToHost));
-            for (int k = 0; k < bc; ++k) { const int ii = hinst[k]; const double inc_ = hio[ii]; if (inc_ < 1e299) close[k] = (inc_ - h_gap[ii] * std::fabs(inc_) - (pre_bound[k] + h_const[ii])) / std::max(1e-9, std::fabs(inc_)); }
-          }
-          std::vector<int> hdep(bc); HIP_OK(hipMemcpy(hdep.data(), B.batch_depth, (size_t)bc * 4, hipMemcpyDeviceToHost));
-          auto dev = [&](int k) { return (hdep[k] & 63) < 62 ? 1 : 0; };   // a sibling that deviates from the reference alternative
-          for (int pass = 0; pass < 7; ++pass) {
-            std::vector<int> ord(bc); for (int k = 0; k < bc; ++k) ord[k] = k;
-            if (pass == 3) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return close[a] < close[b]; });
-            else if (pass == 4) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return dev(a) != dev(b) ? dev(a) > dev(b) : close[a] < close[b]; });
-            else if (pass == 5) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return close[a] - 0.02 * dev(a) < close[b] - 0.02 * dev(b); });
-            else if (pass == 6) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return (hdep[a] & 63) != (hdep[b] & 63) ? (hdep[a] & 63) < (hdep[b] & 63) : close[a] < close[b]; });
-            else if (pass == 0) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return its[a] > its[b]; });
-            else if (pass == 1) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return its[a] < its[b]; });
-            else { unsigned int x = 12345u; for (int k = bc - 1; k > 0; --k) { x = x * 1664525u + 1013904223u; std::swap(ord[k], ord[(x >> 8) % (unsigned int)(k + 1)]); } }
-            HIP_OK(hipMemcpy(d_ord, ord.data(), (size_t)bc * 4, hipMemcpyHostToDevice));
-            DevBuf Bo = B; Bo.batch_order = d_ord;
-            HIP_OK(hipEventRecord(e0, st));
-            for (int r = 0; r < replay; ++r) launch_ipm_batch(X, Bo, bc, st);
-            HIP_OK(hipEventRecord(e1, st)); HIP_OK(hipStreamSynchronize(st));
-            float m2 = 0; HIP_OK(hipEventElapsedTime(&m2, e0, e1));
-            std::fprintf(stderr, "[miqp_gpu replay] %s: %.3f ms per pass\n", pass == 0 ? "longest first" : (pass == 1 ? "shortest first" : (pass == 2 ? "shuffled" : (pass == 3 ? "closest to the cutoff first" : (pass == 4 ? "deviating siblings first, then closeness" : (pass == 5 ? "closeness - 0.02 x deviating" : "by sibling order, then closeness"))))), m2 / replay);
-          }
-          (void)hipFree(d_ord);
-          launch_ipm_batch(X, B, bc, st);
-        }
 #ifdef MIQP_ABLATE
         if (X.oc_grid > 0 && Y.C == 2) {   // cost map of the on-chip kernel: the same batch, 15 iterations per node, parts switched off
           const size_t l_oc = (size_t)oc_lds_layout(Y.N, Y.fixlen).total;

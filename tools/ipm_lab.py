@@ -196,6 +196,19 @@ def main():
         "parent_s mu.01 th.3": dict(mode="parent_s", mu0=0.01, theta=0.3),
         "parent_s mu.001": dict(mode="parent_s", mu0=0.001),
     }
+    if len(sys.argv) > 4 and sys.argv[4] == "proj":   # round 5: the parent's solution moved onto the rows the branching violates before the interior point starts
+        # (the minimiser of the parent's Lagrangian model 1/2 dU' H dU - H: the objective alone, as in the bound lifting - subject to the violated rows holding with a margin)
+        variants = {
+            "cold": dict(start=False),
+            "primal (device rule)": dict(mode="primal"),
+            "proj margin 0": dict(mode="primal", proj=0.0),
+            "proj margin 1e-3": dict(mode="primal", proj=1e-3),
+            "proj margin 1e-2": dict(mode="primal", proj=1e-2),
+            "proj margin 1e-1": dict(mode="primal", proj=1e-1),
+            "proj 1e-2 mu.1": dict(mode="primal", proj=1e-2, mu0=0.1),
+            "proj 1e-2 mu.01": dict(mode="primal", proj=1e-2, mu0=0.01),
+            "proj 1e-1 mu.1": dict(mode="primal", proj=1e-1, mu0=0.1),
+        }
     if len(sys.argv) > 4 and sys.argv[4] == "pc":   # the centring rules against each other, product start (parent's solution, mu0 = 1, delta = 1e-3)
         variants = {
             "cold": dict(start=False),
@@ -222,6 +235,15 @@ def main():
         if par is not None:
             for name, kw in variants.items():
                 kw = dict(kw); st = par if kw.pop("start", True) else None
+                pm = kw.pop("proj", None)
+                if pm is not None and st is not None:
+                    U0 = st["U"]; cres = h - G @ U0
+                    V = np.where((av == 0) & (cres < pm))[0]            # elastic rows that do not hold with the margin at the parent's solution
+                    if len(V):
+                        Hi_Gt = np.linalg.solve(M.H, G[V].T)             # H^-1 G_V'
+                        S_ = G[V] @ Hi_Gt + 1e-12 * np.eye(len(V))
+                        dU = -Hi_Gt @ np.linalg.solve(S_, (pm - cres[V]))
+                        st = dict(U=U0 + dU, lam=st.get("lam"))
                 r = ipm(M, keys, G, h, av, start=st, **kw)
                 its[name].append(r["it"]); sol[name].append(r["solves"])
                 if not r["ok"] or abs(r["obj"] - ref["obj"]) > 1e-4 * max(1.0, abs(ref["obj"])):
