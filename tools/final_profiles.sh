@@ -2,7 +2,7 @@
 # Collects the round's profile artefacts on the GPU box into gpurun_out/final/ (copied to profiles/ afterwards):
 #   kernel trace + stats of one default bench step (1280 in flight, queue of 2560), three separate PMC passes (FETCH_SIZE, WRITE_SIZE, SQ counters;
 #   no tracing together with --pmc) on `bench.py --steps 1 --warmup 0 --no-cpu --time-limit 3` for the counters.
-R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/final; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu --no-extras > $O/trace_bench.log 2>&1
 python3 $R/tools/round_gaps.py $O/trace > $O/round_gaps.txt 2>&1
