@@ -225,6 +225,23 @@ def test_invalid_records_are_refused(lib):
     q = synthetic.generate("mini", 0); q.possible_region = np.zeros_like(q.possible_region)
     w3 = P.CplexWrapper(); w3.resetParameters(q)
     assert w3._push_inputs() != 0
+    # ... and the handle says why (miqp_solver_last_error: the LOG(ERROR) of the reference's callCplex as text)
+    assert "initial_region" in w2.lastError() and "possible region" in w3.lastError(), (w2.lastError(), w3.lastError())
+    assert w.lastError() == ""
+
+
+def test_a_solve_without_a_device_reports_failed_seg_fault_for_every_instance():
+    """no HIP device in this container: every solve entry point fails loudly with the reference's "the solver could not run" code - a status
+    array the library never wrote must not read as SUCCESS (= 0), and a handle without a solution refuses to hand out results"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    ws = []
+    for s in range(3):
+        w = P.CplexWrapper(); w.resetParameters(synthetic.generate("mini", s)); ws.append(w)
+    for sts in (P.solve_batch(ws), P.solve_batch(ws, inflight=2), P.solve_batch(ws, gpus=1)):
+        assert [int(x) for x in sts] == [int(P.OptimizationStatus.FAILED_SEG_FAULT)] * 3
+    assert int(ws[0].callCplex()) == int(P.OptimizationStatus.FAILED_SEG_FAULT) and ws[0].getRawResults() is None
 
 
 def test_all_baseline_configs_generate_and_size(oracle):
