@@ -488,9 +488,29 @@ __device__ inline RowRegs load_row(const double* rc_aq, const double* rc_col, co
 }
 
 // reductions over the one wavefront that solves a node (the xor butterfly leaves the result in every lane)
-template <int NT> __device__ inline double block_sum(double v, double*) { static_assert(NT == 64, "one wavefront per node"); return wave_sum(v); }
-template <int NT> __device__ inline double block_min(double v, double*) { static_assert(NT == 64, "one wavefront per node"); return wave_min(v); }
-template <int NT> __device__ inline double block_max(double v, double*) { static_assert(NT == 64, "one wavefront per node"); return wave_max(v); }
+// reductions over the workgroup of a node: one wavefront (two cars and fewer), or four (three and four cars: `red` holds the partial results
+// of the wavefronts; the barrier in front keeps the result of the previous reduction readable until every thread has it)
+template <int NT> __device__ inline double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  if constexpr (NT > 64) { __syncthreads(); if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v; __syncthreads(); v = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) v += red[w]; }
+  return v;
+}
+template <int NT> __device__ inline double block_min(double v, double* red) {
+  v = wave_min(v);
+  if constexpr (NT > 64) { __syncthreads(); if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v; __syncthreads(); v = red[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) v = fmin(v, red[w]); }
+  return v;
+}
+template <int NT> __device__ inline double block_max(double v, double* red) {
+  v = wave_max(v);
+  if constexpr (NT > 64) { __syncthreads(); if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v; __syncthreads(); v = red[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) v = fmax(v, red[w]); }
+  return v;
+}
 
 #ifdef MIQP_PROFILE
 #define PROF_T(var) long long var = clock64()
@@ -552,11 +572,24 @@ __device__ inline void row_step(double s, double lam, double t, double aq, doubl
 // ------------------------------------------------------------------------------------------------
 //  interior point kernel: one wavefront per node.  The rows of the node are decoded once, compacted per stage
 //  (only active rows are stored) and kept as sparse rows (<= 6 non-zeros) in a block-indexed cache.
+#ifndef MIQP_WIDE_WPE
+#define MIQP_WIDE_WPE 2   // wavefronts per SIMD the multi-wavefront kernel of three and four cars is register-allocated for
+#endif
+#ifndef MIQP_WIDE_NT
+#define MIQP_WIDE_NT 128   // threads per node of the three / four car kernel: 64, 128 or 256
+#endif
 template <int C, int NT>
-__global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(DevBuf B) {
-  static_assert(NT == 64, "one wavefront per node");
+__global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_WIDE_WPE : 1))) ipm_kernel(DevBuf B) {
   static_assert(C <= 4, "stage vectors of at most 32 entries");
   constexpr bool WIDE = C > 2;   // more than two cars: the stage does not fit one 16x16 MFMA tile -> dense LDS stage algebra
+  // Three and four cars (round 5): one WORKGROUP OF TWO WAVEFRONTS per node (MIQP_WIDE_NT = 128; 256 = four wavefronts also builds).  The stage
+  // vector of 24 / 32 entries makes every stage matrix a 2 x 2 tiling of 16 x 16 MFMA tiles: wavefront w owns the tiles t = 2 ti + tj with
+  // t % NW == w of the three products of a Riccati step, the row loops (assembly, step length, update, decode test) run over all NT lanes, and
+  // four nodes' workgroups still share a CU (the dense stage matrices in LDS are per node, not per wavefront: 37 KB at four cars) - 2 wavefronts
+  // per SIMD instead of 1.  Measured on cfg5 (one MI355X, same box): node relaxations/s of a single solve 124 k -> 149 k, of sixteen solves in
+  // flight 153 k -> 217 k; four wavefronts per node (two nodes per CU at 256 VGPRs) 124 k / 166 k.  NT = 64 remains the form of one and two cars.
+  static_assert(NT == 64 || (WIDE && (NT == 128 || NT == 256)), "one wavefront per node, or two / four for the 2 x 2-tiled stage algebra");
+  constexpr int NW = NT / 64;
   constexpr int NX = 6 * C, NU = 2 * C, NZ = 8 * C, GS = WIDE ? NZ + 1 : GSTR;
   constexpr int KB = (NX + 3) / 4;         // k blocks of the products with [A B]
   constexpr int RU = NX / 4, GU0 = NX % 4;  // register / first lane group holding the input rows NX..NZ-1  // rows are zero padded to the 16 columns of the MFMA tile
@@ -648,19 +681,32 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
   // are built 64 at a time with every lane busy (about one slot in five is active).
   double csum = 0.0; int cnt = 0; int base = 0, sbase = 0;
   int* cand = (int*)rs_g;   // the g.dz plane is free until the first step-length loop
-  const unsigned long long lt = (1ull << tid) - 1ull;
+  const unsigned long long lt = (1ull << (tid & 63)) - 1ull;   // the lanes of this wavefront below this one
   int ncand = 0;
+  __shared__ int sh_wcnt[4], sh_nrows[2];
   for (int p0 = 0; p0 < N * NSLOT; p0 += NT) {
     const int pcode = p0 + tid;
     bool act = false;
     if (pcode < N * NSLOT) { const int i = pcode / NSLOT; act = decode_row<C, false>(Y, D, T, fix, i, pcode - i * NSLOT, nullptr).active; }
     const unsigned long long m = __ballot(act);
-    if (act) cand[ncand + __popcll(m & lt)] = pcode;
-    ncand += __popcll(m);
+    if constexpr (NW == 1) {
+      if (act) cand[ncand + __popcll(m & lt)] = pcode;
+      ncand += __popcll(m);
+    } else {   // four wavefronts: the list keeps its (stage, slot) order - wavefront w writes behind the active pairs of the wavefronts before it
+      if ((tid & 63) == 0) sh_wcnt[tid >> 6] = __popcll(m);
+      __syncthreads();
+      int off = 0, tot = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { if (w < (tid >> 6)) off += sh_wcnt[w]; tot += sh_wcnt[w]; }
+      if (act) cand[ncand + off + __popcll(m & lt)] = pcode;
+      ncand += tot;
+      __syncthreads();
+    }
   }
   for (int k = tid; k <= N; k += NT) { sstart[k] = 0; sst[k] = 0; }
   __syncthreads();
-  for (int c0 = 0; c0 < ncand; c0 += NT) {
+  // (pass B is the work of the first wavefront whatever NT: a dense scratch row per lane is 64 rows of LDS, and the pass is 7 % of a node's time)
+  for (int c0 = 0; c0 < ncand && tid < 64; c0 += 64) {
     double* g = dscr + tid * GS;
     RowOut r; r.active = false; r.rhs = 0; r.aq = 0;
     int i = 0;
@@ -691,10 +737,11 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     }
     base += __popcll(maskM); sbase += __popcll(maskS);
   }
+  if (tid == 0) { sh_nrows[0] = base; sh_nrows[1] = sbase; }
   __syncthreads();
   if (tid == 0) for (int i = 1; i <= N; ++i) { sstart[i] += sstart[i - 1]; sst[i] += sst[i - 1]; }   // first row of every stage
   __syncthreads();
-  const int NM = base, NS = sbase, NROWS = NM + NS;
+  const int NM = sh_nrows[0], NS = sh_nrows[1], NROWS = NM + NS;
   // row r of the node (general rows first): its index in the row arrays
   auto ridx = [&](int r) { return r < NM ? r : Y.ROWCAP - 1 - (r - NM); };
   PROF_T(tb1); PROF_ACC(0, tb0, tb1);
@@ -955,8 +1002,10 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
     double* Km = pv + NX;            // [NU][NX+1]
     const double h1 = ts, h2 = 0.5 * ts * ts, h3 = ts * ts * ts / 6.0;
     constexpr int KBW = (NX + 3) / 4;
-    const int wg = tid >> 4, wc = tid & 15;
+    const int wg = (tid & 63) >> 4, wc = tid & 15;
     const bool c1ok = 16 + wc < NZ;   // column of the second tile column inside the stage vector (3 cars: 24 of 32)
+    // two / four wavefronts: tile t = 2 ti + tj (rows 16 ti .., columns 16 tj ..) of every product belongs to wavefront t % NW
+    const int wv = tid >> 6;
     double abw[KBW][2];   // [A B] as MFMA operand: lane (g, c) holds AB[4 kb + g][16 t + c]
 #pragma unroll
     for (int kb = 0; kb < KBW; ++kb)
@@ -1004,7 +1053,22 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
       // T = P [A B] and S = Phi + [A B]' T as 2 x 2 tilings of v_mfma_f64_16x16x4_f64 over the LDS-resident matrices: tile
       // (ti, tj) = rows 16 ti .., columns 16 tj ..; lane (g, c) feeds A[i = c][k = g] / B[k = g][j = c] of a k block and
       // owns D[g + 4 r][c].  [A B] comes from registers (abw), P / T operands and the S accumulators from LDS.
-      {
+      if constexpr (NW > 1) {   // tile (ti, tj) of T: rows 16 ti + g + 4 r of P's columns, columns 16 tj + c of [A B]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if ((t % NW) != wv) continue;   // (wavefront-uniform)
+          const int ti = t >> 1, tj = t & 1;
+          d4_t tt = {0, 0, 0, 0};
+#pragma unroll
+          for (int kb = 0; kb < KBW; ++kb) {
+            const int kr = 4 * kb + wg;
+            const double a = (kr < NX && 16 * ti + wc < NX) ? Pm[kr * NX + 16 * ti + wc] : 0.0;
+            tt = __builtin_amdgcn_mfma_f64_16x16x4f64(a, abw[kb][tj], tt, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int i = 16 * ti + wg + 4 * r; if (i < NX && 16 * tj + wc < NZ) Tm[i * NZ + 16 * tj + wc] = tt[r]; }
+        }
+      } else {
         d4_t t00 = {0, 0, 0, 0}, t01 = {0, 0, 0, 0}, t10 = {0, 0, 0, 0}, t11 = {0, 0, 0, 0};
 #pragma unroll
         for (int kb = 0; kb < KBW; ++kb) {
@@ -1024,7 +1088,25 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
         }
       }
       __syncthreads();
-      {
+      if constexpr (NW > 1) {   // tile (ti, tj) of S: A operand = [A B]' rows 16 ti .., B operand = T's columns 16 tj ..
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if ((t % NW) != wv) continue;
+          const int ti = t >> 1, tj = t & 1;
+          const bool cok = 16 * tj + wc < NZ;
+          d4_t ss;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int i = 16 * ti + wg + 4 * r; ss[r] = (i < NZ && cok) ? Sm[i * NZ + 16 * tj + wc] : 0.0; }
+#pragma unroll
+          for (int kb = 0; kb < KBW; ++kb) {
+            const int kr = 4 * kb + wg;
+            const double b = (kr < NX && cok) ? Tm[kr * NZ + 16 * tj + wc] : 0.0;
+            ss = __builtin_amdgcn_mfma_f64_16x16x4f64(abw[kb][ti], b, ss, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int i = 16 * ti + wg + 4 * r; if (i < NZ && cok) Sm[i * NZ + 16 * tj + wc] = ss[r]; }
+        }
+      } else {
         d4_t s00, s01, s10, s11;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1092,7 +1174,27 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : 1)) ipm_kernel(De
       __syncthreads();
       PROF_T(tw3); PROF_ACC(4, tw2, tw3);
       // P = Sxx - Sxu' K as an MFMA rank-NU update of the tiles of S:  A[i][k = q] = -S[NX + q][i],  B[k = q][j] = K[q][j]
-      {
+      if constexpr (NW > 1) {   // tile (ti, tj) of P = Sxx - Sxu' K
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if ((t % NW) != wv) continue;
+          const int ti = t >> 1, tj = t & 1;
+          const bool cok = 16 * tj + wc < NX;
+          d4_t pp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int i = 16 * ti + wg + 4 * r; pp[r] = (i < NX && cok) ? Sm[i * NZ + 16 * tj + wc] : 0.0; }
+#pragma unroll
+          for (int qb = 0; qb < (NU + 3) / 4; ++qb) {
+            const int q = 4 * qb + wg;
+            const bool qv = q < NU;
+            const double a = (qv && 16 * ti + wc < NZ) ? -Sm[(NX + q) * NZ + 16 * ti + wc] : 0.0;
+            const double b = (qv && cok) ? Km[q * (NX + 1) + 16 * tj + wc] : 0.0;
+            pp = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, pp, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int i = 16 * ti + wg + 4 * r; if (i < NX && cok) Pm[i * NX + 16 * tj + wc] = pp[r]; }
+        }
+      } else {
         d4_t p00, p01, p10, p11;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

@@ -328,7 +328,8 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   const int batch_alloc = std::max(batch_cap, n_inst);   // the final polish solves one node per instance in one launch
   X.Y = Y; X.n_inst = n_call; X.n_slots = n_slots; X.open_cap = open_cap; X.npr = npr; X.batch_cap = batch_cap; X.batch_alloc = batch_alloc;
   { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); int cus = 256; if (hipGetDeviceProperties(&pr, dv) == hipSuccess) cus = pr.multiProcessorCount;
-    size_t l = ipm_lds_bytes(Y); int per = (int)std::max<size_t>(1, std::min<size_t>(4 * (Y.C <= 2 ? MIQP_IPM_WPE : 1), (160 * 1024) / std::max<size_t>(l + 8, 1))); X.ipm_grid_max = cus * per;
+    // resident workgroups of the memory-backed kernel per CU: what its LDS admits, and its wavefronts per SIMD (three and four cars: workgroups of four wavefronts)
+    size_t l = ipm_lds_bytes(Y); int per = (int)std::max<size_t>(1, std::min<size_t>(Y.C <= 2 ? 4 * MIQP_IPM_WPE : (4 * MIQP_WIDE_WPE) / (MIQP_WIDE_NT / 64), (160 * 1024) / std::max<size_t>(l + 8, 1))); X.ipm_grid_max = cus * per;
     // on-chip kernel: up to two cars, horizon within its register slots; 2 wavefronts per SIMD, as many as its LDS admits
     X.oc_grid = 0;
     const OcLds ol = oc_lds_layout(Y.N, Y.fixlen);
@@ -489,7 +490,9 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   return true;
 }
 
-constexpr int IPM_NT = 64;  // one wavefront per node in the interior point kernel
+constexpr int IPM_NT = 64;  // one wavefront per node in the interior point kernel ...
+constexpr int IPM_NT_WIDE = MIQP_WIDE_NT;   // ... two (or four) for three and four cars (ipm_kernel: the four MFMA tiles of the 2 x 2-tiled stage algebra are shared out over the wavefronts)
+constexpr int ipm_nt(int C) { return C >= 3 ? IPM_NT_WIDE : IPM_NT; }
 size_t ipm_lds_bytes(const Layout& Y) {
   int NZ = Y.nz, N = Y.N;
   size_t d = (size_t)N * NZ + (size_t)ipm_scratch_doubles(N, Y.C) + NZ + 8 + 32 + 2 * ((N + 6) / 2 + 1);
@@ -504,7 +507,7 @@ size_t eval_lds_bytes(const Layout& Y) {
 }
 
 // `zero` false: the counters of the launch are the round's parity set, zeroed by roll_kernel one round ahead (no memset in the stream)
-template <int C> void launch_ipm(const DevBuf& B, int nblocks, size_t lds, hipStream_t st, bool zero = true) { if (zero) (void)hipMemsetAsync(B.work_counter, 0, 4, st); hipLaunchKernelGGL((ipm_kernel<C, IPM_NT>), dim3(nblocks), dim3(IPM_NT), lds, st, B); }
+template <int C> void launch_ipm(const DevBuf& B, int nblocks, size_t lds, hipStream_t st, bool zero = true) { if (zero) (void)hipMemsetAsync(B.work_counter, 0, 4, st); hipLaunchKernelGGL((ipm_kernel<C, ipm_nt(C)>), dim3(nblocks), dim3(ipm_nt(C)), lds, st, B); }
 template <int C> void launch_ipm_oc(const DevBuf& B, int nblocks, size_t lds, hipStream_t st, bool zero = true) {
   if (zero) { (void)hipMemsetAsync(B.work_counter, 0, 4, st); (void)hipMemsetAsync(B.ovf_count, 0, 4, st); }
   hipLaunchKernelGGL((ipm_onchip_kernel<C, OC_NSL>), dim3(nblocks), dim3(64), lds, st, B);
@@ -600,7 +603,7 @@ template <int C> bool set_kernel_lds_oc(size_t lds, size_t lds_big) {
   return true;
 }
 template <int C> bool set_kernel_lds_c(size_t ipm_lds, size_t eval_lds) {
-  HIP_OK(hipFuncSetAttribute((const void*)ipm_kernel<C, IPM_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipm_lds));
+  HIP_OK(hipFuncSetAttribute((const void*)ipm_kernel<C, ipm_nt(C)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipm_lds));
   HIP_OK(hipFuncSetAttribute((const void*)eval_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eval_lds));
   return true;
 }
