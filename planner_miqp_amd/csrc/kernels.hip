@@ -487,6 +487,11 @@ __device__ inline RowRegs load_row(const double* rc_aq, const double* rc_col, co
   return R;
 }
 
+// Workgroup barrier for data exchanged through LDS only: __syncthreads() also waits for every global load and store of the wavefront
+// (vmcnt(0): the fence in front of s_barrier covers global memory) - inside the backward sweep of three and four cars that would be the write
+// latency of the gains and the read latency of the prefetched rows of the next stage, once per barrier.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // reductions over the one wavefront that solves a node (the xor butterfly leaves the result in every lane)
 // reductions over the workgroup of a node: one wavefront (two cars and fewer), or four (three and four cars: `red` holds the partial results
 // of the wavefronts; the barrier in front keeps the result of the previous reduction readable until every thread has it)
@@ -1001,27 +1006,24 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
     double* pv = svv + NZ;           // [NX]
     double* Km = pv + NX;            // [NU][NX+1]
     const double h1 = ts, h2 = 0.5 * ts * ts, h3 = ts * ts * ts / 6.0;
-    constexpr int KBW = (NX + 3) / 4;
-    const int wg = (tid & 63) >> 4, wc = tid & 15;
-    const bool c1ok = 16 + wc < NZ;   // column of the second tile column inside the stage vector (3 cars: 24 of 32)
-    // two / four wavefronts: tile t = 2 ti + tj (rows 16 ti .., columns 16 tj ..) of every product belongs to wavefront t % NW
-    const int wv = tid >> 6;
-    double abw[KBW][2];   // [A B] as MFMA operand: lane (g, c) holds AB[4 kb + g][16 t + c]
-#pragma unroll
-    for (int kb = 0; kb < KBW; ++kb)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) abw[kb][t] = (4 * kb + wg < NX && 16 * t + wc < NZ) ? ab_entry<C>(4 * kb + wg, 16 * t + wc, ts) : 0.0;
+    const int wg = (tid & 63) >> 4, wc = tid & 15, wv = tid >> 6;   // lane group / column inside an MFMA tile, wavefront of the workgroup
+    // the first row of every lane for the stage assembled next is requested a stage ahead (the rows of a node stream from HBM: 13 planes of
+    // ROWCAP doubles per resident node are far more than the L2 holds): its latency passes under the T / S / K / P phases of the stage before
+    RowRegs pre;
+    auto stage_row = [&](int j, int r0) { const int nmj = sstart[j + 1] - sstart[j]; return r0 >= nmj ? Y.ROWCAP - 1 - (sst[j] + r0 - nmj) : sstart[j] + r0; };
+    auto stage_rows = [&](int j) { return (sstart[j + 1] - sstart[j]) + (sst[j + 1] - sst[j]); };
+    if (tid < stage_rows(N - 1)) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, stage_row(N - 1, tid));
     for (int j = N - 1; j >= 0; --j) {
       PROF_T(tw0);
       for (int k = tid; k < NZ * NZ; k += NT) Sm[k] = 0.0;
-      __syncthreads();
+      lds_barrier();
       if (tid < NZ) { Sm[tid * NZ + tid] = 2.0 * Wd[tid]; svv[tid] = 2.0 * Wd[tid] * (Z[j * NZ + tid] - Rf[j * NZ + tid]); }
-      __syncthreads();
+      lds_barrier();
       const int nmj = sstart[j + 1] - sstart[j], nsj = sst[j + 1] - sst[j];
       for (int r0 = tid; r0 < nmj + nsj; r0 += NT) {
         const bool sgl = r0 >= nmj;
         const int r = sgl ? Y.ROWCAP - 1 - (sst[j] + r0 - nmj) : sstart[j] + r0;
-        RowRegs R = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, r);
+        RowRegs R = r0 == tid ? pre : load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, r);
         if (sgl) R.aq = 0.0;
         unsigned long long cols = (unsigned long long)__double_as_longlong(R.col);
         const int nn = (int)(cols >> 56);
@@ -1031,103 +1033,50 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
         else zz = frcp(R.aq);
         const double w = frcp(s * il + zz);
         const double lk = lam + ((tau - s * lam) * il - r2mu) * w;
+        // (only the lower triangle of S is kept: the columns of a row are stored in ascending order, and every reader of S below takes
+        // S[max(i, j)][min(i, j)])
+        if (sgl) {
+          const int c = (int)(cols & 255);
+          atomicAdd(&svv[c], R.v[0] * lk); atomicAdd(&Sm[c * NZ + c], w * R.v[0] * R.v[0]);
+        } else {
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          if (a < nn) {
-            const int ca_ = (int)((cols >> (8 * a)) & 255);
-            atomicAdd(&svv[ca_], R.v[a] * lk);
+          for (int a = 0; a < 6; ++a) {
+            if (a < nn) {
+              const int ca_ = (int)((cols >> (8 * a)) & 255);
+              const double wa = w * R.v[a];
+              atomicAdd(&svv[ca_], R.v[a] * lk);
 #pragma unroll
-            for (int b = 0; b < 6; ++b) if (b < nn) atomicAdd(&Sm[ca_ * NZ + (int)((cols >> (8 * b)) & 255)], w * R.v[a] * R.v[b]);
+              for (int b = 0; b <= a; ++b) atomicAdd(&Sm[ca_ * NZ + (int)((cols >> (8 * b)) & 255)], wa * R.v[b]);
+            }
           }
         }
       }
-      __syncthreads();
+      if (j > 0 && tid < stage_rows(j - 1)) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, stage_row(j - 1, tid));
+      lds_barrier();
       PROF_T(tw1); PROF_ACC(1, tw0, tw1);
       if (it == 1 && tid < NZ) rmax = fmax(rmax, fabs(svv[tid]));
       if (j == N - 1) {   // u_{N-1} = 0 (initial_conditions.mod:25-26): P = Phi_xx, p = rr_x
-        for (int k = tid; k < NX * NX; k += NT) Pm[k] = Sm[(k / NX) * NZ + k % NX];
+        for (int k = tid; k < NX * NX; k += NT) { const int i = k / NX, c = k - i * NX; Pm[k] = Sm[(i > c ? i : c) * NZ + (i > c ? c : i)]; }
         if (tid < NX) pv[tid] = svv[tid];
-        __syncthreads();
+        lds_barrier();
         continue;
       }
-      // T = P [A B] and S = Phi + [A B]' T as 2 x 2 tilings of v_mfma_f64_16x16x4_f64 over the LDS-resident matrices: tile
-      // (ti, tj) = rows 16 ti .., columns 16 tj ..; lane (g, c) feeds A[i = c][k = g] / B[k = g][j = c] of a k block and
-      // owns D[g + 4 r][c].  [A B] comes from registers (abw), P / T operands and the S accumulators from LDS.
-      if constexpr (NW > 1) {   // tile (ti, tj) of T: rows 16 ti + g + 4 r of P's columns, columns 16 tj + c of [A B]
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if ((t % NW) != wv) continue;   // (wavefront-uniform)
-          const int ti = t >> 1, tj = t & 1;
-          d4_t tt = {0, 0, 0, 0};
-#pragma unroll
-          for (int kb = 0; kb < KBW; ++kb) {
-            const int kr = 4 * kb + wg;
-            const double a = (kr < NX && 16 * ti + wc < NX) ? Pm[kr * NX + 16 * ti + wc] : 0.0;
-            tt = __builtin_amdgcn_mfma_f64_16x16x4f64(a, abw[kb][tj], tt, 0, 0, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { const int i = 16 * ti + wg + 4 * r; if (i < NX && 16 * tj + wc < NZ) Tm[i * NZ + 16 * tj + wc] = tt[r]; }
-        }
-      } else {
-        d4_t t00 = {0, 0, 0, 0}, t01 = {0, 0, 0, 0}, t10 = {0, 0, 0, 0}, t11 = {0, 0, 0, 0};
-#pragma unroll
-        for (int kb = 0; kb < KBW; ++kb) {
-          const int kr = 4 * kb + wg;   // k index = row of P (P is symmetric: P[i][k] = Pm[k][i])
-          const double a0 = (kr < NX) ? Pm[kr * NX + wc] : 0.0;
-          const double a1 = (kr < NX && 16 + wc < NX) ? Pm[kr * NX + 16 + wc] : 0.0;
-          t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, abw[kb][0], t00, 0, 0, 0);
-          t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, abw[kb][1], t01, 0, 0, 0);
-          t10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, abw[kb][0], t10, 0, 0, 0);
-          t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, abw[kb][1], t11, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i0 = wg + 4 * r, i1 = 16 + wg + 4 * r;
-          Tm[i0 * NZ + wc] = t00[r]; if (c1ok) Tm[i0 * NZ + 16 + wc] = t01[r];
-          if (i1 < NX) { Tm[i1 * NZ + wc] = t10[r]; if (c1ok) Tm[i1 * NZ + 16 + wc] = t11[r]; }
-        }
+      // T = P [A B] and S = Phi + [A B]' T on the VALU: [A B] has 1 / 2 / 3 / 3 entries in the columns (position, velocity, acceleration, input) of
+      // a chain, so a (row, chain) pair of T is 6 fma on three entries of P and a (chain, column) pair of S the same on three entries of T -
+      // 13.5 + 18 fma per lane and stage at four cars.  (Rounds 3-5 ran these as 48 dense v_mfma_f64_16x16x4_f64 per stage: 64 cycles of the
+      // matrix pipe each on gfx950, 8 x the flops the sparsity needs.)
+      for (int pr = tid; pr < NX * NU; pr += NT) {
+        const int i = pr / NU, ch = pr - i * NU, q0 = 3 * ch;
+        const double p0 = Pm[i * NX + q0], p1 = Pm[i * NX + q0 + 1], p2 = Pm[i * NX + q0 + 2];
+        double* tr = Tm + i * NZ;
+        tr[q0] = p0; tr[q0 + 1] = fma(h1, p0, p1); tr[q0 + 2] = fma(h2, p0, fma(h1, p1, p2)); tr[NX + ch] = fma(h3, p0, fma(h2, p1, h1 * p2));
       }
-      __syncthreads();
-      if constexpr (NW > 1) {   // tile (ti, tj) of S: A operand = [A B]' rows 16 ti .., B operand = T's columns 16 tj ..
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if ((t % NW) != wv) continue;
-          const int ti = t >> 1, tj = t & 1;
-          const bool cok = 16 * tj + wc < NZ;
-          d4_t ss;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { const int i = 16 * ti + wg + 4 * r; ss[r] = (i < NZ && cok) ? Sm[i * NZ + 16 * tj + wc] : 0.0; }
-#pragma unroll
-          for (int kb = 0; kb < KBW; ++kb) {
-            const int kr = 4 * kb + wg;
-            const double b = (kr < NX && cok) ? Tm[kr * NZ + 16 * tj + wc] : 0.0;
-            ss = __builtin_amdgcn_mfma_f64_16x16x4f64(abw[kb][ti], b, ss, 0, 0, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { const int i = 16 * ti + wg + 4 * r; if (i < NZ && cok) Sm[i * NZ + 16 * tj + wc] = ss[r]; }
-        }
-      } else {
-        d4_t s00, s01, s10, s11;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i0 = wg + 4 * r, i1 = 16 + wg + 4 * r;
-          s00[r] = Sm[i0 * NZ + wc]; s01[r] = c1ok ? Sm[i0 * NZ + 16 + wc] : 0.0; s10[r] = i1 < NZ ? Sm[i1 * NZ + wc] : 0.0; s11[r] = (i1 < NZ && c1ok) ? Sm[i1 * NZ + 16 + wc] : 0.0;
-        }
-#pragma unroll
-        for (int kb = 0; kb < KBW; ++kb) {
-          const int kr = 4 * kb + wg;   // k index = row of T
-          const double b0 = (kr < NX) ? Tm[kr * NZ + wc] : 0.0, b1 = (kr < NX && c1ok) ? Tm[kr * NZ + 16 + wc] : 0.0;
-          s00 = __builtin_amdgcn_mfma_f64_16x16x4f64(abw[kb][0], b0, s00, 0, 0, 0);
-          s01 = __builtin_amdgcn_mfma_f64_16x16x4f64(abw[kb][0], b1, s01, 0, 0, 0);
-          s10 = __builtin_amdgcn_mfma_f64_16x16x4f64(abw[kb][1], b0, s10, 0, 0, 0);
-          s11 = __builtin_amdgcn_mfma_f64_16x16x4f64(abw[kb][1], b1, s11, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i0 = wg + 4 * r, i1 = 16 + wg + 4 * r;
-          Sm[i0 * NZ + wc] = s00[r]; if (c1ok) Sm[i0 * NZ + 16 + wc] = s01[r];
-          if (i1 < NZ) { Sm[i1 * NZ + wc] = s10[r]; if (c1ok) Sm[i1 * NZ + 16 + wc] = s11[r]; }
-        }
+      lds_barrier();
+      for (int pr = tid; pr < NU * NZ; pr += NT) {
+        const int ch = pr / NZ, c = pr - ch * NZ, q0 = 3 * ch;
+        const double t0 = Tm[q0 * NZ + c], t1 = Tm[(q0 + 1) * NZ + c], t2 = Tm[(q0 + 2) * NZ + c];
+        Sm[q0 * NZ + c] += t0; Sm[(q0 + 1) * NZ + c] += fma(h1, t0, t1); Sm[(q0 + 2) * NZ + c] += fma(h2, t0, fma(h1, t1, t2));
+        Sm[(NX + ch) * NZ + c] += fma(h3, t0, fma(h2, t1, h1 * t2));
       }
       if (tid < NZ) {
         const int a = tid; double v;
@@ -1135,18 +1084,18 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
         else { const int ch = a - NX; v = h3 * pv[3 * ch] + h2 * pv[3 * ch + 1] + h1 * pv[3 * ch + 2]; }
         svv[a] += v;
       }
-      __syncthreads();
+      lds_barrier();
       PROF_T(tw2); PROF_ACC(3, tw1, tw2);
-      // Suu = L D L' in the registers of every lane
-      double Lm[NU][NU], dinv[NU], dvec[NU];
+      // Suu = L D L' in the registers of every lane (Lw[a][q] = L[a][q] d[q] is kept beside L: one fma per term of the elimination)
+      double Lm[NU][NU], Lw[NU][NU], dinv[NU];
 #pragma unroll
       for (int a = 0; a < NU; ++a) {
 #pragma unroll
         for (int b = 0; b <= a; ++b) {
           double v = Sm[(NX + a) * NZ + NX + b];
 #pragma unroll
-          for (int q = 0; q < b; ++q) v -= Lm[a][q] * Lm[b][q] * dvec[q];
-          if (a == b) { dvec[a] = fmax(v, 1e-300); dinv[a] = frcp(dvec[a]); } else Lm[a][b] = v * dinv[b];
+          for (int q = 0; q < b; ++q) v -= Lw[a][q] * Lm[b][q];
+          if (a == b) dinv[a] = frcp(fmax(v, 1e-300)); else { Lw[a][b] = v; Lm[a][b] = v * dinv[b]; }
         }
       }
       // lane c < NX: K[:, c] = Suu^-1 Sux[:, c]; lane NX: k = Suu^-1 su
@@ -1171,54 +1120,29 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
 #pragma unroll
         for (int a = 0; a < NU; ++a) { Km[a * (NX + 1) + tid] = xk[a]; KG[(j * NU + a) * KSTR + tid] = xk[a]; }
       }
-      __syncthreads();
+      lds_barrier();
       PROF_T(tw3); PROF_ACC(4, tw2, tw3);
       // P = Sxx - Sxu' K as an MFMA rank-NU update of the tiles of S:  A[i][k = q] = -S[NX + q][i],  B[k = q][j] = K[q][j]
-      if constexpr (NW > 1) {   // tile (ti, tj) of P = Sxx - Sxu' K
+      // (a 2 x 2 tiling of 16 x 16 tiles: tile t = 2 ti + tj = rows 16 ti .., columns 16 tj .. belongs to wavefront t % NW; lane (g, c) feeds
+      // A[i = c][k = g] / B[k = g][j = c] and owns D[g + 4 r][c])
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if ((t % NW) != wv) continue;
-          const int ti = t >> 1, tj = t & 1;
-          const bool cok = 16 * tj + wc < NX;
-          d4_t pp;
+      for (int t = 0; t < 4; ++t) {
+        if ((t % NW) != wv) continue;   // (wavefront-uniform)
+        const int ti = t >> 1, tj = t & 1;
+        const bool cok = 16 * tj + wc < NX;
+        d4_t pp;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { const int i = 16 * ti + wg + 4 * r; pp[r] = (i < NX && cok) ? Sm[i * NZ + 16 * tj + wc] : 0.0; }
-#pragma unroll
-          for (int qb = 0; qb < (NU + 3) / 4; ++qb) {
-            const int q = 4 * qb + wg;
-            const bool qv = q < NU;
-            const double a = (qv && 16 * ti + wc < NZ) ? -Sm[(NX + q) * NZ + 16 * ti + wc] : 0.0;
-            const double b = (qv && cok) ? Km[q * (NX + 1) + 16 * tj + wc] : 0.0;
-            pp = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, pp, 0, 0, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { const int i = 16 * ti + wg + 4 * r; if (i < NX && cok) Pm[i * NX + 16 * tj + wc] = pp[r]; }
-        }
-      } else {
-        d4_t p00, p01, p10, p11;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i0 = wg + 4 * r, i1 = 16 + wg + 4 * r;
-          p00[r] = Sm[i0 * NZ + wc]; p01[r] = c1ok ? Sm[i0 * NZ + 16 + wc] : 0.0; p10[r] = i1 < NZ ? Sm[i1 * NZ + wc] : 0.0; p11[r] = (i1 < NZ && c1ok) ? Sm[i1 * NZ + 16 + wc] : 0.0;
-        }
+        for (int r = 0; r < 4; ++r) { const int i = 16 * ti + wg + 4 * r, jc = 16 * tj + wc; pp[r] = (i < NX && cok) ? Sm[(i > jc ? i : jc) * NZ + (i > jc ? jc : i)] : 0.0; }
 #pragma unroll
         for (int qb = 0; qb < (NU + 3) / 4; ++qb) {
           const int q = 4 * qb + wg;
           const bool qv = q < NU;
-          const double a0 = qv ? -Sm[(NX + q) * NZ + wc] : 0.0, a1 = (qv && c1ok) ? -Sm[(NX + q) * NZ + 16 + wc] : 0.0;
-          const double b0 = qv ? Km[q * (NX + 1) + wc] : 0.0, b1 = (qv && 16 + wc < NX) ? Km[q * (NX + 1) + 16 + wc] : 0.0;
-          p00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, p00, 0, 0, 0);
-          p01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, p01, 0, 0, 0);
-          p10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, p10, 0, 0, 0);
-          p11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, p11, 0, 0, 0);
+          const double a = (qv && 16 * ti + wc < NZ) ? -Sm[(NX + q) * NZ + 16 * ti + wc] : 0.0;
+          const double b = (qv && cok) ? Km[q * (NX + 1) + 16 * tj + wc] : 0.0;
+          pp = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, pp, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i0 = wg + 4 * r, i1 = 16 + wg + 4 * r;
-          Pm[i0 * NX + wc] = p00[r];
-          if (16 + wc < NX) Pm[i0 * NX + 16 + wc] = p01[r];
-          if (i1 < NX) { Pm[i1 * NX + wc] = p10[r]; if (16 + wc < NX) Pm[i1 * NX + 16 + wc] = p11[r]; }
-        }
+        for (int r = 0; r < 4; ++r) { const int i = 16 * ti + wg + 4 * r; if (i < NX && cok) Pm[i * NX + 16 * tj + wc] = pp[r]; }
       }
       if (tid < NX) {
         double v = svv[tid];
@@ -1226,7 +1150,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
         for (int q = 0; q < NU; ++q) v -= Sm[(NX + q) * NZ + tid] * Km[q * (NX + 1) + NX];
         pv[tid] = v;
       }
-      __syncthreads();
+      lds_barrier();
       PROF_T(tw4); PROF_ACC(5, tw3, tw4);
     }
     }
