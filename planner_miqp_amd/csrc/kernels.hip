@@ -73,7 +73,7 @@ constexpr int GSTR = 17;             // LDS stride of a dense row (16 columns of
 // (more than two cars: the dense stage matrices S, P, T, the vectors and the gains of one stage live there instead)
 __host__ __device__ inline int ipm_stage_doubles(int C) {
   int NX = 6 * C, NU = 2 * C, NZ = 8 * C;
-  return C <= 2 ? GROWS * (GSTR + 1) : NZ * NZ + NX * NX + NX * NZ + NZ + NX + NU * (NX + 1);
+  return C <= 2 ? GROWS * (GSTR + 1) : NZ * (NZ + 1) + NX * (NX + 1) + NX * (NZ + 1) + NZ + NX + NU * (NX + 1);   // (rows padded by one: the column accesses of S, P, T stay off one LDS bank)
 }
 __host__ __device__ inline int ipm_scratch_doubles(int N, int C) {
   int NZ = 8 * C, a = N * NZ + ipm_stage_doubles(C), b = 64 * (C <= 2 ? GSTR : NZ + 1);
@@ -999,12 +999,14 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
     // ================= backward sweep for more than two cars: dense stage algebra in LDS.  [A B] is block sparse (three
     // entries per chain column), so T = P [A B] and S = Phi + [A B]' T cost three terms per element; the NU x NU block is
     // factored redundantly by every lane, lane c solves column c of K, P = Sxx - Sxu' K.
-    double* Sm = dZ + N * NZ;        // [NZ][NZ]
-    double* Pm = Sm + NZ * NZ;       // [NX][NX]
-    double* Tm = Pm + NX * NX;       // [NX][NZ]
-    double* svv = Tm + NX * NZ;      // [NZ]
+    constexpr int SS = NZ + 1, PS = NX + 1;   // row strides of S / T and of P (odd: rows and columns both spread over the LDS banks)
+    double* Sm = dZ + N * NZ;        // [NZ][SS]
+    double* Pm = Sm + NZ * SS;       // [NX][PS]
+    double* Tm = Pm + NX * PS;       // [NX][SS]
+    double* svv = Tm + NX * SS;      // [NZ]
     double* pv = svv + NZ;           // [NX]
     double* Km = pv + NX;            // [NU][NX+1]
+    double* spv = dgq;               // [NZ] [A B]' p of the stage (dgq is the two-car form's)
     const double h1 = ts, h2 = 0.5 * ts * ts, h3 = ts * ts * ts / 6.0;
     const int wg = (tid & 63) >> 4, wc = tid & 15, wv = tid >> 6;   // lane group / column inside an MFMA tile, wavefront of the workgroup
     // the first row of every lane for the stage assembled next is requested a stage ahead (the rows of a node stream from HBM: 13 planes of
@@ -1014,11 +1016,42 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
     auto stage_rows = [&](int j) { return (sstart[j + 1] - sstart[j]) + (sst[j + 1] - sst[j]); };
     if (tid < stage_rows(N - 1)) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, stage_row(N - 1, tid));
     for (int j = N - 1; j >= 0; --j) {
+      // Order of a stage: S = 2W + [A B]' P [A B] is STORED first (no zeroing pass, no read-modify-write), the rows of the stage are then added
+      // on top with LDS atomics: five workgroup barriers per stage (eight when the rows came first).
       PROF_T(tw0);
-      for (int k = tid; k < NZ * NZ; k += NT) Sm[k] = 0.0;
+      if (j == N - 1) {
+        for (int k = tid; k < NZ * NZ; k += NT) { const int a = k / NZ, c = k - a * NZ; Sm[a * SS + c] = c == a ? 2.0 * Wd[a] : 0.0; }
+        if (tid < NZ) spv[tid] = 0.0;
+      } else {
+        // T = P [A B] and S = 2W + [A B]' T on the VALU: [A B] has 1 / 2 / 3 / 3 entries in the columns (position, velocity, acceleration, input)
+        // of a chain, so a (row, chain) pair of T is 6 fma on three entries of P and a (chain, column) pair of S the same on three entries of
+        // T - 13.5 + 18 fma per lane and stage at four cars.  (Rounds 3-5 ran these as 48 dense v_mfma_f64_16x16x4_f64 per stage: 64 cycles of
+        // the matrix pipe each on gfx950, 8 x the flops the sparsity needs.)
+        for (int pr = tid; pr < NX * NU; pr += NT) {
+          const int i = pr / NU, ch = pr - i * NU, q0 = 3 * ch;
+          const double p0 = Pm[i * PS + q0], p1 = Pm[i * PS + q0 + 1], p2 = Pm[i * PS + q0 + 2];
+          double* tr = Tm + i * SS;
+          tr[q0] = p0; tr[q0 + 1] = fma(h1, p0, p1); tr[q0 + 2] = fma(h2, p0, fma(h1, p1, p2)); tr[NX + ch] = fma(h3, p0, fma(h2, p1, h1 * p2));
+        }
+        lds_barrier();
+        for (int pr = tid; pr < NU * NZ; pr += NT) {
+          const int ch = pr / NZ, c = pr - ch * NZ, q0 = 3 * ch;
+          const double t0 = Tm[q0 * SS + c], t1 = Tm[(q0 + 1) * SS + c], t2 = Tm[(q0 + 2) * SS + c];
+          const double dg = 2.0 * Wd[c];   // (the diagonal entry of the four rows of this pair, where the column is theirs)
+          Sm[q0 * SS + c] = t0 + (c == q0 ? dg : 0.0); Sm[(q0 + 1) * SS + c] = fma(h1, t0, t1) + (c == q0 + 1 ? dg : 0.0);
+          Sm[(q0 + 2) * SS + c] = fma(h2, t0, fma(h1, t1, t2)) + (c == q0 + 2 ? dg : 0.0);
+          Sm[(NX + ch) * SS + c] = fma(h3, t0, fma(h2, t1, h1 * t2)) + (c == NX + ch ? dg : 0.0);
+        }
+        if (tid < NZ) {   // [A B]' p, kept apart from the rows' part of the gradient (the first iteration measures the latter: R0)
+          const int a = tid; double v;
+          if (a < NX) { const int ch = a / 3, ka = a - 3 * ch; v = pv[a]; if (ka >= 1) v += h1 * pv[a - 1]; if (ka >= 2) v += h2 * pv[a - 2]; }
+          else { const int ch = a - NX; v = h3 * pv[3 * ch] + h2 * pv[3 * ch + 1] + h1 * pv[3 * ch + 2]; }
+          spv[a] = v;
+        }
+      }
+      if (tid < NZ) svv[tid] = 2.0 * Wd[tid] * (Z[j * NZ + tid] - Rf[j * NZ + tid]);
       lds_barrier();
-      if (tid < NZ) { Sm[tid * NZ + tid] = 2.0 * Wd[tid]; svv[tid] = 2.0 * Wd[tid] * (Z[j * NZ + tid] - Rf[j * NZ + tid]); }
-      lds_barrier();
+      PROF_T(tw1); PROF_ACC(3, tw0, tw1);
       const int nmj = sstart[j + 1] - sstart[j], nsj = sst[j + 1] - sst[j];
       for (int r0 = tid; r0 < nmj + nsj; r0 += NT) {
         const bool sgl = r0 >= nmj;
@@ -1037,7 +1070,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
         // S[max(i, j)][min(i, j)])
         if (sgl) {
           const int c = (int)(cols & 255);
-          atomicAdd(&svv[c], R.v[0] * lk); atomicAdd(&Sm[c * NZ + c], w * R.v[0] * R.v[0]);
+          atomicAdd(&svv[c], R.v[0] * lk); atomicAdd(&Sm[c * SS + c], w * R.v[0] * R.v[0]);
         } else {
 #pragma unroll
           for (int a = 0; a < 6; ++a) {
@@ -1046,53 +1079,28 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
               const double wa = w * R.v[a];
               atomicAdd(&svv[ca_], R.v[a] * lk);
 #pragma unroll
-              for (int b = 0; b <= a; ++b) atomicAdd(&Sm[ca_ * NZ + (int)((cols >> (8 * b)) & 255)], wa * R.v[b]);
+              for (int b = 0; b <= a; ++b) atomicAdd(&Sm[ca_ * SS + (int)((cols >> (8 * b)) & 255)], wa * R.v[b]);
             }
           }
         }
       }
       if (j > 0 && tid < stage_rows(j - 1)) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, stage_row(j - 1, tid));
       lds_barrier();
-      PROF_T(tw1); PROF_ACC(1, tw0, tw1);
+      PROF_T(tw2); PROF_ACC(1, tw1, tw2);
       if (it == 1 && tid < NZ) rmax = fmax(rmax, fabs(svv[tid]));
       if (j == N - 1) {   // u_{N-1} = 0 (initial_conditions.mod:25-26): P = Phi_xx, p = rr_x
-        for (int k = tid; k < NX * NX; k += NT) { const int i = k / NX, c = k - i * NX; Pm[k] = Sm[(i > c ? i : c) * NZ + (i > c ? c : i)]; }
+        for (int k = tid; k < NX * NX; k += NT) { const int i = k / NX, c = k - i * NX; Pm[i * PS + c] = Sm[(i > c ? i : c) * SS + (i > c ? c : i)]; }
         if (tid < NX) pv[tid] = svv[tid];
         lds_barrier();
         continue;
       }
-      // T = P [A B] and S = Phi + [A B]' T on the VALU: [A B] has 1 / 2 / 3 / 3 entries in the columns (position, velocity, acceleration, input) of
-      // a chain, so a (row, chain) pair of T is 6 fma on three entries of P and a (chain, column) pair of S the same on three entries of T -
-      // 13.5 + 18 fma per lane and stage at four cars.  (Rounds 3-5 ran these as 48 dense v_mfma_f64_16x16x4_f64 per stage: 64 cycles of the
-      // matrix pipe each on gfx950, 8 x the flops the sparsity needs.)
-      for (int pr = tid; pr < NX * NU; pr += NT) {
-        const int i = pr / NU, ch = pr - i * NU, q0 = 3 * ch;
-        const double p0 = Pm[i * NX + q0], p1 = Pm[i * NX + q0 + 1], p2 = Pm[i * NX + q0 + 2];
-        double* tr = Tm + i * NZ;
-        tr[q0] = p0; tr[q0 + 1] = fma(h1, p0, p1); tr[q0 + 2] = fma(h2, p0, fma(h1, p1, p2)); tr[NX + ch] = fma(h3, p0, fma(h2, p1, h1 * p2));
-      }
-      lds_barrier();
-      for (int pr = tid; pr < NU * NZ; pr += NT) {
-        const int ch = pr / NZ, c = pr - ch * NZ, q0 = 3 * ch;
-        const double t0 = Tm[q0 * NZ + c], t1 = Tm[(q0 + 1) * NZ + c], t2 = Tm[(q0 + 2) * NZ + c];
-        Sm[q0 * NZ + c] += t0; Sm[(q0 + 1) * NZ + c] += fma(h1, t0, t1); Sm[(q0 + 2) * NZ + c] += fma(h2, t0, fma(h1, t1, t2));
-        Sm[(NX + ch) * NZ + c] += fma(h3, t0, fma(h2, t1, h1 * t2));
-      }
-      if (tid < NZ) {
-        const int a = tid; double v;
-        if (a < NX) { const int ch = a / 3, ka = a - 3 * ch; v = pv[a]; if (ka >= 1) v += h1 * pv[a - 1]; if (ka >= 2) v += h2 * pv[a - 2]; }
-        else { const int ch = a - NX; v = h3 * pv[3 * ch] + h2 * pv[3 * ch + 1] + h1 * pv[3 * ch + 2]; }
-        svv[a] += v;
-      }
-      lds_barrier();
-      PROF_T(tw2); PROF_ACC(3, tw1, tw2);
       // Suu = L D L' in the registers of every lane (Lw[a][q] = L[a][q] d[q] is kept beside L: one fma per term of the elimination)
       double Lm[NU][NU], Lw[NU][NU], dinv[NU];
 #pragma unroll
       for (int a = 0; a < NU; ++a) {
 #pragma unroll
         for (int b = 0; b <= a; ++b) {
-          double v = Sm[(NX + a) * NZ + NX + b];
+          double v = Sm[(NX + a) * SS + NX + b];
 #pragma unroll
           for (int q = 0; q < b; ++q) v -= Lw[a][q] * Lm[b][q];
           if (a == b) dinv[a] = frcp(fmax(v, 1e-300)); else { Lw[a][b] = v; Lm[a][b] = v * dinv[b]; }
@@ -1103,7 +1111,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
         double xk[NU];
 #pragma unroll
         for (int a = 0; a < NU; ++a) {
-          double v = tid < NX ? Sm[(NX + a) * NZ + tid] : svv[NX + a];
+          double v = tid < NX ? Sm[(NX + a) * SS + tid] : svv[NX + a] + spv[NX + a];
 #pragma unroll
           for (int q = 0; q < a; ++q) v -= Lm[a][q] * xk[q];
           xk[a] = v;
@@ -1132,22 +1140,22 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
         const bool cok = 16 * tj + wc < NX;
         d4_t pp;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int i = 16 * ti + wg + 4 * r, jc = 16 * tj + wc; pp[r] = (i < NX && cok) ? Sm[(i > jc ? i : jc) * NZ + (i > jc ? jc : i)] : 0.0; }
+        for (int r = 0; r < 4; ++r) { const int i = 16 * ti + wg + 4 * r, jc = 16 * tj + wc; pp[r] = (i < NX && cok) ? Sm[(i > jc ? i : jc) * SS + (i > jc ? jc : i)] : 0.0; }
 #pragma unroll
         for (int qb = 0; qb < (NU + 3) / 4; ++qb) {
           const int q = 4 * qb + wg;
           const bool qv = q < NU;
-          const double a = (qv && 16 * ti + wc < NZ) ? -Sm[(NX + q) * NZ + 16 * ti + wc] : 0.0;
+          const double a = (qv && 16 * ti + wc < NZ) ? -Sm[(NX + q) * SS + 16 * ti + wc] : 0.0;
           const double b = (qv && cok) ? Km[q * (NX + 1) + 16 * tj + wc] : 0.0;
           pp = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, pp, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int i = 16 * ti + wg + 4 * r; if (i < NX && cok) Pm[i * NX + 16 * tj + wc] = pp[r]; }
+        for (int r = 0; r < 4; ++r) { const int i = 16 * ti + wg + 4 * r; if (i < NX && cok) Pm[i * PS + 16 * tj + wc] = pp[r]; }
       }
       if (tid < NX) {
-        double v = svv[tid];
+        double v = svv[tid] + spv[tid];
 #pragma unroll
-        for (int q = 0; q < NU; ++q) v -= Sm[(NX + q) * NZ + tid] * Km[q * (NX + 1) + NX];
+        for (int q = 0; q < NU; ++q) v -= Sm[(NX + q) * SS + tid] * Km[q * (NX + 1) + NX];
         pv[tid] = v;
       }
       lds_barrier();
@@ -1165,6 +1173,12 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
 #pragma unroll
       for (int m = 0; m < 3; ++m) { int d = m - k3; ca[m] = d < 0 ? 0.0 : (d == 0 ? 1.0 : (d == 1 ? ts : 0.5 * ts * ts)); }
       cb = k3 == 0 ? ts * ts * ts / 6.0 : (k3 == 1 ? 0.5 * ts * ts : ts); }
+    // (three and four cars: lane 4 ch + m of the first wavefront holds the coefficients of entry m < 3 of chain ch, and the chain's state)
+    double fa[3] = {0.0, 0.0, 0.0}, fb = 0.0, fx0 = 0.0, fx1 = 0.0, fx2 = 0.0;
+    if constexpr (WIDE) { const int k3 = tid & 3;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) { int d = m - k3; fa[m] = (k3 == 3 || d < 0) ? 0.0 : (d == 0 ? 1.0 : (d == 1 ? ts : 0.5 * ts * ts)); }
+      fb = k3 == 0 ? ts * ts * ts / 6.0 : (k3 == 1 ? 0.5 * ts * ts : (k3 == 2 ? ts : 0.0)); }
     // the gains come back from L2 in bulk (the row staging area is free now): SPL stages per load, one wait each
     double* KL = dZ + N * NZ;   // the stage area (row staging / dense stage matrices) is free during the forward sweep
     constexpr int KSZ = NU * KSTR;
@@ -1176,6 +1190,23 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
       __syncthreads();
       const int s1 = s0 + SPL < N - 1 ? s0 + SPL : N - 1;
       for (int i = s0; i < s1; ++i) {
+        if constexpr (WIDE) {
+          // four lanes per chain: each sums a quarter of u = -k - K x, two quad_perm butterflies give all four the input, lanes 0-2 advance
+          // one entry of the chain's state each (the state of the own chain travels in registers through quad_perm broadcasts; the other
+          // chains' entries come back from LDS): a dependent chain of NX / 4 + 2 + 4 operations per stage instead of NX + 4
+          if (tid < 4 * NU) {
+            const double* kv = KL + (i - s0) * KSZ + (tid >> 2) * KSTR;
+            const double* xi = dZ + i * NZ;
+            const int fpt = tid & 3;
+            double part = fpt == 0 ? -kv[NX] : 0.0;
+#pragma unroll
+            for (int q = 0; q < NX; q += 4) if (q + fpt < NX) part -= kv[q + fpt] * xi[q + fpt];
+            part += dpp_mov<0xB1>(part); part += dpp_mov<0x4E>(part);   // quad_perm [1,0,3,2], [2,3,0,1]
+            const double xn = fa[0] * fx0 + fa[1] * fx1 + fa[2] * fx2 + fb * part;
+            if (fpt == 3) dZ[i * NZ + NX + (tid >> 2)] = part; else dZ[(i + 1) * NZ + 3 * (tid >> 2) + fpt] = xn;
+            fx0 = dpp_mov<0x00>(xn); fx1 = dpp_mov<0x55>(xn); fx2 = dpp_mov<0xAA>(xn);   // quad_perm broadcasts of lanes 0, 1, 2
+          }
+        } else
         // one phase per stage: the three lanes of a chain compute their input redundantly (u = -k - K x) and advance
         // their own state with it, so the stage needs a single LDS round trip and wave barrier
         if (tid < NX) {
