@@ -1015,6 +1015,12 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
     auto stage_row = [&](int j, int r0) { const int nmj = sstart[j + 1] - sstart[j]; return r0 >= nmj ? Y.ROWCAP - 1 - (sst[j] + r0 - nmj) : sstart[j] + r0; };
     auto stage_rows = [&](int j) { return (sstart[j + 1] - sstart[j]) + (sst[j + 1] - sst[j]); };
     if (tid < stage_rows(N - 1)) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, stage_row(N - 1, tid));
+    double rfn = tid < NZ ? Rf[(N - 1) * NZ + tid] : 0.0;   // reference of the stage assembled next (requested a stage ahead like the rows)
+    // The compiler's s_waitcnt placement follows registers, not paths: a global load whose result is consumed on some paths only (the unused
+    // coefficients of a short row) stays "pending" in its model, and every later reuse of that register waits for ALL younger loads - the
+    // prefetched rows - to land: the prefetch was waited for at the top of the next phase.  An explicit vmcnt(0) where the loads of a
+    // phase have certainly landed (a real s_waitcnt the pass accounts for) keeps its model clean.
+    constexpr int VMCNT0 = 0x0F70;   // s_waitcnt vmcnt(0) (expcnt 7, lgkmcnt 15: not waited for)
     for (int j = N - 1; j >= 0; --j) {
       // Order of a stage: S = 2W + [A B]' P [A B] is STORED first (no zeroing pass, no read-modify-write), the rows of the stage are then added
       // on top with LDS atomics: five workgroup barriers per stage (eight when the rows came first).
@@ -1049,14 +1055,16 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
           spv[a] = v;
         }
       }
-      if (tid < NZ) svv[tid] = 2.0 * Wd[tid] * (Z[j * NZ + tid] - Rf[j * NZ + tid]);
+      __builtin_amdgcn_s_waitcnt(VMCNT0);   // (the rows and the reference requested a stage ago)
+      if (tid < NZ) svv[tid] = 2.0 * Wd[tid] * (Z[j * NZ + tid] - rfn);
       lds_barrier();
       PROF_T(tw1); PROF_ACC(3, tw0, tw1);
       const int nmj = sstart[j + 1] - sstart[j], nsj = sst[j + 1] - sst[j];
       for (int r0 = tid; r0 < nmj + nsj; r0 += NT) {
         const bool sgl = r0 >= nmj;
         const int r = sgl ? Y.ROWCAP - 1 - (sst[j] + r0 - nmj) : sstart[j] + r0;
-        RowRegs R = r0 == tid ? pre : load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, r);
+        RowRegs R = pre;
+        if (r0 != tid) { R = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, r); __builtin_amdgcn_s_waitcnt(VMCNT0); }   // (a stage of more than NT rows)
         if (sgl) R.aq = 0.0;
         unsigned long long cols = (unsigned long long)__double_as_longlong(R.col);
         const int nn = (int)(cols >> 56);
@@ -1085,6 +1093,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
         }
       }
       if (j > 0 && tid < stage_rows(j - 1)) pre = load_row(rc_aq, rc_col, rc_v, rs_s, rs_l, rs_t, Y.ROWCAP, stage_row(j - 1, tid));
+      if (j > 0 && tid < NZ) rfn = Rf[(j - 1) * NZ + tid];
       lds_barrier();
       PROF_T(tw2); PROF_ACC(1, tw1, tw2);
       if (it == 1 && tid < NZ) rmax = fmax(rmax, fabs(svv[tid]));
