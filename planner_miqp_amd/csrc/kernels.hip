@@ -143,6 +143,7 @@ struct DevBuf {
   int* slot_demand; int* slot_take; int share_cap; int base_take; int floor_pct; int young_nodes; int pump_max; int pump_inc; int window_pct; double probe_room;
   double probe_margin;           // > 0: the rounding probe leaves front-point environment / obstacle disjunctions undecided whose completed alternative holds with this much room
   int probe_itcap0;              // the same while the instance has no incumbent
+  int defer_cap;                 // three and four cars: a node (not a probe, not a root) still unconverged after this many iterations is put back on its list with its iterate as its warm start and finished in a later round - ONCE (pool_big bit 3); 0: never
   int probe_itcap;               // iterations after which an unconverged rounding probe is abandoned (0: never)
   int probe_every;               // rounding probes are eligible every probe_every-th round (1: always)
   int det_ties;                  // 1: ties of the node selection are broken by the nodes' own low key bits and sibling preference (reproducible), 0: by arrival
@@ -774,6 +775,14 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
     const bool pump_probe = B.pump_inc && B.pump_max > 0 && is_probe_word(B.batch_depth[node]);   // (re-rounding with an incumbent, pump_inc: a probe is then only cut off by its objective, not by the penalty of its violated rows - an infeasible one converges to its least-violation point and is re-rounded by eval_kernel)
     { const int pcap = (cutoff < 1e299 && (!pump_probe || (B.pump_inc & 2))) ? B.probe_itcap : B.probe_itcap0;   // (without an incumbent the probes are given longer: the re-rounding needs the converged solution of an infeasible one; pump_inc bit 1: the cap of the phase with an incumbent stays)
       if (pcap > 0 && it > pcap && B.ws_on != 2 && is_probe_word(B.batch_depth[node])) { ok = 2; break; } }
+    // A launch lasts as long as its slowest node, and a single solve of three or four cars waits for it with most of the device idle
+    // (infeasible nodes take 36 iterations, the average 14): a node that is still running after defer_cap iterations is put back on its
+    // list (batch_ok 5: eval_kernel re-queues it with the bound it was selected with) with its iterate as its warm start, and runs to the
+    // end the next time it is selected.
+    if constexpr (WIDE) {
+      if (B.defer_cap > 0 && it > B.defer_cap && B.ws_on == 1 && B.pool_Z && (B.batch_depth[node] >> 6) >= 1 && B.batch_node[node] < B.z_cap
+          && !is_probe_word(B.batch_depth[node]) && !(B.pool_big[B.batch_node[node]] & 8)) { ok = 5; break; }
+    }
     // dual bound of the penalised problem: primal value - total complementarity (valid once the iterate is dual feasible)
 #ifdef MIQP_PROFILE
     if (it > 1 && first_proxy == 0 && obj + RHO_EL * tsum - (double)ncomp * comp > cutoff + 1e-9 * fabs(cutoff)) first_proxy = it;
@@ -1282,6 +1291,16 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
     __syncthreads();
     PROF_T(tf3); PROF_ACC(8, tf2, tf3);
     if (!(MIQP_ABL) && alpha < 1e-12) break;
+  }
+  if (ok == 5) {   // deferred: the iterate becomes the record's warm start
+    double* zp = B.pool_Z + (size_t)B.batch_node[node] * N * NZ;
+    for (int k = tid; k < N * NZ; k += NT) zp[k] = Z[k];
+    if (tid == 0) {
+      B.batch_ok[node] = 5; B.pool_big[B.batch_node[node]] |= 8; B.batch_it[node] = it - 1;
+      atomicAdd((unsigned long long*)&B.inst_iters[inst], (unsigned long long)(it - 1));
+      atomicAdd(B.stat_rowiters, rowiters);
+    }
+    continue;
   }
   // ---- final measures: worst elastic violation, slack cost
   double viol = 0.0, scost = 0.0;
@@ -2204,7 +2223,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         B.pool_origin[slots[q]] = (signed char)(kk == -2 ? 15 : 4 * chosen.kind + cls);
       }
     }
-    if (B.pool_big && lane < nk) B.pool_big[slots[lane]] = pumped ? (unsigned char)((((big_parent >> 4) + 1) << 4) | 1) : big_parent;   // (a child has the rows of its parent and more)
+    if (B.pool_big && lane < nk) B.pool_big[slots[lane]] = pumped ? (unsigned char)((((big_parent >> 4) + 1) << 4) | 1) : (unsigned char)(big_parent & ~8);   // (bit 3, "deferred once", is the parent's own)   // (a child has the rows of its parent and more)
     if (B.pool_Z) {   // the children start their relaxation from this node's solution (see DevBuf::pool_Z)
       for (int q = 0; q < nk; ++q) { if (slots[q] >= B.z_cap) continue; double* zd = B.pool_Z + (size_t)slots[q] * N * NZ; for (int k = lane; k < N * NZ; k += 64) zd[k] = Z[k]; }
     }
