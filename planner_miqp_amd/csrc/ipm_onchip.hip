@@ -500,6 +500,9 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
       // ran to the iteration limit (80) and held the launch of the larger variant up
       const bool pump_probe = BIG && B.pump_inc && B.pump_max > 0 && is_probe_word(B.batch_depth[node]);
       if (BIG) { const int pcap = (cutoff < 1e299 && (!pump_probe || (B.pump_inc & 2))) ? B.probe_itcap : B.probe_itcap0; if (pcap > 0 && it > pcap && B.ws_on != 2 && is_probe_word(B.batch_depth[node])) { ok = 2; break; } }
+      // (deferral, see ipm_kernel: a node still unconverged after defer_cap iterations goes back on its list with its iterate as warm start, once)
+      if (B.defer_cap > 0 && it > B.defer_cap && B.ws_on == 1 && B.pool_Z && (B.batch_depth[node] >> 6) >= 1 && B.batch_node[node] < B.z_cap
+          && !is_probe_word(B.batch_depth[node]) && !(B.pool_big[B.batch_node[node]] & 8)) { ok = 5; break; }
       if (it > 1 && resid_fac * R0 < B.cut_gate * (1.0 + fabs(obj)) && obj + (pump_probe ? 0.0 : RHO_EL * tsum) - (double)ncomp * comp - resid_fac * R0 * D[Y.d_misc + 2] > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }   // (dual value minus the allowance for the stationarity residual still left, see batch_bound)
       }
       const double tau = sigma * comp;   // the common centring target of every complementarity pair
@@ -942,6 +945,16 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
       OC_WAVE_SYNC();
       OCP_T(tp_f3); OCP_ACC(9, tp_f2, tp_f3);
       if (!(OC_ABL) && alpha < 1e-12) break;
+    }
+    if (ok == 5) {   // deferred: the iterate becomes the record's warm start (the layout eval_kernel writes: [N][NZ], logical columns)
+      double* zp = B.pool_Z + (size_t)B.batch_node[node] * N * NZ;
+      for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) zp[(k >> 4) * NZ + oc_lcol<C, CM>(q)] = Z[k]; }
+      if (tid == 0) {
+        B.batch_ok[node] = 5; B.pool_big[B.batch_node[node]] |= 8; B.batch_it[node] = it - 1;
+        atomicAdd((unsigned long long*)&B.inst_iters[inst], (unsigned long long)(it - 1));
+        atomicAdd(B.stat_rowiters, rowiters);
+      }
+      continue;
     }
     // ---- final measures: worst elastic violation, slack cost.  Every elastic row keeps g.z + s - t = rhs along the whole
     // iteration (feasible start, ds - dt = -g.dz), so its residual rhs - g.z is s - t

@@ -779,7 +779,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
     // (infeasible nodes take 36 iterations, the average 14): a node that is still running after defer_cap iterations is put back on its
     // list (batch_ok 5: eval_kernel re-queues it with the bound it was selected with) with its iterate as its warm start, and runs to the
     // end the next time it is selected.
-    if constexpr (WIDE) {
+    {
       if (B.defer_cap > 0 && it > B.defer_cap && B.ws_on == 1 && B.pool_Z && (B.batch_depth[node] >> 6) >= 1 && B.batch_node[node] < B.z_cap
           && !is_probe_word(B.batch_depth[node]) && !(B.pool_big[B.batch_node[node]] & 8)) { ok = 5; break; }
     }
@@ -2643,7 +2643,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
       if (pick) {
         int pos = atomicAdd(&sh_pick, 1);
         if (pos < take) { B.batch_node[base + pos] = nd; B.batch_inst[base + pos] = inst; B.batch_bound[base + pos] = b; B.batch_depth[base + pos] = dp;
-                          if (B.batch_large) B.batch_large[base + pos] = (is_probe_word(dp) || (B.pool_big && B.pool_big[nd])) ? 1 : 0; }
+                          if (B.batch_large) B.batch_large[base + pos] = (is_probe_word(dp) || (B.pool_big && (B.pool_big[nd] & 0xF7))) ? 1 : 0; }   // (bit 3 is the deferral mark, not a size mark)
         else pick = false;
       }
     }

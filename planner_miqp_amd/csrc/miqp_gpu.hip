@@ -958,7 +958,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   B.share_cap = std::max(1, KNOB_T("MIQP_SHARE_CAP") ? std::atoi(KNOB_T("MIQP_SHARE_CAP")) : (queue_mode ? 256 : 1024));
   B.floor_pct = std::max(0, std::min(100, KNOB_T("MIQP_FLOOR_PCT") ? std::atoi(KNOB_T("MIQP_FLOOR_PCT")) : (queue_mode ? 50 : 0)));
   B.lns_narrow = std::max(0, KNOB_T("MIQP_LNS_NARROW") ? std::atoi(KNOB_T("MIQP_LNS_NARROW")) : 512);   // width of a round that carries local-search leaves (0: as wide as any)
-  B.defer_cap = KNOB_T("MIQP_DEFER") ? std::atoi(KNOB_T("MIQP_DEFER")) : (Y.C >= 3 ? 24 : 0);   // (three and four cars, see ipm_kernel; measured on cfg5 at 0 / 16 / 20 / 24: seed 8 0.96 / 0.85 / 0.78 / 0.77 s, seed 14 0.75 / 0.67 / 0.65 / 0.66 s, seed 15 2.47 / 2.62 / 2.39 / 2.42 s, node relaxations in seed 11's 10 s 2.22 / 2.25 / 2.43 / 2.49 M, sixteen in flight 3.33 / 3.71 / 3.42 / 3.49 M)
+  B.defer_cap = KNOB_T("MIQP_DEFER") ? std::atoi(KNOB_T("MIQP_DEFER")) : (Y.C >= 3 ? 24 : 0);   // (see ipm_kernel.  Measured on cfg5 at 0 / 16 / 20 / 24: seed 8 0.96 / 0.85 / 0.78 / 0.77 s, seed 14 0.75 / 0.67 / 0.65 / 0.66 s, seed 15 2.47 / 2.62 / 2.39 / 2.42 s, node relaxations in seed 11's 10 s 2.22 / 2.25 / 2.43 / 2.49 M, sixteen in flight 3.33 / 3.71 / 3.42 / 3.49 M.  Two cars (both on-chip variants have the same exit): OFF - the bench on 8 steps at 0 / 16 / 18 / 20 / 24 / 28: 1160 / 1174 / 1176-1182 / 1172 / 1156 / 1160 solves/s (the standard launch 10.0 -> 9.2 ms but 6 % more nodes per instance), single solves p99 46 -> 44 ms; and cfg3 seed 1913 - the pinned hard instance of test_local_search_changes_the_order_not_the_answer - 135 k -> 327 k nodes: a result that arrives a round late reorders the local search's chains)
   B.probe_itcap0 = KNOB_T("MIQP_PROBE_ITCAP0") ? std::atoi(KNOB_T("MIQP_PROBE_ITCAP0")) : (Y.C >= 3 ? 0 : 40);   // (the cap while the instance has no incumbent)
   B.pump_max = std::max(0, std::min(15, KNOB_P("MIQP_PUMP") ? std::atoi(KNOB_P("MIQP_PUMP")) : 6));   // re-rounding of infeasible rounding probes (eval_kernel)
   B.pump_inc = KNOB_T("MIQP_PUMP_INC") ? std::atoi(KNOB_T("MIQP_PUMP_INC")) : (Y.C >= 3 ? 1 : 0);   // re-rounding also with an incumbent (probes whose OBJECTIVE is below it): three and four cars - cfg5 seed 15 proven in 8 s, the gaps of the two seeds left at 10 s with 16 in flight 0.38 / 0.32 -> 0.09 / 0.03; two cars: the probes it lets converge are the critical path of a round (single-solve p99 62 -> 72 ms, queue -1 %)
