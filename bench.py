@@ -238,7 +238,7 @@ def main():
             P.solve_batch(wws, inflight=infl, prepared=True)
     sync()
     t0 = time.time()
-    solved = 0; attempted = 0; ipm_s = 0.0; launches = 0; iters = 0; rowit = 0; nodes = 0; lat = []; results_s = 0.0; nrec = 0
+    solved = 0; attempted = 0; ipm_s = 0.0; launches = 0; iters = 0; rowit = 0; nodes = 0; lat = []; results_s = 0.0; nrec = 0; stream_info = None; stream_ws = None
     # streaming: the queues of the K timed steps are drained as ONE stream (a step = its queue of instances; no idle tail
     # between steps: the slots freed by the last instances of one queue go to the first of the next); --no-stream: step by step
     timed = [batches[s] for s in range(a.warmup, a.warmup + a.steps)]
@@ -260,8 +260,18 @@ def main():
                 lat.append(pr.time)   # seconds from the instance's admission to its proof
         tm = ws[0].lastTiming()
         ipm_s += tm["ipm_s"]; launches += tm["ipm_launches"]; iters += tm["ipm_iters"]; rowit += tm["row_iters"]; nodes += tm["nodes"]
+        stream_ws = (ws, sts)
     sync()
     dt = time.time() - t0
+    if not a.no_stream and stream_ws is not None:   # (outside the timed region) when the stream's last instance was admitted, and what had been proven by then
+        ws, sts = stream_ws
+        adm = [w.lastAdmission() for w in ws]; t_last = max(adm)
+        prs = [w.getSolutionProperties() for w in ws]
+        done_by = sum(1 for x, pr, st in zip(adm, prs, sts) if st == P.OptimizationStatus.SUCCESS and pr.status in (101, 102) and x + pr.time <= t_last)
+        stream_info = dict(last_admission_s=float(t_last), proven_by_then=int(done_by), solves_per_s_with_backlog=(done_by / t_last if t_last > 0 else None),
+                           note="the timed stream on rank 0: its last instance is admitted at last_admission_s, the rest of ms_per_step x steps is the end effect of the finite queue - the stream "
+                                "waits for the instances admitted last, up to the per-instance limit, with most slots empty (a service whose queue stays filled runs at solves_per_s_with_backlog; "
+                                "reported beside `value`, never as it; meaningful only for a stream that lasts several times the per-instance limit - in a short one the slots are still filling up with the slow instances when the queue runs out)")
     from planner_miqp_amd.sharding import gather_counts
     dev = torch.device("cuda", local) if (world > 1 and torch.cuda.is_available() and torch.cuda.device_count() >= world) else None
     g = gather_counts([dt, solved, attempted, ipm_s, launches, iters, rowit, nodes], dev)
@@ -366,6 +376,7 @@ def main():
                                per_rank=[dict(rank=k, seconds=round(x[0], 3), solved=int(x[1]), attempted=int(x[2]), bnb_nodes=int(x[7])) for k, x in enumerate(g)],
                                bnb_nodes=int(sum(x[7] for x in g)), ipm_iterations=int(sum(x[5] for x in g)),
                                solve_latency_s_rank0=dict(p50=float(np.percentile(lat, 50)), p95=float(np.percentile(lat, 95)), p99=float(np.percentile(lat, 99)), max=float(max(lat))) if lat else None,
+                               timed_stream_rank0=stream_info,
                                collective_backend=(dist.get_backend() if world > 1 else None), ranks_seen=int(ranks_seen)),
                    roofline=dict(bound="mfma", achieved=ach / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s", frac=ach / FP64_PEAK, traffic=traffic,
                                  traffic_note=traffic_note, peak_measured=FP64_PEAK_MEASURED / 1e12, frac_of_measured_peak=ach / FP64_PEAK_MEASURED,
