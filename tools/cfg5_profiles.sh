@@ -1,5 +1,5 @@
 #!/bin/bash
-# profile set of the 4-car configuration (cfg5: 4 cars x 30 steps x 64 regions, ipm_kernel<4,64>): kernel trace + stats and one SQ counter pass
+# profile set of the 4-car configuration (cfg5: 4 cars x 30 steps x 64 regions, ipm_kernel<4,128>): kernel trace + stats and one SQ counter pass
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/cfg5prof; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o c5 -- python3 $R/tools/stream_check.py 16 16 0 10 cfg5 > $O/run.json 2>$O/run.err
