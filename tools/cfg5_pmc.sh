@@ -16,3 +16,18 @@ for k in sorted(tot): print("%-28s %16.0f  (%d launches)" % (k, tot[k], n[k]))
 PY
 cat $O/summary.txt; tail -2 $O/a.log
 rm -rf $O/*/*/*counter_collection.csv $O/*/*counter_collection.csv
+# HBM traffic of the kernel (separate passes, as the guide prescribes): bytes = FETCH_SIZE x 64 B x 2 (gfx950: FETCH_SIZE reports half of a wide streaming read), WRITE_SIZE x 64 B
+if [ "$1" = "traffic" ]; then
+  cd /tmp; O=$R/gpurun_out/cfg5_pmc
+  for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c --output-format csv -d $O/t_$c -o p -- python3 $R/tools/cfg5_rounds.py 15 > $O/t_$c.log 2>&1; done
+  cd $R; python3 - <<'PY' >> $O/summary.txt
+import csv, glob, collections
+tot = collections.defaultdict(float); n = collections.Counter()
+for f in glob.glob("gpurun_out/cfg5_pmc/t_*/*/*counter_collection.csv") + glob.glob("gpurun_out/cfg5_pmc/t_*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "ipm_kernel<4" not in r["Kernel_Name"]: continue
+        tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+for k in sorted(tot): print("%-28s %16.0f  (%d launches)" % (k, tot[k], n[k]))
+PY
+  tail -3 $O/summary.txt; rm -rf $O/t_*/*/*counter_collection.csv $O/t_*/*counter_collection.csv
+fi
