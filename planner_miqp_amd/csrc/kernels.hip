@@ -75,6 +75,11 @@ __host__ __device__ inline int ipm_stage_doubles(int C) {
   int NX = 6 * C, NU = 2 * C, NZ = 8 * C;
   return C <= 2 ? GROWS * (GSTR + 1) : NZ * (NZ + 1) + NX * (NX + 1) + NX * (NZ + 1) + NZ + NX + NU * (NX + 1);   // (rows padded by one: the column accesses of S, P, T stay off one LDS bank)
 }
+// eval_kernel: doubles of the LDS region shared by the slow-alternative table (floats) and the dense rows of the lifting
+__host__ __device__ inline int eval_shared_doubles(int C, int N, int P) {
+  const int a = (C * N * P + 1) / 2, b = 64 * (8 * C + 1);
+  return a > b ? a : b;
+}
 __host__ __device__ inline int ipm_scratch_doubles(int N, int C) {
   int NZ = 8 * C, a = N * NZ + ipm_stage_doubles(C), b = 64 * (C <= 2 ? GSTR : NZ + 1);
   return a > b ? a : b;
@@ -1521,8 +1526,12 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   const int N = Y.N, P = Y.P;
   extern __shared__ double lds[];
   double* Z = lds;                                   // [N][NZ]
-  double* slowv = Z + N * NZ;                        // [C*N][P] slow-alternative violation per possible region
-  double* fastv = slowv + C * N * P;                 // [C*N] best fast alternative violation
+  // (one region for two tenants that are never alive together: the slow-alternative table of phase R - read for the last time by the freeze
+  // resolution right behind it - and the dense rows of the lifting.  Apart they were 10 + 9 KB of a two-car workgroup's 28 KB (5 workgroups per
+  // CU of a kernel that waits on memory for 60 % of its cycles; 8 now) and 61 + 17 KB at four cars x 64 regions (ONE workgroup per CU; 3 now).)
+  float* slowv = (float*)(Z + N * NZ);               // [C*N][P] slow-alternative violation per possible region (float: compared with tolerances and with each other only)
+  double* gsc = Z + N * NZ;                          // [64][NZ + 1] one dense row per lane (lifting)
+  double* fastv = Z + N * NZ + eval_shared_doubles(C, N, P);   // [C*N] best fast alternative violation
   double* rlift = fastv + C * N;                     // [C*N] smallest lift over the region alternatives (branching score)
   int* fastc = (int*)(rlift + C * N);                // [C*N] its code
   int* vflag = fastc + C * N;                        // [C*N] region violated
@@ -1531,10 +1540,9 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   signed char* fix = (signed char*)(altval + 64);    // [fixlen]
   signed char* comp = fix + Y.fixlen;                // [fixlen]
   signed char* cfix = comp + Y.fixlen;               // [fixlen] fix record of the child whose rows are being lifted
-  double* gsc = (double*)(cfix + Y.fixlen);          // [64][NZ + 1] one dense row per lane
   // multi-row lifting: up to LIFT_ROWS rows of a child at the branching stage - coefficients g, response y = Sigma g, violation
   // v at the node's solution, diagonal g Sigma g', multiplier; and the running vector w = sum_r lambda_r y_r
-  double* mr_g = gsc + 64 * (NZ + 1);                // [LIFT_ROWS][NZ]
+  double* mr_g = (double*)(cfix + ((Y.fixlen + 7) & ~7));   // [LIFT_ROWS][NZ]
   double* mr_y = mr_g + LIFT_ROWS * NZ;              // [LIFT_ROWS][NZ]
   double* mr_v = mr_y + LIFT_ROWS * NZ;              // [LIFT_ROWS]
   double* mr_d = mr_v + LIFT_ROWS;                   // [LIFT_ROWS]
@@ -1551,9 +1559,11 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
 
   const double* Zi = B.batch_Z + (size_t)node * N * NZ;
   const signed char* src = B.pool_fix + (size_t)B.batch_node[node] * Y.fixlen;
+  PROF_T(te0);
   for (int k = lane; k < N * NZ; k += 64) Z[k] = Zi[k];
   for (int k = lane; k < Y.fixlen; k += 64) { fix[k] = src[k]; comp[k] = src[k]; ploose[k] = 0; }
   __syncthreads();
+  PROF_T(te1);
   const double viol = B.batch_viol[node];
   const int okq = B.batch_ok[node];
   if (okq == 5) {   // returned unsolved by the standard on-chip kernel (too large for it, now marked): back on the list with the bound it came with
@@ -1652,7 +1662,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       // (the completion below looks at every statically possible alternative, whatever the node's set: it labels the solution
       // of THIS node, and the labels stay the canonical ones - first alternative in order that holds)
       for (int q = 0; q < np; ++q) {
-        slowv[(c * N + i) * P + q] = ((nxtq >= 0 && nxtq != q) || !((allow >> (q * 4 + 3)) & 1ull)) ? 1e300 : region_alt_viol(Y, D, T, c, q, 3, s, wj);
+        slowv[(c * N + i) * P + q] = ((nxtq >= 0 && nxtq != q) || !((allow >> (q * 4 + 3)) & 1ull)) ? 3.0e38f : (float)fmin(region_alt_viol(Y, D, T, c, q, 3, s, wj), 3.0e38);
         if (nxtq >= 0 && nxtq != q) continue;
         int nh = T[Y.i_nhs + c * P + q];
         for (int h = 0; h < nh; ++h) {
@@ -1667,6 +1677,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     }
   }
   __syncthreads();
+  PROF_T(te2);
   if (__ballot(dead_lane)) { if (B.stats && lane == 0) atomicAdd(&B.stats[59], 1ull); FREE_NODE(); return; }
   if (lane < C) {  // sequential resolution of the freeze (slow => same region as the previous step)
     int c = lane; int prevj = T[Y.i_initj + c];
@@ -1677,7 +1688,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         double bv = fastv[c * N + i]; int bc = fastc[c * N + i];
         for (int q = 0; q < np; ++q)
           if (T[Y.i_regj + c * P + q] == prevj) {
-            double v = slowv[(c * N + i) * P + q];
+            double v = (double)slowv[(c * N + i) * P + q];
             if (bv > tol && (v <= tol || v < bv)) { bv = v <= tol ? 0.0 : v; bc = q * 4 + 3; }
           }
         if (bc < 0 || bv > tol) { vflag[c * N + i] = 1; if (bc < 0) bc = 0; }
@@ -1858,6 +1869,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   int best = mine.prio;
   for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
   __syncthreads();
+  PROF_T(te3);
   if (best == 0x7FFFFFFF && !pumped) {   // (the solution of a re-rounded probe violates rows of its own: only its completion, solved as the next probe, can be an incumbent)
     if (B.stats && lane == 0) atomicAdd(&B.stats[42], 1ull);
     // integer feasible: candidate incumbent.  The winner of the 64-bit atomicMin owns the low 20 bits (batch slot).
@@ -1997,6 +2009,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     sh_base[2] = nalt;
   }
   __syncthreads();
+  PROF_T(te4);
   nalt = sh_base[2];
   const int base = fam[0], stride = fam[1], jlo = fam[2], jhi = fam[3];
   // ---------------- bound lifting.  With the node's multipliers fixed its Lagrangian grows like 1/2 (z - z*)' H (z - z*)
@@ -2185,6 +2198,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     sh_base[0] = fbase; sh_base[1] = obase; sh_base[2] = nk;
   }
   __syncthreads();
+  PROF_T(te5);
   const int nk = sh_base[2];
   if (nk <= 0) { FREE_NODE(); return; }
   {
@@ -2251,6 +2265,11 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     }
   }
   FREE_NODE();
+#ifdef MIQP_PROFILE
+  { PROF_T(te6);   // (branched nodes only: the early exits - pruned, infeasible, leaves - are not counted)
+    if (lane == 0) { atomicAdd(&B.prof[100], (unsigned long long)(te1 - te0)); atomicAdd(&B.prof[101], (unsigned long long)(te2 - te1)); atomicAdd(&B.prof[102], (unsigned long long)(te3 - te2));
+                     atomicAdd(&B.prof[103], (unsigned long long)(te4 - te3)); atomicAdd(&B.prof[104], (unsigned long long)(te5 - te4)); atomicAdd(&B.prof[105], (unsigned long long)(te6 - te5)); atomicAdd(&B.prof[106], 1ull); } }
+#endif
 #undef FREE_NODE
 }
 

@@ -500,8 +500,8 @@ size_t ipm_lds_bytes(const Layout& Y) {
 }
 bool multi_row_lifting_on() { const char* e = KNOB_P("MIQP_SEQ_KINDS"); return e && (std::strtoul(e, nullptr, 0) & 0x80000000ul) != 0ul; }
 size_t eval_lds_bytes(const Layout& Y) {
-  size_t d = (size_t)Y.N * Y.nz + (size_t)Y.C * Y.N * Y.P + 2 * (size_t)Y.C * Y.N;
-  return d * 8 + (size_t)(2 * Y.C * Y.N + 64) * 4 + 64 * 8 + 3 * (size_t)Y.fixlen + (size_t)64 * (Y.nz + 1) * 8 + 64
+  size_t d = (size_t)Y.N * Y.nz + (size_t)eval_shared_doubles(Y.C, Y.N, Y.P) + 2 * (size_t)Y.C * Y.N;   // (the slow-alternative table and the lifting's dense rows share one region)
+  return d * 8 + (size_t)(2 * Y.C * Y.N + 64) * 4 + 64 * 8 + 3 * (size_t)Y.fixlen + 8 + 64
          + (multi_row_lifting_on() ? (size_t)(LIFT_ROWS * (2 * Y.nz + 3) + Y.nz) * 8 : 0) + 64   // rows of the multi-row lifting (an experiment: MIQP_SEQ_KINDS bit 31)
          + (size_t)Y.fixlen + 16;                                  // ploose
 }
@@ -1257,7 +1257,14 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
         std::fprintf(stderr, "\n"); } }
     std::fprintf(stderr, "[miqp_gpu profile] on-chip nodes %llu iters %llu cycles/node-iter %.0f :", pf[11], pf[10], tot / std::max(1ull, pf[10]));
     for (int q = 0; q < 10; ++q) std::fprintf(stderr, " %s %.1f%% (%.0f)", nm[q], 100.0 * pf[q] / tot, (double)pf[q] / std::max(1ull, pf[10]));
-    std::fprintf(stderr, "\n"); HIP_OK(hipMemset(B.prof, 0, 128 * 8)); }
+    std::fprintf(stderr, "\n");
+    { unsigned long long pe[8]; HIP_OK(hipMemcpy(pe, B.prof + 100, 8 * 8, hipMemcpyDeviceToHost));
+      const char* ne[6] = {"load", "regions", "leaf disjunctions", "branching", "lifting + reservation", "records"};
+      double te = 0; for (int q = 0; q < 6; ++q) te += (double)pe[q];
+      if (pe[6]) { std::fprintf(stderr, "[miqp_gpu profile] eval_kernel, %llu branched nodes, cycles/node %.0f :", pe[6], te / (double)pe[6]);
+        for (int q = 0; q < 6; ++q) std::fprintf(stderr, " %s %.1f%% (%.0f)", ne[q], 100.0 * pe[q] / te, (double)pe[q] / (double)pe[6]);
+        std::fprintf(stderr, "\n"); } }
+    HIP_OK(hipMemset(B.prof, 0, 128 * 8)); }
 #endif
   if (B.stats) {
     unsigned long long hs[256]; HIP_OK(hipMemcpy(hs, B.stats, sizeof(hs), hipMemcpyDeviceToHost)); HIP_OK(hipMemset(B.stats, 0, sizeof(hs)));
