@@ -1964,10 +1964,12 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     };
     // window of undecided steps: all of them when the children fit, else the steps from the violated one onwards
     int tmp[64];   // alternatives of one disjunction: the host admits at most 62 (batch_layout), region alternatives are <= 15 x 3
-    int jlo = 1, jhi = N - 1, total = 1;
-    for (int j = 1; j < N; ++j) if (fix[base + j * stride] < 0) total += alts_of(j, tmp);
-    if (!((B.seq_kinds >> d.kind) & 1)) { jlo = i; jhi = i; total = 1 + alts_of(i, tmp); }  // plain K-way branching on step i (default)
-    else if (total > 63 || ((B.seq_kinds >> 20) & 15)) {
+    int jlo = 1, jhi = N - 1, total = 1, n_i = -1;
+    // (plain K-way branching on step i is the default for every kind: its alternatives are enumerated ONCE - the count over all undecided steps,
+    // which only the first-deviation family needs, cost N - 1 enumerations per node for nothing)
+    if (!((B.seq_kinds >> d.kind) & 1)) { jlo = i; jhi = i; n_i = alts_of(i, tmp); total = 1 + n_i; }
+    else { for (int j = 1; j < N; ++j) if (fix[base + j * stride] < 0) total += alts_of(j, tmp); }
+    if (((B.seq_kinds >> d.kind) & 1) && (total > 63 || ((B.seq_kinds >> 20) & 15))) {
       // window: from the violated step onwards (steps before it hold in the relaxation and stay undecided), at most
       // `win` steps when that experiment switch is set
       const int win = (B.seq_kinds >> 20) & 15;
@@ -1990,7 +1992,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     ck[0] = N; ca[0] = 0; nalt = 1;                       // child_inf
     for (int j = jlo; j <= jhi; ++j) {
       if (fix[base + j * stride] >= 0) continue;
-      int n = alts_of(j, tmp);
+      int n = (j == i && n_i >= 0) ? n_i : alts_of(j, tmp);   // (plain branching: tmp still holds the alternatives of step i)
       for (int q = 0; q < n && nalt < 63; ++q) { ck[nalt] = j; ca[nalt] = tmp[q]; nalt++; }
     }
     }
