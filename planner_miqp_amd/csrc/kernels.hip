@@ -1626,9 +1626,9 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       // canonical choice (ties at sector borders are common): the first non-slow alternative, in (region, half-plane)
       // order, whose rows hold within tol; else the slow alternative if it holds; else the least violated one
       double bv = 1e300; int bc = -1; bool found = false;
-      LiftDiag LX, LYd; lift_diag(Y, D, c, i, LX, LYd);
-      double ml = 1e300;
       const bool want_score = ((B.seq_kinds >> 8) & 15) >= 10;
+      LiftDiag LX = {0.0, 0.0, 0.0, 0.0}, LYd = {0.0, 0.0, 0.0, 0.0}; if (want_score) lift_diag(Y, D, c, i, LX, LYd);   // (the score of the branching orders 10 / 11 only)
+      double ml = 1e300;
       const unsigned long long allow = ((unsigned long long)(unsigned int)T[Y.i_allow + (c * N + i) * 2 + 1] << 32) | (unsigned int)T[Y.i_allow + (c * N + i) * 2];
       int rset = region_set(Y, T, fix, c, i);
       // Region set tightening (bound propagation from the node's dual solution): a region of an undecided step whose every
@@ -1736,7 +1736,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       const double* z = Z + i * NZ;
       CarState s = {z[6 * c], z[6 * c + 1], z[6 * c + 2], z[6 * c + 3], z[6 * c + 4], z[6 * c + 5], z[6 * C + 2 * c], z[6 * C + 2 * c + 1]};
       if (vflag[c * N + i]) consider(i, 0, c, 0, 0, fastv[c * N + i], rlift[c * N + i]);
-      LiftDiag LX, LYd; lift_diag(Y, D, c, i, LX, LYd);
+      LiftDiag LX = {0.0, 0.0, 0.0, 0.0}, LYd = {0.0, 0.0, 0.0, 0.0}; if (prio_mode >= 10 || Y.O > 0) lift_diag(Y, D, c, i, LX, LYd);   // (scores: branching orders 10 / 11, and the obstacles' lifts)
       const double rsc = rlift[c * N + i];
       int code = (int)comp[Y.f_reg + c * N + i];
       const double* rt = D + Y.d_reg + (c * P + (code >> 2)) * REGSZ;
@@ -1799,9 +1799,9 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         CarState s2 = {z[6 * c2], z[6 * c2 + 1], z[6 * c2 + 2], z[6 * c2 + 3], z[6 * c2 + 4], z[6 * c2 + 5], z[6 * C + 2 * c2], z[6 * C + 2 * c2 + 1]};
         int code1 = (int)comp[Y.f_reg + c1 * N + i], code2 = (int)comp[Y.f_reg + c2 * N + i];
         const double* rt1 = D + Y.d_reg + (c1 * P + (code1 >> 2)) * REGSZ; const double* rt2 = D + Y.d_reg + (c2 * P + (code2 >> 2)) * REGSZ;
-        double gx12, gy12;
-        { LiftDiag A1, B1, A2, B2; lift_diag(Y, D, c1, i, A1, B1); lift_diag(Y, D, c2, i, A2, B2); gx12 = A1.p + A2.p; gy12 = B1.p + B2.p; }
-        PosBlk PX1, PY1, PX2, PY2; pos_blocks(Y, D, c1, i, PX1, PY1); pos_blocks(Y, D, c2, i, PX2, PY2);
+        double gx12 = 0.0, gy12 = 0.0;
+        if (prio_mode >= 10) { LiftDiag A1, B1, A2, B2; lift_diag(Y, D, c1, i, A1, B1); lift_diag(Y, D, c2, i, A2, B2); gx12 = A1.p + A2.p; gy12 = B1.p + B2.p; }   // (the score of the branching orders 10 / 11 only)
+        PosBlk PX1, PY1, PX2, PY2; bool have_pos = false;   // (the blocks of the set tightening: fetched when a group of this (pair, step) needs them)
         for (int g = 0; g < 4; ++g) {
           bool need1 = g >= 2, need2 = (g == 1 || g == 3);
           int unf = -1;
@@ -1828,6 +1828,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
               const double room = inc_now - gapi_ * (1e-10 + fabs(inc_now)) - objlb;
               const bool softg = (g == 0 || g == 3); const double smx = softg ? D[Y.d_smax + i] : 0.0;
               const int am0 = am;
+              if (!have_pos) { pos_blocks(Y, D, c1, i, PX1, PY1); pos_blocks(Y, D, c2, i, PX2, PY2); have_pos = true; }
               for (int a = 0; a < 4; ++a) {
                 if (!((am >> a) & 1)) continue;
                 const double hv = c2c_alt_viol(Y, D, p, i, g, a, s1, rr1, s2, rr2, K1, K2) - smx;   // violation of the hard row of the alternative
@@ -1839,7 +1840,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
             for (int a = 0; a < 4; ++a) {
               if (!((amc >> a) & 1)) continue;   // (the completion labels this node's own solution: every statically possible alternative)
               double v = c2c_alt_viol(Y, D, p, i, g, a, s1, rt1, s2, rt2); if (v < bv) { bv = v; ba = a; }
-              sc = fmin(sc, lift1(v, a < 2 ? gx12 : gy12));
+              if (prio_mode >= 10) sc = fmin(sc, lift1(v, a < 2 ? gx12 : gy12));
             }
             okk = bv <= tol; comp[Y.f_c2c + (p * N + i) * 4 + g] = (signed char)ba;
           }
