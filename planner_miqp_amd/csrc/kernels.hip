@@ -2303,7 +2303,8 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   const int cap = B.open_cap;
   __shared__ int sh_take, sh_base, sh_m, sh_keep, sh_pick, sh_ties, sh_w, sh_mv, sh_all, sh_elig;
   __shared__ double sh_inc;
-  __shared__ unsigned int hist[256], dhist[256];
+  __shared__ unsigned int hist[256], dhist[256], sh_wsum[4];
+  __shared__ int sh_bin;
   __shared__ int sh_dkeep, sh_tiecnt, sh_ndef;
   __shared__ unsigned long long sh_thr2;
   __shared__ unsigned long long sh_prefix, sh_thr, sh_fmin;
@@ -2311,6 +2312,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   if (B.inst_done[inst]) return;
   const size_t src = ((size_t)B.open_sel * B.n_slots + slot) * cap, dst = ((size_t)(1 - B.open_sel) * B.n_slots + slot) * cap;
   unsigned long long* keys = B.open_key + (size_t)slot * cap;
+  PROF_T(ts0);
   // ---- incumbent bookkeeping: copy the solution of the atomicMin winner of the last round
   if (tid == 0) {
     unsigned long long key = B.inc_key[inst];
@@ -2359,6 +2361,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     }
     return;
   }
+  PROF_T(ts1);
   const double inc = fmin(sh_inc < 1e300 ? B.inc_obj[inst] : 1e300, B.inc_ext[inst]);   // what prunes: the best incumbent known (own or, in a tree split, another rank's)
   const double cst = B.inst_const[inst];
   const double gap = B.inst_gap[inst];
@@ -2379,13 +2382,34 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
         if (key != ~0ull && (key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255ull], 1u);
       }
       __syncthreads();
-      if (tid == 0) {
-        unsigned int cum = 0; int bin = 0;
-        for (bin = 0; bin < 256; ++bin) { if (cum + hist[bin] >= (unsigned int)need) break; cum += hist[bin]; }
-        if (bin > 255) { bin = 255; if (shift == 56) sh_all = 1; }
-        sh_prefix = prefix | ((unsigned long long)bin << shift);
-        sh_pick = need - (int)cum;   // how many of the keys with this prefix are still needed
-        sh_tiecnt = (int)hist[bin];  // (after the last pass: how many keys share the resolved bits of the threshold)
+      // the first bin whose inclusive prefix count reaches `need`: a scan over the 256 bins by four wavefronts (one thread walking the bins paid an
+      // LDS round trip per bin: 61 % of this kernel's cycles, measured)
+      if (tid == 0) sh_bin = 256;
+      unsigned int hv = 0, hx = 0;
+      if (tid < 256) {
+        hv = hist[tid]; hx = hv;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(hx, o); if ((tid & 63) >= o) hx += y; }
+        if ((tid & 63) == 63) sh_wsum[tid >> 6] = hx;
+      }
+      __syncthreads();
+      if (tid < 256) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) if (w < (tid >> 6)) hx += sh_wsum[w];   // inclusive prefix over all bins up to this one
+        if (hx >= (unsigned int)need) atomicMin(&sh_bin, tid);
+        if (tid == 255) sh_wsum[3] = hx;   // (the total, for the case that no bin reaches `need`)
+      }
+      __syncthreads();
+      {
+        const int bin0 = sh_bin;
+        if (tid == (bin0 < 256 ? bin0 : 255)) {   // the owner of the chosen bin
+          const int bin = bin0 < 256 ? bin0 : 255;
+          const unsigned int cum = bin0 < 256 ? hx - hv : sh_wsum[3];   // keys in the bins before it (none reaches `need`: all of them, as the walk counted)
+          if (bin0 >= 256 && shift == 56) sh_all = 1;
+          sh_prefix = prefix | ((unsigned long long)bin << shift);
+          sh_pick = need - (int)cum;   // how many of the keys with this prefix are still needed
+          sh_tiecnt = (int)hv;         // (after the last pass: how many keys share the resolved bits of the threshold)
+        }
       }
       __syncthreads();
       need = sh_pick;
@@ -2423,6 +2447,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     const double kv = fmax(bb, -1e300);
     const unsigned long long key = d2key(kv); return key == ~0ull ? ~0ull - 1 : key;
   };
+  PROF_T(ts2);
   // ---- pass 1: prune, keys, lower bound, population per tree depth
   for (int k = tid; k < 256; k += SEL_THREADS) dhist[k] = 0u;
   __syncthreads();
@@ -2450,6 +2475,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   if (ndef) atomicAdd(&sh_ndef, ndef);
   __syncthreads();
   int m = sh_m;
+  PROF_T(ts3);
   // ---- far tier: when the near list cannot fill a batch any more, the far entries with the lowest bounds come back
   // (threshold by radix select on their bounds), the ones the incumbent prunes are dropped and the rest is compacted in
   // place, chunk by chunk (a chunk is read completely before anything is written at or below it)
@@ -2515,6 +2541,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
       B.near_thr[inst] = (fc > 0 && thr != ~0ull) ? key2d(thr | lowmask) : 1e300;   // what stays behind lies above the threshold
     }
   }
+  PROF_T(ts4);
   red[tid] = lb; __syncthreads();
   for (int s = SEL_THREADS / 2; s > 0; s >>= 1) { if (tid < s) red[tid] = fmin(red[tid], red[tid + s]); __syncthreads(); }
   lb = red[0];
@@ -2534,6 +2561,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
   // Endgame focus: when only a few instances are still open, the batch is not split evenly but geometrically by gap rank
   // (1/2 to the instance closest to its proof, 1/4 to the next, ...): finishing one instance after the other brings more
   // of them below the gap before the time limit than advancing all of them at the same pace.
+  PROF_T(ts5);
   if (tid == 0) sh_pick = 0;   // reused as rank counter until the selection below resets it
   __syncthreads();
   const int act_now = *B.active_insts;
@@ -2601,6 +2629,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     sh_thr = ~0ull; sh_w = fc; sh_fmin = ~0ull;
   }
   __syncthreads();
+  PROF_T(ts6);
   const int take = sh_take, base = sh_base;
   // ---- radix select: smallest key value T such that count(key <= T) >= take
   // Keys that agree in the resolved bits are ties.  Which of them are taken is decided by a second select on what the node
@@ -2643,6 +2672,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     __syncthreads();
   } else if (tid == 0) { sh_thr = take >= m ? ~0ull : 0ull;   /* ~0: above every masked key */ sh_thr2 = ~0ull; sh_ties = 0x7FFFFFFF; sh_pick = 0; }
   __syncthreads();
+  PROF_T(ts7);
   // ---- pass 3: emit the selected nodes, keep the rest (near list, or far tier when the round spills)
   const unsigned long long thr = sh_thr, thr2 = sh_thr2;
   for (int k0 = 0; k0 < n; k0 += SEL_THREADS) {
@@ -2689,6 +2719,12 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
       B.near_thr[inst] = dive ? -1e300 : (thr_spill != ~0ull ? key2d(thr_spill | lowmask) : 1e300);
     }
   }
+#ifdef MIQP_PROFILE
+  { PROF_T(ts8);
+    if (tid == 0) { const long long tt[9] = {ts0, ts1, ts2, ts3, ts4, ts5, ts6, ts7, ts8};
+      for (int q = 0; q < 8; ++q) atomicAdd(&B.prof[110 + q], (unsigned long long)(tt[q + 1] - tt[q]));
+      atomicAdd(&B.prof[118], 1ull); atomicAdd(&B.prof[119], (unsigned long long)n); } }
+#endif
 }
 
 // admission of queued instances into free slots (one thread per admission): the instance that held the slot leaves it, the

@@ -1264,6 +1264,12 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       if (pe[6]) { std::fprintf(stderr, "[miqp_gpu profile] eval_kernel, %llu branched nodes, cycles/node %.0f :", pe[6], te / (double)pe[6]);
         for (int q = 0; q < 6; ++q) std::fprintf(stderr, " %s %.1f%% (%.0f)", ne[q], 100.0 * pe[q] / te, (double)pe[q] / (double)pe[6]);
         std::fprintf(stderr, "\n"); } }
+    { unsigned long long ps[10]; HIP_OK(hipMemcpy(ps, B.prof + 110, 10 * 8, hipMemcpyDeviceToHost));
+      const char* ns[8] = {"incumbent copy / kill", "setup", "pass 1 (prune, keys)", "far refill", "bound reduce + spill select", "focus + window + share", "radix select + ties", "pass 3 (emit, compact)"};
+      double ts = 0; for (int q = 0; q < 8; ++q) ts += (double)ps[q];
+      if (ps[8]) { std::fprintf(stderr, "[miqp_gpu profile] select_kernel, %llu workgroups that reached the end (thread 0's clock), mean list %.0f entries, cycles each %.0f :", ps[8], (double)ps[9] / (double)ps[8], ts / (double)ps[8]);
+        for (int q = 0; q < 8; ++q) std::fprintf(stderr, " %s %.1f%% (%.0f)", ns[q], 100.0 * ps[q] / ts, (double)ps[q] / (double)ps[8]);
+        std::fprintf(stderr, "\n"); } }
     HIP_OK(hipMemset(B.prof, 0, 128 * 8)); }
 #endif
   if (B.stats) {
