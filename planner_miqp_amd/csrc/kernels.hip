@@ -2542,9 +2542,12 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     }
   }
   PROF_T(ts4);
-  red[tid] = lb; __syncthreads();
-  for (int s = SEL_THREADS / 2; s > 0; s >>= 1) { if (tid < s) red[tid] = fmin(red[tid], red[tid + s]); __syncthreads(); }
-  lb = red[0];
+  lb = wave_min(lb);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = lb;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < SEL_THREADS / 64; ++w) lb = fmin(lb, red[w]);
   if (fc > 0) lb = fmin(lb, key2d(B.far_minkey[inst]));   // the instance's bound covers both tiers
   // ---- spill: a best-bound round that finds the near list long keeps the `keep` lowest keys there and moves the rest to the
   // far tier (pass 3); from then on children above the threshold are appended to the far tier directly (eval_kernel).
@@ -2750,10 +2753,16 @@ __global__ void __launch_bounds__(1024) share_kernel(DevBuf B) {
   __shared__ long long red[1024];
   __shared__ int sh_lo, sh_hi;
   const int tid = threadIdx.x, NSL = B.n_slots;
-  auto bsum = [&](long long v) -> long long {
-    __syncthreads(); red[tid] = v; __syncthreads();
-    for (int st = 512; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
-    return red[0];
+  auto bsum = [&](long long v) -> long long {   // (wavefront sums by shuffles, sixteen partials through LDS: two barriers instead of twelve per sum - this kernel is ~ 15 of them)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();   // (the partials of the previous sum have been read)
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    long long t = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    return t;
   };
   const long long target = (long long)B.batch_cap - (long long)B.batch_cap / 16;   // (demands are one round old: a little head room)
   // The base share is a FLOOR that adapts to the load: the largest F in [base_take, share_cap] with sum_k min(demand_k, F) <= floor_pct % of
@@ -2798,14 +2807,22 @@ __global__ void __launch_bounds__(1024) share_kernel(DevBuf B) {
     return c > b ? c - b : 0;
   };
   // pass by admission order (earliest deadline first), every instance up to the cap
+  // (every slot sums over all slots: the instance of a slot and what it may take are staged in LDS once - read from global memory inside the
+  // double loop this pass was 0.1 ms of every round at 1280 slots)
+  constexpr int SH_SLOTS = 2048;
+  __shared__ int s_inst[SH_SLOTS]; __shared__ long long s_more[SH_SLOTS];
+  const bool staged = NSL <= SH_SLOTS;
+  if (staged) { for (int k = tid; k < NSL; k += 1024) { s_inst[k] = B.slot_inst[k]; s_more[k] = more_of(k); } }
+  __syncthreads();
   long long at = 0;
   for (int k = tid; k < NSL; k += 1024) {
-    const int d = B.slot_demand[k], inst = B.slot_inst[k];
+    const int inst = staged ? s_inst[k] : B.slot_inst[k];
     int take = base_of(k);
-    const long long more = more_of(k);
+    const long long more = staged ? s_more[k] : more_of(k);
     if (inst >= 0 && more > 0 && rest > 0) {
       long long before = 0;   // what the instances admitted earlier take from the rest
-      for (int j = 0; j < NSL; ++j) { const int ij = B.slot_inst[j]; if (ij >= 0 && ij < inst) before += more_of(j); }
+      if (staged) { for (int j = 0; j < NSL; ++j) { const int ij = s_inst[j]; if (ij >= 0 && ij < inst) before += s_more[j]; } }
+      else { for (int j = 0; j < NSL; ++j) { const int ij = B.slot_inst[j]; if (ij >= 0 && ij < inst) before += more_of(j); } }
       long long ex = rest - before; if (ex > more) ex = more;
       if (ex > 0) take += (int)ex;
     }
