@@ -2212,6 +2212,19 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       // and the alternatives of its earlier siblings at that step
       int negidx = -1; const int negm = k_neg[q];
       if (chosen.kind == 3 && kk >= 0 && kk < N && (B.seq_kinds & 0x10000) == 0) negidx = Y.f_c2n + (chosen.c * N + kk) * 4 + chosen.o;
+      if (kk != -2) {
+        // an ordinary child differs from its parent in the bytes of the branching family (one byte with the default plain branching) and the
+        // exclusion mask: the record is assembled in LDS - the parent's bytes copied 8 at a time, the few bytes patched - and stored 8 bytes per
+        // lane (the byte loop below, with a division per byte, was most of this phase; it remains the path of the rounding probe)
+        for (int k8 = lane; k8 < Y.fixlen / 8; k8 += 64) ((unsigned long long*)cfix)[k8] = ((const unsigned long long*)fix)[k8];
+        __syncthreads();
+        for (int j = jlo + lane; j <= jhi; j += 64) { const int k = base + j * stride; if (fix[k] < 0) { if (j < kk) cfix[k] = comp[k]; else if (j == kk) cfix[k] = av; } }
+        __syncthreads();
+        if (lane == 0 && negidx >= 0) cfix[negidx] = (signed char)negm;
+        __syncthreads();
+        for (int k8 = lane; k8 < Y.fixlen / 8; k8 += 64) ((unsigned long long*)dst)[k8] = ((const unsigned long long*)cfix)[k8];
+        __syncthreads();   // (cfix is reused by the next child)
+      } else
       for (int k = lane; k < Y.fixlen; k += 64) {
         signed char v = fix[k];
         int rel = k - base;
