@@ -1561,7 +1561,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   const signed char* src = B.pool_fix + (size_t)B.batch_node[node] * Y.fixlen;
   PROF_T(te0);
   for (int k = lane; k < N * NZ; k += 64) Z[k] = Zi[k];
-  for (int k = lane; k < Y.fixlen; k += 64) { fix[k] = src[k]; comp[k] = src[k]; ploose[k] = 0; }
+  for (int k8 = lane; k8 < Y.fixlen / 8; k8 += 64) { const unsigned long long w8 = ((const unsigned long long*)src)[k8]; ((unsigned long long*)fix)[k8] = w8; ((unsigned long long*)comp)[k8] = w8; ((unsigned long long*)ploose)[k8] = 0ull; }   // (fixlen is a multiple of 16, the records and the LDS arrays 8-byte aligned)
   __syncthreads();
   PROF_T(te1);
   const double viol = B.batch_viol[node];
