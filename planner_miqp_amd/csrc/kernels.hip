@@ -1385,6 +1385,21 @@ __device__ inline double region_alt_viol(const Layout& Y, const double* D, const
   return v;
 }
 
+// region_alt_viol in two parts: what every half-plane alternative h of region q shares (the boxes; the sector and curvature rows), read from the
+// region's table once, and what depends on h.  max is exact: region_viol_from(.., h, ..) == region_alt_viol(.., q, h, ..) bit for bit.
+__device__ inline void region_viol_parts(const Layout& Y, const double* D, int c, int q, const CarState& s, bool with_jerk, double& bx, double& fast) {
+  const double* rt = D + Y.d_reg + (c * Y.P + q) * REGSZ;
+  bx = box_viol(s, rt, with_jerk);
+  fast = fmax(fmax(rt[0] * s.vx + rt[1] * s.vy, rt[2] * s.vx + rt[3] * s.vy),
+              fmax(s.ay - rt[4] * s.ax - rt[6] * s.vx - rt[7] * s.vy - rt[5], -s.ay + rt[4] * s.ax + rt[9] * s.vx + rt[10] * s.vy + rt[8]));
+}
+__device__ inline double region_viol_from(const Layout& Y, const double* D, const int* T, int c, int q, int h, const CarState& s, double bx, double fast) {
+  const double vm = D[Y.d_glob + 6];
+  if (h == 3) return fmax(bx, fmax(fabs(s.vx) - vm, fabs(s.vy) - vm));
+  const int* hs = T + Y.i_hs + ((c * Y.P + q) * 2 + h) * 2;
+  return fmax(fmax(bx, fast), vm - hs[1] * (hs[0] == 0 ? s.vx : s.vy));
+}
+
 __device__ inline double env_alt_viol(const Layout& Y, const double* D, const int* T, int e, double X, double Yc) {
   double v = -1e300; int n = T[Y.i_envn + e];
   for (int k = 0; k < n; ++k) { const double* ed = D + Y.d_env + (e * Y.EL + k) * 3; v = fmax(v, ed[0] * X + ed[1] * Yc - ed[2]); }
@@ -1500,6 +1515,26 @@ __device__ inline double region_alt_lift_exact(const Layout& Y, const double* D,
     const double gam = k2 * k2 * X.vv + 2.0 * k2 * rho * X.va + rho * rho * X.aa + k3 * k3 * Yd.vv - 2.0 * k3 * Yd.va + Yd.aa;
     l = fmax(l, lift1(-s.ay + rho * s.ax + k2 * s.vx + k3 * s.vy + rt[8], gam)); }
   return l;
+}
+
+// region_alt_lift_exact in the same two parts (bit for bit the same value)
+__device__ inline void region_lift_parts(const Layout& Y, const double* D, int c, int q, const CarState& s, bool with_jerk, const LiftBlk& X, const LiftBlk& Yd, double& l0, double& lfast) {
+  const double* rt = D + Y.d_reg + (c * Y.P + q) * REGSZ;
+  l0 = fmax(lift1(fmax(s.ax - rt[12], rt[11] - s.ax), X.aa), lift1(fmax(s.ay - rt[14], rt[13] - s.ay), Yd.aa));
+  if (with_jerk) l0 = fmax(l0, fmax(lift1(fmax(s.ux - rt[16], rt[15] - s.ux), X.uu), lift1(fmax(s.uy - rt[18], rt[17] - s.uy), Yd.uu)));
+  lfast = fmax(lift1(rt[0] * s.vx + rt[1] * s.vy, rt[0] * rt[0] * X.vv + rt[1] * rt[1] * Yd.vv), lift1(rt[2] * s.vx + rt[3] * s.vy, rt[2] * rt[2] * X.vv + rt[3] * rt[3] * Yd.vv));
+  { const double rho = rt[4], k2 = rt[6], k3 = rt[7];
+    const double gam = k2 * k2 * X.vv + 2.0 * k2 * rho * X.va + rho * rho * X.aa + k3 * k3 * Yd.vv - 2.0 * k3 * Yd.va + Yd.aa;
+    lfast = fmax(lfast, lift1(s.ay - rho * s.ax - k2 * s.vx - k3 * s.vy - rt[5], gam)); }
+  { const double rho = rt[4], k2 = rt[9], k3 = rt[10];
+    const double gam = k2 * k2 * X.vv + 2.0 * k2 * rho * X.va + rho * rho * X.aa + k3 * k3 * Yd.vv - 2.0 * k3 * Yd.va + Yd.aa;
+    lfast = fmax(lfast, lift1(-s.ay + rho * s.ax + k2 * s.vx + k3 * s.vy + rt[8], gam)); }
+}
+__device__ inline double region_lift_from(const Layout& Y, const double* D, const int* T, int c, int q, int h, const CarState& s, const LiftBlk& X, const LiftBlk& Yd, double l0, double lfast) {
+  const double vm = D[Y.d_glob + 6];
+  if (h == 3) return fmax(l0, fmax(lift1(fabs(s.vx) - vm, X.vv), lift1(fabs(s.vy) - vm, Yd.vv)));
+  const int* hs = T + Y.i_hs + ((c * Y.P + q) * 2 + h) * 2;
+  return fmax(fmax(l0, lfast), lift1(vm - hs[1] * (hs[0] == 0 ? s.vx : s.vy), hs[0] == 0 ? X.vv : Yd.vv));
 }
 
 struct BranchDesc { int prio; int kind; int c; int o; int i; int pt; int cause; };  // kind: 0 region 1 env 2 obs 3 c2c; cause (diagnostic): what flagged a region disjunction - 0 its own rows, 1 / 2 / 3 an environment / obstacle / car-car row on a front point of a car whose region is undecided
@@ -1644,9 +1679,11 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
           if (nxtq >= 0 && nxtq != q) { rset &= ~(1 << q); continue; }   // the next step is frozen to another region (slow alternative fixed there)
           bool any = false;
           const int nhq = T[Y.i_nhs + c * P + q];
+          double bxq, fq, l0q, lfq;   // (the region's table is read once for its up to four alternatives)
+          region_viol_parts(Y, D, c, q, s, wj, bxq, fq); region_lift_parts(Y, D, c, q, s, wj, BX, BY, l0q, lfq);
           for (int h = 0; h < 4; ++h) {
             if ((h < 3 && h >= nhq) || !((allow >> (q * 4 + h)) & 1ull)) continue;
-            if (region_alt_lift_exact(Y, D, T, c, q, h, s, wj, BX, BY) * (1.0 - 1e-6) >= room && region_alt_viol(Y, D, T, c, q, h, s, wj) > tol) continue;   // this alternative cannot pay off below this node (one that holds at the node's solution always stays)
+            if (region_lift_from(Y, D, T, c, q, h, s, BX, BY, l0q, lfq) * (1.0 - 1e-6) >= room && region_viol_from(Y, D, T, c, q, h, s, bxq, fq) > tol) continue;   // this alternative cannot pay off below this node (one that holds at the node's solution always stays)
             any = true; nleft++; last_code = q * 4 + h;
           }
           if (!any) rset &= ~(1 << q);
@@ -1662,12 +1699,13 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       // (the completion below looks at every statically possible alternative, whatever the node's set: it labels the solution
       // of THIS node, and the labels stay the canonical ones - first alternative in order that holds)
       for (int q = 0; q < np; ++q) {
-        slowv[(c * N + i) * P + q] = ((nxtq >= 0 && nxtq != q) || !((allow >> (q * 4 + 3)) & 1ull)) ? 3.0e38f : (float)fmin(region_alt_viol(Y, D, T, c, q, 3, s, wj), 3.0e38);
-        if (nxtq >= 0 && nxtq != q) continue;
+        if (nxtq >= 0 && nxtq != q) { slowv[(c * N + i) * P + q] = 3.0e38f; continue; }
+        double bxq, fq; region_viol_parts(Y, D, c, q, s, wj, bxq, fq);   // (once per region, not once per alternative)
+        slowv[(c * N + i) * P + q] = !((allow >> (q * 4 + 3)) & 1ull) ? 3.0e38f : (float)fmin(region_viol_from(Y, D, T, c, q, 3, s, bxq, fq), 3.0e38);
         int nh = T[Y.i_nhs + c * P + q];
         for (int h = 0; h < nh; ++h) {
           if (!((allow >> (q * 4 + h)) & 1ull)) continue;  // unreachable velocity set (host presolve)
-          double v = region_alt_viol(Y, D, T, c, q, h, s, wj);
+          double v = region_viol_from(Y, D, T, c, q, h, s, bxq, fq);
           if (want_score) ml = fmin(ml, region_alt_lift(Y, D, T, c, q, h, s, wj, LX, LYd));
           if (!found && v <= tol) { found = true; bv = 0.0; bc = q * 4 + h; }
           if (!found && v < bv) { bv = v; bc = q * 4 + h; }
