@@ -176,6 +176,12 @@ int miqp_solver_solve_fixed(miqp_solver_t* s, const miqp_raw_results_c* fixed, m
  * out[3] = node relaxations solved, out[4] = IPM iterations (summed over nodes), out[5] = rows x iterations */
 int miqp_solver_last_timing(const miqp_solver_t* s, double* out6);
 
+/* the dual active-set launch of the last solve / batch (two cars: the ordinary node relaxations; the reference's counterpart is CPLEX's dual
+ * simplex re-solve of a child node inside cplex.solve(), src/cplex_wrapper.cpp:158-185): out[0] = node relaxations it solved,
+ * out[1] = its steps (rows added + rows dropped; they are part of out[4] of miqp_solver_last_timing and of NrIterations),
+ * out[2] = nodes it handed to the interior point launch behind it, out[3] = rows dropped */
+int miqp_solver_last_active_set(const miqp_solver_t* s, double* out4);
+
 /* host set-up of the last solve / batch / stream call this handle took part in: out[0] = seconds from the entry of the call to
  * the first round, out[1] = of which building the device context (pools, lists: reused by a call of the same shape with no more
  * instances than its per-instance arrays hold), out[2] = 1 when the context was built or rebuilt by that call, else 0 */

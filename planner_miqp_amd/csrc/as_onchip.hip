@@ -1,0 +1,662 @@
+// as_onchip.hip - dual active-set solve of a node relaxation, whole working set on chip (included by kernels.hip behind ipm_onchip.hip).
+//
+// What it replaces: the interior point of ipm_onchip_kernel<2, ...> for the ordinary nodes of a round (everything but the rounding probes, the
+// local-search leaves and the marked large records, which stay with the larger interior point variant: their infeasible relaxations are
+// re-rounded from the least-violation point only an elastic interior point delivers).  Region of the reference this stands for:
+// cplex.solve()'s node re-solves, src/cplex_wrapper.cpp:158-185 (CPLEX re-solves a child by dual simplex pivots from the parent's basis).
+//
+// The node QP  min sum_i (z_i - r_i)' W (z_i - r_i)  s.t. dynamics, rows g.z <= h  has a Hessian that belongs to the OBJECTIVE ALONE: the same
+// for every node of an instance, diagonal per stage, and the dynamics are 2C independent triple integrator chains.  So
+//   * H^-1 (on the trajectories of the dynamics) applied to any stage-wise vector is one backward + one forward substitution per chain with the
+//     CONSTANT gains of the unconstrained regulator (3 x 3 Riccati recursion per chain, once per node; no factorisation per iteration, no MFMA:
+//     there is no dense contraction left - the work is O(N) per chain),
+//   * Goldfarb-Idnani's dual method needs, per added row p: w = H^-1 g_p (one substitution), q = G_A w, the step directions from the inverse
+//     M = (G_A H^-1 G_A')^-1 of the active rows' Schur complement (kept explicitly, one row per lane in registers, updated by symmetric rank-one
+//     terms on add / drop), a ratio test over the multipliers, and the new iterate z = z_unc - H^-1 G' lambda (a second substitution).
+// Every iterate is dual feasible: its dual value is a valid lower bound, rises monotonically and is tested against the incumbent cutoff after
+// every step; an infeasible node shows as a dependent row without a blocking multiplier (or a multiplier beyond the exact penalty rho of the
+// interior point's elastic rows).  Started cold from the unconstrained optimum the method takes |A| + 3..4 steps (tools/active_set_lab.py,
+// profiles/r06_active_set_lab.txt: the parent's active set re-added row by row costs the same as the most-violated order finds it).
+// A node the method cannot finish (64 active rows, step cap, loss of precision) is handed to the interior point launch behind this one.
+//
+// Layout: the LDS block of ipm_onchip_kernel (oc_lds_layout: same decode, same capacities, 8 wavefronts per CU); the region of the decode
+// scratch becomes the substitution vector V | the chain gains, the region of the box keys the feed-forward terms.
+namespace miqp {
+
+#ifdef MIQP_PROFILE
+#define ASP_T(var) const long long var = clock64()
+#define ASP_ACC(k, t0, t1) asp_[k] += (unsigned long long)((t1) - (t0))
+#else
+#define ASP_T(var)
+#define ASP_ACC(k, t0, t1)
+#endif
+constexpr int AS_MAXSTEP = 220;        // adds + drops after which a node goes to the interior point instead
+constexpr double AS_VTOL = 1.0e-8;     // a row is violated above this (rows are normalised: metres, m/s, ...)
+constexpr double AS_DEP = 1.0e-8;      // curvature g P g' below this share of g H^-1 g': the row depends on the active ones
+
+// Column order inside this kernel: CHAIN-CONTIGUOUS - (position, velocity, acceleration, jerk) of chain ch = 2 car + axis at 4 ch .. 4 ch + 3 (the
+// transpose of ipm_onchip_kernel's chain-major 4 k + ch; an involution), so that the lane of a chain reads and writes its stage entries as two
+// 16-byte LDS accesses
+__device__ inline int as_col(int pq) { return ((pq & 3) << 2) | (pq >> 2); }
+
+template <int C, int NSL>
+__global__ void __launch_bounds__(64, 2) as_onchip_kernel(DevBuf B) {
+  static_assert(C == 2, "chain-major columns of two cars");
+  constexpr bool CM = true;
+  constexpr int OC_GCAP = miqp::OC_GCAP, OC_GSLOTS = OC_GCAP / 64, OC_GCOEF = oc_gcoef_of(OC_GCAP);
+  constexpr int NX = 6 * C, NZ = 8 * C, NCH = 2 * C;
+  const Layout& Y = B.Y;
+  const int tid = threadIdx.x, lg = tid >> 4, lc = tid & 15;
+  const int par = lg >> 1, side = lg & 1;
+  const double bsgn = side ? -1.0 : 1.0;
+  const int nbatch = *B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap;
+  const int N = Y.N, NSLOT = Y.NSLOT;
+  extern __shared__ double lds[];
+  char* const L0 = (char*)lds;
+  const OcLds LL = oc_lds_layout(N, Y.fixlen, OC_GCAP);
+  double* const Z = (double*)(L0 + LL.z);                   // [N][16] iterate
+  double* const scr = (double*)(L0 + LL.u);                 // decode: dense scratch rows
+  double* const V = (double*)(L0 + LL.u);                   // [N][16] right-hand side / result of a substitution
+  double* const KS = V + N * 16;                            // [N][4 chains][4]: K (p, v, a) and 1 / S_uu of the unconstrained regulator
+  unsigned long long* const bkey = (unsigned long long*)(L0 + LL.r);
+  double* const kff = (double*)(L0 + LL.r);                 // [N][4] feed-forward of the current substitution
+  double* const kref = kff + N * 4;                         // [N][4] feed-forward of the objective's linear term
+  uint4* const gmeta = (uint4*)(L0 + LL.gmeta);
+  double* const gcoef = (double*)(L0 + LL.gcoef);
+  double* const grhs = (double*)(L0 + LL.grhs);
+  double* const Wd = (double*)(L0 + LL.wd);
+  int* const sstart = (int*)(L0 + LL.sstart);
+  unsigned short* const cand = (unsigned short*)(L0 + LL.cand);
+  signed char* const fix = (signed char*)(L0 + LL.fix);
+  __shared__ int sh_node;
+  const unsigned long long lt = (1ull << tid) - 1ull;
+
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) sh_node = atomicAdd(B.work_counter, 1);
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(sh_node) >= nbatch) break;
+    const int node = __builtin_amdgcn_readfirstlane(sh_node);
+    if (B.skip_probes) {   // the concurrent launch of the larger interior point variant solves the probes and the marked records
+      const bool marked = B.batch_large ? B.batch_large[node] != 0 : is_probe_word(B.batch_depth[node]);
+      if (marked) continue;
+    }
+    const int inst = __builtin_amdgcn_readfirstlane(B.batch_inst[node]);
+    const double* D = B.inst_d + (size_t)inst * Y.dstride;
+    const int* T = B.inst_i + (size_t)inst * Y.istride;
+    const double ts = D[Y.d_glob + 7];
+    const double aqs = 2.0 * D[Y.d_misc + 0];
+    const double iaq = aqs > 0.0 ? 1.0 / aqs : 0.0;
+    {
+      const signed char* src = B.pool_fix + (size_t)B.batch_node[node] * Y.fixlen;
+      for (int k = tid; k < Y.fixlen; k += 64) fix[k] = src[k];
+      if (tid < 16) Wd[tid] = tid < NZ ? D[Y.d_wd + oc_lcol<C, CM>(as_col(tid))] : 0.0;
+      for (int k = tid; k < N * 32; k += 64) bkey[k] = ~0ull;
+      for (int k = tid; k <= N + 1; k += 64) sstart[k] = 0;
+    }
+    __syncthreads();
+    const double* Rf = D + Y.d_ref;
+    double cutoff = 1e300;
+    {
+      const double inc0 = fmin(inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]), B.inc_ext[inst]);
+      if (B.use_cutoff && inc0 < 1e300) cutoff = inc0 - B.inst_gap[inst] * (1e-10 + fabs(inc0)) - B.inst_const[inst];
+    }
+
+#ifdef MIQP_PROFILE
+    unsigned long long asp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    ASP_T(ta0);
+    // ---- decode (the two passes of ipm_onchip_kernel, unchanged: box rows to their (stage, side, column) key, general rows packed per stage)
+    int ngen = 0;
+    {
+      unsigned long long* const bmp = (unsigned long long*)scr;
+      const int nw = (N * NSLOT + 63) >> 6;
+      unsigned short* const pre = (unsigned short*)(bmp + nw);
+      for (int k = tid; k < nw; k += 64) bmp[k] = 0ull;
+      OC_WAVE_SYNC();
+      const int cls_off[8] = {0, 7, 11, 16, 16 + Y.EL, 16 + 5 * Y.EL, C * Y.SC, C * Y.SC + 8 * Y.NP};
+      const int cls_cnt[8] = {7, 4, 5, Y.EL, 4 * Y.EL, 5 * Y.O, 8 * Y.NP, 16 * Y.NP};
+      auto take = [&](int i, int slot) {
+        if (decode_row<C, false>(Y, D, T, fix, i, slot, nullptr).active) {
+          int col; double sg, rh;
+          if (box_of_slot<C>(Y, D, T, fix, i, slot, col, sg, rh)) atomicMin(&bkey[(i * 2 + (sg < 0.0 ? 1 : 0)) * 16 + as_col(oc_pcol<C, CM>(col))], d2key(rh));
+          else { const int pcode = i * NSLOT + slot; atomicOr(&bmp[pcode >> 6], 1ull << (pcode & 63)); }
+        }
+      };
+      unsigned short* const plist = pre + ((nw + 1 + 3) & ~3);
+      const int LCAP = (int)(((char*)(L0 + LL.r) - (char*)plist) / 2) - 64;
+      int nlist = 0;
+      auto flush = [&]() {
+        OC_WAVE_SYNC();
+        for (int j0 = 0; j0 < nlist; j0 += 64) if (j0 + tid < nlist) { const int pc = plist[j0 + tid]; const int i = pc / NSLOT; take(i, pc - i * NSLOT); }
+        OC_WAVE_SYNC();
+        nlist = 0;
+      };
+#pragma unroll 1
+      for (int cl = 0; cl < 8; ++cl) {
+        const int cnt = cls_cnt[cl], off = cls_off[cl];
+        const bool percar = cl < 6;
+        const int per = percar ? C * cnt : cnt, total = N * per;
+        for (int e0 = 0; e0 < total; e0 += 64) {
+          const int e = e0 + tid;
+          int i = 0, slot = 0; bool in = e < total;
+          if (in) { i = e / per; const int rem = e - i * per; slot = percar ? (rem / cnt) * Y.SC + off + rem % cnt : off + rem; }
+          if (cl < 2) { if (in) take(i, slot); continue; }
+          const bool cnd = in && slot_maybe<C>(Y, fix, i, slot);
+          const unsigned long long mk = __ballot(cnd);
+          if (cnd) plist[nlist + __popcll(mk & lt)] = (unsigned short)(i * NSLOT + slot);
+          nlist += __popcll(mk);
+          if (nlist > LCAP) flush();
+        }
+      }
+      flush();
+      if (tid == 0) { int a = 0; for (int k = 0; k < nw; ++k) { pre[k] = (unsigned short)(a < 65535 ? a : 65535); a += __popcll(bmp[k]); } pre[nw] = (unsigned short)(a < 65535 ? a : 65535); }
+      OC_WAVE_SYNC();
+      ngen = pre[nw];
+      if (ngen <= OC_GCAP)
+        for (int k = tid; k < nw; k += 64) {
+          unsigned long long bits = bmp[k]; int pos = pre[k];
+          while (bits) { const int b = __ffsll((long long)bits) - 1; cand[pos++] = (unsigned short)(k * 64 + b); bits &= bits - 1ull; }
+        }
+      OC_WAVE_SYNC();
+    }
+    bool overflow = ngen > OC_GCAP;
+    int ncoef = 0;
+    for (int c0 = 0; c0 < ngen && !overflow; c0 += OC_SCR) {
+      double* g = scr + (tid & (OC_SCR - 1)) * OC_SSTR;
+      RowOut r; r.active = false; r.rhs = 0; r.aq = 0;
+      int i = 0, nn = 0;
+      const bool mine = tid < OC_SCR && c0 + tid < ngen;
+      int slot_ = 0;
+      if (mine) { const int pcode = cand[c0 + tid]; i = pcode / NSLOT; slot_ = pcode - i * NSLOT; r = decode_row<C, true>(Y, D, T, fix, i, slot_, g); }
+      unsigned long long map = 0ull; unsigned int cols = 0u;
+      double v6[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v6[k] = 0.0;
+      if (mine) {
+        for (int q = 0; q < NZ; ++q) {
+          const double v = g[q];
+          if (v != 0.0 && nn < 6) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (k == nn) v6[k] = v;
+            const int pq = as_col(oc_pcol<C, CM>(q));
+            map |= (unsigned long long)(nn + 1) << (4 * pq); cols |= (unsigned int)pq << (4 * nn); nn++;
+          }
+        }
+      }
+      const bool keep = mine && nn > 0;
+      const unsigned long long mk = __ballot(keep);
+      const unsigned long long b0 = __ballot(keep && (nn & 1)), b1 = __ballot(keep && (nn & 2)), b2 = __ballot(keep && (nn & 4));
+      const int tot = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+      if (ncoef + tot > OC_GCOEF) { overflow = true; break; }
+      if (keep) {
+        const int idx = sstart[N + 1] + __popcll(mk & lt);
+        const int off = ncoef + __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k < nn) gcoef[off + k] = v6[k];
+        uint4 m4; m4.x = (unsigned int)map; m4.y = (unsigned int)(map >> 32);
+        m4.z = (unsigned int)off | ((unsigned int)nn << 16) | ((unsigned int)i << 20) | (r.aq > 0.0 ? 0x80000000u : 0u); m4.w = cols;
+        gmeta[idx] = m4; grhs[idx] = r.rhs;
+        cand[idx] = (unsigned short)(i * NSLOT + slot_);   // identity of the packed row (idx <= its position in the candidate list: in-place compaction)
+      }
+      OC_WAVE_SYNC();
+      if (tid == 0) sstart[N + 1] += __popcll(mk);
+      ncoef += tot;
+      OC_WAVE_SYNC();
+    }
+    if (overflow) {
+      if (tid == 0) {
+        if (B.bounce) { B.batch_ok[node] = 5; B.pool_big[B.batch_node[node]] |= 1; if (B.stats) { atomicAdd(&B.stats[3], 1ull); atomicAdd(&B.stats[8 + (ngen >= 512 ? 15 : ngen / 32)], 1ull); } }
+        else { B.batch_ok[node] = 6; const int q = atomicAdd(B.as_count, 1); B.as_list[q] = node; }
+      }
+      continue;
+    }
+    const int NM = sstart[N + 1];
+    OC_WAVE_SYNC();
+
+    ASP_T(ta1); ASP_ACC(0, ta0, ta1);
+    // ---- the box rows of this lane (column lc, side, stages 2 k + par) into registers
+    double brhs[NSL];
+    unsigned int bact = 0u, binA = 0u, ginA = 0u;
+#pragma unroll
+    for (int k = 0; k < NSL; ++k) {
+      const int i = 2 * k + par;
+      brhs[k] = 1e300;
+      if (i < N && lc < NZ) {
+        const unsigned long long key = bkey[(i * 2 + side) * 16 + lc];
+        if (key != ~0ull) { brhs[k] = key2d(key); bact |= 1u << k; }
+      }
+    }
+    OC_WAVE_SYNC();   // the keys are consumed: their region becomes the feed-forward terms
+
+    // ---- constant gains of the unconstrained regulator, per chain (lane = chain): P' = Q + A' P A - K S_xu', K = S_xu / S_uu
+    const double h1 = ts, h2 = 0.5 * ts * ts, h3 = ts * ts * ts / 6.0;
+    if (tid < NCH) {
+      const int ch = tid;
+      const double q0 = 2.0 * Wd[4 * ch], q1 = 2.0 * Wd[4 * ch + 1], q2 = 2.0 * Wd[4 * ch + 2], rr = 2.0 * Wd[4 * ch + 3];
+      double p00 = q0, p01 = 0.0, p02 = 0.0, p11 = q1, p12 = 0.0, p22 = q2;
+      for (int i = N - 2; i >= 0; --i) {
+        // T = P A (rows k, columns 0..2), PB = P B
+        const double t00 = p00, t01 = p00 * h1 + p01, t02 = p00 * h2 + p01 * h1 + p02;
+        const double t10 = p01, t11 = p01 * h1 + p11, t12 = p01 * h2 + p11 * h1 + p12;
+        const double t20 = p02, t21 = p02 * h1 + p12, t22 = p02 * h2 + p12 * h1 + p22;
+        const double b0 = p00 * h3 + p01 * h2 + p02 * h1, b1 = p01 * h3 + p11 * h2 + p12 * h1, b2 = p02 * h3 + p12 * h2 + p22 * h1;
+        const double suu = rr + h3 * b0 + h2 * b1 + h1 * b2;
+        const double x0 = b0, x1 = h1 * b0 + b1, x2 = h2 * b0 + h1 * b1 + b2;            // S_xu = A' P B
+        // S_xx = Q + A' T (symmetric)
+        const double s00 = q0 + t00, s01 = t01, s02 = t02;
+        const double s11 = q1 + h1 * t01 + t11, s12 = h1 * t02 + t12;
+        const double s22 = q2 + h2 * t02 + h1 * t12 + t22;
+        (void)t10; (void)t20; (void)t21;
+        const double is = 1.0 / fmax(suu, 1e-300);
+        const double k0 = x0 * is, k1 = x1 * is, k2 = x2 * is;
+        double* ks = KS + (i * 4 + ch) * 4;
+        ks[0] = k0; ks[1] = k1; ks[2] = k2; ks[3] = is;
+        p00 = s00 - k0 * x0; p01 = s01 - k0 * x1; p02 = s02 - k0 * x2;
+        p11 = s11 - k1 * x1; p12 = s12 - k1 * x2; p22 = s22 - k2 * x2;
+      }
+    }
+    OC_WAVE_SYNC();
+    // one substitution: V holds a stage-wise vector v (zero above stage itop) on entry; `out` receives, for the stages up to iend, the minimiser of
+    // 1/2 z' H z + v' z over the trajectories of the dynamics from x_0 = 0 (fromx0 false: a response, -H^-1 v), or the minimiser of the
+    // objective + v' z from the true x_0 (fromx0 true: kref carries the objective's own linear term).  One lane per chain; the loads of a
+    // stage are requested one stage ahead of their use
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    auto subst = [&](const bool fromx0, const int itop, const int iend, double* const out) {
+      for (int k = tid; k < (N - 1) * 4; k += 64) if ((k >> 2) > itop) kff[k] = fromx0 ? kref[k] : 0.0;
+      if (tid < NCH) {
+        const int ch = tid;
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+        int i0 = itop;
+        if (itop >= N - 1) { const d2_t a = *(const d2_t*)(V + (N - 1) * 16 + 4 * ch); p0 = a[0]; p1 = a[1]; p2 = V[(N - 1) * 16 + 4 * ch + 2]; i0 = N - 2; }
+        if (i0 >= 0) {
+          d2_t va = *(const d2_t*)(V + i0 * 16 + 4 * ch), vb = *(const d2_t*)(V + i0 * 16 + 4 * ch + 2);
+          d2_t ka = *(const d2_t*)(KS + (i0 * 4 + ch) * 4), kb = *(const d2_t*)(KS + (i0 * 4 + ch) * 4 + 2);
+          double kr = fromx0 ? kref[i0 * 4 + ch] : 0.0;
+          for (int i = i0; i >= 0; --i) {
+            const int j = i > 0 ? i - 1 : 0;
+            const d2_t nva = *(const d2_t*)(V + j * 16 + 4 * ch), nvb = *(const d2_t*)(V + j * 16 + 4 * ch + 2);
+            const d2_t nka = *(const d2_t*)(KS + (j * 4 + ch) * 4), nkb = *(const d2_t*)(KS + (j * 4 + ch) * 4 + 2);
+            const double nkr = fromx0 ? kref[j * 4 + ch] : 0.0;
+            const double su = vb[1] + h3 * p0 + h2 * p1 + h1 * p2;
+            const double sx0 = va[0] + p0, sx1 = va[1] + h1 * p0 + p1, sx2 = vb[0] + h2 * p0 + h1 * p1 + p2;
+            kff[i * 4 + ch] = fma(su, kb[1], kr);
+            p0 = sx0 - ka[0] * su; p1 = sx1 - ka[1] * su; p2 = sx2 - kb[0] * su;
+            va = nva; vb = nvb; ka = nka; kb = nkb; kr = nkr;
+          }
+        }
+      }
+      OC_WAVE_SYNC();
+      if (tid < NCH) {
+        const int ch = tid;
+        double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+        if (fromx0) { const int c = ch >> 1, s = ch & 1; x0 = D[Y.d_x0 + 6 * c + 3 * s]; x1 = D[Y.d_x0 + 6 * c + 3 * s + 1]; x2 = D[Y.d_x0 + 6 * c + 3 * s + 2]; }
+        const int ie = iend < N - 1 ? iend : N - 2;       // last stage with an input
+        d2_t ka = *(const d2_t*)(KS + ch * 4), kb = *(const d2_t*)(KS + ch * 4 + 2);
+        double kf = kff[ch];
+        for (int i = 0; i <= ie; ++i) {
+          const int j = i < N - 2 ? i + 1 : N - 2;
+          const d2_t nka = *(const d2_t*)(KS + (j * 4 + ch) * 4), nkb = *(const d2_t*)(KS + (j * 4 + ch) * 4 + 2);
+          const double nkf = kff[j * 4 + ch];
+          const double u = -kf - (ka[0] * x0 + ka[1] * x1 + kb[0] * x2);
+          d2_t oa, ob; oa[0] = x0; oa[1] = x1; ob[0] = x2; ob[1] = u;
+          *(d2_t*)(out + i * 16 + 4 * ch) = oa; *(d2_t*)(out + i * 16 + 4 * ch + 2) = ob;
+          const double n0 = x0 + h1 * x1 + h2 * x2 + h3 * u, n1 = x1 + h1 * x2 + h2 * u, n2 = x2 + h1 * u;
+          x0 = n0; x1 = n1; x2 = n2;
+          ka = nka; kb = nkb; kf = nkf;
+        }
+        if (iend >= N - 1 || ie == N - 2) { d2_t oa, ob; oa[0] = x0; oa[1] = x1; ob[0] = x2; ob[1] = 0.0; *(d2_t*)(out + (ie + 1) * 16 + 4 * ch) = oa; *(d2_t*)(out + (ie + 1) * 16 + 4 * ch + 2) = ob; }
+      }
+      OC_WAVE_SYNC();
+    };
+    // feed-forward of the objective's linear term -2 W r (once per node)
+    for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; V[k] = q < NZ ? -2.0 * Wd[q] * Rf[(k >> 4) * NZ + oc_lcol<C, CM>(as_col(q))] : 0.0; }
+    OC_WAVE_SYNC();
+    subst(false, N - 1, 0, V);
+    if (tid < N * 4) kref[tid] = kff[tid];
+    if (tid + 64 < N * 4) kref[tid + 64] = kff[tid + 64];
+    OC_WAVE_SYNC();
+
+    // value of a row at a stage-wise vector: box rows id = (stage * 2 + side) * 16 + column, general rows id = 1024 + index
+    auto row_dot = [&](int id, const double* vec) -> double {
+      if (id < 1024) return (((id >> 4) & 1) ? -1.0 : 1.0) * vec[(id >> 5) * 16 + (id & 15)];
+      const uint4 m4 = gmeta[id - 1024];
+      const int off = (int)(m4.z & 0xFFFFu), nn = (int)((m4.z >> 16) & 7u), i = (int)((m4.z >> 20) & 0x7FFu);
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) if (k < nn) a += gcoef[off + k] * vec[i * 16 + ((m4.w >> (4 * k)) & 15u)];
+      return a;
+    };
+    auto row_soft = [&](int id) -> bool { return id >= 1024 && (gmeta[id - 1024].z & 0x80000000u) != 0u; };
+    auto zeroV = [&]() { for (int k = tid; k < N * 16; k += 64) V[k] = 0.0; OC_WAVE_SYNC(); };
+    auto objective = [&]() -> double {
+      double o = 0.0;
+      for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) { const double d = Z[k] - Rf[(k >> 4) * NZ + oc_lcol<C, CM>(as_col(q))]; o += Wd[q] * d * d; } }
+      return wave_sum(o);
+    };
+
+    // ---- the active set: slot a lives in lane a (its row, its multiplier, row a of M)
+    int arow = -1, astage = -1; double alam = 0.0;
+    double M[64];
+#pragma unroll
+    for (int b = 0; b < 64; ++b) M[b] = 0.0;
+    unsigned long long used = 0ull;
+    // symmetric rank-one term M += alpha u u' over the columns of `mask` (u_b = 0 elsewhere)
+    auto rank1 = [&](const double u, const double alpha, const unsigned long long mask) {
+#pragma unroll
+      for (int g8 = 0; g8 < 8; ++g8) {
+        if ((mask >> (8 * g8)) & 0xFFull) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const int b = 8 * g8 + j; M[b] = fma(u * readlane_d(u, b), alpha, M[b]); }
+        }
+      }
+    };
+    // iterate of the current multipliers: z = argmin objective + lambda' G z
+    auto refresh = [&]() {
+      zeroV();
+      if (arow >= 0 && alam != 0.0) {
+        if (arow < 1024) atomicAdd(&V[(arow >> 5) * 16 + (arow & 15)], (((arow >> 4) & 1) ? -alam : alam));
+        else {
+          const uint4 m4 = gmeta[arow - 1024];
+          const int off = (int)(m4.z & 0xFFFFu), nn = (int)((m4.z >> 16) & 7u), i = (int)((m4.z >> 20) & 0x7FFu);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) if (k < nn) atomicAdd(&V[i * 16 + ((m4.w >> (4 * k)) & 15u)], gcoef[off + k] * alam);
+        }
+      }
+      const int amax = (int)wave_max((double)astage);
+      OC_WAVE_SYNC();
+      subst(true, amax, N - 1, Z);
+    };
+    refresh();                       // lambda = 0: the unconstrained optimum
+    ASP_T(ta2); ASP_ACC(1, ta1, ta2);
+    int steps = 0, ndrop = 0, ok = 1, nwarm = 0;
+    bool infeas = false, fail = false;
+    // ---- warm start: the rows that were active at the parent's optimum (their identities travel with the record: box rows by their key, general
+    // rows by their (stage, slot) code) are taken as the first active set where this node still has them.  S_A0 = G_A0 H^-1 G_A0' column by
+    // column (one response each), inverted in the registers by symmetric sweeps; multipliers that come out negative leave (the rows the branching
+    // made slack), and Goldfarb-Idnani goes on from that dual feasible point.  Right-hand sides are this node's own: nothing is assumed about them.
+    if (B.pool_A && (B.batch_depth[node] >> 6) >= 1 && B.batch_node[node] < B.z_cap) {
+      const unsigned int pa = B.pool_A[(size_t)B.batch_node[node] * 64 + tid];
+      int cid = -1;
+      int ownl = 0;
+      if (pa < 1024u) ownl = (int)((((pa >> 5) & 1u) * 2u + ((pa >> 4) & 1u)) << 4 | (pa & 15u));
+      const unsigned int ob = (unsigned int)__shfl((int)bact, ownl);
+      if (pa < 1024u) { if ((ob >> (pa >> 6)) & 1u) cid = (int)pa; }
+      else if (pa != 0xFFFFu) {
+        const int pc = (int)pa - 1024;
+        int lo = 0, hi = NM;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)cand[mid] < pc) lo = mid + 1; else hi = mid; }
+        if (lo < NM && (int)cand[lo] == pc) cid = 1024 + lo;
+      }
+      const unsigned long long u0 = __ballot(cid >= 0);
+      if (u0) {
+        arow = cid;
+        astage = cid < 0 ? -1 : (cid < 1024 ? (cid >> 5) : (int)((gmeta[cid - 1024].z >> 20) & 0x7FFu));
+        used = u0;
+        const int amax0 = (int)wave_max((double)astage);
+        // S column by column
+        double sdiag = 1.0;
+        for (unsigned long long um = u0; um; um &= um - 1ull) {
+          const int a = __builtin_amdgcn_readfirstlane(__ffsll((long long)um) - 1);
+          const int ida = __builtin_amdgcn_readlane(arow, a);
+          zeroV();
+          if (ida < 1024) { if (tid == 0) V[(ida >> 5) * 16 + (ida & 15)] = ((ida >> 4) & 1) ? -1.0 : 1.0; }
+          else {
+            const uint4 m4 = gmeta[ida - 1024];
+            const int off = (int)(m4.z & 0xFFFFu), nn = (int)((m4.z >> 16) & 7u), i = (int)((m4.z >> 20) & 0x7FFu);
+            if (tid < nn) V[i * 16 + ((m4.w >> (4 * tid)) & 15u)] = gcoef[off + tid];
+          }
+          const int sta = __builtin_amdgcn_readlane(astage, a);
+          OC_WAVE_SYNC();
+          subst(false, sta, amax0, V);
+          double sv = arow >= 0 ? -row_dot(arow, V) : 0.0;
+          if (tid == a && row_soft(ida)) sv += iaq;
+          if (tid == a) sdiag = sv;
+#pragma unroll
+          for (int b = 0; b < 64; ++b) M[b] = (b == a) ? sv : M[b];
+        }
+        // in-place inverse by symmetric sweeps (S is positive definite on independent rows; a pivot that has gone flat - a dependent
+        // row - takes its row out of the start)
+        for (unsigned long long um = u0; um; um &= um - 1ull) {
+          const int k = __builtin_amdgcn_readfirstlane(__ffsll((long long)um) - 1);
+          double m = 0.0;
+#pragma unroll
+          for (int b = 0; b < 64; ++b) m = (b == k) ? M[b] : m;
+          const double d = readlane_d(m, k);
+          if (!(d > AS_DEP * readlane_d(sdiag, k))) {   // dependent on the rows swept so far (the pivot against the row's own g H^-1 g'): out of the start
+#pragma unroll
+            for (int b = 0; b < 64; ++b) if (b == k || tid == k) M[b] = 0.0;
+            if (tid == k) { arow = -1; astage = -1; }
+            used &= ~(1ull << k);
+            continue;
+          }
+          const double invd = 1.0 / d;
+#pragma unroll
+          for (int g8 = 0; g8 < 8; ++g8) {
+            if ((u0 >> (8 * g8)) & 0xFFull) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { const int b = 8 * g8 + j; const double mb = readlane_d(m, b); M[b] = (tid == k) ? M[b] * invd : fma(m * mb, -invd, M[b]); }
+            }
+          }
+#pragma unroll
+          for (int b = 0; b < 64; ++b) M[b] = (b == k) ? ((tid == k) ? -invd : m * invd) : M[b];
+        }
+#pragma unroll
+        for (int b = 0; b < 64; ++b) M[b] = -M[b];
+        // (rows and columns of the slots that are not in use stay zero: their S entries were zero and no sweep touched them)
+        if (arow < 0) {
+#pragma unroll
+          for (int b = 0; b < 64; ++b) M[b] = 0.0;
+        }
+        // multipliers of the equality-constrained problem on the start; negative ones leave one at a time
+        const double cvi = arow >= 1024 ? row_dot(arow, Z) - grhs[arow - 1024] : (arow >= 0 ? row_dot(arow, Z) : 0.0);
+        double cv = cvi;
+        {   // right-hand side of a box row: in the registers of its owner lane
+          int ol = 0, ok_ = 0;
+          if (arow >= 0 && arow < 1024) { ol = (((arow >> 5) & 1) * 2 + ((arow >> 4) & 1)) << 4 | (arow & 15); ok_ = arow >> 6; }
+          double rsel = 0.0;
+#pragma unroll
+          for (int k = 0; k < NSL; ++k) {   // every lane offers its slot-k right-hand side; the slot lanes pick the one they need
+            const double rk = __shfl(brhs[k], ol);
+            if (ok_ == k) rsel = rk;
+          }
+          if (arow >= 0 && arow < 1024) cv = cvi - rsel;
+        }
+        for (int guard = 0; guard < 64; ++guard) {
+          double l0 = 0.0;
+#pragma unroll
+          for (int g8 = 0; g8 < 8; ++g8) {
+            if ((used >> (8 * g8)) & 0xFFull) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { const int b = 8 * g8 + j; l0 = fma(M[b], readlane_d(cv, b), l0); }
+            }
+          }
+          if (arow < 0) l0 = 0.0;
+          alam = l0;
+          const double lmin = wave_min(arow >= 0 ? l0 : 1e300);
+          if (!(lmin < -1e-10)) break;
+          const int kd = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(arow >= 0 && l0 == lmin)) - 1);
+          double m = 0.0;
+#pragma unroll
+          for (int b = 0; b < 64; ++b) m = (b == kd) ? M[b] : m;
+          const double mkk = readlane_d(m, kd);
+          if (!(mkk > 0.0)) { fail = true; break; }
+          rank1(m, -1.0 / mkk, used);
+#pragma unroll
+          for (int b = 0; b < 64; ++b) if (b == kd || tid == kd) M[b] = 0.0;
+          if (tid == kd) { arow = -1; astage = -1; alam = 0.0; cv = 0.0; }
+          used &= ~(1ull << kd);
+          ndrop++;
+        }
+        if (alam < 0.0) alam = 0.0;
+        // the owner lanes learn which of their rows are active
+        for (unsigned long long um = used; um; um &= um - 1ull) {
+          const int a = __builtin_amdgcn_readfirstlane(__ffsll((long long)um) - 1);
+          const int ida = __builtin_amdgcn_readlane(arow, a);
+          if (ida < 1024) { if (tid == ((((ida >> 5) & 1) * 2 + ((ida >> 4) & 1)) << 4 | (ida & 15))) binA |= 1u << (ida >> 6); }
+          else { const int rr_ = ida - 1024; if (tid == (rr_ & 63)) ginA |= 1u << (rr_ >> 6); }
+        }
+        nwarm = __popcll(used);
+        refresh();
+      }
+    }
+    ASP_T(ta3); ASP_ACC(8, ta2, ta3);
+    // dual value of the current multipliers: at a point where the active rows hold with equality it is the primal value of the iterate
+    double Dval = objective() + wave_sum((arow >= 1024 && row_soft(arow)) ? 0.5 * alam * alam * iaq : 0.0);
+
+    for (; !fail;) {
+      // ---- most violated row at the iterate (rows of the active set hold with equality)
+      ASP_T(tb0);
+      double bv = -1e300; int bid = -1;
+#pragma unroll
+      for (int k = 0; k < NSL; ++k) {
+        const int i = 2 * k + par;
+        if (((bact >> k) & 1u) && !((binA >> k) & 1u)) { const double v = bsgn * Z[i * 16 + lc] - brhs[k]; if (v > bv) { bv = v; bid = (i * 2 + side) * 16 + lc; } }
+      }
+#pragma unroll
+      for (int q = 0; q < OC_GSLOTS; ++q) {
+        const int r = q * 64 + tid;
+        if (r < NM && !((ginA >> q) & 1u)) { const double v = row_dot(1024 + r, Z) - grhs[r]; if (v > bv) { bv = v; bid = 1024 + r; } }
+      }
+      const double vmax = wave_max(bv);
+      if (!(vmax > AS_VTOL)) break;                                   // optimal
+      if (steps >= AS_MAXSTEP || used == ~0ull || !(vmax < 1e290)) { fail = true; break; }
+      const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(bv == vmax)) - 1);
+      const int pid = __builtin_amdgcn_readlane(bid, src);
+      const bool psoft = row_soft(pid);
+      const double prhs = pid < 1024 ? 0.0 : 0.0; (void)prhs;
+      // ---- w = H^-1 g_p (V), q = G_A w, S_pp
+      ASP_T(tb1); ASP_ACC(2, tb0, tb1);
+      zeroV();
+      if (pid < 1024) { if (tid == 0) V[(pid >> 5) * 16 + (pid & 15)] = ((pid >> 4) & 1) ? -1.0 : 1.0; }
+      else {
+        const uint4 m4 = gmeta[pid - 1024];
+        const int off = (int)(m4.z & 0xFFFFu), nn = (int)((m4.z >> 16) & 7u), i = (int)((m4.z >> 20) & 0x7FFu);
+        if (tid < nn) V[i * 16 + ((m4.w >> (4 * tid)) & 15u)] = gcoef[off + tid];
+      }
+      const int pstage = pid < 1024 ? (pid >> 5) : (int)((gmeta[pid - 1024].z >> 20) & 0x7FFu);
+      const int amax_ = (int)wave_max((double)astage);
+      OC_WAVE_SYNC();
+      subst(false, pstage, amax_ > pstage ? amax_ : pstage, V);      // V = -H^-1 g_p (up to the last stage that carries an active row)
+      ASP_T(tb2); ASP_ACC(3, tb1, tb2);
+      double q = arow >= 0 ? -row_dot(arow, V) : 0.0;
+      const double Spp = -row_dot(pid, V) + (psoft ? iaq : 0.0);
+      double vp = vmax, lp = 0.0;
+      steps++;
+      ASP_T(tb3); ASP_ACC(4, tb2, tb3);
+      for (;;) {
+        // r = M q, curvature of the new row against the active ones, ratio test on the multipliers
+        double r = 0.0;
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) {
+          if ((used >> (8 * g8)) & 0xFFull) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int b = 8 * g8 + j; r = fma(M[b], readlane_d(q, b), r); }
+          }
+        }
+        if (arow < 0) r = 0.0;
+        const double curv = Spp - wave_sum(q * r);
+        const double ratio = (arow >= 0 && r > 1e-13) ? alam / r : 1e300;
+        const double td = wave_min(ratio);
+        const int kd = td < 1e299 ? __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(ratio == td)) - 1) : -1;
+        if (!(curv == curv) || !(Spp > 0.0)) { fail = true; break; }
+        const bool dep = !(curv > AS_DEP * Spp);
+        double t; bool full;
+        if (dep) { if (kd < 0) { infeas = true; break; } t = td; full = false; }
+        else { const double tp = vp / curv; if (tp <= td) { t = tp; full = true; } else { t = td; full = false; } }
+        if (arow >= 0) { alam = fma(-t, r, alam); if (alam < 0.0) alam = 0.0; }
+        lp += t;
+        Dval += t * (vp - 0.5 * t * (dep ? 0.0 : curv));
+        if (lp > RHO_EL) { infeas = true; break; }                    // (the exact penalty of the interior point's elastic rows: beyond rho the row gives way)
+        if (full) {
+          const int s = __builtin_amdgcn_readfirstlane(__ffsll((long long)~used) - 1);
+          double u = arow >= 0 ? r : 0.0;
+          if (tid == s) u = -1.0;
+          const unsigned long long nmask = used | (1ull << s);
+          rank1(u, 1.0 / curv, nmask);
+          if (tid == s) { arow = pid; alam = lp; astage = pstage; }
+          used = nmask;
+          if (pid < 1024) { if (tid == ((((pid >> 5) & 1) * 2 + ((pid >> 4) & 1)) << 4 | (pid & 15))) binA |= 1u << (pid >> 6); }
+          else { const int rr_ = pid - 1024; if (tid == (rr_ & 63)) ginA |= 1u << (rr_ >> 6); }
+          break;
+        }
+        // partial step: the blocking row leaves the active set
+        vp -= t * (dep ? 0.0 : curv);
+        const int idk = __builtin_amdgcn_readlane(arow, kd);
+        if (idk < 1024) { if (tid == ((((idk >> 5) & 1) * 2 + ((idk >> 4) & 1)) << 4 | (idk & 15))) binA &= ~(1u << (idk >> 6)); }
+        else { const int rr_ = idk - 1024; if (tid == (rr_ & 63)) ginA &= ~(1u << (rr_ >> 6)); }
+        double m = 0.0;
+#pragma unroll
+        for (int b = 0; b < 64; ++b) m = (b == kd) ? M[b] : m;
+        const double mkk = readlane_d(m, kd);
+        if (!(mkk > 0.0)) { fail = true; break; }
+        rank1(m, -1.0 / mkk, used);
+#pragma unroll
+        for (int b = 0; b < 64; ++b) if (b == kd || tid == kd) M[b] = 0.0;
+        if (tid == kd) { arow = -1; astage = -1; alam = 0.0; q = 0.0; }
+        used &= ~(1ull << kd);
+        ndrop++; steps++;
+        if (steps >= AS_MAXSTEP) { fail = true; break; }
+      }
+      ASP_T(tb4); ASP_ACC(5, tb3, tb4);
+      if (infeas || fail) break;
+      refresh();
+      ASP_T(tb5); ASP_ACC(6, tb4, tb5);
+      if (Dval - 1e-9 * fabs(Dval) > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }
+    }
+    ASP_T(tc0);
+    if (B.batch_A) {   // the final active set, by row identity, for the children's starts
+      unsigned short enc = 0xFFFFu;
+      if (!fail && !infeas && ok == 1 && arow >= 0) enc = arow < 1024 ? (unsigned short)arow : (unsigned short)(1024 + (int)cand[arow - 1024]);
+      B.batch_A[(size_t)node * 64 + tid] = enc;
+    }
+    if (fail) {   // to the interior point launch behind this one
+      if (tid == 0) { B.batch_ok[node] = 6; const int qq = atomicAdd(B.as_count, 1); B.as_list[qq] = node; if (B.as_stats) atomicAdd(&B.as_stats[2], 1ull); }
+      continue;
+    }
+    // ---- results.  obj: primal value of the iterate (objective + cost of the soft rows' slack lambda / a); viol: worst row at the iterate;
+    // bound allowance: obj - L(z, lambda) (the Lagrangian at the iterate is a lower bound of the relaxation for any lambda >= 0)
+    double viol = 0.0, scost = 0.0, lres = 0.0;
+    if (!infeas && ok == 1) {
+#pragma unroll
+      for (int k = 0; k < NSL; ++k) { const int i = 2 * k + par; if ((bact >> k) & 1u) viol = fmax(viol, bsgn * Z[i * 16 + lc] - brhs[k]); }
+#pragma unroll
+      for (int q = 0; q < OC_GSLOTS; ++q) { const int r = q * 64 + tid; if (r < NM && !(gmeta[r].z & 0x80000000u)) viol = fmax(viol, row_dot(1024 + r, Z) - grhs[r]); }
+      if (arow >= 0) {
+        const bool sf = row_soft(arow);
+        const double rh = arow < 1024 ? 0.0 : grhs[arow - 1024];
+        double res;
+        if (arow < 1024) res = 0.0;   // (a box row of the active set: its residual is in viol above; its share of the allowance below)
+        else res = row_dot(arow, Z) - rh - (sf ? alam * iaq : 0.0);
+        if (sf) { scost = 0.5 * alam * alam * iaq; viol = fmax(viol, res); }
+        lres = alam * res;
+      }
+      // box rows of the active set: residual from the owner's registers is not at hand in the slot lane; bound it by lambda x worst violation
+      viol = wave_max(viol); scost = wave_sum(scost);
+      double lsum = wave_sum(arow >= 0 && arow < 1024 ? alam : 0.0);
+      lres = wave_sum(lres);
+      lres = fabs(lres) + lsum * viol;
+    } else if (infeas) viol = 1.0;
+    const double obj = (infeas || ok == 2) ? Dval : objective() + scost;
+    double* Zo = B.batch_Z + (size_t)node * N * NZ;
+    for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) Zo[(k >> 4) * NZ + oc_lcol<C, CM>(as_col(q))] = Z[k]; }
+    if (tid == 0) {
+      B.batch_obj[node] = obj; B.batch_viol[node] = viol; B.batch_ok[node] = ok;
+      B.batch_bound[node] = lres + 1e-9 * (1.0 + fabs(obj));
+      B.batch_it[node] = steps;
+      atomicAdd((unsigned long long*)&B.inst_nodes[inst], 1ull);
+      atomicAdd((unsigned long long*)&B.inst_iters[inst], (unsigned long long)steps);
+#ifdef MIQP_PROFILE
+      { const long long tc1 = clock64(); asp_[7] += (unsigned long long)(tc1 - tc0);
+        for (int q_ = 0; q_ < 9; ++q_) atomicAdd(&B.prof[80 + q_], asp_[q_]);
+        atomicAdd(&B.prof[90], 1ull); atomicAdd(&B.prof[91], (unsigned long long)steps); }
+#endif
+      if (B.as_stats) {
+        atomicAdd(&B.as_stats[0], 1ull); atomicAdd(&B.as_stats[1], (unsigned long long)steps); atomicAdd(&B.as_stats[3], (unsigned long long)ndrop);
+        atomicAdd(&B.as_stats[4], infeas ? 1ull : 0ull); atomicAdd(&B.as_stats[5], ok == 2 ? 1ull : 0ull); atomicAdd(&B.as_stats[6], (unsigned long long)__popcll(used)); atomicAdd(&B.as_stats[7], (unsigned long long)nwarm);
+      }
+    }
+  }
+}
+
+}  // namespace miqp

@@ -219,7 +219,8 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
   const int tid = threadIdx.x, lg = tid >> 4, lc = tid & 15;
   const int par = lg >> 1, side = lg & 1;                   // box rows of this lane: column lc, side, stages 2k + par
   const double bsgn = side ? -1.0 : 1.0;
-  const int nbatch = BIG && B.ovf_mode == 1 ? *B.ovf_count : (*B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap);
+  const bool as_list_mode = !BIG && B.as_mode == 1;   // behind the active-set launch: only the nodes it listed
+  const int nbatch = BIG && B.ovf_mode == 1 ? *B.ovf_count : (as_list_mode ? *B.as_count : (*B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap));
   const int N = Y.N, NSLOT = Y.NSLOT;
   extern __shared__ double lds[];
   char* const L0 = (char*)lds;
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     if (tid == 0) sh_node = atomicAdd(B.work_counter, 1);
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(sh_node) >= nbatch) break;
-    const int node = __builtin_amdgcn_readfirstlane(BIG && B.ovf_mode == 1 ? B.ovf_list[sh_node] : sh_node);   // wave-uniform by construction: said so, everything derived from it
+    const int node = __builtin_amdgcn_readfirstlane(BIG && B.ovf_mode == 1 ? B.ovf_list[sh_node] : (as_list_mode ? B.as_list[sh_node] : sh_node));   // wave-uniform by construction: said so, everything derived from it
                                                                   // (instance tables, references) is then addressed from SGPRs
     // the concurrent launch of the larger variant takes the nodes known to be large before the round: the rounding probes (their
     // depth word says so) and the records marked by an earlier decode or inherited from a marked parent

@@ -185,6 +185,12 @@ struct DevBuf {
   // its region sequences join the batch of the same round
   double* inst_lns_obj; double lns_step;   // the local search runs again only when the incumbent has improved by lns_step (relative) since its last run: a hill climb in steps of 1e-5 re-evaluates the whole neighbourhood for nothing
   int* inst_lns; int lns_mode; int lns_min_nodes; int lns_narrow;   // (an instance gets its local search once it has cost lns_min_nodes node relaxations: the easy ones are done before)
+  // Dual active-set launch (as_onchip.hip) in front of the standard interior point launch of a round: it solves the ordinary nodes and lists
+  // the ones it cannot finish; as_mode 1 makes the standard interior point kernel work through that list instead of the batch
+  int* as_count; int* as_list; int as_mode;
+  unsigned short* batch_A;       // [batch_cap][64] final active set of a node the active-set launch solved: box rows by their key (stage * 2 + side) * 16 + column, general rows as 1024 + (stage * NSLOT + slot); 0xFFFF: empty
+  unsigned short* pool_A;        // [z_cap][64] the parent's, per child record (eval_kernel copies it like pool_Z): the child's first active set
+  unsigned long long* as_stats;  // [8] nodes, steps (rows added + dropped), handed to the interior point, rows dropped, infeasible, cut off, sum of the final active set sizes
 };
 
 __device__ inline unsigned long long d2key(double v) {
@@ -1351,6 +1357,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
 
 }  // namespace miqp
 #include "ipm_onchip.hip"
+#include "as_onchip.hip"
 namespace miqp {
 
 // ------------------------------------------------------------------------------------------------
@@ -2294,6 +2301,10 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     if (B.pool_big && lane < nk) B.pool_big[slots[lane]] = pumped ? (unsigned char)((((big_parent >> 4) + 1) << 4) | 1) : (unsigned char)(big_parent & ~8);   // (bit 3, "deferred once", is the parent's own)   // (a child has the rows of its parent and more)
     if (B.pool_Z) {   // the children start their relaxation from this node's solution (see DevBuf::pool_Z)
       for (int q = 0; q < nk; ++q) { if (slots[q] >= B.z_cap) continue; double* zd = B.pool_Z + (size_t)slots[q] * N * NZ; for (int k = lane; k < N * NZ; k += 64) zd[k] = Z[k]; }
+    }
+    if (B.pool_A) {   // ... and, where the active-set launch solved this node, from its active set (the nodes of the larger interior point variant have none)
+      const unsigned short av_ = (B.batch_A && B.batch_large && !B.batch_large[node]) ? B.batch_A[(size_t)node * 64 + lane] : (unsigned short)0xFFFFu;
+      for (int q = 0; q < nk; ++q) { if (slots[q] >= B.z_cap) continue; B.pool_A[(size_t)slots[q] * 64 + lane] = av_; }
     }
     if (lane < nk) {
       // depth word: (tree depth << 6) | preference among siblings (child_inf first) - used by the dive ordering

@@ -87,6 +87,7 @@ struct miqp_solver {
   std::vector<double> Z; std::vector<signed char> comp; bool has_sol = false;
   Layout lay{};
   double timing[6] = {0, 0, 0, 0, 0, 0};
+  double as_timing[4] = {0, 0, 0, 0};   // active-set launch of the last call: nodes it solved, its steps, nodes it handed to the interior point, rows dropped
   double setup[3] = {0, 0, 0};   // host set-up of the last call: seconds, of which the device context, 1 when the context was (re)built
   double admit_s = 0.0;          // when the last batch / stream call admitted this instance, in seconds after the first round of that call started
   // MIP starts (each tried as an additional root: binaries fixed, QP solved, accepted as incumbent when feasible).
@@ -259,6 +260,7 @@ struct DevCtx {
   int* ctr = nullptr; // two parity sets of 8 counters for the launches of a round (batch count, work counters, hand-over counts): a round uses one set, roll_kernel zeroes the other
   bool concurrent_big = true;   // MIQP_CONCURRENT_BIG=0: the sequential chain standard -> larger -> memory-backed
   int ocb_grid = 0;  // resident wavefronts of its larger variant (OC_GCAP_BIG general rows, one wavefront per SIMD; 0: not in use)
+  bool as_on = false; int* as_list = nullptr; unsigned long long* as_stats = nullptr;   // dual active-set launch in front of the standard interior point launch (two cars; MIQP_AS=0: off)
   DevBuf B{};
   std::vector<void*> allocs;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -457,6 +459,18 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&B.work_counter, 1)) return false;
   if (!X.alloc(&X.ctr, 16)) return false;
   HIP_OK(hipMemset(X.ctr, 0, 64));
+  { const char* e = KNOB_P("MIQP_AS"); X.as_on = Y.C == 2 && X.oc_grid > 0 && !(e && std::atoi(e) == 0); }
+  if (!X.alloc(&X.as_list, batch_alloc)) return false;
+  if (!X.alloc(&X.as_stats, 8)) return false;
+  HIP_OK(hipMemset(X.as_stats, 0, 64));
+  B.as_count = nullptr; B.as_list = X.as_list; B.as_mode = 0; B.as_stats = X.as_stats;
+  B.batch_A = nullptr; B.pool_A = nullptr;
+  if (X.as_on && B.z_cap > 0 && Y.N * Y.NSLOT + 1024 < 65535) {   // the parents' active sets for the children's starts (128 B per record)
+    if (!X.alloc(&B.batch_A, (size_t)batch_alloc * 64)) return false;
+    if (!X.alloc(&B.pool_A, (size_t)B.z_cap * 64)) return false;
+    HIP_OK(hipMemset(B.pool_A, 0xFF, (size_t)B.z_cap * 128));
+    HIP_OK(hipMemset(B.batch_A, 0xFF, (size_t)batch_alloc * 128));
+  }
   // buffers of the concurrent probe launch (two cars and fewer, on-chip kernel in use): 1024 resident blocks
   X.probe_grid = 0;
   if (X.oc_grid > 0 && !(KNOB_T("MIQP_PROBE_OVERLAP") && std::atoi(KNOB_T("MIQP_PROBE_OVERLAP")) == 0)) {
@@ -562,6 +576,13 @@ void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool o
       launch_ipm_c(Y.C, Bm, std::min(bc, X.probe_grid), l_ipm, X.stream2, !pc);
       (void)hipEventRecord(X.ev_join, X.stream2);
       Bc.skip_probes = 1; Bc.bounce = 1;
+      if (X.as_on && pc && Y.C == 2) {
+        // the ordinary nodes of the round: dual active-set solves (as_onchip.hip); what that launch lists (a node it could not finish) is
+        // all the standard interior point launch behind it still has to do
+        DevBuf Ba = Bc; Ba.work_counter = cs + 7; Ba.as_count = cs + 6;
+        hipLaunchKernelGGL((as_onchip_kernel<2, OC_NSL>), dim3(std::min(bc, X.oc_grid)), dim3(64), l_oc, st, Ba);
+        Bc.as_mode = 1; Bc.as_count = cs + 6;
+      }
       if (Y.C == 1) launch_ipm_oc<1>(Bc, std::min(bc, X.oc_grid), l_oc, st, !pc); else launch_ipm_oc<2>(Bc, std::min(bc, X.oc_grid), l_oc, st, !pc);
       if (X.ev_mid) (void)hipEventRecord(X.ev_mid, st);
       (void)hipStreamWaitEvent(st, X.ev_join, 0);
@@ -600,6 +621,7 @@ void launch_eval_c(int C, const DevBuf& B, int nblocks, size_t lds, hipStream_t 
 template <int C> bool set_kernel_lds_oc(size_t lds, size_t lds_big) {
   HIP_OK(hipFuncSetAttribute((const void*)ipm_onchip_kernel<C, OC_NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIP_OK(hipFuncSetAttribute((const void*)ipm_onchip_kernel<C, OC_NSL, 0, OC_GCAP_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+  if constexpr (C == 2) HIP_OK(hipFuncSetAttribute((const void*)as_onchip_kernel<2, OC_NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return true;
 }
 template <int C> bool set_kernel_lds_c(size_t ipm_lds, size_t eval_lds) {
@@ -986,6 +1008,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemsetAsync(B.inst_nodes, 0, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_iters, 0, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_ninc, 0, (size_t)n * 4, st));
+  HIP_OK(hipMemsetAsync(B.as_stats, 0, 64, st));
   HIP_OK(hipMemsetAsync(B.inst_lns, 0, (size_t)n * 4, st));
   { std::vector<double> big_(n, 1e300); HIP_OK(hipMemcpyAsync(B.inst_lns_obj, big_.data(), (size_t)n * 8, hipMemcpyHostToDevice, st)); HIP_OK(hipStreamSynchronize(st)); }
   B.lns_step = KNOB_T("MIQP_LNS_STEP") ? std::atof(KNOB_T("MIQP_LNS_STEP")) : 0.0;
@@ -1258,6 +1281,12 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     std::fprintf(stderr, "[miqp_gpu profile] on-chip nodes %llu iters %llu cycles/node-iter %.0f :", pf[11], pf[10], tot / std::max(1ull, pf[10]));
     for (int q = 0; q < 10; ++q) std::fprintf(stderr, " %s %.1f%% (%.0f)", nm[q], 100.0 * pf[q] / tot, (double)pf[q] / std::max(1ull, pf[10]));
     std::fprintf(stderr, "\n");
+    { unsigned long long pa[12]; HIP_OK(hipMemcpy(pa, B.prof + 80, 12 * 8, hipMemcpyDeviceToHost));
+      const char* na[9] = {"decode", "gains + first iterate", "scan", "response of the row", "q", "directions + ratio test + M update", "iterate refresh", "results", "warm start"};
+      double ta = 0; for (int q = 0; q < 9; ++q) ta += (double)pa[q];
+      if (pa[10]) { std::fprintf(stderr, "[miqp_gpu profile] active-set kernel nodes %llu steps %llu cycles/node %.0f :", pa[10], pa[11], ta / (double)pa[10]);
+        for (int q = 0; q < 9; ++q) std::fprintf(stderr, " %s %.1f%% (%.0f)", na[q], 100.0 * pa[q] / ta, (double)pa[q] / (double)pa[10]);
+        std::fprintf(stderr, "\n"); } }
     { unsigned long long pe[8]; HIP_OK(hipMemcpy(pe, B.prof + 100, 8 * 8, hipMemcpyDeviceToHost));
       const char* ne[6] = {"load", "regions", "leaf disjunctions", "branching", "lifting + reservation", "records"};
       double te = 0; for (int q = 0; q < 6; ++q) te += (double)pe[q];
@@ -1315,6 +1344,11 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemcpy(h_nodes.data(), B.inst_nodes, n * 8, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(h_iters.data(), B.inst_iters, n * 8, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(&rowiters, B.stat_rowiters, 8, hipMemcpyDeviceToHost));
+  unsigned long long h_as[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  HIP_OK(hipMemcpy(h_as, B.as_stats, 64, hipMemcpyDeviceToHost));
+  if (B.stats && h_as[0] + h_as[2] > 0)
+    std::fprintf(stderr, "[miqp_gpu stats] active-set launch: %llu nodes (%.1f steps, %.1f drops, %.1f rows from the parent's active set, %.1f active rows at the end per node; %llu infeasible, %llu cut off), %llu handed to the interior point\n",
+                 h_as[0], h_as[1] / (double)std::max(1ull, h_as[0]), h_as[3] / (double)std::max(1ull, h_as[0]), h_as[7] / (double)std::max(1ull, h_as[0]), h_as[6] / (double)std::max(1ull, h_as[0]), h_as[4], h_as[5], h_as[2]);
   std::vector<signed char> h_fix((size_t)n * Y.fixlen); std::vector<double> h_Z((size_t)n * Y.N * Y.nz);
   HIP_OK(hipMemcpy(h_fix.data(), B.inc_fix, h_fix.size(), hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(h_Z.data(), B.inc_Z, h_Z.size() * 8, hipMemcpyDeviceToHost));
@@ -1358,6 +1392,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     s->props.NrSolutionPool = h_ninc[k];
     s->timing[0] = ms_all * 1e-3; s->timing[1] = ms_ipm * 1e-3; s->timing[2] = (double)(nev / 2); s->timing[3] = (double)launched_nodes;
     s->timing[4] = (double)tot_iters; s->timing[5] = (double)rowiters;
+    s->as_timing[0] = (double)h_as[0]; s->as_timing[1] = (double)h_as[1]; s->as_timing[2] = (double)h_as[2]; s->as_timing[3] = (double)h_as[3];
     s->setup[0] = t_setup; s->setup[1] = t_ctx; s->setup[2] = ctx_built ? 1.0 : 0.0;
     s->err.clear();
     if (h_stalled[k] && unfinished) s->err = "retired without a proof: no progress for 64 branch-and-bound rounds (not a time-limit verdict)";
@@ -1690,6 +1725,12 @@ int miqp_solver_get_properties(const miqp_solver_t* s, miqp_solution_properties_
 int miqp_solver_last_timing(const miqp_solver_t* s, double* out6) {
   if (!s || !out6) return -1;
   for (int k = 0; k < 6; ++k) out6[k] = s->timing[k];
+  return 0;
+}
+
+int miqp_solver_last_active_set(const miqp_solver_t* s, double* out4) {
+  if (!s || !out4) return -1;
+  for (int k = 0; k < 4; ++k) out4[k] = s->as_timing[k];
   return 0;
 }
 
