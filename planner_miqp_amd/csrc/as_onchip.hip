@@ -17,7 +17,8 @@
 // every step; an infeasible node shows as a dependent row without a blocking multiplier (or a multiplier beyond the exact penalty rho of the
 // interior point's elastic rows).  Started cold from the unconstrained optimum the method takes |A| + 3..4 steps (tools/active_set_lab.py,
 // profiles/r06_active_set_lab.txt: the parent's active set re-added row by row costs the same as the most-violated order finds it).
-// A node the method cannot finish (64 active rows, step cap, loss of precision) is handed to the interior point launch behind this one.
+// A node the method cannot finish (64 active rows, step cap, loss of precision) is marked and returned unsolved; the larger interior point
+// variant takes it in its concurrent launch of the next round (the same path as a node with more rows than the LDS block holds).
 //
 // Layout: the LDS block of ipm_onchip_kernel (oc_lds_layout: same decode, same capacities, 8 wavefronts per CU); the region of the decode
 // scratch becomes the substitution vector V | the chain gains, the region of the box keys the feed-forward terms.
@@ -32,18 +33,24 @@ namespace miqp {
 #endif
 constexpr int AS_MAXSTEP = 220;        // adds + drops after which a node goes to the interior point instead
 constexpr double AS_VTOL = 1.0e-8;     // a row is violated above this (rows are normalised: metres, m/s, ...)
-constexpr double AS_DEP = 1.0e-8;      // curvature g P g' below this share of g H^-1 g': the row depends on the active ones
+constexpr double AS_DEP = 1.0e-8;
+constexpr int AS_MT = 48;               // active sets of up to this many rows hand their M to the children
+constexpr int AS_MSTR = AS_MT * (AS_MT + 1) / 2;   // doubles per record of pool_M / batch_M (packed triangle)      // curvature g P g' below this share of g H^-1 g': the row depends on the active ones
 
 // Column order inside this kernel: CHAIN-CONTIGUOUS - (position, velocity, acceleration, jerk) of chain ch = 2 car + axis at 4 ch .. 4 ch + 3 (the
 // transpose of ipm_onchip_kernel's chain-major 4 k + ch; an involution), so that the lane of a chain reads and writes its stage entries as two
 // 16-byte LDS accesses
 __device__ inline int as_col(int pq) { return ((pq & 3) << 2) | (pq >> 2); }
 
-template <int C, int NSL>
-__global__ void __launch_bounds__(64, 2) as_onchip_kernel(DevBuf B) {
+// GCAP = OC_GCAP: the ordinary nodes of a round (8 wavefronts per CU).  GCAP = OC_GCAP_BIG: the nodes known to be large before the round - rounding
+// probes, local-search leaves, marked records - beside it on a third stream (4 wavefronts per CU), except the ones as_big_takes() leaves to the
+// interior point chain on the second stream (records the method failed on before or that exceed even this block, probes that may be re-rounded)
+template <int C, int NSL, int GCAP = miqp::OC_GCAP>
+__global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(DevBuf B) {
   static_assert(C == 2, "chain-major columns of two cars");
   constexpr bool CM = true;
-  constexpr int OC_GCAP = miqp::OC_GCAP, OC_GSLOTS = OC_GCAP / 64, OC_GCOEF = oc_gcoef_of(OC_GCAP);
+  constexpr bool BIG = GCAP > 128;
+  constexpr int OC_GCAP = GCAP, OC_GSLOTS = OC_GCAP / 64, OC_GCOEF = oc_gcoef_of(OC_GCAP);
   constexpr int NX = 6 * C, NZ = 8 * C, NCH = 2 * C;
   const Layout& Y = B.Y;
   const int tid = threadIdx.x, lg = tid >> 4, lc = tid & 15;
@@ -77,10 +84,11 @@ __global__ void __launch_bounds__(64, 2) as_onchip_kernel(DevBuf B) {
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(sh_node) >= nbatch) break;
     const int node = __builtin_amdgcn_readfirstlane(sh_node);
-    if (B.skip_probes) {   // the concurrent launch of the larger interior point variant solves the probes and the marked records
+    {   // the split of the round between the two launches: select_kernel's snapshot (probes, local-search leaves, marked records: the larger block)
       const bool marked = B.batch_large ? B.batch_large[node] != 0 : is_probe_word(B.batch_depth[node]);
-      if (marked) continue;
+      if (BIG ? !marked : marked) continue;
     }
+    if (BIG && !as_big_takes(B, node)) continue;   // the interior point chain on the second stream keeps it
     const int inst = __builtin_amdgcn_readfirstlane(B.batch_inst[node]);
     const double* D = B.inst_d + (size_t)inst * Y.dstride;
     const int* T = B.inst_i + (size_t)inst * Y.istride;
@@ -204,10 +212,11 @@ __global__ void __launch_bounds__(64, 2) as_onchip_kernel(DevBuf B) {
       ncoef += tot;
       OC_WAVE_SYNC();
     }
-    if (overflow) {
+    if (overflow) {   // marked and returned unsolved: next round the larger block takes the record - or, from there, the interior point chain
+      if (B.batch_A) B.batch_A[(size_t)node * 64 + tid] = 0xFFFFu;
       if (tid == 0) {
-        if (B.bounce) { B.batch_ok[node] = 5; B.pool_big[B.batch_node[node]] |= 1; if (B.stats) { atomicAdd(&B.stats[3], 1ull); atomicAdd(&B.stats[8 + (ngen >= 512 ? 15 : ngen / 32)], 1ull); } }
-        else { B.batch_ok[node] = 6; const int q = atomicAdd(B.as_count, 1); B.as_list[q] = node; }
+        if (B.batch_M) B.batch_Mn[node] = 0;
+        B.batch_ok[node] = 5; B.pool_big[B.batch_node[node]] |= (BIG ? 2 : 1); if (B.stats) { atomicAdd(&B.stats[3], 1ull); atomicAdd(&B.stats[8 + (ngen >= 512 ? 15 : ngen / 32)], 1ull); }
       }
       continue;
     }
@@ -230,8 +239,15 @@ __global__ void __launch_bounds__(64, 2) as_onchip_kernel(DevBuf B) {
     OC_WAVE_SYNC();   // the keys are consumed: their region becomes the feed-forward terms
 
     // ---- constant gains of the unconstrained regulator, per chain (lane = chain): P' = Q + A' P A - K S_xu', K = S_xu / S_uu
+    // (gains, the objective's feed-forward and the unconstrained optimum are the same for every node of an instance: the first node of an
+    // instance to get here computes them and publishes them in as_tab, the others load 5.8 KB)
     const double h1 = ts, h2 = 0.5 * ts * ts, h3 = ts * ts * ts / 6.0;
-    if (tid < NCH) {
+    double* const tb = B.as_tab ? B.as_tab + (size_t)inst * B.as_tab_stride : nullptr;
+    const bool tab = tb && __builtin_amdgcn_readfirstlane(*(volatile int*)&B.as_tab_ready[inst]) == 1;
+    if (tab) {
+      for (int k = tid; k < N * 16; k += 64) KS[k] = tb[k];
+      for (int k = tid; k < N * 4; k += 64) kref[k] = tb[N * 16 + k];
+    } else if (tid < NCH) {
       const int ch = tid;
       const double q0 = 2.0 * Wd[4 * ch], q1 = 2.0 * Wd[4 * ch + 1], q2 = 2.0 * Wd[4 * ch + 2], rr = 2.0 * Wd[4 * ch + 3];
       double p00 = q0, p01 = 0.0, p02 = 0.0, p11 = q1, p12 = 0.0, p22 = q2;
@@ -309,13 +325,14 @@ __global__ void __launch_bounds__(64, 2) as_onchip_kernel(DevBuf B) {
       }
       OC_WAVE_SYNC();
     };
-    // feed-forward of the objective's linear term -2 W r (once per node)
-    for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; V[k] = q < NZ ? -2.0 * Wd[q] * Rf[(k >> 4) * NZ + oc_lcol<C, CM>(as_col(q))] : 0.0; }
-    OC_WAVE_SYNC();
-    subst(false, N - 1, 0, V);
-    if (tid < N * 4) kref[tid] = kff[tid];
-    if (tid + 64 < N * 4) kref[tid + 64] = kff[tid + 64];
-    OC_WAVE_SYNC();
+    if (!tab) {   // feed-forward of the objective's linear term -2 W r
+      for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; V[k] = q < NZ ? -2.0 * Wd[q] * Rf[(k >> 4) * NZ + oc_lcol<C, CM>(as_col(q))] : 0.0; }
+      OC_WAVE_SYNC();
+      subst(false, N - 1, 0, V);
+      if (tid < N * 4) kref[tid] = kff[tid];
+      if (tid + 64 < N * 4) kref[tid + 64] = kff[tid + 64];
+      OC_WAVE_SYNC();
+    }
 
     // value of a row at a stage-wise vector: box rows id = (stage * 2 + side) * 16 + column, general rows id = 1024 + index
     auto row_dot = [&](int id, const double* vec) -> double {
@@ -336,7 +353,7 @@ __global__ void __launch_bounds__(64, 2) as_onchip_kernel(DevBuf B) {
     };
 
     // ---- the active set: slot a lives in lane a (its row, its multiplier, row a of M)
-    int arow = -1, astage = -1; double alam = 0.0;
+    int arow = -1, astage = -1; double alam = 0.0, arhs = 0.0;   // (arhs: the row's right-hand side, at hand in its slot lane)
     double M[64];
 #pragma unroll
     for (int b = 0; b < 64; ++b) M[b] = 0.0;
@@ -367,16 +384,31 @@ __global__ void __launch_bounds__(64, 2) as_onchip_kernel(DevBuf B) {
       OC_WAVE_SYNC();
       subst(true, amax, N - 1, Z);
     };
-    refresh();                       // lambda = 0: the unconstrained optimum
+    if (tab) { for (int k = tid; k < N * 16; k += 64) Z[k] = tb[N * 20 + k]; OC_WAVE_SYNC(); }
+    else {
+      refresh();                     // lambda = 0: the unconstrained optimum
+      if (tb) {
+        for (int k = tid; k < N * 16; k += 64) { tb[k] = KS[k]; tb[N * 20 + k] = Z[k]; }
+        for (int k = tid; k < N * 4; k += 64) tb[N * 16 + k] = kref[k];
+        __threadfence();
+        if (tid == 0) atomicExch(&B.as_tab_ready[inst], 1);
+      }
+    }
     ASP_T(ta2); ASP_ACC(1, ta1, ta2);
-    int steps = 0, ndrop = 0, ok = 1, nwarm = 0;
+    int steps = 0, ndrop = 0, ok = 1, nwarm = 0, nfast = 0, ncold = 0;
     bool infeas = false, fail = false;
+    int why = 0;   // (diagnostic) what stopped a node the method could not finish: 1 no free slot, 2 step cap, 3 curvature / S_pp, 4 pivot of a down-date, 5 rows off their equalities at the end, 6 start
     // ---- warm start: the rows that were active at the parent's optimum (their identities travel with the record: box rows by their key, general
-    // rows by their (stage, slot) code) are taken as the first active set where this node still has them.  S_A0 = G_A0 H^-1 G_A0' column by
-    // column (one response each), inverted in the registers by symmetric sweeps; multipliers that come out negative leave (the rows the branching
-    // made slack), and Goldfarb-Idnani goes on from that dual feasible point.  Right-hand sides are this node's own: nothing is assumed about them.
+    // rows by their (stage, slot) code) are taken as the first active set where this node still has them, in the parent's slots.  M = S_A0^-1
+    // comes from the parent as well (packed triangle over its slots in rank order, copied per child by eval_kernel; a row this node no longer
+    // has leaves by the usual rank-one down-date) - or, where the record carries none, is rebuilt: S_A0 = G_A0 H^-1 G_A0' column by column (one
+    // response each) and inverted in the registers by symmetric sweeps.  Multipliers of the equality-constrained problem on A0 that come out
+    // negative leave one at a time (the rows the branching made slack), and Goldfarb-Idnani goes on from that dual feasible point.  Right-hand
+    // sides are this node's own; that the inherited M still fits the rows is CHECKED (the active rows must hold with equality at the first
+    // iterate), else the node starts cold.
     if (B.pool_A && (B.batch_depth[node] >> 6) >= 1 && B.batch_node[node] < B.z_cap) {
-      const unsigned int pa = B.pool_A[(size_t)B.batch_node[node] * 64 + tid];
+      const int rec = B.batch_node[node];
+      const unsigned int pa = B.pool_A[(size_t)rec * 64 + tid];
       int cid = -1;
       int ownl = 0;
       if (pa < 1024u) ownl = (int)((((pa >> 5) & 1u) * 2u + ((pa >> 4) & 1u)) << 4 | (pa & 15u));
@@ -388,80 +420,104 @@ __global__ void __launch_bounds__(64, 2) as_onchip_kernel(DevBuf B) {
         while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)cand[mid] < pc) lo = mid + 1; else hi = mid; }
         if (lo < NM && (int)cand[lo] == pc) cid = 1024 + lo;
       }
-      const unsigned long long u0 = __ballot(cid >= 0);
+      const unsigned long long u0p = __ballot(pa != 0xFFFFu);   // the parent's slots
+      const unsigned long long u0 = __ballot(cid >= 0);        // ... that this node still has
       if (u0) {
         arow = cid;
         astage = cid < 0 ? -1 : (cid < 1024 ? (cid >> 5) : (int)((gmeta[cid - 1024].z >> 20) & 0x7FFu));
-        used = u0;
-        const int amax0 = (int)wave_max((double)astage);
-        // S column by column
-        double sdiag = 1.0;
-        for (unsigned long long um = u0; um; um &= um - 1ull) {
-          const int a = __builtin_amdgcn_readfirstlane(__ffsll((long long)um) - 1);
-          const int ida = __builtin_amdgcn_readlane(arow, a);
-          zeroV();
-          if (ida < 1024) { if (tid == 0) V[(ida >> 5) * 16 + (ida & 15)] = ((ida >> 4) & 1) ? -1.0 : 1.0; }
-          else {
-            const uint4 m4 = gmeta[ida - 1024];
-            const int off = (int)(m4.z & 0xFFFFu), nn = (int)((m4.z >> 16) & 7u), i = (int)((m4.z >> 20) & 0x7FFu);
-            if (tid < nn) V[i * 16 + ((m4.w >> (4 * tid)) & 15u)] = gcoef[off + tid];
-          }
-          const int sta = __builtin_amdgcn_readlane(astage, a);
-          OC_WAVE_SYNC();
-          subst(false, sta, amax0, V);
-          double sv = arow >= 0 ? -row_dot(arow, V) : 0.0;
-          if (tid == a && row_soft(ida)) sv += iaq;
-          if (tid == a) sdiag = sv;
+        const int nmp = (B.pool_M && rec < B.m_cap) ? (int)B.pool_Mn[rec] : 0;
+        if (nmp > 0 && nmp == __popcll(u0p)) {
+          // the parent's M: entry (a, b) of the packed triangle at tri(max rank) + min rank
+          const double* pm = B.pool_M + (size_t)rec * AS_MSTR;
+          const int ra = __popcll(u0p & lt);
+          const bool mine = (u0p >> tid) & 1ull;
 #pragma unroll
-          for (int b = 0; b < 64; ++b) M[b] = (b == a) ? sv : M[b];
-        }
-        // in-place inverse by symmetric sweeps (S is positive definite on independent rows; a pivot that has gone flat - a dependent
-        // row - takes its row out of the start)
-        for (unsigned long long um = u0; um; um &= um - 1ull) {
-          const int k = __builtin_amdgcn_readfirstlane(__ffsll((long long)um) - 1);
-          double m = 0.0;
-#pragma unroll
-          for (int b = 0; b < 64; ++b) m = (b == k) ? M[b] : m;
-          const double d = readlane_d(m, k);
-          if (!(d > AS_DEP * readlane_d(sdiag, k))) {   // dependent on the rows swept so far (the pivot against the row's own g H^-1 g'): out of the start
-#pragma unroll
-            for (int b = 0; b < 64; ++b) if (b == k || tid == k) M[b] = 0.0;
-            if (tid == k) { arow = -1; astage = -1; }
-            used &= ~(1ull << k);
-            continue;
-          }
-          const double invd = 1.0 / d;
-#pragma unroll
-          for (int g8 = 0; g8 < 8; ++g8) {
-            if ((u0 >> (8 * g8)) & 0xFFull) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) { const int b = 8 * g8 + j; const double mb = readlane_d(m, b); M[b] = (tid == k) ? M[b] * invd : fma(m * mb, -invd, M[b]); }
+          for (int b8 = 0; b8 < 64; ++b8) {
+            if ((u0p >> b8) & 1ull) {
+              const int rb = __popcll(u0p & ((1ull << b8) - 1ull));
+              const int hi_ = ra > rb ? ra : rb, lo_ = ra > rb ? rb : ra;
+              M[b8] = mine ? pm[hi_ * (hi_ + 1) / 2 + lo_] : 0.0;
             }
           }
+          used = u0p;
+          for (unsigned long long um = u0p & ~u0; um; um &= um - 1ull) {   // rows this node no longer has
+            const int kd = __builtin_amdgcn_readfirstlane(__ffsll((long long)um) - 1);
+            double m = 0.0;
 #pragma unroll
-          for (int b = 0; b < 64; ++b) M[b] = (b == k) ? ((tid == k) ? -invd : m * invd) : M[b];
-        }
+            for (int b = 0; b < 64; ++b) m = (b == kd) ? M[b] : m;
+            const double mkk = readlane_d(m, kd);
+            if (mkk > 0.0) rank1(m, -1.0 / mkk, used);
 #pragma unroll
-        for (int b = 0; b < 64; ++b) M[b] = -M[b];
-        // (rows and columns of the slots that are not in use stay zero: their S entries were zero and no sweep touched them)
-        if (arow < 0) {
+            for (int b = 0; b < 64; ++b) if (b == kd || tid == kd) M[b] = 0.0;
+            used &= ~(1ull << kd);
+          }
+          nfast = 1;
+        } else {
+          used = u0;
+          const int amax0 = (int)wave_max((double)astage);
+          // S column by column
+          double sdiag = 1.0;
+          for (unsigned long long um = u0; um; um &= um - 1ull) {
+            const int a = __builtin_amdgcn_readfirstlane(__ffsll((long long)um) - 1);
+            const int ida = __builtin_amdgcn_readlane(arow, a);
+            zeroV();
+            if (ida < 1024) { if (tid == 0) V[(ida >> 5) * 16 + (ida & 15)] = ((ida >> 4) & 1) ? -1.0 : 1.0; }
+            else {
+              const uint4 m4 = gmeta[ida - 1024];
+              const int off = (int)(m4.z & 0xFFFFu), nn = (int)((m4.z >> 16) & 7u), i = (int)((m4.z >> 20) & 0x7FFu);
+              if (tid < nn) V[i * 16 + ((m4.w >> (4 * tid)) & 15u)] = gcoef[off + tid];
+            }
+            const int sta = __builtin_amdgcn_readlane(astage, a);
+            OC_WAVE_SYNC();
+            subst(false, sta, amax0, V);
+            double sv = arow >= 0 ? -row_dot(arow, V) : 0.0;
+            if (tid == a && row_soft(ida)) sv += iaq;
+            if (tid == a) sdiag = sv;
 #pragma unroll
-          for (int b = 0; b < 64; ++b) M[b] = 0.0;
+            for (int b = 0; b < 64; ++b) M[b] = (b == a) ? sv : M[b];
+          }
+          // in-place inverse by symmetric sweeps (S is positive definite on independent rows; a pivot that has gone flat - a dependent
+          // row - takes its row out of the start)
+          for (unsigned long long um = u0; um; um &= um - 1ull) {
+            const int k = __builtin_amdgcn_readfirstlane(__ffsll((long long)um) - 1);
+            double m = 0.0;
+#pragma unroll
+            for (int b = 0; b < 64; ++b) m = (b == k) ? M[b] : m;
+            const double d = readlane_d(m, k);
+            if (!(d > AS_DEP * readlane_d(sdiag, k))) {   // dependent on the rows swept so far (the pivot against the row's own g H^-1 g'): out of the start
+#pragma unroll
+              for (int b = 0; b < 64; ++b) if (b == k || tid == k) M[b] = 0.0;
+              if (tid == k) { arow = -1; astage = -1; }
+              used &= ~(1ull << k);
+              continue;
+            }
+            const double invd = 1.0 / d;
+#pragma unroll
+            for (int g8 = 0; g8 < 8; ++g8) {
+              if ((u0 >> (8 * g8)) & 0xFFull) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int b = 8 * g8 + j; const double mb = readlane_d(m, b); M[b] = (tid == k) ? M[b] * invd : fma(m * mb, -invd, M[b]); }
+              }
+            }
+#pragma unroll
+            for (int b = 0; b < 64; ++b) M[b] = (b == k) ? ((tid == k) ? -invd : m * invd) : M[b];
+          }
+#pragma unroll
+          for (int b = 0; b < 64; ++b) M[b] = (arow < 0) ? 0.0 : -M[b];
         }
         // multipliers of the equality-constrained problem on the start; negative ones leave one at a time
-        const double cvi = arow >= 1024 ? row_dot(arow, Z) - grhs[arow - 1024] : (arow >= 0 ? row_dot(arow, Z) : 0.0);
-        double cv = cvi;
-        {   // right-hand side of a box row: in the registers of its owner lane
-          int ol = 0, ok_ = 0;
+        {   // right-hand sides into the slot lanes (a box row's: in the registers of its owner lane)
+          int ol = 0, ok_ = -1;
           if (arow >= 0 && arow < 1024) { ol = (((arow >> 5) & 1) * 2 + ((arow >> 4) & 1)) << 4 | (arow & 15); ok_ = arow >> 6; }
-          double rsel = 0.0;
+          double rsel = arow >= 1024 ? grhs[arow - 1024] : 0.0;
 #pragma unroll
           for (int k = 0; k < NSL; ++k) {   // every lane offers its slot-k right-hand side; the slot lanes pick the one they need
             const double rk = __shfl(brhs[k], ol);
             if (ok_ == k) rsel = rk;
           }
-          if (arow >= 0 && arow < 1024) cv = cvi - rsel;
+          arhs = rsel;
         }
+        double cv = arow >= 0 ? row_dot(arow, Z) - arhs : 0.0;
         for (int guard = 0; guard < 64; ++guard) {
           double l0 = 0.0;
 #pragma unroll
@@ -489,15 +545,30 @@ __global__ void __launch_bounds__(64, 2) as_onchip_kernel(DevBuf B) {
           ndrop++;
         }
         if (alam < 0.0) alam = 0.0;
-        // the owner lanes learn which of their rows are active
-        for (unsigned long long um = used; um; um &= um - 1ull) {
-          const int a = __builtin_amdgcn_readfirstlane(__ffsll((long long)um) - 1);
-          const int ida = __builtin_amdgcn_readlane(arow, a);
-          if (ida < 1024) { if (tid == ((((ida >> 5) & 1) * 2 + ((ida >> 4) & 1)) << 4 | (ida & 15))) binA |= 1u << (ida >> 6); }
-          else { const int rr_ = ida - 1024; if (tid == (rr_ & 63)) ginA |= 1u << (rr_ >> 6); }
-        }
         nwarm = __popcll(used);
         refresh();
+        // the start is a point of the method only if its rows hold with equality (an inherited M that no longer fits the rows, or one that
+        // has lost its precision over the generations, shows here): else the node starts cold
+        double resid = arow >= 0 ? fabs(row_dot(arow, Z) - arhs - ((arow >= 1024 && row_soft(arow)) ? alam * iaq : 0.0)) : 0.0;
+        resid = wave_max(resid);
+        if (!(resid <= 1e-7) || fail) {   // cold
+          fail = false;
+          arow = -1; astage = -1; alam = 0.0; arhs = 0.0; used = 0ull; nwarm = 0; nfast = 0; ncold = 1;
+#pragma unroll
+          for (int b = 0; b < 64; ++b) M[b] = 0.0;
+          refresh();
+        } else {
+          // the owner lanes learn which of their rows are active (one LDS word per owner lane, in the spent region of the fix record)
+          unsigned int* const inab = (unsigned int*)fix;
+          inab[tid] = 0u;
+          OC_WAVE_SYNC();
+          if (arow >= 0) {
+            if (arow < 1024) atomicOr(&inab[(((arow >> 5) & 1) * 2 + ((arow >> 4) & 1)) << 4 | (arow & 15)], 1u << (arow >> 6));
+            else { const int rr_ = arow - 1024; atomicOr(&inab[rr_ & 63], 1u << (16 + (rr_ >> 6))); }
+          }
+          OC_WAVE_SYNC();
+          { const unsigned int w_ = inab[tid]; binA = w_ & 0xFFFFu; ginA = w_ >> 16; }
+        }
       }
     }
     ASP_T(ta3); ASP_ACC(8, ta2, ta3);
@@ -507,24 +578,24 @@ __global__ void __launch_bounds__(64, 2) as_onchip_kernel(DevBuf B) {
     for (; !fail;) {
       // ---- most violated row at the iterate (rows of the active set hold with equality)
       ASP_T(tb0);
-      double bv = -1e300; int bid = -1;
+      double bv = -1e300, brh = 0.0; int bid = -1;
 #pragma unroll
       for (int k = 0; k < NSL; ++k) {
         const int i = 2 * k + par;
-        if (((bact >> k) & 1u) && !((binA >> k) & 1u)) { const double v = bsgn * Z[i * 16 + lc] - brhs[k]; if (v > bv) { bv = v; bid = (i * 2 + side) * 16 + lc; } }
+        if (((bact >> k) & 1u) && !((binA >> k) & 1u)) { const double v = bsgn * Z[i * 16 + lc] - brhs[k]; if (v > bv) { bv = v; brh = brhs[k]; bid = (i * 2 + side) * 16 + lc; } }
       }
 #pragma unroll
       for (int q = 0; q < OC_GSLOTS; ++q) {
         const int r = q * 64 + tid;
-        if (r < NM && !((ginA >> q) & 1u)) { const double v = row_dot(1024 + r, Z) - grhs[r]; if (v > bv) { bv = v; bid = 1024 + r; } }
+        if (r < NM && !((ginA >> q) & 1u)) { const double rh_ = grhs[r]; const double v = row_dot(1024 + r, Z) - rh_; if (v > bv) { bv = v; brh = rh_; bid = 1024 + r; } }
       }
       const double vmax = wave_max(bv);
       if (!(vmax > AS_VTOL)) break;                                   // optimal
-      if (steps >= AS_MAXSTEP || used == ~0ull || !(vmax < 1e290)) { fail = true; break; }
+      if (steps >= AS_MAXSTEP || used == ~0ull || !(vmax < 1e290)) { fail = true; why = used == ~0ull ? 1 : 2; break; }
       const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(bv == vmax)) - 1);
       const int pid = __builtin_amdgcn_readlane(bid, src);
       const bool psoft = row_soft(pid);
-      const double prhs = pid < 1024 ? 0.0 : 0.0; (void)prhs;
+      const double prhs = readlane_d(brh, src);
       // ---- w = H^-1 g_p (V), q = G_A w, S_pp
       ASP_T(tb1); ASP_ACC(2, tb0, tb1);
       zeroV();
@@ -559,7 +630,7 @@ __global__ void __launch_bounds__(64, 2) as_onchip_kernel(DevBuf B) {
         const double ratio = (arow >= 0 && r > 1e-13) ? alam / r : 1e300;
         const double td = wave_min(ratio);
         const int kd = td < 1e299 ? __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(ratio == td)) - 1) : -1;
-        if (!(curv == curv) || !(Spp > 0.0)) { fail = true; break; }
+        if (!(curv == curv) || !(Spp > 0.0)) { fail = true; why = 3; break; }
         const bool dep = !(curv > AS_DEP * Spp);
         double t; bool full;
         if (dep) { if (kd < 0) { infeas = true; break; } t = td; full = false; }
@@ -574,7 +645,7 @@ __global__ void __launch_bounds__(64, 2) as_onchip_kernel(DevBuf B) {
           if (tid == s) u = -1.0;
           const unsigned long long nmask = used | (1ull << s);
           rank1(u, 1.0 / curv, nmask);
-          if (tid == s) { arow = pid; alam = lp; astage = pstage; }
+          if (tid == s) { arow = pid; alam = lp; astage = pstage; arhs = prhs; }
           used = nmask;
           if (pid < 1024) { if (tid == ((((pid >> 5) & 1) * 2 + ((pid >> 4) & 1)) << 4 | (pid & 15))) binA |= 1u << (pid >> 6); }
           else { const int rr_ = pid - 1024; if (tid == (rr_ & 63)) ginA |= 1u << (rr_ >> 6); }
@@ -589,14 +660,14 @@ __global__ void __launch_bounds__(64, 2) as_onchip_kernel(DevBuf B) {
 #pragma unroll
         for (int b = 0; b < 64; ++b) m = (b == kd) ? M[b] : m;
         const double mkk = readlane_d(m, kd);
-        if (!(mkk > 0.0)) { fail = true; break; }
+        if (!(mkk > 0.0)) { fail = true; why = 4; break; }
         rank1(m, -1.0 / mkk, used);
 #pragma unroll
         for (int b = 0; b < 64; ++b) if (b == kd || tid == kd) M[b] = 0.0;
         if (tid == kd) { arow = -1; astage = -1; alam = 0.0; q = 0.0; }
         used &= ~(1ull << kd);
         ndrop++; steps++;
-        if (steps >= AS_MAXSTEP) { fail = true; break; }
+        if (steps >= AS_MAXSTEP) { fail = true; why = 2; break; }
       }
       ASP_T(tb4); ASP_ACC(5, tb3, tb4);
       if (infeas || fail) break;
@@ -605,41 +676,61 @@ __global__ void __launch_bounds__(64, 2) as_onchip_kernel(DevBuf B) {
       if (Dval - 1e-9 * fabs(Dval) > cutoff + 1e-9 * fabs(cutoff)) { ok = 2; break; }
     }
     ASP_T(tc0);
-    if (B.batch_A) {   // the final active set, by row identity, for the children's starts
-      unsigned short enc = 0xFFFFu;
-      if (!fail && !infeas && ok == 1 && arow >= 0) enc = arow < 1024 ? (unsigned short)arow : (unsigned short)(1024 + (int)cand[arow - 1024]);
-      B.batch_A[(size_t)node * 64 + tid] = enc;
-    }
-    if (fail) {   // to the interior point launch behind this one
-      if (tid == 0) { B.batch_ok[node] = 6; const int qq = atomicAdd(B.as_count, 1); B.as_list[qq] = node; if (B.as_stats) atomicAdd(&B.as_stats[2], 1ull); }
-      continue;
-    }
     // ---- results.  obj: primal value of the iterate (objective + cost of the soft rows' slack lambda / a); viol: worst row at the iterate;
     // bound allowance: obj - L(z, lambda) (the Lagrangian at the iterate is a lower bound of the relaxation for any lambda >= 0)
     double viol = 0.0, scost = 0.0, lres = 0.0;
-    if (!infeas && ok == 1) {
+    if (!fail && !infeas && ok == 1) {
 #pragma unroll
       for (int k = 0; k < NSL; ++k) { const int i = 2 * k + par; if ((bact >> k) & 1u) viol = fmax(viol, bsgn * Z[i * 16 + lc] - brhs[k]); }
 #pragma unroll
       for (int q = 0; q < OC_GSLOTS; ++q) { const int r = q * 64 + tid; if (r < NM && !(gmeta[r].z & 0x80000000u)) viol = fmax(viol, row_dot(1024 + r, Z) - grhs[r]); }
       if (arow >= 0) {
-        const bool sf = row_soft(arow);
-        const double rh = arow < 1024 ? 0.0 : grhs[arow - 1024];
-        double res;
-        if (arow < 1024) res = 0.0;   // (a box row of the active set: its residual is in viol above; its share of the allowance below)
-        else res = row_dot(arow, Z) - rh - (sf ? alam * iaq : 0.0);
+        const bool sf = arow >= 1024 && row_soft(arow);
+        const double res = row_dot(arow, Z) - arhs - (sf ? alam * iaq : 0.0);
         if (sf) { scost = 0.5 * alam * alam * iaq; viol = fmax(viol, res); }
         lres = alam * res;
       }
-      // box rows of the active set: residual from the owner's registers is not at hand in the slot lane; bound it by lambda x worst violation
       viol = wave_max(viol); scost = wave_sum(scost);
-      double lsum = wave_sum(arow >= 0 && arow < 1024 ? alam : 0.0);
-      lres = wave_sum(lres);
-      lres = fabs(lres) + lsum * viol;
+      lres = fabs(wave_sum(lres));
     } else if (infeas) viol = 1.0;
+    if (!fail && !infeas && ok == 1 && !(viol <= 5.0e-7)) { fail = true; why = 5; }   // (the rows of the active set drifted off their equalities: not a result)
+    if (fail) {
+      // marked and returned unsolved: the interior point chain takes the record next round (as_big_takes)
+      if (B.batch_A) B.batch_A[(size_t)node * 64 + tid] = 0xFFFFu;
+      if (B.batch_M && tid == 0) B.batch_Mn[node] = 0;
+      if (tid == 0) { B.batch_ok[node] = 5; B.pool_big[B.batch_node[node]] |= 4; if (B.as_stats) { atomicAdd(&B.as_stats[2], 1ull); atomicAdd(&B.as_stats[10 + (why < 6 ? why : 5)], 1ull); } }
+      continue;
+    }
     const double obj = (infeas || ok == 2) ? Dval : objective() + scost;
     double* Zo = B.batch_Z + (size_t)node * N * NZ;
     for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; if (q < NZ) Zo[(k >> 4) * NZ + oc_lcol<C, CM>(as_col(q))] = Z[k]; }
+    if (B.batch_A) {   // the final active set, by row identity, for the children's starts
+      unsigned short enc = 0xFFFFu;
+      if (!fail && !infeas && ok == 1 && arow >= 0) enc = arow < 1024 ? (unsigned short)arow : (unsigned short)(1024 + (int)cand[arow - 1024]);
+      B.batch_A[(size_t)node * 64 + tid] = enc;
+    }
+    if (B.batch_M) {   // ... and its M, packed over the slots in rank order (staged in LDS - the iterate, the vector and the gains are spent - so that the stores are contiguous)
+      const int n_ = __popcll(used);
+      int nn_ = 0;
+      OC_WAVE_SYNC();
+      if (!fail && !infeas && ok == 1 && n_ >= 1 && n_ <= AS_MT) {
+        double* const stg = (double*)L0;
+        const int ra = __popcll(used & lt);
+#pragma unroll
+        for (int b8 = 0; b8 < 64; ++b8) {
+          if ((used >> b8) & 1ull) {
+            const int rb = __popcll(used & ((1ull << b8) - 1ull));
+            if (arow >= 0 && ra >= rb) stg[ra * (ra + 1) / 2 + rb] = M[b8];
+          }
+        }
+        OC_WAVE_SYNC();
+        const int len = n_ * (n_ + 1) / 2;
+        double* dst = B.batch_M + (size_t)node * AS_MSTR;
+        for (int k = tid; k < len; k += 64) dst[k] = stg[k];
+        nn_ = n_;
+      }
+      if (tid == 0) B.batch_Mn[node] = (unsigned char)nn_;
+    }
     if (tid == 0) {
       B.batch_obj[node] = obj; B.batch_viol[node] = viol; B.batch_ok[node] = ok;
       B.batch_bound[node] = lres + 1e-9 * (1.0 + fabs(obj));
@@ -653,7 +744,7 @@ __global__ void __launch_bounds__(64, 2) as_onchip_kernel(DevBuf B) {
 #endif
       if (B.as_stats) {
         atomicAdd(&B.as_stats[0], 1ull); atomicAdd(&B.as_stats[1], (unsigned long long)steps); atomicAdd(&B.as_stats[3], (unsigned long long)ndrop);
-        atomicAdd(&B.as_stats[4], infeas ? 1ull : 0ull); atomicAdd(&B.as_stats[5], ok == 2 ? 1ull : 0ull); atomicAdd(&B.as_stats[6], (unsigned long long)__popcll(used)); atomicAdd(&B.as_stats[7], (unsigned long long)nwarm);
+        atomicAdd(&B.as_stats[4], infeas ? 1ull : 0ull); atomicAdd(&B.as_stats[5], ok == 2 ? 1ull : 0ull); atomicAdd(&B.as_stats[6], (unsigned long long)__popcll(used)); atomicAdd(&B.as_stats[7], (unsigned long long)nwarm); atomicAdd(&B.as_stats[8], (unsigned long long)nfast); atomicAdd(&B.as_stats[9], (unsigned long long)ncold);
       }
     }
   }

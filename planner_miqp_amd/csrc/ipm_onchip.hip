@@ -219,8 +219,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
   const int tid = threadIdx.x, lg = tid >> 4, lc = tid & 15;
   const int par = lg >> 1, side = lg & 1;                   // box rows of this lane: column lc, side, stages 2k + par
   const double bsgn = side ? -1.0 : 1.0;
-  const bool as_list_mode = !BIG && B.as_mode == 1;   // behind the active-set launch: only the nodes it listed
-  const int nbatch = BIG && B.ovf_mode == 1 ? *B.ovf_count : (as_list_mode ? *B.as_count : (*B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap));
+  const int nbatch = BIG && B.ovf_mode == 1 ? *B.ovf_count : (*B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap);
   const int N = Y.N, NSLOT = Y.NSLOT;
   extern __shared__ double lds[];
   char* const L0 = (char*)lds;
@@ -258,7 +257,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     if (tid == 0) sh_node = atomicAdd(B.work_counter, 1);
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(sh_node) >= nbatch) break;
-    const int node = __builtin_amdgcn_readfirstlane(BIG && B.ovf_mode == 1 ? B.ovf_list[sh_node] : (as_list_mode ? B.as_list[sh_node] : sh_node));   // wave-uniform by construction: said so, everything derived from it
+    const int node = __builtin_amdgcn_readfirstlane(BIG && B.ovf_mode == 1 ? B.ovf_list[sh_node] : sh_node);   // wave-uniform by construction: said so, everything derived from it
                                                                   // (instance tables, references) is then addressed from SGPRs
     // the concurrent launch of the larger variant takes the nodes known to be large before the round: the rounding probes (their
     // depth word says so) and the records marked by an earlier decode or inherited from a marked parent
@@ -266,6 +265,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     if ((BIG && B.ovf_mode == 2) || (!BIG && B.skip_probes)) {
       const bool marked = B.batch_large ? B.batch_large[node] != 0 : is_probe_word(B.batch_depth[node]);
       if (BIG ? !marked : marked) continue;   // the other launch of the round solves it
+      if (BIG && B.as_split && (as_big_takes(B, node) || (B.pool_big[B.batch_node[node]] & 2))) continue;   // ... or the larger active-set launch, or (a record known to exceed this block) the memory-backed launch on its own stream
     }
     const int inst = __builtin_amdgcn_readfirstlane(B.batch_inst[node]);
     const double* D = B.inst_d + (size_t)inst * Y.dstride;
@@ -418,7 +418,11 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
       OC_WAVE_SYNC();
     }
     if (overflow && !BIG && B.bounce) {   // found too large here: marked and returned unsolved; the concurrent launch of the larger variant takes it next round
-      if (tid == 0) { B.batch_ok[node] = 5; B.pool_big[B.batch_node[node]] = 1; if (B.stats) { atomicAdd(&B.stats[3], 1ull); atomicAdd(&B.stats[8 + (ngen >= 512 ? 15 : ngen / 32)], 1ull); } }
+      if (tid == 0) { B.batch_ok[node] = 5; B.pool_big[B.batch_node[node]] |= 1; if (B.stats) { atomicAdd(&B.stats[3], 1ull); atomicAdd(&B.stats[8 + (ngen >= 512 ? 15 : ngen / 32)], 1ull); } }
+      continue;
+    }
+    if (overflow && BIG && B.as_split) {   // (four concurrent launches: no hand-over list) marked and returned unsolved; the memory-backed launch of the next round takes the record
+      if (tid == 0) { B.batch_ok[node] = 5; B.pool_big[B.batch_node[node]] |= 2; }
       continue;
     }
     if (overflow) {   // more general rows than fit on chip: the memory-backed kernel takes the node

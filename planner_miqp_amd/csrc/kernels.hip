@@ -171,7 +171,7 @@ struct DevBuf {
   unsigned char* pool_big;       // per record: 1 = more general rows than the standard on-chip kernel holds (found by that kernel at its decode, inherited by the children)
   int bounce;                    // 1: the standard on-chip kernel does not hand such a node on but marks it (pool_big) and returns it unsolved (batch_ok 5): eval_kernel
                                  // puts it back on its list, and from the next round on the larger variant takes it in its concurrent launch
-  int ovf_mode;                  // 1: ipm_kernel works through ovf_list instead of the whole batch; 2: through the batch, rounding probes only
+  int ovf_mode;                  // 1: ipm_kernel works through ovf_list instead of the whole batch; 2: through the batch, rounding probes only; 3: through the batch, the marked records with pool_big bit 1
   int skip_probes;               // on-chip kernel: the rounding probes of the batch (depth word: sibling preference 63) are solved by a concurrent launch of ipm_kernel (ovf_mode 2)
   unsigned long long* stats;     // [32] diagnostic counters of the on-chip kernel (MIQP_STATS=1), else null
   signed char* pool_origin;      // diagnostic build: 2*kind + (deviating child) of the branching that created a node record
@@ -185,11 +185,15 @@ struct DevBuf {
   // its region sequences join the batch of the same round
   double* inst_lns_obj; double lns_step;   // the local search runs again only when the incumbent has improved by lns_step (relative) since its last run: a hill climb in steps of 1e-5 re-evaluates the whole neighbourhood for nothing
   int* inst_lns; int lns_mode; int lns_min_nodes; int lns_narrow;   // (an instance gets its local search once it has cost lns_min_nodes node relaxations: the easy ones are done before)
-  // Dual active-set launch (as_onchip.hip) in front of the standard interior point launch of a round: it solves the ordinary nodes and lists
-  // the ones it cannot finish; as_mode 1 makes the standard interior point kernel work through that list instead of the batch
-  int* as_count; int* as_list; int as_mode;
+  // Dual active-set launch (as_onchip.hip) in place of the standard interior point launch of a round: it solves the ordinary nodes; one it cannot
+  // finish is marked (pool_big bit 2: this record only, not inherited) and returned unsolved like a node that is too large (batch_ok 5), so that
+  // the larger interior point variant takes it in its concurrent launch of the next round
   unsigned short* batch_A;       // [batch_cap][64] final active set of a node the active-set launch solved: box rows by their key (stage * 2 + side) * 16 + column, general rows as 1024 + (stage * NSLOT + slot); 0xFFFF: empty
   unsigned short* pool_A;        // [z_cap][64] the parent's, per child record (eval_kernel copies it like pool_Z): the child's first active set
+  double* batch_M; double* pool_M;   // [batch_cap] / [m_cap] x AS_MSTR: the inverse of the active rows' Schur complement, packed triangle over the slots in rank order
+  unsigned char* batch_Mn; unsigned char* pool_Mn; int m_cap;   // rows of that triangle (0: none)
+  int as_split;                  // 1: the larger interior point variant leaves the marked nodes of as_big_takes() to the larger active-set launch on the third stream
+  double* as_tab; int* as_tab_ready; int as_tab_stride;   // per instance: regulator gains [N][16], feed-forward of the objective [N][4], unconstrained optimum [N][16] (published by the first node of the instance that needs them)
   unsigned long long* as_stats;  // [8] nodes, steps (rows added + dropped), handed to the interior point, rows dropped, infeasible, cut off, sum of the final active set sizes
 };
 
@@ -288,6 +292,20 @@ __device__ inline void pair_cars(int p, int C, int& c1, int& c2) {
 struct RowOut { double rhs; double aq; bool active; };
 // depth word of a rounding probe: tree depth >= 1, low bits 63 (eval_kernel: the children of a node carry 62 - their preference)
 __device__ inline bool is_probe_word(int dw) { return (dw & 63) == 63 && (dw >> 6) >= 1; }
+// The marked nodes of a round (rounding probes, local-search leaves, large records) are split between the larger active-set launch and the
+// interior point chain beside it; this is the rule, evaluated by both (nothing it reads changes during the launches of a round): the interior
+// point keeps the records the active-set method failed on (pool_big bit 2) or that exceed even the larger block (bit 1), and the rounding
+// probes of an instance whose infeasible probes are re-rounded (eval_kernel: no incumbent yet, or pump_inc) - the re-rounding starts from the
+// least-violation point that only the elastic interior point delivers
+__device__ inline bool as_big_takes(const DevBuf& B, int node) {
+  if (B.pool_big[B.batch_node[node]] & 6) return false;
+  if (is_probe_word(B.batch_depth[node]) && B.pump_max > 0) {
+    const int inst = B.batch_inst[node];
+    const bool noinc = !(fmin(inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]), B.inc_ext[inst]) < 1e300);
+    if (noinc || B.pump_inc) return false;
+  }
+  return true;
+}
 
 // region set of (car, step) in a node: the bits of its fix record that the static reachability presolve allows
 __device__ inline int region_set(const Layout& Y, const int* T, const signed char* fix, int c, int i) {
@@ -642,6 +660,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
   if (sh_node >= nbatch) break;
   const int node = __builtin_amdgcn_readfirstlane(B.ovf_mode == 1 ? B.ovf_list[sh_node] : sh_node);   // wave-uniform: addressed from SGPRs
   if (B.ovf_mode == 2 && !is_probe_word(B.batch_depth[node])) continue;   // (this launch takes the rounding probes only)
+  if (B.ovf_mode == 3 && !(B.batch_large[node] && (B.pool_big[B.batch_node[node]] & 2))) continue;   // (... the marked records known to exceed the larger on-chip block)
   const int inst = __builtin_amdgcn_readfirstlane(B.batch_inst[node]);
   const double* D = B.inst_d + (size_t)inst * Y.dstride;
   const int* T = B.inst_i + (size_t)inst * Y.istride;
@@ -1549,6 +1568,7 @@ struct BranchDesc { int prio; int kind; int c; int o; int i; int pt; int cause; 
 #ifndef MIQP_EVAL_WPE
 #define MIQP_EVAL_WPE 0   // wavefronts per SIMD eval_kernel is register-allocated for (0: the compiler's choice - 141 VGPRs, 3 per SIMD; measured against 2 and 4, tools/eval_wpe.sh)
 #endif
+constexpr int AS_MSTR_ = 48 * 49 / 2;   // (= AS_MSTR of as_onchip.hip)
 template <int C>
 #if MIQP_EVAL_WPE > 0
 __global__ void __launch_bounds__(64, MIQP_EVAL_WPE) eval_kernel(DevBuf B) {
@@ -2298,13 +2318,24 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         B.pool_origin[slots[q]] = (signed char)(kk == -2 ? 15 : 4 * chosen.kind + cls);
       }
     }
-    if (B.pool_big && lane < nk) B.pool_big[slots[lane]] = pumped ? (unsigned char)((((big_parent >> 4) + 1) << 4) | 1) : (unsigned char)(big_parent & ~8);   // (bit 3, "deferred once", is the parent's own)   // (a child has the rows of its parent and more)
+    if (B.pool_big && lane < nk) B.pool_big[slots[lane]] = pumped ? (unsigned char)((((big_parent >> 4) + 1) << 4) | 1) : (unsigned char)(big_parent & ~12);   // (bit 3, "deferred once", and bit 2, "the active-set launch could not finish it", are the parent's own)   // (a child has the rows of its parent and more)
     if (B.pool_Z) {   // the children start their relaxation from this node's solution (see DevBuf::pool_Z)
       for (int q = 0; q < nk; ++q) { if (slots[q] >= B.z_cap) continue; double* zd = B.pool_Z + (size_t)slots[q] * N * NZ; for (int k = lane; k < N * NZ; k += 64) zd[k] = Z[k]; }
     }
     if (B.pool_A) {   // ... and, where the active-set launch solved this node, from its active set (the nodes of the larger interior point variant have none)
-      const unsigned short av_ = (B.batch_A && B.batch_large && !B.batch_large[node]) ? B.batch_A[(size_t)node * 64 + lane] : (unsigned short)0xFFFFu;
+      const unsigned short av_ = B.batch_A ? B.batch_A[(size_t)node * 64 + lane] : (unsigned short)0xFFFFu;   // (every node of a round passes one of the two active-set launches, which writes its set or 0xFFFF)
       for (int q = 0; q < nk; ++q) { if (slots[q] >= B.z_cap) continue; B.pool_A[(size_t)slots[q] * 64 + lane] = av_; }
+      if (B.pool_M) {
+        const int nm = B.batch_A ? (int)B.batch_Mn[node] : 0;
+        const int len = nm * (nm + 1) / 2;
+        const double* ms = B.batch_M + (size_t)node * AS_MSTR_;
+        for (int q = 0; q < nk; ++q) {
+          if (slots[q] >= B.m_cap) continue;
+          double* md = B.pool_M + (size_t)slots[q] * AS_MSTR_;
+          for (int k = lane; k < len; k += 64) md[k] = ms[k];
+          if (lane == 0) B.pool_Mn[slots[q]] = (unsigned char)nm;
+        }
+      }
     }
     if (lane < nk) {
       // depth word: (tree depth << 6) | preference among siblings (child_inf first) - used by the dive ordering
@@ -3100,6 +3131,7 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
       const double* zs = B.inc_Z + (size_t)inst * N * Y.nz; double* zd = B.pool_Z + (size_t)rec * N * Y.nz;
       for (int k = lane; k < N * Y.nz; k += 64) zd[k] = zs[k];
     }
+    if (B.pool_A && rec < B.z_cap) B.pool_A[(size_t)rec * 64 + lane] = (unsigned short)0xFFFFu;   // (a recycled record: no active set of a parent)
     if (lane == 0) {
       if (B.pool_big) B.pool_big[rec] = 1;
       if (B.pool_origin) B.pool_origin[rec] = 14;

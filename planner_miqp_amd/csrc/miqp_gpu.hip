@@ -253,6 +253,7 @@ struct DevCtx {
   // concurrent launch of the memory-backed kernel on the rounding probes of a batch (second stream, its own work counter and
   // per-block buffers): see launch_ipm_batch
   hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t stream3 = nullptr, stream4 = nullptr; hipEvent_t ev_join3 = nullptr, ev_join4 = nullptr; double* kgain3 = nullptr;   // the larger active-set launch beside the interior point chain of stream2
   hipEvent_t ev_mid = nullptr;   // MIQP_LAUNCH_TRACE
   int* work_counter2 = nullptr; double* rowstate2 = nullptr; double* rowcache2 = nullptr; double* kgain2 = nullptr; int probe_grid = 0;
   int oc_grid = 0;   // resident wavefronts of the on-chip interior point kernel (0: the shape does not qualify)
@@ -260,7 +261,7 @@ struct DevCtx {
   int* ctr = nullptr; // two parity sets of 8 counters for the launches of a round (batch count, work counters, hand-over counts): a round uses one set, roll_kernel zeroes the other
   bool concurrent_big = true;   // MIQP_CONCURRENT_BIG=0: the sequential chain standard -> larger -> memory-backed
   int ocb_grid = 0;  // resident wavefronts of its larger variant (OC_GCAP_BIG general rows, one wavefront per SIMD; 0: not in use)
-  bool as_on = false; int* as_list = nullptr; unsigned long long* as_stats = nullptr;   // dual active-set launch in front of the standard interior point launch (two cars; MIQP_AS=0: off)
+  bool as_on = false; unsigned long long* as_stats = nullptr;   // dual active-set launch in front of the standard interior point launch (two cars; MIQP_AS=0: off)
   DevBuf B{};
   std::vector<void*> allocs;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -460,16 +461,31 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&X.ctr, 16)) return false;
   HIP_OK(hipMemset(X.ctr, 0, 64));
   { const char* e = KNOB_P("MIQP_AS"); X.as_on = Y.C == 2 && X.oc_grid > 0 && !(e && std::atoi(e) == 0); }
-  if (!X.alloc(&X.as_list, batch_alloc)) return false;
-  if (!X.alloc(&X.as_stats, 8)) return false;
-  HIP_OK(hipMemset(X.as_stats, 0, 64));
-  B.as_count = nullptr; B.as_list = X.as_list; B.as_mode = 0; B.as_stats = X.as_stats;
-  B.batch_A = nullptr; B.pool_A = nullptr;
+  if (!X.alloc(&X.as_stats, 16)) return false;
+  HIP_OK(hipMemset(X.as_stats, 0, 128));
+  B.as_stats = X.as_stats;
+  B.as_tab = nullptr; B.as_tab_ready = nullptr; B.as_tab_stride = (36 * Y.N + 15) & ~15;
+  if (X.as_on) {
+    if (!X.alloc(&B.as_tab, (size_t)n_inst * B.as_tab_stride)) return false;
+    if (!X.alloc(&B.as_tab_ready, n_inst)) return false;
+    HIP_OK(hipMemset(B.as_tab_ready, 0, (size_t)n_inst * 4));
+  }
+  B.batch_A = nullptr; B.pool_A = nullptr; B.batch_M = nullptr; B.pool_M = nullptr; B.batch_Mn = nullptr; B.pool_Mn = nullptr; B.m_cap = 0;
   if (X.as_on && B.z_cap > 0 && Y.N * Y.NSLOT + 1024 < 65535) {   // the parents' active sets for the children's starts (128 B per record)
     if (!X.alloc(&B.batch_A, (size_t)batch_alloc * 64)) return false;
     if (!X.alloc(&B.pool_A, (size_t)B.z_cap * 64)) return false;
     HIP_OK(hipMemset(B.pool_A, 0xFF, (size_t)B.z_cap * 128));
     HIP_OK(hipMemset(B.batch_A, 0xFF, (size_t)batch_alloc * 128));
+    // ... and their M (9.4 KB per record) for the first m_cap records: within a sixteenth of the free memory
+    size_t mc = std::min<size_t>((size_t)B.z_cap, free_b / 16 / ((size_t)AS_MSTR * 8));
+    if (mc >= 4096) {
+      if (!X.alloc(&B.batch_M, (size_t)batch_alloc * AS_MSTR)) return false;
+      if (!X.alloc(&B.batch_Mn, batch_alloc)) return false;
+      if (!X.alloc(&B.pool_M, mc * AS_MSTR)) return false;
+      if (!X.alloc(&B.pool_Mn, mc)) return false;
+      HIP_OK(hipMemset(B.pool_Mn, 0, mc)); HIP_OK(hipMemset(B.batch_Mn, 0, batch_alloc));
+      B.m_cap = (int)mc;
+    }
   }
   // buffers of the concurrent probe launch (two cars and fewer, on-chip kernel in use): 1024 resident blocks
   X.probe_grid = 0;
@@ -480,6 +496,8 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
     if (!X.alloc(&X.rowcache2, (size_t)X.probe_grid * NCACHE * Y.ROWCAP)) return false;
     if (!X.alloc(&X.kgain2, (size_t)X.probe_grid * std::max(Y.N * Y.nu * (Y.nx + 2), oc_gain_doubles(Y.N)))) return false;
     if (!X.stream2) { HIP_OK(hipStreamCreate(&X.stream2)); HIP_OK(hipEventCreate(&X.ev_fork)); HIP_OK(hipEventCreate(&X.ev_join)); }
+    if (!X.stream3) { HIP_OK(hipStreamCreate(&X.stream3)); HIP_OK(hipEventCreate(&X.ev_join3)); HIP_OK(hipStreamCreate(&X.stream4)); HIP_OK(hipEventCreate(&X.ev_join4)); }
+    if (!X.alloc(&X.kgain3, (size_t)X.probe_grid * std::max(Y.N * Y.nu * (Y.nx + 2), oc_gain_doubles(Y.N)))) return false;
   }
   if (!X.alloc(&B.ovf_count, 1)) return false;
   if (!X.alloc(&B.ovf_list, batch_alloc)) return false;
@@ -571,21 +589,37 @@ void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool o
       DevBuf Bp = Bc; Bp.ovf_mode = 2; Bp.work_counter = pc ? cs + 4 : X.work_counter2; Bp.rowstate = X.rowstate2; Bp.rowcache = X.rowcache2; Bp.kgain = X.kgain2;
       static const int big_grid_cap = KNOB_T("MIQP_BIG_GRID") ? std::atoi(KNOB_T("MIQP_BIG_GRID")) : 1 << 30;
       const int gb = std::min(std::min(bc, big_grid_cap), std::min(X.probe_grid, X.ocb_grid));
+      const bool as2 = X.as_on && pc && Y.C == 2 && X.stream3;
+      if (as2) {
+        // the large nodes of the round that the active-set method takes (as_big_takes): its larger block, on a third stream beside the interior
+        // point chain, which keeps the rest of them
+        (void)hipStreamWaitEvent(X.stream3, X.ev_fork, 0);
+        DevBuf Bq = Bp; Bq.work_counter = cs + 6;
+        hipLaunchKernelGGL((as_onchip_kernel<2, OC_NSL, OC_GCAP_BIG>), dim3(gb), dim3(64), l_ocb, X.stream3, Bq);
+        (void)hipEventRecord(X.ev_join3, X.stream3);
+        Bp.as_split = 1;
+      }
       if (Y.C == 1) launch_ipm_oc_big<1>(Bp, gb, l_ocb, X.stream2, !pc); else launch_ipm_oc_big<2>(Bp, gb, l_ocb, X.stream2, !pc);
       DevBuf Bm = Bp; Bm.ovf_mode = 1; Bm.ovf_count = Bc.ovf2_count; Bm.ovf_list = B.ovf2_list; if (pc) Bm.work_counter = cs + 5;
+      if (as2 && X.stream4) {   // the records known to exceed the larger block: the memory-backed kernel beside the three others, on a fourth stream (gain buffer of its own)
+        (void)hipStreamWaitEvent(X.stream4, X.ev_fork, 0);
+        Bm.ovf_mode = 3; Bm.kgain = X.kgain3;
+        launch_ipm_c(Y.C, Bm, std::min(bc, X.probe_grid), l_ipm, X.stream4, !pc);
+        (void)hipEventRecord(X.ev_join4, X.stream4);
+      } else
       launch_ipm_c(Y.C, Bm, std::min(bc, X.probe_grid), l_ipm, X.stream2, !pc);
       (void)hipEventRecord(X.ev_join, X.stream2);
       Bc.skip_probes = 1; Bc.bounce = 1;
       if (X.as_on && pc && Y.C == 2) {
-        // the ordinary nodes of the round: dual active-set solves (as_onchip.hip); what that launch lists (a node it could not finish) is
-        // all the standard interior point launch behind it still has to do
-        DevBuf Ba = Bc; Ba.work_counter = cs + 7; Ba.as_count = cs + 6;
+        // the ordinary nodes of the round: dual active-set solves (as_onchip.hip) in place of the standard interior point launch; a node that
+        // launch cannot finish comes back marked, like a node that is too large, and the larger interior point variant takes it next round
+        DevBuf Ba = Bc; Ba.work_counter = cs + 1;
         hipLaunchKernelGGL((as_onchip_kernel<2, OC_NSL>), dim3(std::min(bc, X.oc_grid)), dim3(64), l_oc, st, Ba);
-        Bc.as_mode = 1; Bc.as_count = cs + 6;
-      }
-      if (Y.C == 1) launch_ipm_oc<1>(Bc, std::min(bc, X.oc_grid), l_oc, st, !pc); else launch_ipm_oc<2>(Bc, std::min(bc, X.oc_grid), l_oc, st, !pc);
+      } else if (Y.C == 1) launch_ipm_oc<1>(Bc, std::min(bc, X.oc_grid), l_oc, st, !pc); else launch_ipm_oc<2>(Bc, std::min(bc, X.oc_grid), l_oc, st, !pc);
       if (X.ev_mid) (void)hipEventRecord(X.ev_mid, st);
       (void)hipStreamWaitEvent(st, X.ev_join, 0);
+      if (as2) (void)hipStreamWaitEvent(st, X.ev_join3, 0);
+      if (as2 && X.stream4) (void)hipStreamWaitEvent(st, X.ev_join4, 0);
       return;
     }
     if (ov) {
@@ -621,7 +655,8 @@ void launch_eval_c(int C, const DevBuf& B, int nblocks, size_t lds, hipStream_t 
 template <int C> bool set_kernel_lds_oc(size_t lds, size_t lds_big) {
   HIP_OK(hipFuncSetAttribute((const void*)ipm_onchip_kernel<C, OC_NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIP_OK(hipFuncSetAttribute((const void*)ipm_onchip_kernel<C, OC_NSL, 0, OC_GCAP_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
-  if constexpr (C == 2) HIP_OK(hipFuncSetAttribute((const void*)as_onchip_kernel<2, OC_NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if constexpr (C == 2) { HIP_OK(hipFuncSetAttribute((const void*)as_onchip_kernel<2, OC_NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_OK(hipFuncSetAttribute((const void*)as_onchip_kernel<2, OC_NSL, OC_GCAP_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big)); }
   return true;
 }
 template <int C> bool set_kernel_lds_c(size_t ipm_lds, size_t eval_lds) {
@@ -1008,7 +1043,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemsetAsync(B.inst_nodes, 0, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_iters, 0, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_ninc, 0, (size_t)n * 4, st));
-  HIP_OK(hipMemsetAsync(B.as_stats, 0, 64, st));
+  HIP_OK(hipMemsetAsync(B.as_stats, 0, 128, st));
+  if (B.as_tab_ready) HIP_OK(hipMemsetAsync(B.as_tab_ready, 0, (size_t)n * 4, st));
   HIP_OK(hipMemsetAsync(B.inst_lns, 0, (size_t)n * 4, st));
   { std::vector<double> big_(n, 1e300); HIP_OK(hipMemcpyAsync(B.inst_lns_obj, big_.data(), (size_t)n * 8, hipMemcpyHostToDevice, st)); HIP_OK(hipStreamSynchronize(st)); }
   B.lns_step = KNOB_T("MIQP_LNS_STEP") ? std::atof(KNOB_T("MIQP_LNS_STEP")) : 0.0;
@@ -1344,11 +1380,11 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemcpy(h_nodes.data(), B.inst_nodes, n * 8, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(h_iters.data(), B.inst_iters, n * 8, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(&rowiters, B.stat_rowiters, 8, hipMemcpyDeviceToHost));
-  unsigned long long h_as[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  HIP_OK(hipMemcpy(h_as, B.as_stats, 64, hipMemcpyDeviceToHost));
+  unsigned long long h_as[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  HIP_OK(hipMemcpy(h_as, B.as_stats, 128, hipMemcpyDeviceToHost));
   if (B.stats && h_as[0] + h_as[2] > 0)
-    std::fprintf(stderr, "[miqp_gpu stats] active-set launch: %llu nodes (%.1f steps, %.1f drops, %.1f rows from the parent's active set, %.1f active rows at the end per node; %llu infeasible, %llu cut off), %llu handed to the interior point\n",
-                 h_as[0], h_as[1] / (double)std::max(1ull, h_as[0]), h_as[3] / (double)std::max(1ull, h_as[0]), h_as[7] / (double)std::max(1ull, h_as[0]), h_as[6] / (double)std::max(1ull, h_as[0]), h_as[4], h_as[5], h_as[2]);
+    std::fprintf(stderr, "[miqp_gpu stats] active-set launch: %llu nodes (%.1f steps, %.1f drops, %.1f rows from the parent's active set, %.1f active rows at the end per node; %llu infeasible, %llu cut off; %llu started from the parent's M, %llu fell back to a cold start), %llu handed to the interior point (no free slot %llu, step cap %llu, curvature %llu, down-date pivot %llu, rows off their equalities %llu, other %llu)\n",
+                 h_as[0], h_as[1] / (double)std::max(1ull, h_as[0]), h_as[3] / (double)std::max(1ull, h_as[0]), h_as[7] / (double)std::max(1ull, h_as[0]), h_as[6] / (double)std::max(1ull, h_as[0]), h_as[4], h_as[5], h_as[8], h_as[9], h_as[2], h_as[11], h_as[12], h_as[13], h_as[14], h_as[15], h_as[10]);
   std::vector<signed char> h_fix((size_t)n * Y.fixlen); std::vector<double> h_Z((size_t)n * Y.N * Y.nz);
   HIP_OK(hipMemcpy(h_fix.data(), B.inc_fix, h_fix.size(), hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(h_Z.data(), B.inc_Z, h_Z.size() * 8, hipMemcpyDeviceToHost));

@@ -10,7 +10,8 @@ with open(f) as fh:
 rows.sort()
 t0, t1 = rows[0][0], max(r[1] for r in rows)
 # the steady state: between the first and the last launch of the standard on-chip kernel
-oc = [r for r in rows if "ipm_onchip_kernel<2, 10, 0, 128>" in r[2]]
+ANCHOR = "as_onchip_kernel<2, 10, 128>" if any("as_onchip_kernel<2, 10, 128>" in r[2] for r in rows) else "ipm_onchip_kernel<2, 10, 0, 128>"   # the standard launch of a round
+oc = [r for r in rows if ANCHOR in r[2]]
 lo, hi = oc[len(oc) // 10][0], oc[-len(oc) // 10][1]
 sel = [r for r in rows if r[0] >= lo and r[1] <= hi]
 busy = collections.Counter(); cnt = collections.Counter()
@@ -23,7 +24,7 @@ for a, b in ev[1:]:
     if a > cur: idle += a - cur; gaps.append(a - cur)
     cur = max(cur, b)
 span = hi - lo
-nr = len([r for r in sel if "ipm_onchip_kernel<2, 10, 0, 128>" in r[2]])
+nr = len([r for r in sel if ANCHOR in r[2]])
 print("steady span %.3f s, %d rounds, %.3f ms per round; device idle (no kernel running) %.1f %% = %.3f ms per round" % (span / 1e9, nr, span / 1e6 / nr, 100.0 * idle / span, idle / 1e6 / nr))
 for k, v in busy.most_common(12):
     print("  %-60s %7.3f ms per round (%5.1f %% of the span, %d launches)" % (k, v / 1e6 / nr, 100.0 * v / span, cnt[k]))
