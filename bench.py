@@ -32,6 +32,20 @@ def f_iter(C, N):
 
 
 F_ROW = 2 * 6 * (6 + 2)  # sparse assembly per active row and iteration (<= 6 non-zeros per row)
+HBM_PEAK = 8.0e12        # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def as_node_units(C, N, fixlen, rows_end, rows_parent, steps):
+    """algorithmic work of ONE node relaxation of the dual active-set launch (as_onchip.hip), from the averages of the run:
+    bytes = what the node has to move through HBM whatever the implementation: its fix record in, the parent's active set (64 ids) and the
+    parent's M (packed triangle over rows_parent rows) in, the solution, the own active set and the own M (rows_end rows) out, the result scalars;
+    flops = per step two substitutions with the constant regulator gains (2C chains x N stages x 26 flop each way), the matrix-vector
+    product and the symmetric rank-one update on M (4 n^2), the scan for the most violated row (~2 flop per non-zero, ~700 non-zeros), plus the
+    multipliers of the start (n^2).  The instance tables the decode reads (28 KB per instance, shared by its nodes) stay in L2."""
+    tri = lambda n: n * (n + 1) / 2.0
+    nbytes = fixlen + 128 + 8 * tri(rows_parent) + 8 * N * 8 * C + 128 + 8 * tri(rows_end) + 48
+    flops = steps * (2 * 2 * (2 * C) * N * 26 + 4 * rows_end ** 2 + 1400) + rows_parent ** 2 * 2
+    return nbytes, flops
 
 
 def cpu_baseline(params_list, gap, time_limit, budget_s=45.0):
@@ -238,7 +252,7 @@ def main():
             P.solve_batch(wws, inflight=infl, prepared=True)
     sync()
     t0 = time.time()
-    solved = 0; attempted = 0; ipm_s = 0.0; launches = 0; iters = 0; rowit = 0; nodes = 0; lat = []; results_s = 0.0; nrec = 0; stream_info = None; stream_ws = None
+    solved = 0; attempted = 0; ipm_s = 0.0; launches = 0; iters = 0; rowit = 0; nodes = 0; asx = [0.0] * 8; lat = []; results_s = 0.0; nrec = 0; stream_info = None; stream_ws = None
     # streaming: the queues of the K timed steps are drained as ONE stream (a step = its queue of instances; no idle tail
     # between steps: the slots freed by the last instances of one queue go to the first of the next); --no-stream: step by step
     timed = [batches[s] for s in range(a.warmup, a.warmup + a.steps)]
@@ -260,6 +274,8 @@ def main():
                 lat.append(pr.time)   # seconds from the instance's admission to its proof
         tm = ws[0].lastTiming()
         ipm_s += tm["ipm_s"]; launches += tm["ipm_launches"]; iters += tm["ipm_iters"]; rowit += tm["row_iters"]; nodes += tm["nodes"]
+        for k_, key_ in enumerate(("as_nodes", "as_steps", "as_unfinished", "as_drops", "as_rows_end", "as_rows_parent", "std_launch_s", "std_launches")):
+            asx[k_] += tm[key_]
         stream_ws = (ws, sts)
     sync()
     dt = time.time() - t0
@@ -352,15 +368,49 @@ def main():
         T = max(x[0] for x in g)
         tot_solved = sum(x[1] for x in g); tot_att = sum(x[2] for x in g)
         Cc, N = synthetic.CONFIGS[a.config][0], synthetic.CONFIGS[a.config][1]
-        # roofline of the dominant kernel (ipm_kernel), rank 0: algorithmic flops / HIP-event time of its launches
-        flops = iters * f_iter(Cc, N) + rowit * F_ROW
-        ach = flops / ipm_s if ipm_s > 0 else 0.0
-        # L2<->fabric bytes per launch of the interior point kernels: not measurable inside this process; the figure of the
-        # committed rocprofv3 --pmc passes of the same configuration (profiles/r02_traffic.json says how it was taken)
+        # roofline of the dominant kernel, rank 0.  Two cars with the active-set launches (the default since round 6): the standard launch
+        # as_onchip_kernel<2,10,128>, timed alone with HIP events on the solver stream; its algorithmic unit is one node relaxation
+        # (as_node_units); by its arithmetic intensity (~3 flop per byte against a machine balance of ~10) the bounding roofline is HBM.
+        # Otherwise (one, three, four cars; MIQP_AS=0): the interior point launches, algorithmic flops / HIP-event time of the launch group
+        as_nodes, as_steps = asx[0], asx[1]
+        ipm_iters_only = max(0.0, iters - as_steps)           # (the steps of the active-set launches are part of NrIterations, not interior point iterations)
+        flops = ipm_iters_only * f_iter(Cc, N) + rowit * F_ROW
+        use_as = as_nodes > 0 and asx[6] > 0 and asx[7] > 0
+        # L2<->fabric bytes per launch: not measurable inside this process; the figure of the committed rocprofv3 --pmc passes of the same configuration
         traffic = None; traffic_note = None
-        tj = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_traffic.json" % r) for r in (5, 4, 3, 2)) if os.path.exists(q)), "")
+        tj = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_traffic.json" % r) for r in (6, 5, 4, 3, 2)) if os.path.exists(q)), "")
         if os.path.exists(tj) and a.config == "cfg3":
             tjd = json.load(open(tj)); traffic = tjd.get("bytes_per_round_corrected"); traffic_note = "%s [file %s, from %s]" % (tjd.get("note"), os.path.basename(tj), tjd.get("source"))
+        if use_as:
+            fixlen = 16 * ((Cc * N * (1 + 5 + 5 * synthetic.CONFIGS[a.config][4]) + (Cc * (Cc - 1) // 2) * N * 8 + Cc * N * 2 + 15) // 16)   # bytes of a node's fix record
+            n_end = asx[4] / as_nodes; n_par = asx[5] / as_nodes; st_ = as_steps / as_nodes
+            nb_, fl_ = as_node_units(Cc, N, fixlen, n_end, n_par, st_)
+            std_s = asx[6]; std_l = asx[7]
+            # (nodes of the STANDARD launch: all active-set nodes but the ones of the larger block, which are not counted apart; the share of the
+            # larger block is 5-7 % of the nodes - the figure below attributes every node to the standard launch and is an upper bound by that much)
+            ach = as_nodes * nb_ / std_s
+            roof = dict(bound="hbm", achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK, traffic=traffic, traffic_note=traffic_note,
+                        kernel="as_onchip_kernel<2,10,128>: the dual active-set solves of the ordinary nodes of a B&B round (the standard launch of the round's four concurrent launches; "
+                               "HIP events on the solver stream from the start of the launch group to the end of this kernel)",
+                        launches=int(std_l), avg_launch_ms=1e3 * std_s / max(1.0, std_l), bytes_per_launch=as_nodes * nb_ / max(1.0, std_l),
+                        algorithmic_bytes_per_node=nb_, algorithmic_flops_per_node=fl_, flops_achieved_tflops=as_nodes * fl_ / std_s / 1e12,
+                        nodes_per_launch=as_nodes / max(1.0, std_l), nodes_per_s=as_nodes / std_s,
+                        steps_per_node=st_, active_rows_per_node=n_end, rows_from_parent_per_node=n_par, unfinished_nodes=int(asx[2]),
+                        launch_group_ms=1e3 * ipm_s / max(1, launches), launch_groups=int(launches),
+                        interior_point_beside_it=dict(iterations=int(ipm_iters_only), tflops=(flops / ipm_s / 1e12 if ipm_s > 0 else 0.0),
+                                                      note="the larger interior point variant and the memory-backed kernel on their own streams: the nodes the active-set launches leave to them, and the polish"),
+                        note="the node relaxation is no dense contraction any more: the Hessian of a node QP is the objective's alone, so H^-1 is a substitution with constant gains over 2C scalar chains and "
+                             "the only dense object is the inverse of the active rows' Schur complement (n ~ 35); per node ~0.1 Mflop and ~17 KB instead of 12.2 interior point iterations x 253 kflop. "
+                             "By intensity (flop per byte against 78.6 TFLOP/s : 8 TB/s) the roofline that bounds the kernel is HBM, and it is far from it: the kernel is bound by latency - the dependent "
+                             "L2 loads of the row decode and LDS round trips of one wavefront per node (DESIGN.md 6); the figure of merit is nodes_per_s")
+        else:
+            ach = flops / ipm_s if ipm_s > 0 else 0.0
+            roof = dict(bound="fp64_vector", achieved=ach / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s", frac=ach / FP64_PEAK, traffic=traffic,
+                        traffic_note=traffic_note, peak_measured=FP64_PEAK_MEASURED / 1e12, frac_of_measured_peak=ach / FP64_PEAK_MEASURED,
+                        kernel="the interior point launches of a B&B round (HIP events around the group on the solver stream)",
+                        launches=int(launches), avg_launch_ms=1e3 * ipm_s / max(1, launches), flops_per_launch=flops / max(1, launches),
+                        nodes_per_s=(nodes / ipm_s if ipm_s > 0 else 0.0),
+                        note="FP64 vector roofline: on gfx950 the FP64 MFMA peak equals the FP64 VALU peak, and MFMA instructions are < 1 % of these kernels' vector instructions")
         out = dict(metric="MIQP solves/sec to 1% gap, 2-agent x 20-step x 32-region", value=tot_solved / T, unit="MIQP solves/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * T / a.steps, higher_is_better=True, scaling="strong" if a.total > 0 else "weak",
                    vs_baseline=None, dtype="f64", data="synthetic",
@@ -374,14 +424,12 @@ def main():
                                result_records_built=int(nrec), result_records_seconds_rank0=round(results_s, 3),
                                instances_attempted=int(tot_att), instances_solved_to_gap=int(tot_solved),
                                per_rank=[dict(rank=k, seconds=round(x[0], 3), solved=int(x[1]), attempted=int(x[2]), bnb_nodes=int(x[7])) for k, x in enumerate(g)],
-                               bnb_nodes=int(sum(x[7] for x in g)), ipm_iterations=int(sum(x[5] for x in g)),
+                               bnb_nodes=int(sum(x[7] for x in g)), ipm_iterations=int(sum(x[5] for x in g)), active_set_steps_rank0=int(asx[1]), active_set_nodes_rank0=int(asx[0]),
                                solve_latency_s_rank0=dict(p50=float(np.percentile(lat, 50)), p95=float(np.percentile(lat, 95)), p99=float(np.percentile(lat, 99)), max=float(max(lat))) if lat else None,
                                timed_stream_rank0=stream_info,
                                collective_backend=(dist.get_backend() if world > 1 else None), ranks_seen=int(ranks_seen)),
-                   roofline=dict(bound="mfma", achieved=ach / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s", frac=ach / FP64_PEAK, traffic=traffic,
-                                 traffic_note=traffic_note, peak_measured=FP64_PEAK_MEASURED / 1e12, frac_of_measured_peak=ach / FP64_PEAK_MEASURED,
-                                 kernel="the interior point launches of a B&B round: ipm_onchip_kernel<2,10,0,128> and, beside it on a second stream, its larger variant <2,10,0,320> (rounding probes, large nodes) and ipm_kernel<2,64> (what that one cannot hold); HIP events around the group on the solver stream" if a.config in ("cfg3", "cfg4") else "interior point kernels of the configuration (one launch pair per B&B round)",
-                                 launches=int(launches), avg_launch_ms=1e3 * ipm_s / max(1, launches), flops_per_launch=flops / max(1, launches)))
+                   roofline=roof)
+        out["schema"] = 6   # (round 6: roofline describes the active-set launch where it runs; `time_to_prove_all` is what rounds <= 4 called `all_proven`)
         if extras:
             # `value` depends on the instances in flight (more in flight = the hardest instances are abandoned at their limit sooner);
             # the knob-free figure is the rate at a setting that proves EVERY instance of its queue

@@ -176,11 +176,14 @@ int miqp_solver_solve_fixed(miqp_solver_t* s, const miqp_raw_results_c* fixed, m
  * out[3] = node relaxations solved, out[4] = IPM iterations (summed over nodes), out[5] = rows x iterations */
 int miqp_solver_last_timing(const miqp_solver_t* s, double* out6);
 
-/* the dual active-set launch of the last solve / batch (two cars: the ordinary node relaxations; the reference's counterpart is CPLEX's dual
- * simplex re-solve of a child node inside cplex.solve(), src/cplex_wrapper.cpp:158-185): out[0] = node relaxations it solved,
- * out[1] = its steps (rows added + rows dropped; they are part of out[4] of miqp_solver_last_timing and of NrIterations),
- * out[2] = nodes it handed to the interior point launch behind it, out[3] = rows dropped */
-int miqp_solver_last_active_set(const miqp_solver_t* s, double* out4);
+/* the dual active-set launches of the last solve / batch (two cars: the node relaxations of a round; the reference's counterpart is CPLEX's dual
+ * simplex re-solve of a child node inside cplex.solve(), src/cplex_wrapper.cpp:158-185): out[0] = node relaxations they solved,
+ * out[1] = their steps (rows added + rows dropped; they are part of out[4] of miqp_solver_last_timing and of NrIterations),
+ * out[2] = nodes they could not finish (returned unsolved, solved by the interior point a round later), out[3] = rows dropped,
+ * out[4] = sum over the nodes of the active rows at the end, out[5] = sum of the rows taken over from the parents' active sets,
+ * out[6] = seconds of the STANDARD active-set launches alone (HIP events on the solver stream: from the start of a round's launch group
+ * to the end of that kernel; the other three launches of the group run beside it on their own streams), out[7] = number of those launches */
+int miqp_solver_last_active_set(const miqp_solver_t* s, double* out8);
 
 /* host set-up of the last solve / batch / stream call this handle took part in: out[0] = seconds from the entry of the call to
  * the first round, out[1] = of which building the device context (pools, lists: reused by a call of the same shape with no more

@@ -34,8 +34,8 @@ namespace miqp {
 constexpr int AS_MAXSTEP = 220;        // adds + drops after which a node goes to the interior point instead
 constexpr double AS_VTOL = 1.0e-8;     // a row is violated above this (rows are normalised: metres, m/s, ...)
 constexpr double AS_DEP = 1.0e-8;
-constexpr int AS_MT = 48;               // active sets of up to this many rows hand their M to the children
-constexpr int AS_MSTR = AS_MT * (AS_MT + 1) / 2;   // doubles per record of pool_M / batch_M (packed triangle)      // curvature g P g' below this share of g H^-1 g': the row depends on the active ones
+constexpr int AS_MT = 56;               // active sets of up to this many rows hand their M to the children
+constexpr int AS_MSTR = AS_MT * (AS_MT + 1) / 2;   // doubles per slot of the ring (packed triangle)      // curvature g P g' below this share of g H^-1 g': the row depends on the active ones
 
 // Column order inside this kernel: CHAIN-CONTIGUOUS - (position, velocity, acceleration, jerk) of chain ch = 2 car + axis at 4 ch .. 4 ch + 3 (the
 // transpose of ipm_onchip_kernel's chain-major 4 k + ch; an involution), so that the lane of a chain reads and writes its stage entries as two
@@ -64,10 +64,14 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
   double* const Z = (double*)(L0 + LL.z);                   // [N][16] iterate
   double* const scr = (double*)(L0 + LL.u);                 // decode: dense scratch rows
   double* const V = (double*)(L0 + LL.u);                   // [N][16] right-hand side / result of a substitution
-  double* const KS = V + N * 16;                            // [N][4 chains][4]: K (p, v, a) and 1 / S_uu of the unconstrained regulator
   unsigned long long* const bkey = (unsigned long long*)(L0 + LL.r);
-  double* const kff = (double*)(L0 + LL.r);                 // [N][4] feed-forward of the current substitution
-  double* const kref = kff + N * 4;                         // [N][4] feed-forward of the objective's linear term
+  // (the regions of the decode scratch and of the box keys, contiguous, after the decode: V at the bottom, the gains and feed-forward terms at the
+  // top, and between them room that - with V - stages the parent's M on its way from memory into the registers)
+  const int SPAN = LL.gmeta - LL.u;                         // bytes of the two regions
+  double* const kref = (double*)(L0 + LL.u + SPAN - N * 32);   // [N][4] feed-forward of the objective's linear term
+  double* const kff = kref - N * 4;                         // [N][4] feed-forward of the current substitution
+  double* const KS = kff - N * 16;                          // [N][4 chains][4]: K (p, v, a) and 1 / S_uu of the unconstrained regulator
+  const int STG_CAP = (SPAN - N * 192) / 8;                 // doubles from V up to the gains
   uint4* const gmeta = (uint4*)(L0 + LL.gmeta);
   double* const gcoef = (double*)(L0 + LL.gcoef);
   double* const grhs = (double*)(L0 + LL.grhs);
@@ -78,12 +82,20 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
   __shared__ int sh_node;
   const unsigned long long lt = (1ull << tid) - 1ull;
 
+  // nodes are handed out in runs of `chunk` consecutive batch slots (a batch lists an instance's nodes next to each other: the nodes of a run
+  // read the same instance tables - 28 KB, most of the decode's loads - from this CU's L1 instead of from L2)
+  const int chunk = B.as_chunk > 0 ? B.as_chunk : 1;
+  int run_next = 0, run_end = 0;
   for (;;) {
     __syncthreads();
-    if (tid == 0) sh_node = atomicAdd(B.work_counter, 1);
-    __syncthreads();
-    if (__builtin_amdgcn_readfirstlane(sh_node) >= nbatch) break;
-    const int node = __builtin_amdgcn_readfirstlane(sh_node);
+    if (run_next >= run_end) {
+      if (tid == 0) sh_node = atomicAdd(B.work_counter, chunk);
+      __syncthreads();
+      run_next = __builtin_amdgcn_readfirstlane(sh_node); run_end = run_next + chunk;
+      if (run_next >= nbatch) break;
+    }
+    const int node = run_next++;
+    if (node >= nbatch) { run_next = run_end; continue; }
     {   // the split of the round between the two launches: select_kernel's snapshot (probes, local-search leaves, marked records: the larger block)
       const bool marked = B.batch_large ? B.batch_large[node] != 0 : is_probe_word(B.batch_depth[node]);
       if (BIG ? !marked : marked) continue;
@@ -215,7 +227,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
     if (overflow) {   // marked and returned unsolved: next round the larger block takes the record - or, from there, the interior point chain
       if (B.batch_A) B.batch_A[(size_t)node * 64 + tid] = 0xFFFFu;
       if (tid == 0) {
-        if (B.batch_M) B.batch_Mn[node] = 0;
+        if (B.ring_M) B.batch_Mtag[node] = 0ull;
         B.batch_ok[node] = 5; B.pool_big[B.batch_node[node]] |= (BIG ? 2 : 1); if (B.stats) { atomicAdd(&B.stats[3], 1ull); atomicAdd(&B.stats[8 + (ngen >= 512 ? 15 : ngen / 32)], 1ull); }
       }
       continue;
@@ -425,20 +437,42 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
       if (u0) {
         arow = cid;
         astage = cid < 0 ? -1 : (cid < 1024 ? (cid >> 5) : (int)((gmeta[cid - 1024].z >> 20) & 0x7FFu));
-        const int nmp = (B.pool_M && rec < B.m_cap) ? (int)B.pool_Mn[rec] : 0;
+        // the parent's M lives in a ring of slots that its solve wrote and nobody frees: the record carries (slot, tag), and the slot still holds
+        // that M as long as the tag in the ring is the record's (a ring of millions of slots against ~15 k writes per round: seconds of history;
+        // a node selected later than that rebuilds M below)
+        int nmp = 0; unsigned long long moff = 0ull;
+        if (B.ring_M) {
+          const unsigned long long tg = B.pool_Mtag[rec];
+          const unsigned long long c_ = tg >> 8;
+          // (still whole: nothing allocated since can have come round to it - the head only grows, by less than the margin during one launch)
+          if (tg != 0ull && *(volatile unsigned long long*)B.ring_head - c_ < B.ring_doubles - B.ring_margin) { nmp = (int)(tg & 255ull); moff = c_ % B.ring_doubles; }
+        }
+        nmp = __builtin_amdgcn_readfirstlane(nmp);
+        if (B.as_stats && tid == 0 && !(nmp > 0 && nmp == __popcll(u0p))) atomicAdd(&B.as_stats[16 + (B.ring_M == nullptr ? 0 : (B.pool_Mtag[rec] == 0ull ? 1 : (nmp == 0 ? 2 : 3)))], 1ull);   // (diagnostic) why M is rebuilt: no ring, the parent left none, the ring has come round, another row count
         if (nmp > 0 && nmp == __popcll(u0p)) {
-          // the parent's M: entry (a, b) of the packed triangle at tri(max rank) + min rank
-          const double* pm = B.pool_M + (size_t)rec * AS_MSTR;
+          // the parent's M: entry (a, b) of the packed triangle at tri(max rank) + min rank.  The triangle comes in with contiguous loads, all in
+          // flight at once, into LDS; the lanes pick their rows there (loads of single entries, one wait each, cost 4 x the rest of a node in a
+          // long stream, where the records of a queue spread over tens of GB)
+          const double* const rm = B.ring_M; const unsigned long long rd_ = B.ring_doubles;
           const int ra = __popcll(u0p & lt);
           const bool mine = (u0p >> tid) & 1ull;
+          const int len = nmp * (nmp + 1) / 2;
+          for (int c0 = 0; c0 < len; c0 += STG_CAP) {   // (the staging room holds 800 doubles: a triangle of more than 39 rows comes in two or three parts)
+            const int c1 = c0 + STG_CAP < len ? c0 + STG_CAP : len;
+            OC_WAVE_SYNC();
+            for (int k = c0 + tid; k < c1; k += 64) { unsigned long long q_ = moff + (unsigned long long)k; if (q_ >= rd_) q_ -= rd_; V[k - c0] = rm[q_]; }
+            OC_WAVE_SYNC();
 #pragma unroll
-          for (int b8 = 0; b8 < 64; ++b8) {
-            if ((u0p >> b8) & 1ull) {
-              const int rb = __popcll(u0p & ((1ull << b8) - 1ull));
-              const int hi_ = ra > rb ? ra : rb, lo_ = ra > rb ? rb : ra;
-              M[b8] = mine ? pm[hi_ * (hi_ + 1) / 2 + lo_] : 0.0;
+            for (int b8 = 0; b8 < 64; ++b8) {
+              if ((u0p >> b8) & 1ull) {
+                const int rb = __popcll(u0p & ((1ull << b8) - 1ull));
+                const int hi_ = ra > rb ? ra : rb, lo_ = ra > rb ? rb : ra;
+                const int ix = hi_ * (hi_ + 1) / 2 + lo_;
+                if (mine && ix >= c0 && ix < c1) M[b8] = V[ix - c0];
+              }
             }
           }
+          OC_WAVE_SYNC();
           used = u0p;
           for (unsigned long long um = u0p & ~u0; um; um &= um - 1ull) {   // rows this node no longer has
             const int kd = __builtin_amdgcn_readfirstlane(__ffsll((long long)um) - 1);
@@ -697,7 +731,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
     if (fail) {
       // marked and returned unsolved: the interior point chain takes the record next round (as_big_takes)
       if (B.batch_A) B.batch_A[(size_t)node * 64 + tid] = 0xFFFFu;
-      if (B.batch_M && tid == 0) B.batch_Mn[node] = 0;
+      if (B.ring_M && tid == 0) B.batch_Mtag[node] = 0ull;
       if (tid == 0) { B.batch_ok[node] = 5; B.pool_big[B.batch_node[node]] |= 4; if (B.as_stats) { atomicAdd(&B.as_stats[2], 1ull); atomicAdd(&B.as_stats[10 + (why < 6 ? why : 5)], 1ull); } }
       continue;
     }
@@ -709,9 +743,9 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
       if (!fail && !infeas && ok == 1 && arow >= 0) enc = arow < 1024 ? (unsigned short)arow : (unsigned short)(1024 + (int)cand[arow - 1024]);
       B.batch_A[(size_t)node * 64 + tid] = enc;
     }
-    if (B.batch_M) {   // ... and its M, packed over the slots in rank order (staged in LDS - the iterate, the vector and the gains are spent - so that the stores are contiguous)
+    if (B.ring_M) {   // ... and its M, packed over the slots in rank order, into the next slot of the ring (staged in LDS - the iterate, the vector and the gains are spent - so that the stores are contiguous); the children inherit (slot, tag)
       const int n_ = __popcll(used);
-      int nn_ = 0;
+      unsigned long long tg_ = 0ull;
       OC_WAVE_SYNC();
       if (!fail && !infeas && ok == 1 && n_ >= 1 && n_ <= AS_MT) {
         double* const stg = (double*)L0;
@@ -723,13 +757,16 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
             if (arow >= 0 && ra >= rb) stg[ra * (ra + 1) / 2 + rb] = M[b8];
           }
         }
-        OC_WAVE_SYNC();
         const int len = n_ * (n_ + 1) / 2;
-        double* dst = B.batch_M + (size_t)node * AS_MSTR;
-        for (int k = tid; k < len; k += 64) dst[k] = stg[k];
-        nn_ = n_;
+        unsigned long long cnt_ = 0ull;
+        if (tid == 0) cnt_ = atomicAdd(B.ring_head, (unsigned long long)len);
+        cnt_ = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(cnt_ >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)cnt_);
+        tg_ = (cnt_ << 8) | (unsigned long long)n_;
+        OC_WAVE_SYNC();
+        const unsigned long long o_ = cnt_ % B.ring_doubles, rd_ = B.ring_doubles;
+        for (int k = tid; k < len; k += 64) { unsigned long long q_ = o_ + (unsigned long long)k; if (q_ >= rd_) q_ -= rd_; B.ring_M[q_] = stg[k]; }
       }
-      if (tid == 0) B.batch_Mn[node] = (unsigned char)nn_;
+      if (tid == 0) B.batch_Mtag[node] = tg_;
     }
     if (tid == 0) {
       B.batch_obj[node] = obj; B.batch_viol[node] = viol; B.batch_ok[node] = ok;

@@ -190,8 +190,15 @@ struct DevBuf {
   // the larger interior point variant takes it in its concurrent launch of the next round
   unsigned short* batch_A;       // [batch_cap][64] final active set of a node the active-set launch solved: box rows by their key (stage * 2 + side) * 16 + column, general rows as 1024 + (stage * NSLOT + slot); 0xFFFF: empty
   unsigned short* pool_A;        // [z_cap][64] the parent's, per child record (eval_kernel copies it like pool_Z): the child's first active set
-  double* batch_M; double* pool_M;   // [batch_cap] / [m_cap] x AS_MSTR: the inverse of the active rows' Schur complement, packed triangle over the slots in rank order
-  unsigned char* batch_Mn; unsigned char* pool_Mn; int m_cap;   // rows of that triangle (0: none)
+  // M = the inverse of the active rows' Schur complement, packed triangle over the slots in rank order (n (n + 1) / 2 doubles), goes from a node to
+  // its children through a RING of doubles: the solve of the node allocates its triangle at the head (a 64-bit count of doubles that only grows) and
+  // writes it; the tag (start count << 8 | rows) travels with the children's records; nobody frees anything - a triangle is whole as long as the
+  // head has not come within ring_margin of a full turn past its start, which a child checks against the head before it loads
+  double* ring_M; unsigned long long* ring_head; unsigned long long ring_doubles, ring_margin;
+  unsigned long long* batch_Mtag;   // [batch_cap]
+  unsigned long long* pool_Mtag;    // [z_cap]
+  int width_cap;                 // > 0: nodes a single solve takes per round at most (the host widens it when the solve is bound-limited)
+  int as_chunk;                  // consecutive batch slots a wavefront of the active-set launches takes at a time
   int as_split;                  // 1: the larger interior point variant leaves the marked nodes of as_big_takes() to the larger active-set launch on the third stream
   double* as_tab; int* as_tab_ready; int as_tab_stride;   // per instance: regulator gains [N][16], feed-forward of the objective [N][4], unconstrained optimum [N][16] (published by the first node of the instance that needs them)
   unsigned long long* as_stats;  // [8] nodes, steps (rows added + dropped), handed to the interior point, rows dropped, infeasible, cut off, sum of the final active set sizes
@@ -1568,7 +1575,6 @@ struct BranchDesc { int prio; int kind; int c; int o; int i; int pt; int cause; 
 #ifndef MIQP_EVAL_WPE
 #define MIQP_EVAL_WPE 0   // wavefronts per SIMD eval_kernel is register-allocated for (0: the compiler's choice - 141 VGPRs, 3 per SIMD; measured against 2 and 4, tools/eval_wpe.sh)
 #endif
-constexpr int AS_MSTR_ = 48 * 49 / 2;   // (= AS_MSTR of as_onchip.hip)
 template <int C>
 #if MIQP_EVAL_WPE > 0
 __global__ void __launch_bounds__(64, MIQP_EVAL_WPE) eval_kernel(DevBuf B) {
@@ -2325,17 +2331,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     if (B.pool_A) {   // ... and, where the active-set launch solved this node, from its active set (the nodes of the larger interior point variant have none)
       const unsigned short av_ = B.batch_A ? B.batch_A[(size_t)node * 64 + lane] : (unsigned short)0xFFFFu;   // (every node of a round passes one of the two active-set launches, which writes its set or 0xFFFF)
       for (int q = 0; q < nk; ++q) { if (slots[q] >= B.z_cap) continue; B.pool_A[(size_t)slots[q] * 64 + lane] = av_; }
-      if (B.pool_M) {
-        const int nm = B.batch_A ? (int)B.batch_Mn[node] : 0;
-        const int len = nm * (nm + 1) / 2;
-        const double* ms = B.batch_M + (size_t)node * AS_MSTR_;
-        for (int q = 0; q < nk; ++q) {
-          if (slots[q] >= B.m_cap) continue;
-          double* md = B.pool_M + (size_t)slots[q] * AS_MSTR_;
-          for (int k = lane; k < len; k += 64) md[k] = ms[k];
-          if (lane == 0) B.pool_Mn[slots[q]] = (unsigned char)nm;
-        }
-      }
+      if (B.ring_M && lane < nk && slots[lane] < B.z_cap) B.pool_Mtag[slots[lane]] = B.batch_Mtag[node];
     }
     if (lane < nk) {
       // depth word: (tree depth << 6) | preference among siblings (child_inf first) - used by the dive ordering
@@ -2704,6 +2700,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
       w = (focus && !(B.seq_kinds & 0x10000000)) ? (B.batch_cap >> (rank + 1 < 30 ? rank + 1 : 30)) : B.batch_cap / act;
       if (w < B.nodes_per_round) w = B.nodes_per_round;
     } else { w = B.slot_take[slot]; if (w < B.base_take && !(B.young_nodes > 0 && B.inst_nodes[inst] >= (long long)B.young_nodes)) w = B.base_take; }   // (an older instance may be told to wait: share 0)
+    if (B.width_cap > 0 && w > B.width_cap) w = B.width_cap;
     if (!(inc < 1e300) && w > 512) w = 512;   // no incumbent yet: a narrow dive (a wide one degenerates into breadth first)
     // a round that carries the neighbours of a new incumbent is kept narrow: the local search is a chain - a better neighbour, ITS neighbours the
     // round after - and what the tree would solve beside it in a wide round is mostly what the next incumbent of the chain prunes
@@ -2846,6 +2843,7 @@ __global__ void __launch_bounds__(1024) share_kernel(DevBuf B) {
   __shared__ long long red[1024];
   __shared__ int sh_lo, sh_hi;
   const int tid = threadIdx.x, NSL = B.n_slots;
+  const int WCAP = NSL == 1 ? (B.batch_cap > 8192 ? B.batch_cap : 8192) : 8192;   // most nodes one instance takes per round (a single solve: its widest round, see width_cap)
   auto bsum = [&](long long v) -> long long {   // (wavefront sums by shuffles, sixteen partials through LDS: two barriers instead of twelve per sum - this kernel is ~ 15 of them)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -2922,24 +2920,24 @@ __global__ void __launch_bounds__(1024) share_kernel(DevBuf B) {
     B.slot_take[k] = take; at += take;
   }
   // capacity still free (few hard instances in flight): the same extra allowance for every instance that can use it, so that the
-  // batch is full - an idle device is worse than the nodes a wider round wastes - up to 8192 nodes per instance
+  // batch is full - an idle device is worse than the nodes a wider round wastes - up to WCAP nodes per instance
   const long long left = target - bsum(at);
   if (left <= 0) return;
-  if (tid == 0) { sh_lo = 0; sh_hi = 8192; }
+  if (tid == 0) { sh_lo = 0; sh_hi = WCAP; }
   __syncthreads();
   for (int itn = 0; itn < 16; ++itn) {
     const int lo = sh_lo, hi = sh_hi;
     if (lo >= hi) break;
     const int mid = lo + (hi - lo + 1) / 2;
     long long a = 0;
-    for (int k = tid; k < NSL; k += 1024) { long long r = (long long)B.slot_demand[k] - B.slot_take[k]; if (r > 8192 - B.slot_take[k]) r = 8192 - B.slot_take[k]; a += r < mid ? (r > 0 ? r : 0) : mid; }
+    for (int k = tid; k < NSL; k += 1024) { long long r = (long long)B.slot_demand[k] - B.slot_take[k]; if (r > WCAP - B.slot_take[k]) r = WCAP - B.slot_take[k]; a += r < mid ? (r > 0 ? r : 0) : mid; }
     const long long tot = bsum(a);
     if (tid == 0) { if (tot <= left) sh_lo = mid; else sh_hi = mid - 1; }
     __syncthreads();
   }
   const int L = sh_lo;
   for (int k = tid; k < NSL; k += 1024) {
-    long long r = (long long)B.slot_demand[k] - B.slot_take[k]; if (r > 8192 - B.slot_take[k]) r = 8192 - B.slot_take[k];
+    long long r = (long long)B.slot_demand[k] - B.slot_take[k]; if (r > WCAP - B.slot_take[k]) r = WCAP - B.slot_take[k];
     if (r > 0) B.slot_take[k] += (int)(r < L ? r : L);
   }
 }
@@ -3131,7 +3129,7 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
       const double* zs = B.inc_Z + (size_t)inst * N * Y.nz; double* zd = B.pool_Z + (size_t)rec * N * Y.nz;
       for (int k = lane; k < N * Y.nz; k += 64) zd[k] = zs[k];
     }
-    if (B.pool_A && rec < B.z_cap) B.pool_A[(size_t)rec * 64 + lane] = (unsigned short)0xFFFFu;   // (a recycled record: no active set of a parent)
+    if (B.pool_A && rec < B.z_cap) { B.pool_A[(size_t)rec * 64 + lane] = (unsigned short)0xFFFFu; if (B.ring_M && lane == 0) B.pool_Mtag[rec] = 0ull; }   // (a recycled record: no active set of a parent)
     if (lane == 0) {
       if (B.pool_big) B.pool_big[rec] = 1;
       if (B.pool_origin) B.pool_origin[rec] = 14;

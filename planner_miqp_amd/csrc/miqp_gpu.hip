@@ -87,7 +87,7 @@ struct miqp_solver {
   std::vector<double> Z; std::vector<signed char> comp; bool has_sol = false;
   Layout lay{};
   double timing[6] = {0, 0, 0, 0, 0, 0};
-  double as_timing[4] = {0, 0, 0, 0};   // active-set launch of the last call: nodes it solved, its steps, nodes it handed to the interior point, rows dropped
+  double as_timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // active-set launches of the last call (miqp_solver_last_active_set)
   double setup[3] = {0, 0, 0};   // host set-up of the last call: seconds, of which the device context, 1 when the context was (re)built
   double admit_s = 0.0;          // when the last batch / stream call admitted this instance, in seconds after the first round of that call started
   // MIP starts (each tried as an additional root: binaries fixed, QP solved, accepted as incumbent when feasible).
@@ -261,11 +261,13 @@ struct DevCtx {
   int* ctr = nullptr; // two parity sets of 8 counters for the launches of a round (batch count, work counters, hand-over counts): a round uses one set, roll_kernel zeroes the other
   bool concurrent_big = true;   // MIQP_CONCURRENT_BIG=0: the sequential chain standard -> larger -> memory-backed
   int ocb_grid = 0;  // resident wavefronts of its larger variant (OC_GCAP_BIG general rows, one wavefront per SIMD; 0: not in use)
-  bool as_on = false; unsigned long long* as_stats = nullptr;   // dual active-set launch in front of the standard interior point launch (two cars; MIQP_AS=0: off)
+  bool as_on = false, as_cap = false; unsigned long long* as_stats = nullptr;
+  unsigned short* as_batch_A = nullptr; unsigned short* as_pool_A = nullptr;   // (kept here: a call with MIQP_AS=0 runs with the DevBuf pointers nulled)   // dual active-set launch in front of the standard interior point launch (two cars; MIQP_AS=0: off)
   DevBuf B{};
   std::vector<void*> allocs;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> ipm_ev;  // pairs
+  std::vector<hipEvent_t> std_ev;  // per round: the end of the standard launch on the solver stream
   template <class Tp> bool alloc(Tp** p, size_t n) {
     void* q = nullptr;
     if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(Tp)) != hipSuccess) { std::fprintf(stderr, "[miqp_gpu] hipMalloc of %zu bytes failed\n", n * sizeof(Tp)); return false; }
@@ -276,6 +278,8 @@ struct DevCtx {
     allocs.clear();
     for (auto e : ipm_ev) (void)hipEventDestroy(e);
     ipm_ev.clear();
+    for (auto e : std_ev) (void)hipEventDestroy(e);
+    std_ev.clear();
     ready = false;
   }
 };
@@ -460,31 +464,35 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&B.work_counter, 1)) return false;
   if (!X.alloc(&X.ctr, 16)) return false;
   HIP_OK(hipMemset(X.ctr, 0, 64));
-  { const char* e = KNOB_P("MIQP_AS"); X.as_on = Y.C == 2 && X.oc_grid > 0 && !(e && std::atoi(e) == 0); }
-  if (!X.alloc(&X.as_stats, 16)) return false;
-  HIP_OK(hipMemset(X.as_stats, 0, 128));
-  B.as_stats = X.as_stats;
+  X.as_cap = Y.C == 2 && X.oc_grid > 0;   // the shape has the active-set launches (whether a call uses them: MIQP_AS, read per call)
+  X.as_on = X.as_cap;
+  if (!X.alloc(&X.as_stats, 24)) return false;
+  HIP_OK(hipMemset(X.as_stats, 0, 192));
+  B.as_stats = X.as_stats; B.as_chunk = KNOB_T("MIQP_AS_CHUNK") ? std::atoi(KNOB_T("MIQP_AS_CHUNK")) : 1;   // (runs of 2 / 4 / 8 / 16: the standard launch 4.7 -> 5.2 / 6.6 / 7.9 / 10.3 ms - a wavefront solves ~14 nodes per launch, longer runs only lengthen its tail)
   B.as_tab = nullptr; B.as_tab_ready = nullptr; B.as_tab_stride = (36 * Y.N + 15) & ~15;
   if (X.as_on) {
     if (!X.alloc(&B.as_tab, (size_t)n_inst * B.as_tab_stride)) return false;
     if (!X.alloc(&B.as_tab_ready, n_inst)) return false;
     HIP_OK(hipMemset(B.as_tab_ready, 0, (size_t)n_inst * 4));
   }
-  B.batch_A = nullptr; B.pool_A = nullptr; B.batch_M = nullptr; B.pool_M = nullptr; B.batch_Mn = nullptr; B.pool_Mn = nullptr; B.m_cap = 0;
+  B.batch_A = nullptr; B.pool_A = nullptr; X.as_batch_A = nullptr; X.as_pool_A = nullptr; B.ring_M = nullptr; B.ring_head = nullptr; B.ring_doubles = 0; B.ring_margin = 0; B.batch_Mtag = nullptr; B.pool_Mtag = nullptr;
   if (X.as_on && B.z_cap > 0 && Y.N * Y.NSLOT + 1024 < 65535) {   // the parents' active sets for the children's starts (128 B per record)
     if (!X.alloc(&B.batch_A, (size_t)batch_alloc * 64)) return false;
     if (!X.alloc(&B.pool_A, (size_t)B.z_cap * 64)) return false;
     HIP_OK(hipMemset(B.pool_A, 0xFF, (size_t)B.z_cap * 128));
     HIP_OK(hipMemset(B.batch_A, 0xFF, (size_t)batch_alloc * 128));
-    // ... and their M (9.4 KB per record) for the first m_cap records: within a sixteenth of the free memory
-    size_t mc = std::min<size_t>((size_t)B.z_cap, free_b / 16 / ((size_t)AS_MSTR * 8));
-    if (mc >= 4096) {
-      if (!X.alloc(&B.batch_M, (size_t)batch_alloc * AS_MSTR)) return false;
-      if (!X.alloc(&B.batch_Mn, batch_alloc)) return false;
-      if (!X.alloc(&B.pool_M, mc * AS_MSTR)) return false;
-      if (!X.alloc(&B.pool_Mn, mc)) return false;
-      HIP_OK(hipMemset(B.pool_Mn, 0, mc)); HIP_OK(hipMemset(B.batch_Mn, 0, batch_alloc));
-      B.m_cap = (int)mc;
+    X.as_batch_A = B.batch_A; X.as_pool_A = B.pool_A;
+    // ... and the ring their M travels through (4 KB per node on average, at most 12.8): a quarter of the free memory, at most 96 GB
+    size_t rd = std::min<size_t>((size_t)12 << 30, free_b / 4 / 8);   // doubles
+    const size_t margin = (size_t)batch_alloc * AS_MSTR + ((size_t)1 << 20);   // what one round's launches can allocate, and more
+    if (rd >= 16 * margin) {
+      if (!X.alloc(&B.ring_M, rd)) return false;
+      if (!X.alloc(&B.ring_head, 1)) return false;
+      if (!X.alloc(&B.batch_Mtag, batch_alloc)) return false;
+      if (!X.alloc(&B.pool_Mtag, (size_t)B.z_cap)) return false;
+      { const unsigned long long h0 = 1024ull; HIP_OK(hipMemcpy(B.ring_head, &h0, 8, hipMemcpyHostToDevice)); }
+      HIP_OK(hipMemset(B.pool_Mtag, 0, (size_t)B.z_cap * 8)); HIP_OK(hipMemset(B.batch_Mtag, 0, (size_t)batch_alloc * 8));
+      B.ring_doubles = (unsigned long long)rd; B.ring_margin = (unsigned long long)margin;
     }
   }
   // buffers of the concurrent probe launch (two cars and fewer, on-chip kernel in use): 1024 resident blocks
@@ -565,7 +573,7 @@ void launch_ipm_c(int C, const DevBuf& B, int nblocks, size_t lds, hipStream_t s
 // by VALU issue, and the probes no longer cost a generation of their own behind it.  `overlap` false (the polish, solve_fixed): the
 // serial order of round 2.
 // `par` >= 0 (the rounds of a solve): the counters of this launch group are set `par` of X.ctr, zeroed one round ahead by roll_kernel
-void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool overlap = false, int par = -1) {
+void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool overlap = false, int par = -1, hipEvent_t ev_std_end = nullptr) {
   const Layout& Y = X.Y;
   const size_t l_ipm = ipm_lds_bytes(Y);
   if (X.oc_grid > 0) {
@@ -617,6 +625,7 @@ void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool o
         hipLaunchKernelGGL((as_onchip_kernel<2, OC_NSL>), dim3(std::min(bc, X.oc_grid)), dim3(64), l_oc, st, Ba);
       } else if (Y.C == 1) launch_ipm_oc<1>(Bc, std::min(bc, X.oc_grid), l_oc, st, !pc); else launch_ipm_oc<2>(Bc, std::min(bc, X.oc_grid), l_oc, st, !pc);
       if (X.ev_mid) (void)hipEventRecord(X.ev_mid, st);
+      if (ev_std_end) (void)hipEventRecord(ev_std_end, st);   // (where the standard launch of the round ends: the dominant kernel's own time)
       (void)hipStreamWaitEvent(st, X.ev_join, 0);
       if (as2) (void)hipStreamWaitEvent(st, X.ev_join3, 0);
       if (as2 && X.stream4) (void)hipStreamWaitEvent(st, X.ev_join4, 0);
@@ -897,6 +906,12 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   // relaxations), 92 -> 75 ms at 0.01; p50 / p90 unchanged (5 / 18 ms); 1024: 51 / 76 ms (too narrow: more rounds), 4096: 51 / 86, 8192: 58 / 90
   if (O0.nodes_per_round <= 0 && Y.C <= 2 && NS == 1) npr = std::min(npr, 2048);
   if (O0.nodes_per_round <= 0 && KNOB_P("MIQP_NPR")) npr = std::max(1, std::atoi(KNOB_P("MIQP_NPR")));  // tuning knob
+  // A single solve starts narrow (above) and WIDENS its rounds once it is bound-limited: the incumbent has not moved for 16 rounds and the
+  // batch is full - then the tree needs node throughput, not fresher incumbents (cfg5 seed 11: 1.61 / 2.17 / 2.92 M relaxations in 10 s at
+  // 1024 / 2048 / 4096 nodes per round).  The batch arrays are sized for the widest round, select_kernel caps at width_cap
+  const bool adaptive_width = NS == 1 && !split && O0.nodes_per_round <= 0 && !KNOB_P("MIQP_NPR");
+  const int width0 = npr, width_max = 16384;
+  if (adaptive_width) npr = width_max;
   int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (KNOB_P("MIQP_OPEN_CAP") ? std::atoi(KNOB_P("MIQP_OPEN_CAP")) : std::max(1 << 17, std::min(1 << 20, (1 << 28) / NS)));   // near lists: 1 M entries per instance up to n = 256 (10 GB of list entries), 262144 at n = 1024; records are shared
   if (open_cap < 64) open_cap = 64;
   if (split && open_cap < SPLIT_MAXROOTS + 4 + 64) open_cap = SPLIT_MAXROOTS + 4 + 64;   // the root records of a tree split are the head of the list
@@ -1043,7 +1058,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemsetAsync(B.inst_nodes, 0, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_iters, 0, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_ninc, 0, (size_t)n * 4, st));
-  HIP_OK(hipMemsetAsync(B.as_stats, 0, 128, st));
+  HIP_OK(hipMemsetAsync(B.as_stats, 0, 192, st));
   if (B.as_tab_ready) HIP_OK(hipMemsetAsync(B.as_tab_ready, 0, (size_t)n * 4, st));
   HIP_OK(hipMemsetAsync(B.inst_lns, 0, (size_t)n * 4, st));
   { std::vector<double> big_(n, 1e300); HIP_OK(hipMemcpyAsync(B.inst_lns_obj, big_.data(), (size_t)n * 8, hipMemcpyHostToDevice, st)); HIP_OK(hipStreamSynchronize(st)); }
@@ -1051,6 +1066,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   // (read per call, not only when the device context is built: a context is reused by every later call of the same shape)
   B.cut_gate = KNOB_P("MIQP_CUT_GATE") ? std::atof(KNOB_P("MIQP_CUT_GATE")) : 1.0e-5;
   B.seq_kinds = KNOB_P("MIQP_SEQ_KINDS") ? (int)std::strtoul(KNOB_P("MIQP_SEQ_KINDS"), nullptr, 0) : (5 << 8);
+  { const char* e = KNOB_P("MIQP_AS"); X.as_on = X.as_cap && !(e && std::atoi(e) == 0);   // (per call, like the other search switches: a context is reused by later calls of the same shape)
+    B.batch_A = X.as_on ? X.as_batch_A : nullptr; B.pool_A = X.as_on ? X.as_pool_A : nullptr; }
   B.lns_mode = KNOB_P("MIQP_LNS") ? std::atoi(KNOB_P("MIQP_LNS")) : 45;
 #ifndef MIQP_TUNING
   B.lns_mode &= 127;   // (bits 7-9: the neighbourhood sub-problems of round 4 - measured without effect, DESIGN.md 2b - exist in a tuning build only)
@@ -1103,8 +1120,10 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   // roll_kernel zeroes the other for the round after - six 4-byte memsets per round less in the stream (0.65 ms of the 1.4 ms round of a single solve)
   const bool use_par = X.ctr && X.oc_grid > 0 && X.ocb_grid > 0 && X.concurrent_big && X.stream2 && X.probe_grid > 0 && !KNOB_T("MIQP_MEMSETS");
   if (use_par) HIP_OK(hipMemsetAsync(X.ctr, 0, 64, st));
+  int width_now = adaptive_width ? width0 : 0, width_since = 0; unsigned long long width_key = ~0ull, kinc_now = ~0ull;
   for (;;) {
     const int par = rounds & 1;
+    B.width_cap = width_now;
     if (use_par) B.batch_count = X.ctr + 8 * par; else HIP_OK(hipMemsetAsync(B.batch_count, 0, 4, st));
     B.open_sel = rounds & 1;
     B.prev_bc = prev_bc;
@@ -1116,7 +1135,12 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     int bc = 0;
     HIP_OK(hipMemcpyAsync(&bc, B.batch_count, 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(h_done_now.data(), B.inst_done, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (adaptive_width) HIP_OK(hipMemcpyAsync(&kinc_now, B.inc_key, 8, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
+    if (adaptive_width) {
+      if (kinc_now != width_key) { width_key = kinc_now; width_since = rounds; }
+      else if (kinc_now < 0xFFF0000000000000ull && rounds - width_since >= 16 && bc >= width_now && width_now < width_max) { width_now *= 2; width_since = rounds; }
+    }
     const double tnow = wall_s() - t0;
     for (int sl = 0; sl < NS; ++sl) { const int k = h_slot_inst[sl]; if (k >= 0 && h_done_now[k] && h_tdone[k] < 0) h_tdone[k] = tnow - t_admit[k]; }   // time from admission to proof
     if (split) {   // once per round: the ranks agree on incumbent, bound and whether to go on (identical decisions everywhere)
@@ -1175,8 +1199,9 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     if (X.ipm_ev.size() < nev + 2) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); X.ipm_ev.push_back(a); X.ipm_ev.push_back(b); }
     static const bool launch_trace = KNOB_T("MIQP_LAUNCH_TRACE") != nullptr;
     if (launch_trace && !X.ev_mid) HIP_OK(hipEventCreate(&X.ev_mid));
+    if (X.std_ev.size() < nev / 2 + 1) { hipEvent_t a_; HIP_OK(hipEventCreate(&a_)); X.std_ev.push_back(a_); }
     HIP_OK(hipEventRecord(X.ipm_ev[nev], st));
-    launch_ipm_batch(X, B, bc, st, true, use_par ? par : -1);
+    launch_ipm_batch(X, B, bc, st, true, use_par ? par : -1, X.std_ev[nev / 2]);
     HIP_OK(hipEventRecord(X.ipm_ev[nev + 1], st));
     if (launch_trace) {   // diagnostic: the two interior point launches of the round apart, and what the memory-backed one had to solve
       HIP_OK(hipStreamSynchronize(st));
@@ -1364,6 +1389,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   if (round_log) { std::fprintf(stderr, "[rounds]"); for (int v : round_bc) std::fprintf(stderr, " %d", v); std::fprintf(stderr, "\n"); }
   double ms_ipm = 0;
   for (size_t e = 0; e + 1 < nev; e += 2) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, X.ipm_ev[e], X.ipm_ev[e + 1])); ms_ipm += ms; }
+  double ms_std = 0; const bool std_timed = use_par;   // (the event is recorded in the concurrent launch path only)
+  if (std_timed) for (size_t e = 0; e + 1 < nev; e += 2) { float ms = 0; if (hipEventElapsedTime(&ms, X.ipm_ev[e], X.std_ev[e / 2]) == hipSuccess) ms_std += ms; }
   double t_solve = wall_s() - t0;
 
   // ---- results
@@ -1380,11 +1407,11 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemcpy(h_nodes.data(), B.inst_nodes, n * 8, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(h_iters.data(), B.inst_iters, n * 8, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(&rowiters, B.stat_rowiters, 8, hipMemcpyDeviceToHost));
-  unsigned long long h_as[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  HIP_OK(hipMemcpy(h_as, B.as_stats, 128, hipMemcpyDeviceToHost));
+  unsigned long long h_as[24] = {0};
+  HIP_OK(hipMemcpy(h_as, B.as_stats, 192, hipMemcpyDeviceToHost));
   if (B.stats && h_as[0] + h_as[2] > 0)
-    std::fprintf(stderr, "[miqp_gpu stats] active-set launch: %llu nodes (%.1f steps, %.1f drops, %.1f rows from the parent's active set, %.1f active rows at the end per node; %llu infeasible, %llu cut off; %llu started from the parent's M, %llu fell back to a cold start), %llu handed to the interior point (no free slot %llu, step cap %llu, curvature %llu, down-date pivot %llu, rows off their equalities %llu, other %llu)\n",
-                 h_as[0], h_as[1] / (double)std::max(1ull, h_as[0]), h_as[3] / (double)std::max(1ull, h_as[0]), h_as[7] / (double)std::max(1ull, h_as[0]), h_as[6] / (double)std::max(1ull, h_as[0]), h_as[4], h_as[5], h_as[8], h_as[9], h_as[2], h_as[11], h_as[12], h_as[13], h_as[14], h_as[15], h_as[10]);
+    std::fprintf(stderr, "[miqp_gpu stats] active-set launch: %llu nodes (%.1f steps, %.1f drops, %.1f rows from the parent's active set, %.1f active rows at the end per node; %llu infeasible, %llu cut off; %llu started from the parent's M, %llu fell back to a cold start), %llu handed to the interior point (no free slot %llu, step cap %llu, curvature %llu, down-date pivot %llu, rows off their equalities %llu, other %llu); M rebuilt because: the parent left none %llu, the ring had come round %llu, another row count %llu\n",
+                 h_as[0], h_as[1] / (double)std::max(1ull, h_as[0]), h_as[3] / (double)std::max(1ull, h_as[0]), h_as[7] / (double)std::max(1ull, h_as[0]), h_as[6] / (double)std::max(1ull, h_as[0]), h_as[4], h_as[5], h_as[8], h_as[9], h_as[2], h_as[11], h_as[12], h_as[13], h_as[14], h_as[15], h_as[10], h_as[17], h_as[18], h_as[19]);
   std::vector<signed char> h_fix((size_t)n * Y.fixlen); std::vector<double> h_Z((size_t)n * Y.N * Y.nz);
   HIP_OK(hipMemcpy(h_fix.data(), B.inc_fix, h_fix.size(), hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(h_Z.data(), B.inc_Z, h_Z.size() * 8, hipMemcpyDeviceToHost));
@@ -1429,6 +1456,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     s->timing[0] = ms_all * 1e-3; s->timing[1] = ms_ipm * 1e-3; s->timing[2] = (double)(nev / 2); s->timing[3] = (double)launched_nodes;
     s->timing[4] = (double)tot_iters; s->timing[5] = (double)rowiters;
     s->as_timing[0] = (double)h_as[0]; s->as_timing[1] = (double)h_as[1]; s->as_timing[2] = (double)h_as[2]; s->as_timing[3] = (double)h_as[3];
+    s->as_timing[4] = (double)h_as[6]; s->as_timing[5] = (double)h_as[7]; s->as_timing[6] = ms_std * 1e-3; s->as_timing[7] = std_timed ? (double)(nev / 2) : 0.0;
     s->setup[0] = t_setup; s->setup[1] = t_ctx; s->setup[2] = ctx_built ? 1.0 : 0.0;
     s->err.clear();
     if (h_stalled[k] && unfinished) s->err = "retired without a proof: no progress for 64 branch-and-bound rounds (not a time-limit verdict)";
@@ -1764,9 +1792,9 @@ int miqp_solver_last_timing(const miqp_solver_t* s, double* out6) {
   return 0;
 }
 
-int miqp_solver_last_active_set(const miqp_solver_t* s, double* out4) {
-  if (!s || !out4) return -1;
-  for (int k = 0; k < 4; ++k) out4[k] = s->as_timing[k];
+int miqp_solver_last_active_set(const miqp_solver_t* s, double* out8) {
+  if (!s || !out8) return -1;
+  for (int k = 0; k < 8; ++k) out8[k] = s->as_timing[k];
   return 0;
 }
 

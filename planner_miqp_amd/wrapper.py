@@ -79,6 +79,7 @@ def load_library():
     L.miqp_solver_solve_fixed.argtypes = [vp, C.POINTER(RawResultsC), C.POINTER(RawResultsC), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.miqp_solver_last_timing.restype = C.c_int; L.miqp_solver_last_timing.argtypes = [vp, C.POINTER(C.c_double)]
     L.miqp_solver_last_setup.restype = C.c_int; L.miqp_solver_last_setup.argtypes = [vp, C.POINTER(C.c_double)]
+    L.miqp_solver_last_active_set.restype = C.c_int; L.miqp_solver_last_active_set.argtypes = [vp, C.POINTER(C.c_double)]
     L.miqp_solver_last_error.restype = C.c_char_p; L.miqp_solver_last_error.argtypes = [vp]
     L.miqp_solver_last_admission.restype = C.c_int; L.miqp_solver_last_admission.argtypes = [vp, C.POINTER(C.c_double)]
     L.miqp_gpu_version.restype = C.c_char_p
@@ -90,7 +91,7 @@ EXPORTED_SYMBOLS = ["miqp_solver_create", "miqp_solver_destroy", "miqp_solver_se
                     "miqp_solver_override_settings", "miqp_solver_set_warmstart", "miqp_solver_solve",
                     "miqp_solver_solve_batch", "miqp_solver_get_results", "miqp_solver_get_properties",
                     "miqp_solver_get_dims", "miqp_solver_export_lp", "miqp_solver_solve_fixed",
-                    "miqp_solver_last_timing", "miqp_solver_last_setup", "miqp_solver_last_error", "miqp_solver_last_admission", "miqp_gpu_version", "miqp_solver_write_dat", "miqp_solver_write_solution",
+                    "miqp_solver_last_timing", "miqp_solver_last_active_set", "miqp_solver_last_setup", "miqp_solver_last_error", "miqp_solver_last_admission", "miqp_gpu_version", "miqp_solver_write_dat", "miqp_solver_write_solution",
                     "miqp_solver_write_mst", "miqp_solver_read_mst", "miqp_fraction_parameters", "miqp_mean_angles",
                     "miqp_limits_per_region", "miqp_calculate_region_idx", "miqp_reserve_neighbor_regions",
                     "miqp_calculate_possible_regions", "miqp_calculate_warmstart", "miqp_plan",
@@ -392,8 +393,12 @@ class CplexWrapper:
         self._L.miqp_solver_last_timing(self._h, t)
         u = (C.c_double * 3)()
         self._L.miqp_solver_last_setup(self._h, u)
+        v = (C.c_double * 8)()
+        self._L.miqp_solver_last_active_set(self._h, v)
         return dict(solve_s=t[0], ipm_s=t[1], ipm_launches=int(t[2]), nodes=int(t[3]), ipm_iters=int(t[4]), row_iters=int(t[5]),
-                    setup_s=u[0], context_s=u[1], context_built=bool(u[2]))
+                    setup_s=u[0], context_s=u[1], context_built=bool(u[2]),
+                    as_nodes=int(v[0]), as_steps=int(v[1]), as_unfinished=int(v[2]), as_drops=int(v[3]), as_rows_end=int(v[4]), as_rows_parent=int(v[5]),
+                    std_launch_s=v[6], std_launches=int(v[7]))
 
 
 def prepare_batch(wrappers):
