@@ -119,7 +119,11 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
     double cutoff = 1e300;
     {
       const double inc0 = fmin(inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]), B.inc_ext[inst]);
-      if (B.use_cutoff && inc0 < 1e300) cutoff = inc0 - B.inst_gap[inst] * (1e-10 + fabs(inc0)) - B.inst_const[inst];
+      // (a heuristic leaf - rounding probe, neighbour of the local search - is cut off at the incumbent itself, not a gap below it: a leaf that is
+      // better by less than the gap IS the next incumbent, and the local search climbs in such steps.  The interior point never met this: it tests
+      // the cutoff only once it is nearly stationary, and a leaf started from the incumbent's solution has converged by then)
+      const double gap_ = is_probe_word(B.batch_depth[node]) ? 0.0 : B.inst_gap[inst];
+      if (B.use_cutoff && inc0 < 1e300) cutoff = inc0 - gap_ * (1e-10 + fabs(inc0)) - B.inst_const[inst];
     }
 
 #ifdef MIQP_PROFILE
