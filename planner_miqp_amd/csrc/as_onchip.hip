@@ -43,7 +43,7 @@ constexpr int AS_MSTR = AS_MT * (AS_MT + 1) / 2;   // doubles per slot of the ri
 __device__ inline int as_col(int pq) { return ((pq & 3) << 2) | (pq >> 2); }
 
 // GCAP = OC_GCAP: the ordinary nodes of a round (8 wavefronts per CU).  GCAP = OC_GCAP_BIG: the nodes known to be large before the round - rounding
-// probes, local-search leaves, marked records - beside it on a third stream (4 wavefronts per CU), except the ones as_big_takes() leaves to the
+// probes, local-search leaves, marked records - beside it on a third stream (4 wavefronts per CU), except the ones large_class() leaves to the
 // interior point chain on the second stream (records the method failed on before or that exceed even this block, probes that may be re-rounded)
 template <int C, int NSL, int GCAP = miqp::OC_GCAP>
 __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(DevBuf B) {
@@ -96,11 +96,10 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
     }
     const int node = run_next++;
     if (node >= nbatch) { run_next = run_end; continue; }
-    {   // the split of the round between the two launches: select_kernel's snapshot (probes, local-search leaves, marked records: the larger block)
-      const bool marked = B.batch_large ? B.batch_large[node] != 0 : is_probe_word(B.batch_depth[node]);
-      if (BIG ? !marked : marked) continue;
+    {   // the split of the round between the launches: select_kernel's snapshot (large_class)
+      const int cls = B.batch_large ? (int)B.batch_large[node] : (is_probe_word(B.batch_depth[node]) ? 1 : 0);
+      if (cls != (BIG ? 1 : 0)) continue;
     }
-    if (BIG && !as_big_takes(B, node)) continue;   // the interior point chain on the second stream keeps it
     const int inst = __builtin_amdgcn_readfirstlane(B.batch_inst[node]);
     const double* D = B.inst_d + (size_t)inst * Y.dstride;
     const int* T = B.inst_i + (size_t)inst * Y.istride;
@@ -255,39 +254,11 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
     OC_WAVE_SYNC();   // the keys are consumed: their region becomes the feed-forward terms
 
     // ---- constant gains of the unconstrained regulator, per chain (lane = chain): P' = Q + A' P A - K S_xu', K = S_xu / S_uu
-    // (gains, the objective's feed-forward and the unconstrained optimum are the same for every node of an instance: the first node of an
-    // instance to get here computes them and publishes them in as_tab, the others load 5.8 KB)
+    // (gains, the objective's feed-forward and the unconstrained optimum are the same for every node of an instance: host tables, host_inst.hpp::as_tables)
     const double h1 = ts, h2 = 0.5 * ts * ts, h3 = ts * ts * ts / 6.0;
-    double* const tb = B.as_tab ? B.as_tab + (size_t)inst * B.as_tab_stride : nullptr;
-    const bool tab = tb && __builtin_amdgcn_readfirstlane(*(volatile int*)&B.as_tab_ready[inst]) == 1;
-    if (tab) {
-      for (int k = tid; k < N * 16; k += 64) KS[k] = tb[k];
-      for (int k = tid; k < N * 4; k += 64) kref[k] = tb[N * 16 + k];
-    } else if (tid < NCH) {
-      const int ch = tid;
-      const double q0 = 2.0 * Wd[4 * ch], q1 = 2.0 * Wd[4 * ch + 1], q2 = 2.0 * Wd[4 * ch + 2], rr = 2.0 * Wd[4 * ch + 3];
-      double p00 = q0, p01 = 0.0, p02 = 0.0, p11 = q1, p12 = 0.0, p22 = q2;
-      for (int i = N - 2; i >= 0; --i) {
-        // T = P A (rows k, columns 0..2), PB = P B
-        const double t00 = p00, t01 = p00 * h1 + p01, t02 = p00 * h2 + p01 * h1 + p02;
-        const double t10 = p01, t11 = p01 * h1 + p11, t12 = p01 * h2 + p11 * h1 + p12;
-        const double t20 = p02, t21 = p02 * h1 + p12, t22 = p02 * h2 + p12 * h1 + p22;
-        const double b0 = p00 * h3 + p01 * h2 + p02 * h1, b1 = p01 * h3 + p11 * h2 + p12 * h1, b2 = p02 * h3 + p12 * h2 + p22 * h1;
-        const double suu = rr + h3 * b0 + h2 * b1 + h1 * b2;
-        const double x0 = b0, x1 = h1 * b0 + b1, x2 = h2 * b0 + h1 * b1 + b2;            // S_xu = A' P B
-        // S_xx = Q + A' T (symmetric)
-        const double s00 = q0 + t00, s01 = t01, s02 = t02;
-        const double s11 = q1 + h1 * t01 + t11, s12 = h1 * t02 + t12;
-        const double s22 = q2 + h2 * t02 + h1 * t12 + t22;
-        (void)t10; (void)t20; (void)t21;
-        const double is = 1.0 / fmax(suu, 1e-300);
-        const double k0 = x0 * is, k1 = x1 * is, k2 = x2 * is;
-        double* ks = KS + (i * 4 + ch) * 4;
-        ks[0] = k0; ks[1] = k1; ks[2] = k2; ks[3] = is;
-        p00 = s00 - k0 * x0; p01 = s01 - k0 * x1; p02 = s02 - k0 * x2;
-        p11 = s11 - k1 * x1; p12 = s12 - k1 * x2; p22 = s22 - k2 * x2;
-      }
-    }
+    const double* const tb = D + Y.d_astab;
+    for (int k = tid; k < N * 16; k += 64) KS[k] = tb[k];
+    for (int k = tid; k < N * 4; k += 64) kref[k] = tb[N * 16 + k];
     OC_WAVE_SYNC();
     // one substitution: V holds a stage-wise vector v (zero above stage itop) on entry; `out` receives, for the stages up to iend, the minimiser of
     // 1/2 z' H z + v' z over the trajectories of the dynamics from x_0 = 0 (fromx0 false: a response, -H^-1 v), or the minimiser of the
@@ -341,15 +312,6 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
       }
       OC_WAVE_SYNC();
     };
-    if (!tab) {   // feed-forward of the objective's linear term -2 W r
-      for (int k = tid; k < N * 16; k += 64) { const int q = k & 15; V[k] = q < NZ ? -2.0 * Wd[q] * Rf[(k >> 4) * NZ + oc_lcol<C, CM>(as_col(q))] : 0.0; }
-      OC_WAVE_SYNC();
-      subst(false, N - 1, 0, V);
-      if (tid < N * 4) kref[tid] = kff[tid];
-      if (tid + 64 < N * 4) kref[tid + 64] = kff[tid + 64];
-      OC_WAVE_SYNC();
-    }
-
     // value of a row at a stage-wise vector: box rows id = (stage * 2 + side) * 16 + column, general rows id = 1024 + index
     auto row_dot = [&](int id, const double* vec) -> double {
       if (id < 1024) return (((id >> 4) & 1) ? -1.0 : 1.0) * vec[(id >> 5) * 16 + (id & 15)];
@@ -387,29 +349,28 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
     // iterate of the current multipliers: z = argmin objective + lambda' G z
     auto refresh = [&]() {
       zeroV();
-      if (arow >= 0 && alam != 0.0) {
-        if (arow < 1024) atomicAdd(&V[(arow >> 5) * 16 + (arow & 15)], (((arow >> 4) & 1) ? -alam : alam));
-        else {
+      // lambda' G, stage by stage: the box rows first, all at once (an entry collects at most the two sides of one bound: a sum of two terms does not
+      // depend on their order), then the general rows ONE SLOT AFTER THE OTHER - several of them can meet in one entry, and the order in which
+      // the LDS serves colliding atomic adds is not ours to fix (a last-bit difference in the iterate can flip a tie of the ratio test: repeated
+      // solves of one instance differed by one step in 5 of 8 runs)
+      if (arow >= 0 && arow < 1024 && alam != 0.0) atomicAdd(&V[(arow >> 5) * 16 + (arow & 15)], (((arow >> 4) & 1) ? -alam : alam));
+      OC_WAVE_SYNC();
+      for (unsigned long long gm = __ballot(arow >= 1024 && alam != 0.0); gm; gm &= gm - 1ull) {
+        const int a = __builtin_amdgcn_readfirstlane(__ffsll((long long)gm) - 1);
+        if (tid == a) {
           const uint4 m4 = gmeta[arow - 1024];
           const int off = (int)(m4.z & 0xFFFFu), nn = (int)((m4.z >> 16) & 7u), i = (int)((m4.z >> 20) & 0x7FFu);
 #pragma unroll
-          for (int k = 0; k < 6; ++k) if (k < nn) atomicAdd(&V[i * 16 + ((m4.w >> (4 * k)) & 15u)], gcoef[off + k] * alam);
+          for (int k = 0; k < 6; ++k) if (k < nn) { double* e_ = &V[i * 16 + ((m4.w >> (4 * k)) & 15u)]; *e_ = fma(gcoef[off + k], alam, *e_); }
         }
+        OC_WAVE_SYNC();
       }
       const int amax = (int)wave_max((double)astage);
       OC_WAVE_SYNC();
       subst(true, amax, N - 1, Z);
     };
-    if (tab) { for (int k = tid; k < N * 16; k += 64) Z[k] = tb[N * 20 + k]; OC_WAVE_SYNC(); }
-    else {
-      refresh();                     // lambda = 0: the unconstrained optimum
-      if (tb) {
-        for (int k = tid; k < N * 16; k += 64) { tb[k] = KS[k]; tb[N * 20 + k] = Z[k]; }
-        for (int k = tid; k < N * 4; k += 64) tb[N * 16 + k] = kref[k];
-        __threadfence();
-        if (tid == 0) atomicExch(&B.as_tab_ready[inst], 1);
-      }
-    }
+    for (int k = tid; k < N * 16; k += 64) Z[k] = tb[N * 20 + k];   // lambda = 0: the unconstrained optimum
+    OC_WAVE_SYNC();
     ASP_T(ta2); ASP_ACC(1, ta1, ta2);
     int steps = 0, ndrop = 0, ok = 1, nwarm = 0, nfast = 0, ncold = 0;
     bool infeas = false, fail = false;
@@ -733,7 +694,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
     } else if (infeas) viol = 1.0;
     if (!fail && !infeas && ok == 1 && !(viol <= 5.0e-7)) { fail = true; why = 5; }   // (the rows of the active set drifted off their equalities: not a result)
     if (fail) {
-      // marked and returned unsolved: the interior point chain takes the record next round (as_big_takes)
+      // marked and returned unsolved: the interior point chain takes the record next round (large_class 2)
       if (B.batch_A) B.batch_A[(size_t)node * 64 + tid] = 0xFFFFu;
       if (B.ring_M && tid == 0) B.batch_Mtag[node] = 0ull;
       if (tid == 0) { B.batch_ok[node] = 5; B.pool_big[B.batch_node[node]] |= 4; if (B.as_stats) { atomicAdd(&B.as_stats[2], 1ull); atomicAdd(&B.as_stats[10 + (why < 6 ? why : 5)], 1ull); } }

@@ -261,7 +261,7 @@ struct Layout {
   int C, N, R, P, E, EL, O, L, NP;   // P = max possible regions per car, EL = max edges per environment piece
   int nx, nu, nz, SC, NSLOT, ROWCAP;
   // double offsets
-  int d_x0, d_wd, d_ref, d_glob, d_u0box, d_misc, d_dsep, d_ssl, d_smax, d_reg, d_env, d_obs, d_theta, d_lift, d_hull, d_hullm, d_fpk, dstride;
+  int d_x0, d_wd, d_ref, d_glob, d_u0box, d_misc, d_dsep, d_ssl, d_smax, d_reg, d_env, d_obs, d_theta, d_lift, d_hull, d_hullm, d_fpk, d_astab, dstride;
   int PT;   // bits of the region-set index of d_hullm: min(P, HULLM_MAXBITS)
   int relax_front_off;   // 1 (default): car/car rows on front points wait for the region of their car; 0: experiment, see make_layout
   // int offsets
@@ -287,7 +287,7 @@ inline Layout make_layout(int C, int N, int R, int P, int E, int EL, int O, int 
   Y.d_x0 = o; o += C * 6; Y.d_wd = o; o += Y.nz; Y.d_ref = o; o += N * Y.nz; Y.d_glob = o; o += 8; Y.d_u0box = o; o += C * 4;
   Y.d_misc = o; o += 4; Y.d_dsep = o; o += Y.NP * N; Y.d_ssl = o; o += N; Y.d_smax = o; o += N; Y.d_reg = o; o += C * P * REGSZ;
   Y.d_env = o; o += E * EL * 3; Y.d_obs = o; o += O * N * L * 3; Y.d_theta = o; o += C * 4; Y.d_lift = o; o += C * 2 * N * 16; Y.d_hull = o; o += C * N * HULLSZ;
-  Y.PT = P < HULLM_MAXBITS ? P : HULLM_MAXBITS; Y.d_hullm = o; o += C * (1 << Y.PT) * 8; Y.d_fpk = o; o += C * (1 << Y.PT) * 8; Y.dstride = (o + 7) & ~7;
+  Y.PT = P < HULLM_MAXBITS ? P : HULLM_MAXBITS; Y.d_hullm = o; o += C * (1 << Y.PT) * 8; Y.d_fpk = o; o += C * (1 << Y.PT) * 8; o = (o + 1) & ~1; Y.d_astab = o; o += 18 * C * N; Y.dstride = (o + 7) & ~7;
   o = 0;
   Y.i_nposs = o; o += C; Y.i_regj = o; o += C * P; Y.i_nhs = o; o += C * P; Y.i_hs = o; o += C * P * 4; Y.i_envn = o; o += E;
   Y.i_obssoft = o; o += O; Y.i_initj = o; o += C; Y.i_dom = o; o += C * P * 4; Y.i_allow = o; o += C * N * 2; Y.i_boxskip = o; o += C * N; Y.i_c2callow = o; o += Y.NP * N; Y.i_rallow = o; o += C * N; Y.istride = (o + 3) & ~3;
@@ -400,6 +400,55 @@ inline void lift_tables(const HostInst& I, const Layout& Y, double* D) {
     }
 }
 
+// Tables of the active-set node solver (as_onchip.hip): the Hessian of every node QP of an instance is the objective's alone, so the regulator of
+// the unconstrained problem - per chain (car, axis) a scalar-input triple integrator with weights (Wp, Wv, Wa | Wj) - is an instance constant:
+//   KS   [N][2C][4]  feedback gain K (p, v, a) and 1 / S_uu per stage and chain (3 x 3 Riccati recursion, S_uu = 2 Wj + B' P B),
+//   kref [N][2C]     feed-forward of the objective's linear term -2 W r,
+//   zunc [N][8C]     the unconstrained optimum from x_0, columns chain-contiguous (4 ch + {p, v, a, u}).
+// Computed HERE, once, so that every launch of every kernel variant reads the same bits (computed on the device by whichever wavefront came first,
+// two template instantiations could publish last-bit-different values and repeated solves differed by one step).
+inline void as_tables(const HostInst& I, const Layout& Y, double* D) {
+  const int N = Y.N, NCH = 2 * Y.C;
+  double* KS = D + Y.d_astab; double* kref = KS + (size_t)N * NCH * 4; double* zunc = kref + (size_t)N * NCH;
+  const double h1 = I.ts, h2 = 0.5 * I.ts * I.ts, h3 = I.ts * I.ts * I.ts / 6.0;
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int c = ch >> 1, s = ch & 1;
+    const double q0 = 2.0 * I.W[c * 8 + 3 * s], q1 = 2.0 * I.W[c * 8 + 3 * s + 1], q2 = 2.0 * I.W[c * 8 + 3 * s + 2], rr = 2.0 * I.W[c * 8 + 6 + s];
+    double p00 = q0, p01 = 0.0, p02 = 0.0, p11 = q1, p12 = 0.0, p22 = q2;
+    for (int i = N - 2; i >= 0; --i) {
+      const double t01 = p00 * h1 + p01, t02 = p00 * h2 + p01 * h1 + p02, t11 = p01 * h1 + p11, t12 = p01 * h2 + p11 * h1 + p12, t22 = p02 * h2 + p12 * h1 + p22;
+      const double b0 = p00 * h3 + p01 * h2 + p02 * h1, b1 = p01 * h3 + p11 * h2 + p12 * h1, b2 = p02 * h3 + p12 * h2 + p22 * h1;
+      const double suu = rr + h3 * b0 + h2 * b1 + h1 * b2;
+      const double x0 = b0, x1 = h1 * b0 + b1, x2 = h2 * b0 + h1 * b1 + b2;
+      const double s00 = q0 + p00, s01 = t01, s02 = t02, s11 = q1 + h1 * t01 + t11, s12 = h1 * t02 + t12, s22 = q2 + h2 * t02 + h1 * t12 + t22;
+      const double is = 1.0 / std::max(suu, 1e-300);
+      const double k0 = x0 * is, k1 = x1 * is, k2 = x2 * is;
+      double* ks = KS + ((size_t)i * NCH + ch) * 4; ks[0] = k0; ks[1] = k1; ks[2] = k2; ks[3] = is;
+      p00 = s00 - k0 * x0; p01 = s01 - k0 * x1; p02 = s02 - k0 * x2; p11 = s11 - k1 * x1; p12 = s12 - k1 * x2; p22 = s22 - k2 * x2;
+    }
+    // feed-forward of v = -2 W r (no reference on the jerk), then the roll-out from x_0
+    const double w[3] = {I.W[c * 8 + 3 * s], I.W[c * 8 + 3 * s + 1], I.W[c * 8 + 3 * s + 2]};
+    auto vref = [&](int i, int k) { return -2.0 * w[k] * I.ref[((size_t)c * N + i) * 6 + 3 * s + k]; };
+    double p0 = vref(N - 1, 0), p1 = vref(N - 1, 1), p2 = vref(N - 1, 2);
+    for (int i = N - 2; i >= 0; --i) {
+      const double* ks = KS + ((size_t)i * NCH + ch) * 4;
+      const double su = h3 * p0 + h2 * p1 + h1 * p2;
+      const double sx0 = vref(i, 0) + p0, sx1 = vref(i, 1) + h1 * p0 + p1, sx2 = vref(i, 2) + h2 * p0 + h1 * p1 + p2;
+      kref[(size_t)i * NCH + ch] = su * ks[3];
+      p0 = sx0 - ks[0] * su; p1 = sx1 - ks[1] * su; p2 = sx2 - ks[2] * su;
+    }
+    kref[(size_t)(N - 1) * NCH + ch] = 0.0;
+    double x0 = I.x0[c * 6 + 3 * s], x1 = I.x0[c * 6 + 3 * s + 1], x2 = I.x0[c * 6 + 3 * s + 2];
+    for (int i = 0; i < N; ++i) {
+      double u = 0.0;
+      if (i < N - 1) { const double* ks = KS + ((size_t)i * NCH + ch) * 4; u = -kref[(size_t)i * NCH + ch] - (ks[0] * x0 + ks[1] * x1 + ks[2] * x2); }
+      double* z = zunc + (size_t)i * 4 * NCH + 4 * ch; z[0] = x0; z[1] = x1; z[2] = x2; z[3] = u;
+      const double n0 = x0 + h1 * x1 + h2 * x2 + h3 * u, n1 = x1 + h1 * x2 + h2 * u, n2 = x2 + h1 * u;
+      x0 = n0; x1 = n1; x2 = n2;
+    }
+  }
+}
+
 // fills one instance's block of the device tables
 inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int* T) {
   std::fill(D, D + Y.dstride, 0.0); std::fill(T, T + Y.istride, 0);
@@ -413,6 +462,7 @@ inline void compile_instance(const HostInst& I, const Layout& Y, double* D, int*
     D[Y.d_theta + c * 4 + 0] = I.x0[c * 6 + 0] + std::cos(th) * I.wb[c]; D[Y.d_theta + c * 4 + 1] = I.x0[c * 6 + 3] + std::sin(th) * I.wb[c];
   }
   lift_tables(I, Y, D);
+  as_tables(I, Y, D);
   double* G = D + Y.d_glob; G[0] = I.vmin; G[1] = I.vmax; G[2] = I.amin; G[3] = I.amax; G[4] = I.jmin; G[5] = I.jmax; G[6] = I.vm; G[7] = I.ts;
   for (int c = 0; c < C; ++c) {  // initial_conditions.mod:30-48
     int j0 = I.init_region[c] - 1;

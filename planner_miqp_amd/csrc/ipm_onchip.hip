@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     if ((BIG && B.ovf_mode == 2) || (!BIG && B.skip_probes)) {
       const bool marked = B.batch_large ? B.batch_large[node] != 0 : is_probe_word(B.batch_depth[node]);
       if (BIG ? !marked : marked) continue;   // the other launch of the round solves it
-      if (BIG && B.as_split && (as_big_takes(B, node) || (B.pool_big[B.batch_node[node]] & 2))) continue;   // ... or the larger active-set launch, or (a record known to exceed this block) the memory-backed launch on its own stream
+      if (BIG && B.as_split && B.batch_large[node] != 2) continue;   // ... or the larger active-set launch (class 1), or the memory-backed launch on its own stream (class 3): large_class
     }
     const int inst = __builtin_amdgcn_readfirstlane(B.batch_inst[node]);
     const double* D = B.inst_d + (size_t)inst * Y.dstride;

@@ -199,8 +199,7 @@ struct DevBuf {
   unsigned long long* pool_Mtag;    // [z_cap]
   int width_cap;                 // > 0: nodes a single solve takes per round at most (the host widens it when the solve is bound-limited)
   int as_chunk;                  // consecutive batch slots a wavefront of the active-set launches takes at a time
-  int as_split;                  // 1: the larger interior point variant leaves the marked nodes of as_big_takes() to the larger active-set launch on the third stream
-  double* as_tab; int* as_tab_ready; int as_tab_stride;   // per instance: regulator gains [N][16], feed-forward of the objective [N][4], unconstrained optimum [N][16] (published by the first node of the instance that needs them)
+  int as_split;                  // 1: the larger interior point variant takes only the nodes of large_class 2 (class 1: the larger active-set launch on the third stream, class 3: the memory-backed launch on the fourth)
   unsigned long long* as_stats;  // [8] nodes, steps (rows added + dropped), handed to the interior point, rows dropped, infeasible, cut off, sum of the final active set sizes
 };
 
@@ -299,19 +298,24 @@ __device__ inline void pair_cars(int p, int C, int& c1, int& c2) {
 struct RowOut { double rhs; double aq; bool active; };
 // depth word of a rounding probe: tree depth >= 1, low bits 63 (eval_kernel: the children of a node carry 62 - their preference)
 __device__ inline bool is_probe_word(int dw) { return (dw & 63) == 63 && (dw >> 6) >= 1; }
-// The marked nodes of a round (rounding probes, local-search leaves, large records) are split between the larger active-set launch and the
-// interior point chain beside it; this is the rule, evaluated by both (nothing it reads changes during the launches of a round): the interior
-// point keeps the records the active-set method failed on (pool_big bit 2) or that exceed even the larger block (bit 1), and the rounding
-// probes of an instance whose infeasible probes are re-rounded (eval_kernel: no incumbent yet, or pump_inc) - the re-rounding starts from the
-// least-violation point that only the elastic interior point delivers
-__device__ inline bool as_big_takes(const DevBuf& B, int node) {
-  if (B.pool_big[B.batch_node[node]] & 6) return false;
-  if (is_probe_word(B.batch_depth[node]) && B.pump_max > 0) {
-    const int inst = B.batch_inst[node];
-    const bool noinc = !(fmin(inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]), B.inc_ext[inst]) < 1e300);
-    if (noinc || B.pump_inc) return false;
-  }
-  return true;
+// The nodes of a round go to one of four concurrent launches, and which one is decided ONCE, by select_kernel / lns_kernel when they write the batch
+// (batch_large: nothing a launch of the round writes - the marks on the records, the incumbents - can then change the split while the launches
+// run beside each other; a decision read live from pool_big made the iteration counts of repeated solves differ):
+//   0 the ordinary nodes: the standard launch;
+//   1 the large nodes - rounding probes, local-search leaves, marked records - that the active-set method takes: its larger block;
+//   2 ... that the interior point keeps: records the active-set method failed on (pool_big bit 2), and the rounding probes of an instance whose
+//     infeasible probes are re-rounded (eval_kernel: no incumbent yet, or pump_inc) - the re-rounding starts from the least-violation point that
+//     only the elastic interior point delivers;
+//   3 records known to exceed even the larger on-chip block (pool_big bit 1): the memory-backed kernel.
+// (Without the active-set launches - one, three, four cars, MIQP_AS=0 - only zero / non-zero matters.)
+__device__ inline unsigned char large_class(const DevBuf& B, int rec, int dw, bool has_inc) {
+  const unsigned int pb = B.pool_big ? (unsigned int)B.pool_big[rec] : 0u;
+  const bool probe = is_probe_word(dw);
+  if (!probe && !(pb & 0xF7u)) return 0;
+  if (pb & 2u) return 3;
+  if (pb & 4u) return 2;
+  if (probe && B.pump_max > 0 && (!has_inc || B.pump_inc)) return 2;
+  return 1;
 }
 
 // region set of (car, step) in a node: the bits of its fix record that the static reachability presolve allows
@@ -667,7 +671,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
   if (sh_node >= nbatch) break;
   const int node = __builtin_amdgcn_readfirstlane(B.ovf_mode == 1 ? B.ovf_list[sh_node] : sh_node);   // wave-uniform: addressed from SGPRs
   if (B.ovf_mode == 2 && !is_probe_word(B.batch_depth[node])) continue;   // (this launch takes the rounding probes only)
-  if (B.ovf_mode == 3 && !(B.batch_large[node] && (B.pool_big[B.batch_node[node]] & 2))) continue;   // (... the marked records known to exceed the larger on-chip block)
+  if (B.ovf_mode == 3 && B.batch_large[node] != 3) continue;   // (... the records known to exceed the larger on-chip block: large_class 3)
   const int inst = __builtin_amdgcn_readfirstlane(B.batch_inst[node]);
   const double* D = B.inst_d + (size_t)inst * Y.dstride;
   const int* T = B.inst_i + (size_t)inst * Y.istride;
@@ -2329,9 +2333,10 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       for (int q = 0; q < nk; ++q) { if (slots[q] >= B.z_cap) continue; double* zd = B.pool_Z + (size_t)slots[q] * N * NZ; for (int k = lane; k < N * NZ; k += 64) zd[k] = Z[k]; }
     }
     if (B.pool_A) {   // ... and, where the active-set launch solved this node, from its active set (the nodes of the larger interior point variant have none)
-      const unsigned short av_ = B.batch_A ? B.batch_A[(size_t)node * 64 + lane] : (unsigned short)0xFFFFu;   // (every node of a round passes one of the two active-set launches, which writes its set or 0xFFFF)
+      const bool as_node = B.batch_A && B.batch_large && B.batch_large[node] <= 1;   // (large_class 0 / 1: one of the two active-set launches solved this node and wrote its set - or 0xFFFF; the batch slots of the interior point's nodes hold what an earlier round left there)
+      const unsigned short av_ = as_node ? B.batch_A[(size_t)node * 64 + lane] : (unsigned short)0xFFFFu;
       for (int q = 0; q < nk; ++q) { if (slots[q] >= B.z_cap) continue; B.pool_A[(size_t)slots[q] * 64 + lane] = av_; }
-      if (B.ring_M && lane < nk && slots[lane] < B.z_cap) B.pool_Mtag[slots[lane]] = B.batch_Mtag[node];
+      if (B.ring_M && lane < nk && slots[lane] < B.z_cap) B.pool_Mtag[slots[lane]] = as_node ? B.batch_Mtag[node] : 0ull;
     }
     if (lane < nk) {
       // depth word: (tree depth << 6) | preference among siblings (child_inf first) - used by the dive ordering
@@ -2788,7 +2793,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
       if (pick) {
         int pos = atomicAdd(&sh_pick, 1);
         if (pos < take) { B.batch_node[base + pos] = nd; B.batch_inst[base + pos] = inst; B.batch_bound[base + pos] = b; B.batch_depth[base + pos] = dp;
-                          if (B.batch_large) B.batch_large[base + pos] = (is_probe_word(dp) || (B.pool_big && (B.pool_big[nd] & 0xF7))) ? 1 : 0; }   // (bit 3 is the deferral mark, not a size mark)
+                          if (B.batch_large) B.batch_large[base + pos] = large_class(B, nd, dp, inc < 1e300); }   // (the launch of the round that solves the node)
         else pick = false;
       }
     }
@@ -3134,7 +3139,7 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
       if (B.pool_big) B.pool_big[rec] = 1;
       if (B.pool_origin) B.pool_origin[rec] = 14;
       B.batch_node[bs] = rec; B.batch_inst[bs] = inst; B.batch_bound[bs] = lbq; B.batch_depth[bs] = (1 << 6) | 63;   // (the probe mark: a heuristic node - one that has not converged after probe_itcap iterations is abandoned)
-      if (B.batch_large) B.batch_large[bs] = 1;
+      if (B.batch_large) B.batch_large[bs] = large_class(B, rec, (1 << 6) | 63, true);
     }
   }
 }

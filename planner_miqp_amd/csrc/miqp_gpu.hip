@@ -469,12 +469,6 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&X.as_stats, 24)) return false;
   HIP_OK(hipMemset(X.as_stats, 0, 192));
   B.as_stats = X.as_stats; B.as_chunk = KNOB_T("MIQP_AS_CHUNK") ? std::atoi(KNOB_T("MIQP_AS_CHUNK")) : 1;   // (runs of 2 / 4 / 8 / 16: the standard launch 4.7 -> 5.2 / 6.6 / 7.9 / 10.3 ms - a wavefront solves ~14 nodes per launch, longer runs only lengthen its tail)
-  B.as_tab = nullptr; B.as_tab_ready = nullptr; B.as_tab_stride = (36 * Y.N + 15) & ~15;
-  if (X.as_on) {
-    if (!X.alloc(&B.as_tab, (size_t)n_inst * B.as_tab_stride)) return false;
-    if (!X.alloc(&B.as_tab_ready, n_inst)) return false;
-    HIP_OK(hipMemset(B.as_tab_ready, 0, (size_t)n_inst * 4));
-  }
   B.batch_A = nullptr; B.pool_A = nullptr; X.as_batch_A = nullptr; X.as_pool_A = nullptr; B.ring_M = nullptr; B.ring_head = nullptr; B.ring_doubles = 0; B.ring_margin = 0; B.batch_Mtag = nullptr; B.pool_Mtag = nullptr;
   if (X.as_on && B.z_cap > 0 && Y.N * Y.NSLOT + 1024 < 65535) {   // the parents' active sets for the children's starts (128 B per record)
     if (!X.alloc(&B.batch_A, (size_t)batch_alloc * 64)) return false;
@@ -483,9 +477,9 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
     HIP_OK(hipMemset(B.batch_A, 0xFF, (size_t)batch_alloc * 128));
     X.as_batch_A = B.batch_A; X.as_pool_A = B.pool_A;
     // ... and the ring their M travels through (4 KB per node on average, at most 12.8): a quarter of the free memory, at most 96 GB
-    size_t rd = std::min<size_t>((size_t)12 << 30, free_b / 4 / 8);   // doubles
+    size_t rd = std::min<size_t>(std::min<size_t>((size_t)12 << 30, free_b / 4 / 8), std::max<size_t>((size_t)512 << 20, (size_t)n_slots * ((size_t)8 << 20)));   // doubles: 64 MB per instance in flight, at least 4 GB (a single solve: hundreds of its rounds; a large allocation costs seconds when the context is built)
     const size_t margin = (size_t)batch_alloc * AS_MSTR + ((size_t)1 << 20);   // what one round's launches can allocate, and more
-    if (rd >= 16 * margin) {
+    if (rd >= 4 * margin) {
       if (!X.alloc(&B.ring_M, rd)) return false;
       if (!X.alloc(&B.ring_head, 1)) return false;
       if (!X.alloc(&B.batch_Mtag, batch_alloc)) return false;
@@ -599,7 +593,7 @@ void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool o
       const int gb = std::min(std::min(bc, big_grid_cap), std::min(X.probe_grid, X.ocb_grid));
       const bool as2 = X.as_on && pc && Y.C == 2 && X.stream3;
       if (as2) {
-        // the large nodes of the round that the active-set method takes (as_big_takes): its larger block, on a third stream beside the interior
+        // the large nodes of the round that the active-set method takes (large_class 1): its larger block, on a third stream beside the interior
         // point chain, which keeps the rest of them
         (void)hipStreamWaitEvent(X.stream3, X.ev_fork, 0);
         DevBuf Bq = Bp; Bq.work_counter = cs + 6;
@@ -906,8 +900,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   // relaxations), 92 -> 75 ms at 0.01; p50 / p90 unchanged (5 / 18 ms); 1024: 51 / 76 ms (too narrow: more rounds), 4096: 51 / 86, 8192: 58 / 90
   if (O0.nodes_per_round <= 0 && Y.C <= 2 && NS == 1) npr = std::min(npr, 2048);
   if (O0.nodes_per_round <= 0 && KNOB_P("MIQP_NPR")) npr = std::max(1, std::atoi(KNOB_P("MIQP_NPR")));  // tuning knob
-  // A single solve starts narrow (above) and WIDENS its rounds once it is bound-limited: the incumbent has not moved for 16 rounds and the
-  // batch is full - then the tree needs node throughput, not fresher incumbents (cfg5 seed 11: 1.61 / 2.17 / 2.92 M relaxations in 10 s at
+  // A single solve starts narrow (above) and WIDENS its rounds once it is bound-limited: the incumbent has not moved for 32 rounds and the
+  // near list offers eight rounds' worth of eligible nodes - then the tree needs node throughput, not fresher incumbents (cfg5 seed 11: 1.61 / 2.17 / 2.92 M relaxations in 10 s at
   // 1024 / 2048 / 4096 nodes per round).  The batch arrays are sized for the widest round, select_kernel caps at width_cap
   const bool adaptive_width = NS == 1 && !split && O0.nodes_per_round <= 0 && !KNOB_P("MIQP_NPR");
   const int width0 = npr, width_max = 16384;
@@ -1059,7 +1053,6 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemsetAsync(B.inst_iters, 0, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_ninc, 0, (size_t)n * 4, st));
   HIP_OK(hipMemsetAsync(B.as_stats, 0, 192, st));
-  if (B.as_tab_ready) HIP_OK(hipMemsetAsync(B.as_tab_ready, 0, (size_t)n * 4, st));
   HIP_OK(hipMemsetAsync(B.inst_lns, 0, (size_t)n * 4, st));
   { std::vector<double> big_(n, 1e300); HIP_OK(hipMemcpyAsync(B.inst_lns_obj, big_.data(), (size_t)n * 8, hipMemcpyHostToDevice, st)); HIP_OK(hipStreamSynchronize(st)); }
   B.lns_step = KNOB_T("MIQP_LNS_STEP") ? std::atof(KNOB_T("MIQP_LNS_STEP")) : 0.0;
@@ -1120,7 +1113,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   // roll_kernel zeroes the other for the round after - six 4-byte memsets per round less in the stream (0.65 ms of the 1.4 ms round of a single solve)
   const bool use_par = X.ctr && X.oc_grid > 0 && X.ocb_grid > 0 && X.concurrent_big && X.stream2 && X.probe_grid > 0 && !KNOB_T("MIQP_MEMSETS");
   if (use_par) HIP_OK(hipMemsetAsync(X.ctr, 0, 64, st));
-  int width_now = adaptive_width ? width0 : 0, width_since = 0; unsigned long long width_key = ~0ull, kinc_now = ~0ull;
+  int width_now = adaptive_width ? width0 : 0, width_since = 0, demand_now = 0; unsigned long long width_key = ~0ull, kinc_now = ~0ull;
   for (;;) {
     const int par = rounds & 1;
     B.width_cap = width_now;
@@ -1135,11 +1128,11 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     int bc = 0;
     HIP_OK(hipMemcpyAsync(&bc, B.batch_count, 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(h_done_now.data(), B.inst_done, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    if (adaptive_width) HIP_OK(hipMemcpyAsync(&kinc_now, B.inc_key, 8, hipMemcpyDeviceToHost, st));
+    if (adaptive_width) { HIP_OK(hipMemcpyAsync(&kinc_now, B.inc_key, 8, hipMemcpyDeviceToHost, st)); HIP_OK(hipMemcpyAsync(&demand_now, B.slot_demand, 4, hipMemcpyDeviceToHost, st)); }
     HIP_OK(hipStreamSynchronize(st));
     if (adaptive_width) {
       if (kinc_now != width_key) { width_key = kinc_now; width_since = rounds; }
-      else if (kinc_now < 0xFFF0000000000000ull && rounds - width_since >= 16 && bc >= width_now && width_now < width_max) { width_now *= 2; width_since = rounds; }
+      else if (kinc_now < 0xFFF0000000000000ull && rounds - width_since >= 32 && demand_now >= 8 * width_now && width_now < width_max) { width_now *= 2; width_since = rounds; }
     }
     const double tnow = wall_s() - t0;
     for (int sl = 0; sl < NS; ++sl) { const int k = h_slot_inst[sl]; if (k >= 0 && h_done_now[k] && h_tdone[k] < 0) h_tdone[k] = tnow - t_admit[k]; }   // time from admission to proof
