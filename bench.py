@@ -440,6 +440,7 @@ def main():
             out["value_limit_lifted"] = aph_["solves_per_s"]; out["proven_share_limit_lifted"] = aph_["proven_share"]
             out["value_all_proven"] = aph_["solves_per_s"] if aph_["proven_share"] >= 1.0 else None
             out["all_proven_at_bench_in_flight"] = aph_; out["time_to_prove_all"] = extras["time_to_prove_all"]
+            out["all_proven"] = extras["time_to_prove_all"]   # (alias: the key of rounds <= 4 for the same leg - 2048 instances at 256 in flight, limit 60 s)
             out["in_flight_sweep"] = extras["in_flight_sweep"]; out["one_batch_control"] = extras["one_batch_control"]
         out["proven_share"] = tot_solved / max(1, tot_att)
         if not a.no_cpu and world == 1:

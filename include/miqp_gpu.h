@@ -199,8 +199,9 @@ int miqp_solver_last_admission(const miqp_solver_t* s, double* out1);
  * until the next call on the handle).  The reference logs such conditions with LOG(ERROR) inside callCplex
  * (src/cplex_wrapper.cpp:97-109, 162-180); here the status code says WHAT (the four OptimizationStatus values), this says WHY:
  * malformed parameters, the queue abandoned before the instance was admitted, an instance retired because it made no progress
- * for 64 branch-and-bound rounds (it then reports FAILED_SEG_FAULT without an incumbent, SUCCESS / time-limit-feasible with one -
- * never the time-limit verdict of an instance that really used up max_solution_time). */
+ * for 64 branch-and-bound rounds.  Such an instance reports FAILED_SEG_FAULT without an incumbent (never FAILED_TIMEOUT) and SUCCESS with
+ * one; its props.status stays the CPLEX code of an unfinished solve (107 with, 108 without an incumbent - CPLEX has no code for "stalled"):
+ * what tells it from an instance that really used up max_solution_time is this text and, without an incumbent, the status code. */
 const char* miqp_solver_last_error(const miqp_solver_t* s);
 
 /* ---- planner core: the host logic directly above the solve ---- */

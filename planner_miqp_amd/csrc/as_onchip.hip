@@ -155,8 +155,46 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
         OC_WAVE_SYNC();
         nlist = 0;
       };
+      // The state / input bounds (slots 0..10 of every car and stage: decode_row's cases rr < 11 with box_of_slot's right-hand sides) - three
+      // quarters of a node's rows - one LANE PER (car, stage): its skip word, its region code and the eight box values (the region's table or the
+      // hull of the region set) are loaded once for the eleven rows, instead of eleven walks through decode_row and box_of_slot in eight passes
+      for (int e0 = 0; e0 < C * N; e0 += 64) {
+        const int e = e0 + tid;
+        if (e < C * N) {
+          const int c = e / N, i = e - c * N;
+          const double* G = D + Y.d_glob;
+          const int code = i >= 1 ? (int)fix[Y.f_reg + c * N + i] : -1;
+          const unsigned int skip = i >= 1 ? (unsigned int)T[Y.i_boxskip + c * N + i] : 0x7Fu;   // (stage 0: no state rows)
+          const double* rt = code >= 0 ? D + Y.d_reg + (c * Y.P + (code >> 2)) * REGSZ : nullptr;
+          const double* Hc = (!rt && i >= 1) ? region_hull(Y, D, T, fix, c, i) : nullptr;
+          auto put = [&](int col, bool neg, double rh) { atomicMin(&bkey[(i * 2 + (neg ? 1 : 0)) * 16 + as_col(oc_pcol<C, CM>(col))], d2key(rh)); };
+          if (i >= 1) {
+            const double a_lo_x = rt ? rt[11] : Hc[0], a_hi_x = rt ? rt[12] : Hc[1], a_lo_y = rt ? rt[13] : Hc[2], a_hi_y = rt ? rt[14] : Hc[3];
+            if (!(skip & 1u)) put(6 * c + 1, true, -G[0]);
+            if (!(skip & 2u)) put(6 * c + 4, true, -G[0]);
+            if (!(skip & 4u)) put(6 * c + 1, false, G[1]);
+            if (!(skip & 8u)) put(6 * c + 2, false, a_hi_x);
+            if (!(skip & 16u)) put(6 * c + 2, true, -a_lo_x);
+            if (!(skip & 32u)) put(6 * c + 5, false, a_hi_y);
+            if (!(skip & 64u)) put(6 * c + 5, true, -a_lo_y);
+          }
+          if (i <= N - 2) {
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+              double lo, hi;
+              if (i == 0) { lo = D[Y.d_u0box + c * 4 + 2 * s_]; hi = D[Y.d_u0box + c * 4 + 2 * s_ + 1]; }
+              else if (rt) { lo = rt[15 + 2 * s_]; hi = rt[16 + 2 * s_]; }
+              else { lo = Hc[4 + 2 * s_]; hi = Hc[5 + 2 * s_]; }
+              put(6 * C + 2 * c + s_, false, hi); put(6 * C + 2 * c + s_, true, -lo);
+            }
+          }
+        }
+      }
 #pragma unroll 1
       for (int cl = 0; cl < 8; ++cl) {
+#ifdef MIQP_PROFILE
+        if (cl == 2) { const long long tq_ = clock64(); asp_[9] += (unsigned long long)(tq_ - ta0); }
+#endif
         const int cnt = cls_cnt[cl], off = cls_off[cl];
         const bool percar = cl < 6;
         const int per = percar ? C * cnt : cnt, total = N * per;
@@ -164,7 +202,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
           const int e = e0 + tid;
           int i = 0, slot = 0; bool in = e < total;
           if (in) { i = e / per; const int rem = e - i * per; slot = percar ? (rem / cnt) * Y.SC + off + rem % cnt : off + rem; }
-          if (cl < 2) { if (in) take(i, slot); continue; }
+          if (cl < 2) continue;   // (the velocity / acceleration / jerk bounds: decoded per (car, stage) below)
           const bool cnd = in && slot_maybe<C>(Y, fix, i, slot);
           const unsigned long long mk = __ballot(cnd);
           if (cnd) plist[nlist + __popcll(mk & lt)] = (unsigned short)(i * NSLOT + slot);
@@ -183,6 +221,9 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
         }
       OC_WAVE_SYNC();
     }
+#ifdef MIQP_PROFILE
+    const long long tq1_ = clock64();
+#endif
     bool overflow = ngen > OC_GCAP;
     int ncoef = 0;
     for (int c0 = 0; c0 < ngen && !overflow; c0 += OC_SCR) {
@@ -239,6 +280,9 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
     OC_WAVE_SYNC();
 
     ASP_T(ta1); ASP_ACC(0, ta0, ta1);
+#ifdef MIQP_PROFILE
+    asp_[11] += (unsigned long long)(ta1 - tq1_);
+#endif
     // ---- the box rows of this lane (column lc, side, stages 2 k + par) into registers
     double brhs[NSL];
     unsigned int bact = 0u, binA = 0u, ginA = 0u;
@@ -349,22 +393,23 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
     // iterate of the current multipliers: z = argmin objective + lambda' G z
     auto refresh = [&]() {
       zeroV();
-      // lambda' G, stage by stage: the box rows first, all at once (an entry collects at most the two sides of one bound: a sum of two terms does not
-      // depend on their order), then the general rows ONE SLOT AFTER THE OTHER - several of them can meet in one entry, and the order in which
-      // the LDS serves colliding atomic adds is not ours to fix (a last-bit difference in the iterate can flip a tie of the ratio test: repeated
-      // solves of one instance differed by one step in 5 of 8 runs)
-      if (arow >= 0 && arow < 1024 && alam != 0.0) atomicAdd(&V[(arow >> 5) * 16 + (arow & 15)], (((arow >> 4) & 1) ? -alam : alam));
-      OC_WAVE_SYNC();
-      for (unsigned long long gm = __ballot(arow >= 1024 && alam != 0.0); gm; gm &= gm - 1ull) {
-        const int a = __builtin_amdgcn_readfirstlane(__ffsll((long long)gm) - 1);
-        if (tid == a) {
+      // lambda' G, stage by stage, in FIXED POINT (2^-38, 64-bit integer LDS atomics): several rows can meet in one entry, the order in which the
+      // LDS serves colliding atomic adds is not ours to fix, and a floating point sum that depends on it can flip a tie of the ratio test (repeated
+      // solves of one instance differed by one step in 5 of 8 runs) - integer sums do not depend on the order.  What the rounding (4e-12 absolute)
+      // changes is the linear term the iterate minimises, far inside the allowance of the bound; a multiplier large enough to overflow the sum
+      // (rho x a coefficient of ~20 is 2e6 of the 3e7 that fit) is beyond the exact penalty, where the node counts as infeasible anyway
+      const double FX = 274877906944.0, IFX = 1.0 / 274877906944.0;   // 2^38
+      if (arow >= 0 && alam != 0.0) {
+        if (arow < 1024) atomicAdd((unsigned long long*)&V[(arow >> 5) * 16 + (arow & 15)], (unsigned long long)(long long)__double2ll_rn((((arow >> 4) & 1) ? -alam : alam) * FX));
+        else {
           const uint4 m4 = gmeta[arow - 1024];
           const int off = (int)(m4.z & 0xFFFFu), nn = (int)((m4.z >> 16) & 7u), i = (int)((m4.z >> 20) & 0x7FFu);
 #pragma unroll
-          for (int k = 0; k < 6; ++k) if (k < nn) { double* e_ = &V[i * 16 + ((m4.w >> (4 * k)) & 15u)]; *e_ = fma(gcoef[off + k], alam, *e_); }
+          for (int k = 0; k < 6; ++k) if (k < nn) atomicAdd((unsigned long long*)&V[i * 16 + ((m4.w >> (4 * k)) & 15u)], (unsigned long long)(long long)__double2ll_rn(gcoef[off + k] * alam * FX));
         }
-        OC_WAVE_SYNC();
       }
+      OC_WAVE_SYNC();
+      for (int k = tid; k < N * 16; k += 64) V[k] = (double)(long long)__double_as_longlong(V[k]) * IFX;
       const int amax = (int)wave_max((double)astage);
       OC_WAVE_SYNC();
       subst(true, amax, N - 1, Z);
@@ -742,6 +787,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
 #ifdef MIQP_PROFILE
       { const long long tc1 = clock64(); asp_[7] += (unsigned long long)(tc1 - tc0);
         for (int q_ = 0; q_ < 9; ++q_) atomicAdd(&B.prof[80 + q_], asp_[q_]);
+        atomicAdd(&B.prof[92], asp_[9]); atomicAdd(&B.prof[93], asp_[11]);
         atomicAdd(&B.prof[90], 1ull); atomicAdd(&B.prof[91], (unsigned long long)steps); }
 #endif
       if (B.as_stats) {

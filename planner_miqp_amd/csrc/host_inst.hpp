@@ -28,7 +28,28 @@
 #define KNOB_T(name) ((const char*)nullptr)
 #endif
 
+extern char** environ;
+
 namespace miqp {
+
+// A MIQP_* variable that the shipped library does not read (a switch of a tuning build, a typo) is named once on stderr instead of being a
+// silent no-op (advisor finding of round 5).  The names the product build reads (KNOB_P) and the two of the Python side:
+inline void warn_ignored_switches() {
+#ifndef MIQP_TUNING
+  static bool done = false;
+  if (done) return;
+  done = true;
+  static const char* const known[] = {"MIQP_SEQ_KINDS", "MIQP_LNS", "MIQP_PUMP", "MIQP_CUT_GATE", "MIQP_NPR", "MIQP_OPEN_CAP", "MIQP_FAR_CAP", "MIQP_LANES", "MIQP_AS",
+                                      "MIQP_STATS", "MIQP_DEBUG_SYNC", "MIQP_TRACE", "MIQP_ROUND_LOG", "MIQP_GPU_LIB", "MIQP_BENCH_DUMP_SEEDS"};
+  for (char** e = environ; e && *e; ++e) {
+    if (std::strncmp(*e, "MIQP_", 5) != 0) continue;
+    const char* eq = std::strchr(*e, '='); const size_t len = eq ? (size_t)(eq - *e) : std::strlen(*e);
+    bool ok = false;
+    for (const char* k : known) if (std::strlen(k) == len && std::strncmp(k, *e, len) == 0) { ok = true; break; }
+    if (!ok) std::fprintf(stderr, "[miqp_gpu] environment variable %.*s is ignored: the shipped library reads only the switches of INTEGRATION.md section 5 (experiment switches exist in a tuning build, tools/build_variants.sh)\n", (int)len, *e);
+  }
+#endif
+}
 
 constexpr int MAXC = 4;          // cars supported by the device kernels (stage vector of at most 32 entries)
 constexpr int REGSZ = 32;        // doubles per (car, possible region) table entry

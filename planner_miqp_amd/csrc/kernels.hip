@@ -1601,7 +1601,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   // (one region for two tenants that are never alive together: the slow-alternative table of phase R - read for the last time by the freeze
   // resolution right behind it - and the dense rows of the lifting.  Apart they were 10 + 9 KB of a two-car workgroup's 28 KB (5 workgroups per
   // CU of a kernel that waits on memory for 60 % of its cycles; 8 now) and 61 + 17 KB at four cars x 64 regions (ONE workgroup per CU; 3 now).)
-  float* slowv = (float*)(Z + N * NZ);               // [C*N][P] slow-alternative violation per possible region (float: compared with tolerances and with each other only)
+  float* slowv = (float*)(Z + N * NZ);               // [C*N][P] slow-alternative violation per possible region (float: compared with tolerances and with each other only - a violation within one float ulp of the tolerance may be labelled differently from the double path; the label is a canonical choice among alternatives that hold, never a feasibility verdict)
   double* gsc = Z + N * NZ;                          // [64][NZ + 1] one dense row per lane (lifting)
   double* fastv = Z + N * NZ + eval_shared_doubles(C, N, P);   // [C*N] best fast alternative violation
   double* rlift = fastv + C * N;                     // [C*N] smallest lift over the region alternatives (branching score)

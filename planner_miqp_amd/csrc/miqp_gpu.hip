@@ -880,6 +880,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   const double t_enter = wall_s();
   DevCtx* Xp = ctx_for_device(O0.device, lane);
   if (!Xp) return fail_all(nullptr);
+  warn_ignored_switches();
   DevCtx& X = *Xp;
   std::lock_guard<std::mutex> ctx_lock(X.mu);
   if (hipSetDevice(X.device) != hipSuccess) return fail_all("hipSetDevice failed");
@@ -904,7 +905,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   // near list offers eight rounds' worth of eligible nodes - then the tree needs node throughput, not fresher incumbents (cfg5 seed 11: 1.61 / 2.17 / 2.92 M relaxations in 10 s at
   // 1024 / 2048 / 4096 nodes per round).  The batch arrays are sized for the widest round, select_kernel caps at width_cap
   const bool adaptive_width = NS == 1 && !split && O0.nodes_per_round <= 0 && !KNOB_P("MIQP_NPR");
-  const int width0 = npr, width_max = 16384;
+  const int width0 = npr, width_max = Y.C >= 3 ? 4096 : 16384;   // (three and four cars: 4096 - cfg5 seed 11 relaxes 2.57 / 3.21 / 3.09 / 2.96 M nodes in its 10 s at 2048 / 4096 / 8192 / 16384, its gap 2.1 / 1.8 / 3.4 / 45 %)
   if (adaptive_width) npr = width_max;
   int open_cap = O0.max_open_nodes > 0 ? O0.max_open_nodes : (KNOB_P("MIQP_OPEN_CAP") ? std::atoi(KNOB_P("MIQP_OPEN_CAP")) : std::max(1 << 17, std::min(1 << 20, (1 << 28) / NS)));   // near lists: 1 M entries per instance up to n = 256 (10 GB of list entries), 262144 at n = 1024; records are shared
   if (open_cap < 64) open_cap = 64;
@@ -1113,7 +1114,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   // roll_kernel zeroes the other for the round after - six 4-byte memsets per round less in the stream (0.65 ms of the 1.4 ms round of a single solve)
   const bool use_par = X.ctr && X.oc_grid > 0 && X.ocb_grid > 0 && X.concurrent_big && X.stream2 && X.probe_grid > 0 && !KNOB_T("MIQP_MEMSETS");
   if (use_par) HIP_OK(hipMemsetAsync(X.ctr, 0, 64, st));
-  int width_now = adaptive_width ? width0 : 0, width_since = 0, demand_now = 0; unsigned long long width_key = ~0ull, kinc_now = ~0ull;
+  int width_now = adaptive_width ? width0 : 0, width_since = 0, demand_now = 0; unsigned long long width_key = ~0ull, kinc_now = ~0ull; double lb_now = -1e300;
   for (;;) {
     const int par = rounds & 1;
     B.width_cap = width_now;
@@ -1128,11 +1129,16 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     int bc = 0;
     HIP_OK(hipMemcpyAsync(&bc, B.batch_count, 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(h_done_now.data(), B.inst_done, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    if (adaptive_width) { HIP_OK(hipMemcpyAsync(&kinc_now, B.inc_key, 8, hipMemcpyDeviceToHost, st)); HIP_OK(hipMemcpyAsync(&demand_now, B.slot_demand, 4, hipMemcpyDeviceToHost, st)); }
+    if (adaptive_width) { HIP_OK(hipMemcpyAsync(&kinc_now, B.inc_key, 8, hipMemcpyDeviceToHost, st)); HIP_OK(hipMemcpyAsync(&demand_now, B.slot_demand, 4, hipMemcpyDeviceToHost, st)); HIP_OK(hipMemcpyAsync(&lb_now, B.lower_bound, 8, hipMemcpyDeviceToHost, st)); }
     HIP_OK(hipStreamSynchronize(st));
     if (adaptive_width) {
       if (kinc_now != width_key) { width_key = kinc_now; width_since = rounds; }
-      else if (kinc_now < 0xFFF0000000000000ull && rounds - width_since >= 32 && demand_now >= 8 * width_now && width_now < width_max) { width_now *= 2; width_since = rounds; }
+      else if (kinc_now < 0xFFF0000000000000ull && rounds - width_since >= 32 && demand_now >= 8 * width_now && width_now < width_max) {
+        // ... and the incumbent is already close to the bound (within 5 %): with a poor incumbent a wide round solves what a better one would have pruned
+        // (cfg5 seed 11 widened on a stale incumbent alone ended at a gap of 45 % instead of 2 %)
+        const double io_ = host_key2d(kinc_now & ~0xFFFFFull);
+        if (lb_now > -1e299 && io_ - lb_now <= 0.05 * std::fabs(io_)) { width_now *= 2; width_since = rounds; }
+      }
     }
     const double tnow = wall_s() - t0;
     for (int sl = 0; sl < NS; ++sl) { const int k = h_slot_inst[sl]; if (k >= 0 && h_done_now[k] && h_tdone[k] < 0) h_tdone[k] = tnow - t_admit[k]; }   // time from admission to proof
@@ -1167,7 +1173,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
         // retired like instances at their time limit - the slots go to the rest of the queue, which is NOT abandoned; a second such
         // streak with nothing admitted in between ends the call with an error
         if (++empty_rounds > 64) {
-          if (stuck_once) { abandoned = true; break; }
+          if (stuck_once) { for (int sl = 0; sl < NS; ++sl) { const int k = h_slot_inst[sl]; if (k >= 0 && !h_done_now[k]) h_stalled[k] = 1; } abandoned = true; break; }   // (the instances in flight did not run out of time either)
           stuck_once = true; empty_rounds = 0;
           for (int sl = 0; sl < NS; ++sl) { const int k = h_slot_inst[sl]; if (k >= 0 && !h_done_now[k]) { h_kill[k] = 1; h_stalled[k] = 1; } }
           HIP_OK(hipMemcpyAsync(B.inst_kill, h_kill.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -1335,11 +1341,12 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     std::fprintf(stderr, "[miqp_gpu profile] on-chip nodes %llu iters %llu cycles/node-iter %.0f :", pf[11], pf[10], tot / std::max(1ull, pf[10]));
     for (int q = 0; q < 10; ++q) std::fprintf(stderr, " %s %.1f%% (%.0f)", nm[q], 100.0 * pf[q] / tot, (double)pf[q] / std::max(1ull, pf[10]));
     std::fprintf(stderr, "\n");
-    { unsigned long long pa[12]; HIP_OK(hipMemcpy(pa, B.prof + 80, 12 * 8, hipMemcpyDeviceToHost));
+    { unsigned long long pa[14]; HIP_OK(hipMemcpy(pa, B.prof + 80, 14 * 8, hipMemcpyDeviceToHost));
       const char* na[9] = {"decode", "gains + first iterate", "scan", "response of the row", "q", "directions + ratio test + M update", "iterate refresh", "results", "warm start"};
       double ta = 0; for (int q = 0; q < 9; ++q) ta += (double)pa[q];
       if (pa[10]) { std::fprintf(stderr, "[miqp_gpu profile] active-set kernel nodes %llu steps %llu cycles/node %.0f :", pa[10], pa[11], ta / (double)pa[10]);
         for (int q = 0; q < 9; ++q) std::fprintf(stderr, " %s %.1f%% (%.0f)", na[q], 100.0 * pa[q] / ta, (double)pa[q] / (double)pa[10]);
+        std::fprintf(stderr, "; inside the decode: bound classes %.0f, general-row pass %.0f", (double)pa[12] / (double)pa[10], (double)pa[13] / (double)pa[10]);
         std::fprintf(stderr, "\n"); } }
     { unsigned long long pe[8]; HIP_OK(hipMemcpy(pe, B.prof + 100, 8 * 8, hipMemcpyDeviceToHost));
       const char* ne[6] = {"load", "regions", "leaf disjunctions", "branching", "lifting + reservation", "records"};
