@@ -380,7 +380,10 @@ def main():
         traffic = None; traffic_note = None
         tj = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_traffic.json" % r) for r in (6, 5, 4, 3, 2)) if os.path.exists(q)), "")
         if os.path.exists(tj) and a.config == "cfg3":
-            tjd = json.load(open(tj)); traffic = tjd.get("bytes_per_round_corrected"); traffic_note = "%s [file %s, from %s]" % (tjd.get("note"), os.path.basename(tj), tjd.get("source"))
+            tjd = json.load(open(tj))
+            dk_ = tjd.get("dominant_kernel_bytes_per_launch_corrected") if use_as else None   # (per launch of the dominant kernel, like `achieved`; files of rounds <= 5: the interior point launches of a round)
+            traffic = dk_ if dk_ is not None else tjd.get("bytes_per_round_corrected")
+            traffic_note = "%s%s [file %s, from %s]" % ("L2<->fabric bytes per launch of as_onchip_kernel<2,10,128> alone; " if dk_ is not None else "", tjd.get("note"), os.path.basename(tj), tjd.get("source"))
         if use_as:
             fixlen = 16 * ((Cc * N * (1 + 5 + 5 * synthetic.CONFIGS[a.config][4]) + (Cc * (Cc - 1) // 2) * N * 8 + Cc * N * 2 + 15) // 16)   # bytes of a node's fix record
             n_end = asx[4] / as_nodes; n_par = asx[5] / as_nodes; st_ = as_steps / as_nodes

@@ -473,7 +473,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (X.as_on && B.z_cap > 0 && Y.N * Y.NSLOT + 1024 < 65535) {   // the parents' active sets for the children's starts (128 B per record)
     if (!X.alloc(&B.batch_A, (size_t)batch_alloc * 64)) return false;
     if (!X.alloc(&B.pool_A, (size_t)B.z_cap * 64)) return false;
-    HIP_OK(hipMemset(B.pool_A, 0xFF, (size_t)B.z_cap * 128));
+    // (pool_A / pool_Mtag need no initial value: a record's entries are written when the record is created - eval_kernel, lns_kernel - and roots start cold)
     HIP_OK(hipMemset(B.batch_A, 0xFF, (size_t)batch_alloc * 128));
     X.as_batch_A = B.batch_A; X.as_pool_A = B.pool_A;
     // ... and the ring their M travels through (4 KB per node on average, at most 12.8): a quarter of the free memory, at most 96 GB
@@ -485,7 +485,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
       if (!X.alloc(&B.batch_Mtag, batch_alloc)) return false;
       if (!X.alloc(&B.pool_Mtag, (size_t)B.z_cap)) return false;
       { const unsigned long long h0 = 1024ull; HIP_OK(hipMemcpy(B.ring_head, &h0, 8, hipMemcpyHostToDevice)); }
-      HIP_OK(hipMemset(B.pool_Mtag, 0, (size_t)B.z_cap * 8)); HIP_OK(hipMemset(B.batch_Mtag, 0, (size_t)batch_alloc * 8));
+      HIP_OK(hipMemset(B.batch_Mtag, 0, (size_t)batch_alloc * 8));
       B.ring_doubles = (unsigned long long)rd; B.ring_margin = (unsigned long long)margin;
     }
   }
