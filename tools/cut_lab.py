@@ -50,9 +50,11 @@ def sector_polygon(I, j, box, slow=False):
 
 
 def node_rows(M, sol, regions=None, sets=None, cuts=None, extra=()):
-    """rows of the node: c2c (rear/rear only unless regions are given) + env rear as in `sol`; regions: None = undecided (hull of sets[c][i])"""
+    """rows of the node: c2c (rear/rear only unless regions are given) + env rear as in `sol`; regions: None = undecided (hull of sets[c][i]),
+    True = all fixed as in the optimum, an int k = the regions of steps 1..k fixed, the later ones undecided (round 6: nodes deeper in the tree)"""
     I = M.I; rows = []
     reg = sol["region"]
+    fixed = lambda i: regions is True or (regions is not None and regions is not False and not isinstance(regions, bool) and i <= regions)
     for c in range(I.C):
         for i in range(I.N):
             rows += M.global_rows(c, i)
@@ -61,7 +63,7 @@ def node_rows(M, sol, regions=None, sets=None, cuts=None, extra=()):
     for p, (c1, c2) in enumerate(M.pairs):
         for i in range(1, I.N):
             for g in range(4):
-                if regions is None and g != 0 and 'c2cfront' not in extra: continue
+                if not fixed(i) and g != 0 and 'c2cfront' not in extra: continue
                 alt = next((a for a in range(4) if c2c[c1, c2 - 1, i, 4 * g + a] == 0), None)
                 if alt is None: continue
                 rows += M.c2c_rows(p, i, g, alt, reg[c1][i], reg[c2][i])
@@ -69,7 +71,7 @@ def node_rows(M, sol, regions=None, sets=None, cuts=None, extra=()):
     for c in range(I.C):
         for i in range(1, I.N):
             for pt in range(5):
-                if regions is None and pt != 0 and 'envfront' not in extra: continue
+                if not fixed(i) and pt != 0 and 'envfront' not in extra: continue
                 e = next((e for e in range(I.E) if env[pt][c][e][i] == 0), None)
                 if e is None: continue
                 rows += M.env_rows(c, i, pt, e, reg[c][i])
@@ -77,7 +79,7 @@ def node_rows(M, sol, regions=None, sets=None, cuts=None, extra=()):
     for c in range(I.C):
         o = 6 * c; u = 6 * I.C + 2 * c
         for i in range(1, I.N):
-            if regions is not None:
+            if fixed(i):
                 j = reg[c][i]
                 if rc[4][c][i] == 1: h = -1
                 else:
