@@ -395,6 +395,84 @@ def test_cfg5s_four_cars_against_the_oracle(oracle):
         oracle.free(h)
 
 
+def test_what_a_stream_retires_at_its_limit_is_still_a_valid_answer(oracle):
+    """round 5's review, item 6: on the driver's stream a few instances in a thousand end with the time-limit verdict (CPLEX status 107:
+    `cplex.solve()` returned an incumbent, not a proof - src/cplex_wrapper.cpp:190-248 maps it to SUCCESS).  What such an instance
+    returns must still be right: the incumbent feasible for every row of the raw big-M model and evaluated correctly, its best_bound
+    below the optimum the CPU oracle proves and its objective not below it.  A queue with a limit short enough that a good number of
+    its instances are retired unfinished (0.15 s each, 48 in flight)"""
+    seeds = list(range(3300, 3396))
+    ps = [synthetic.generate("cfg3", s, gap=1e-4, max_time=0.15) for s in seeds]
+    ws = []
+    for p in ps:
+        w = P.CplexWrapper(); w.resetParameters(p); ws.append(w)
+    sts = P.solve_batch(ws, inflight=48)
+    retired = [(s, p, w) for s, p, w, st in zip(seeds, ps, ws, sts) if int(st) == 0 and w.getSolutionProperties().status == 107]
+    print("[count] retired at their limit with an incumbent:", len(retired), "of", len(seeds))
+    assert len(retired) >= 8, len(retired)
+    for p in ps:
+        p.max_solution_time = 60.0
+    for _, p, _ in retired:
+        p.relative_mip_gap_tolerance = 1e-2
+    res = _oracle_many(oracle, [p for _, p, _ in retired], 1e-2, 40)   # (these are the hard ones: whatever the oracle has after 40 s - an incumbent is an upper bound of the optimum, its best bound a lower one)
+    compared = 0
+    for (s, p, w), (ost, ores, op) in zip(retired, res):
+        pr = w.getSolutionProperties()
+        h = oracle.from_params(p, 10)
+        v, obj, worst = oracle.raw_eval(h, w.getRawResults())
+        oracle.free(h)
+        assert v < 1e-5 and abs(obj - pr.objective) <= 1e-6 * max(1.0, abs(obj)), (s, worst, obj, pr.objective)
+        assert pr.best_bound <= pr.objective + 1e-9 and pr.gap > 1e-4, (s, pr.best_bound, pr.objective, pr.gap)
+        if ost == 0 and op.status in (101, 102, 107):
+            compared += 1
+            tol = 1e-7 * max(1.0, abs(op.objective))
+            assert pr.best_bound <= op.objective + tol, (s, pr.best_bound, op.objective)      # what it had proven so far is true: below a feasible point's value
+            assert pr.objective >= op.best_bound - tol, (s, pr.objective, op.best_bound)      # and its incumbent is not below what the oracle has proven
+    print("[count] of those, compared with the oracle's incumbent and bound:", compared)
+    assert compared >= 4, compared
+
+
+def test_four_cars_on_the_64_region_tables_against_the_oracle(oracle):
+    """round 5's review, item 6: beyond cfg5s (32 regions) nothing with four cars was compared with anything but itself.  Four cars x 10
+    steps on the 64-REGION tables of BASELINE config 5 (common/parameter/fitting_polynomial_parameters.hpp:875-1281; cfg5 itself - 30
+    steps - is beyond the CPU oracle): at gap 1e-4 on the seeds the oracle proves within its limit the objectives agree within the two
+    gaps, each side's bound lies below the other's solution, the regions agree (up to ties on a sector border) and the states to 1e-3
+    where they do, and the device result is feasible for the raw big-M model"""
+    G = 1e-4
+    cfg = (4, 10, 64, 2, 0)
+    seeds = list(range(8))
+    ps = [synthetic.generate(cfg, s, gap=G, max_time=60) for s in seeds]
+    ws = []
+    for p in ps:
+        w = P.CplexWrapper(); w.resetParameters(p); ws.append(w)
+    sts = [w.callCplex() for w in ws]
+    res = _oracle_many(oracle, ps, G, 90)
+    compared = same_leaf = 0
+    for s, p, w, st, (ost, ores, op) in zip(seeds, ps, ws, sts, res):
+        pr = w.getSolutionProperties()
+        assert int(st) == 0 and pr.status in (101, 102) and pr.gap <= G + 1e-12, (s, int(st), pr.status, pr.gap)
+        h = oracle.from_params(p, 10)
+        v, obj, worst = oracle.raw_eval(h, w.getRawResults())
+        oracle.free(h)
+        assert v < 1e-5 and abs(obj - pr.objective) <= 1e-6 * max(1.0, abs(obj)), (s, worst)
+        if ost != 0 or op.status not in (101, 102) or op.gap > G + 1e-12:
+            continue
+        compared += 1
+        assert abs(pr.objective - op.objective) <= 2 * G * abs(op.objective), (s, pr.objective, op.objective)
+        assert pr.best_bound <= op.objective * (1 + 1e-9) and op.best_bound <= pr.objective * (1 + 1e-9), (s, pr.best_bound, op.best_bound)
+        r = w.getRawResults()
+        # the same leaf on both sides (regions equal up to ties on a sector border): then the same states.  Two leaves within the gap of each
+        # other - with 64 sectors of 5.6 degrees a velocity a few mm/s off a border is common - are both right at this gap
+        try:
+            assert_regions_canonical_equal(p, r, ores)
+        except AssertionError:
+            continue
+        same_leaf += 1
+        assert_states_close(r, ores, tol=1e-3, fields=CONT_FIELDS[:8])
+    print("[count] four cars x 64 regions compared with the oracle:", compared, "of", len(seeds), "- the same leaf on both sides:", same_leaf)
+    assert compared >= 3 and same_leaf >= 1, (compared, same_leaf)
+
+
 def test_three_car_reference_fixture_beats_the_recorded_cplex_point(oracle):
     """cplexmodel.dat (K5: 3 cars, 8 steps, 11 environment pieces; the reference's modelRun.txt point evaluates to
     741.22 in the raw model): the device result within 5 s is feasible for the raw big-M model and not worse"""
