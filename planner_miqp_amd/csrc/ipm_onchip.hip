@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     double cutoff = 1e300;
     {
       const double inc0 = fmin(inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]), B.inc_ext[inst]);
-      if (B.use_cutoff && inc0 < 1e300) cutoff = inc0 - B.inst_gap[inst] * (1e-10 + fabs(inc0)) - B.inst_const[inst];
+      if (B.use_cutoff && inc0 < 1e300) cutoff = inc0 - (is_probe_word(B.batch_depth[node]) ? 0.0 : B.inst_gap[inst]) * (1e-10 + fabs(inc0)) - B.inst_const[inst];   // (a heuristic leaf is cut off at the incumbent itself: as_onchip.hip)
     }
 #ifdef MIQP_PROFILE
     unsigned long long ocp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

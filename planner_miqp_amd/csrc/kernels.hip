@@ -708,7 +708,7 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
   double cutoff = 1e300;
   {
     const double inc0 = fmin(inc_from_key(*(volatile unsigned long long*)&B.inc_key[inst]), B.inc_ext[inst]);
-    if (B.use_cutoff && inc0 < 1e300) cutoff = inc0 - B.inst_gap[inst] * (1e-10 + fabs(inc0)) - B.inst_const[inst];
+    if (B.use_cutoff && inc0 < 1e300) cutoff = inc0 - (is_probe_word(B.batch_depth[node]) ? 0.0 : B.inst_gap[inst]) * (1e-10 + fabs(inc0)) - B.inst_const[inst];   // (a heuristic leaf is cut off at the incumbent itself: as_onchip.hip)
   }
   double tsum = 0.0;   // sum of the elastic slacks of the current iterate
   double abr[KB];  // [A B] as MFMA operand: lane (g, c) holds AB[4kb + g][c]

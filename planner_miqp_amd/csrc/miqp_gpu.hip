@@ -477,9 +477,9 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
     HIP_OK(hipMemset(B.batch_A, 0xFF, (size_t)batch_alloc * 128));
     X.as_batch_A = B.batch_A; X.as_pool_A = B.pool_A;
     // ... and the ring their M travels through (4 KB per node on average, at most 12.8): a quarter of the free memory, at most 96 GB
-    size_t rd = std::min<size_t>(std::min<size_t>((size_t)12 << 30, free_b / 4 / 8), std::max<size_t>((size_t)512 << 20, (size_t)n_slots * ((size_t)8 << 20)));   // doubles: 64 MB per instance in flight, at least 4 GB (a single solve: hundreds of its rounds; a large allocation costs seconds when the context is built)
+    size_t rd = std::min<size_t>(std::min<size_t>((size_t)12 << 30, free_b / 4 / 8), std::max<size_t>((size_t)1 << 30, (size_t)n_slots * ((size_t)8 << 20)));   // doubles: 64 MB per instance in flight, at least 8 GB (a single solve: hundreds of its rounds; a large allocation costs seconds when the context is built)
     const size_t margin = (size_t)batch_alloc * AS_MSTR + ((size_t)1 << 20);   // what one round's launches can allocate, and more
-    if (rd >= 4 * margin) {
+    if (rd >= 2 * margin) {
       if (!X.alloc(&B.ring_M, rd)) return false;
       if (!X.alloc(&B.ring_head, 1)) return false;
       if (!X.alloc(&B.batch_Mtag, batch_alloc)) return false;
@@ -885,7 +885,11 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   std::lock_guard<std::mutex> ctx_lock(X.mu);
   if (hipSetDevice(X.device) != hipSuccess) return fail_all("hipSetDevice failed");
   const int NS = (split || inflight <= 0 || inflight >= n) ? n : inflight;   // slots = instances in flight
-  int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(16384, 32768 / (NS * lanes)));   // (the lanes of a call keep the round width of the undivided call)
+  // nodes of a round, all instances together: 32768 for three and four cars (and one), 98304 for two - since the node relaxations of two cars are active-set
+  // solves (round 6) a round of 32768 lasts 5-6 ms of which 1.1 ms are the serial kernels and the tail of the launch; the driver's stream at 32 k / 49 k / 65 k /
+  // 97 k / 131 k / 164 k nodes per round: 1783 / 1849 / 1864 / 1911 / 1856 / 1826 solves/s (time to a proof p50 0.043 -> 0.106 s, p99 7.4 -> 4.3 s at 97 k)
+  const int round_nodes = Y.C == 2 ? 98304 : 32768;
+  int npr = O0.nodes_per_round > 0 ? O0.nodes_per_round : std::max(16, std::min(16384, round_nodes / (NS * lanes)));   // (the lanes of a call keep the round width of the undivided call)
   // three and four cars: a node relaxation costs ~15 x that of two cars (memory-backed kernel, stage vector 24 / 32), a round of 32768 nodes
   // lasts 0.13 s and an instance that shares the device gets 80 rounds in its 10 s - fewer than the levels of its first dive.  Rounds of
   // 5120 nodes (0.035 s) give the tree its depth back at a quarter less node throughput: cfg5, 16 in flight, 7 -> 11 of 16 proven in 10 s.
