@@ -738,6 +738,8 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
       lres = fabs(wave_sum(lres));
     } else if (infeas) viol = 1.0;
     if (!fail && !infeas && ok == 1 && !(viol <= 5.0e-7)) { fail = true; why = 5; }   // (the rows of the active set drifted off their equalities: not a result)
+    // (as_probe_first) a rounding probe that turns out infeasible while the re-rounding applies: the interior point solves it again, for its least-violation point
+    if (BIG && infeas && B.as_probe_first && B.pump_max > 0 && is_probe_word(B.batch_depth[node]) && (cutoff > 1e299 || B.pump_inc)) fail = true;
     if (fail) {
       // marked and returned unsolved: the interior point chain takes the record next round (large_class 2)
       if (B.batch_A) B.batch_A[(size_t)node * 64 + tid] = 0xFFFFu;

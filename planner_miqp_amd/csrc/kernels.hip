@@ -198,6 +198,7 @@ struct DevBuf {
   unsigned long long* batch_Mtag;   // [batch_cap]
   unsigned long long* pool_Mtag;    // [z_cap]
   int width_cap;                 // > 0: nodes a single solve takes per round at most (the host widens it when the solve is bound-limited)
+  int as_probe_first;            // 1: a rounding probe that may be re-rounded goes to the active-set launch first and to the interior point only when it turns out infeasible (a round later)
   int as_chunk;                  // consecutive batch slots a wavefront of the active-set launches takes at a time
   int as_split;                  // 1: the larger interior point variant takes only the nodes of large_class 2 (class 1: the larger active-set launch on the third stream, class 3: the memory-backed launch on the fourth)
   unsigned long long* as_stats;  // [8] nodes, steps (rows added + dropped), handed to the interior point, rows dropped, infeasible, cut off, sum of the final active set sizes
@@ -314,7 +315,7 @@ __device__ inline unsigned char large_class(const DevBuf& B, int rec, int dw, bo
   if (!probe && !(pb & 0xF7u)) return 0;
   if (pb & 2u) return 3;
   if (pb & 4u) return 2;
-  if (probe && B.pump_max > 0 && (!has_inc || B.pump_inc)) return 2;
+  if (probe && B.pump_max > 0 && (!has_inc || B.pump_inc) && !B.as_probe_first) return 2;
   return 1;
 }
 

@@ -1064,6 +1064,10 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   // (read per call, not only when the device context is built: a context is reused by every later call of the same shape)
   B.cut_gate = KNOB_P("MIQP_CUT_GATE") ? std::atof(KNOB_P("MIQP_CUT_GATE")) : 1.0e-5;
   B.seq_kinds = KNOB_P("MIQP_SEQ_KINDS") ? (int)std::strtoul(KNOB_P("MIQP_SEQ_KINDS"), nullptr, 0) : (5 << 8);
+  // a single solve sends its re-roundable rounding probes to the active-set launch first (the interior point - up to 40 iterations of 70 us on the
+  // critical path of its round - only sees the ones that turn out infeasible, a round later): seeds 0-95 p50 5.0 -> 4.0 ms at gap 0.1, 5.7 -> 5.0 at
+  // 0.01, p90 / p99 unchanged; a queue keeps the direct route (1898 against 1868 solves/s on the driver's stream)
+  B.as_probe_first = KNOB_T("MIQP_AS_PROBE_FIRST") ? std::atoi(KNOB_T("MIQP_AS_PROBE_FIRST")) : (NS == 1 ? 1 : 0);
   { const char* e = KNOB_P("MIQP_AS"); X.as_on = X.as_cap && !(e && std::atoi(e) == 0);   // (per call, like the other search switches: a context is reused by later calls of the same shape)
     B.batch_A = X.as_on ? X.as_batch_A : nullptr; B.pool_A = X.as_on ? X.as_pool_A : nullptr; }
   B.lns_mode = KNOB_P("MIQP_LNS") ? std::atoi(KNOB_P("MIQP_LNS")) : 45;
