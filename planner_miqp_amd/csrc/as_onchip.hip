@@ -56,11 +56,13 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
   const int tid = threadIdx.x, lg = tid >> 4, lc = tid & 15;
   const int par = lg >> 1, side = lg & 1;
   const double bsgn = side ? -1.0 : 1.0;
-  const int nbatch = *B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap;
+  WAVE_DUMP(BIG ? 1 : 4);
+  const int* const clist = BIG && B.cls_take ? B.cls_list + (size_t)(B.cls_take - 1) * B.batch_cap : nullptr;   // (the larger launch: the list of its class, nothing to scan)
+  const int nbatch = clist ? (B.cls_count[B.cls_take - 1] < B.batch_cap ? B.cls_count[B.cls_take - 1] : B.batch_cap) : (*B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap);
   const int N = Y.N, NSLOT = Y.NSLOT;
   extern __shared__ double lds[];
   char* const L0 = (char*)lds;
-  const OcLds LL = oc_lds_layout(N, Y.fixlen, OC_GCAP);
+  const OcLds LL = oc_lds_layout(N, Y.fixlen, OC_GCAP, !BIG);
   double* const Z = (double*)(L0 + LL.z);                   // [N][16] iterate
   double* const scr = (double*)(L0 + LL.u);                 // decode: dense scratch rows
   double* const V = (double*)(L0 + LL.u);                   // [N][16] right-hand side / result of a substitution
@@ -80,26 +82,40 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
   unsigned short* const cand = (unsigned short*)(L0 + LL.cand);
   signed char* const fix = (signed char*)(L0 + LL.fix);
   __shared__ int sh_node;
+  // the counters of the launches' statistics, per wavefront, added to the device's once at its end: ten adds per node to adjacent words were
+  // 8.5 ms of the memory system's atomic unit per round of 87 k nodes (9.8 ns each, one after the other: tools/atomic_lab.hip) - as long as the launch itself
+  __shared__ unsigned long long sh_stat[32];
+  if (tid < 32) sh_stat[tid] = 0ull;
   const unsigned long long lt = (1ull << tid) - 1ull;
 
   // nodes are handed out in runs of `chunk` consecutive batch slots (a batch lists an instance's nodes next to each other: the nodes of a run
   // read the same instance tables - 28 KB, most of the decode's loads - from this CU's L1 instead of from L2)
   const int chunk = B.as_chunk > 0 ? B.as_chunk : 1;
   int run_next = 0, run_end = 0;
+  const int quota = BIG ? 0 : B.as_quota; int handed = 0;
+#ifdef MIQP_PROFILE   // residence of this wavefront: shader cycles and the 100 MHz clock; per launch the first start, the first wavefront out of work, the last end
+  const unsigned long long wv_c0 = __builtin_amdgcn_s_memtime(), wv_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long wv_first = 0; int wv_nodes = 0;
+  if (!BIG && tid == 0) wv_first = atomicMin(&B.prof[120], wv_r0);
+#endif
   for (;;) {
     __syncthreads();
     if (run_next >= run_end) {
+      if (quota > 0 && handed >= quota) break;
+      ++handed;
       if (tid == 0) sh_node = atomicAdd(B.work_counter, chunk);
       __syncthreads();
       run_next = __builtin_amdgcn_readfirstlane(sh_node); run_end = run_next + chunk;
       if (run_next >= nbatch) break;
     }
-    const int node = run_next++;
-    if (node >= nbatch) { run_next = run_end; continue; }
+    const int slot_ = run_next++;
+    if (slot_ >= nbatch) { run_next = run_end; continue; }
+    const int node = clist ? __builtin_amdgcn_readfirstlane(clist[slot_]) : slot_;
     {   // the split of the round between the launches: select_kernel's snapshot (large_class)
       const int cls = B.batch_large ? (int)B.batch_large[node] : (is_probe_word(B.batch_depth[node]) ? 1 : 0);
       if (cls != (BIG ? 1 : 0)) continue;
     }
+    WAVE_DUMP_NODE();
     const int inst = __builtin_amdgcn_readfirstlane(B.batch_inst[node]);
     const double* D = B.inst_d + (size_t)inst * Y.dstride;
     const int* T = B.inst_i + (size_t)inst * Y.istride;
@@ -458,7 +474,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
           if (tg != 0ull && *(volatile unsigned long long*)B.ring_head - c_ < B.ring_doubles - B.ring_margin) { nmp = (int)(tg & 255ull); moff = c_ % B.ring_doubles; }
         }
         nmp = __builtin_amdgcn_readfirstlane(nmp);
-        if (B.as_stats && tid == 0 && !(nmp > 0 && nmp == __popcll(u0p))) atomicAdd(&B.as_stats[16 + (B.ring_M == nullptr ? 0 : (B.pool_Mtag[rec] == 0ull ? 1 : (nmp == 0 ? 2 : 3)))], 1ull);   // (diagnostic) why M is rebuilt: no ring, the parent left none, the ring has come round, another row count
+        if (B.as_stats && tid == 0 && !(nmp > 0 && nmp == __popcll(u0p))) sh_stat[16 + (B.ring_M == nullptr ? 0 : (B.pool_Mtag[rec] == 0ull ? 1 : (nmp == 0 ? 2 : 3)))] += 1ull;   // (diagnostic) why M is rebuilt: no ring, the parent left none, the ring has come round, another row count
         if (nmp > 0 && nmp == __popcll(u0p)) {
           // the parent's M: entry (a, b) of the packed triangle at tri(max rank) + min rank.  The triangle comes in with contiguous loads, all in
           // flight at once, into LDS; the lanes pick their rows there (loads of single entries, one wait each, cost 4 x the rest of a node in a
@@ -744,7 +760,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
       // marked and returned unsolved: the interior point chain takes the record next round (large_class 2)
       if (B.batch_A) B.batch_A[(size_t)node * 64 + tid] = 0xFFFFu;
       if (B.ring_M && tid == 0) B.batch_Mtag[node] = 0ull;
-      if (tid == 0) { B.batch_ok[node] = 5; B.pool_big[B.batch_node[node]] |= 4; if (B.as_stats) { atomicAdd(&B.as_stats[2], 1ull); atomicAdd(&B.as_stats[10 + (why < 6 ? why : 5)], 1ull); } }
+      if (tid == 0) { B.batch_ok[node] = 5; B.pool_big[B.batch_node[node]] |= 4; if (B.as_stats) { sh_stat[2] += 1ull; sh_stat[10 + (why < 6 ? why : 5)] += 1ull; } }
       continue;
     }
     const double obj = (infeas || ok == 2) ? Dval : objective() + scost;
@@ -787,17 +803,42 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
       atomicAdd((unsigned long long*)&B.inst_nodes[inst], 1ull);
       atomicAdd((unsigned long long*)&B.inst_iters[inst], (unsigned long long)steps);
 #ifdef MIQP_PROFILE
+      ++wv_nodes;
       { const long long tc1 = clock64(); asp_[7] += (unsigned long long)(tc1 - tc0);
         for (int q_ = 0; q_ < 9; ++q_) atomicAdd(&B.prof[80 + q_], asp_[q_]);
         atomicAdd(&B.prof[92], asp_[9]); atomicAdd(&B.prof[93], asp_[11]);
         atomicAdd(&B.prof[90], 1ull); atomicAdd(&B.prof[91], (unsigned long long)steps); }
 #endif
       if (B.as_stats) {
-        atomicAdd(&B.as_stats[0], 1ull); atomicAdd(&B.as_stats[1], (unsigned long long)steps); atomicAdd(&B.as_stats[3], (unsigned long long)ndrop);
-        atomicAdd(&B.as_stats[4], infeas ? 1ull : 0ull); atomicAdd(&B.as_stats[5], ok == 2 ? 1ull : 0ull); atomicAdd(&B.as_stats[6], (unsigned long long)__popcll(used)); atomicAdd(&B.as_stats[7], (unsigned long long)nwarm); atomicAdd(&B.as_stats[8], (unsigned long long)nfast); atomicAdd(&B.as_stats[9], (unsigned long long)ncold);
+        sh_stat[0] += 1ull; sh_stat[1] += (unsigned long long)steps; sh_stat[3] += (unsigned long long)ndrop;
+        sh_stat[4] += infeas ? 1ull : 0ull; sh_stat[5] += ok == 2 ? 1ull : 0ull; sh_stat[6] += (unsigned long long)__popcll(used); sh_stat[7] += (unsigned long long)nwarm; sh_stat[8] += (unsigned long long)nfast; sh_stat[9] += (unsigned long long)ncold;
+        if (BIG) { const int og_ = B.pool_origin ? (int)B.pool_origin[B.batch_node[node]] : 0; sh_stat[20] += 1ull; sh_stat[21] += (unsigned long long)steps; if (og_ == 14) { sh_stat[22] += 1ull; sh_stat[23] += (unsigned long long)steps; }
+          sh_stat[24 + (ngen <= 64 ? 0 : ngen <= 96 ? 1 : ngen <= 128 ? 2 : ngen <= 192 ? 3 : 4)] += 1ull; if (is_probe_word(B.batch_depth[node]) && og_ != 14) sh_stat[29] += 1ull; }   // (the larger block: its nodes and steps, the local search's leaves among them)
       }
     }
   }
+  __syncthreads();
+  if (B.as_stats && tid < 32 && sh_stat[tid] != 0ull) atomicAdd(&B.as_stats[tid], sh_stat[tid]);
+#ifdef MIQP_PROFILE
+  if (!BIG && tid == 0) {
+    const unsigned long long wv_c1 = __builtin_amdgcn_s_memtime(), wv_r1 = __builtin_amdgcn_s_memrealtime();
+    atomicAdd(&B.prof[94], wv_c1 - wv_c0); atomicAdd(&B.prof[95], wv_r1 - wv_r0); atomicAdd(&B.prof[96], 1ull);
+    atomicMin(&B.prof[122], wv_r1); atomicMax(&B.prof[121], wv_r1);
+    // start of this wavefront after the launch's first (100 MHz ticks): < 0.05, 0.2, 0.5, 1, 2, 4, 8 ms, later; nodes it solved: 0, <= 4, <= 16, <= 32, <= 64, more
+    const unsigned long long dl = wv_r0 > wv_first ? wv_r0 - wv_first : 0ull;
+    const int hb = dl < 5000 ? 0 : dl < 20000 ? 1 : dl < 50000 ? 2 : dl < 100000 ? 3 : dl < 200000 ? 4 : dl < 400000 ? 5 : dl < 800000 ? 6 : 7;
+    atomicAdd(&B.prof[128 + hb], 1ull);
+    const int nb = wv_nodes == 0 ? 0 : wv_nodes <= 4 ? 1 : wv_nodes <= 16 ? 2 : wv_nodes <= 32 ? 3 : wv_nodes <= 64 ? 4 : 5;
+    atomicAdd(&B.prof[136 + nb], 1ull);
+    if (B.prof[125] == 300 && blockIdx.x < 4096) {   // one launch from the middle of the stream, wavefront by wavefront (MIQP_WAVE_DUMP)
+      unsigned int hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned long long* const w = B.prof + 160 + 4 * blockIdx.x;
+      w[0] = wv_r0; w[1] = wv_r1; w[2] = ((unsigned long long)xcc << 32) | hw; w[3] = (unsigned long long)wv_nodes;
+    }
+  }
+#endif
 }
 
 }  // namespace miqp

@@ -44,12 +44,15 @@ struct OcLds { int z, u, r, gmeta, gcoef, grhs, wd, sstart, cand, fix, total; };
 // to OC_GCAP_BIG general rows): 5 register slots per lane, one wavefront per SIMD, 4 blocks of ~34 KB per CU
 constexpr int OC_GCAP_BIG = 320;
 __host__ __device__ constexpr int oc_gcoef_of(int gcap) { return gcap == 128 ? 432 : gcap * 7 / 2; }
-__host__ __device__ inline OcLds oc_lds_layout(int N, int fixlen, int OC_GCAP = miqp::OC_GCAP) {
+// (as_std: the block of the standard active-set launch - its second region holds one stage vector and the decode scratch, its third the box keys
+// alone: 768 B less at N = 20, so that eight blocks leave 6 KB of a CU's 160 KB free instead of none - with none, the holes the larger launches'
+// 34 KB blocks leave behind kept every CU at six or seven blocks, tools/wave_dump.py)
+__host__ __device__ inline OcLds oc_lds_layout(int N, int fixlen, int OC_GCAP = miqp::OC_GCAP, bool as_std = false) {
   const int OC_GCOEF = oc_gcoef_of(OC_GCAP);
   OcLds L; int o = 0;
   L.z = o; o += N * 16 * 8;
-  L.u = o; { int a = N * 32 * 8, b = OC_SCR * OC_SSTR * 8; o += a > b ? a : b; }    // D | Gd  /  dZ | gains  /  decode scratch
-  L.r = o; { int a = N * 32 * 8, b = OC_GCAP * 16 + OC_KL0 * 64 * 8; o += a > b ? a : b; }   // box right-hand side keys (decode) / (sqrt(w), f) of the general rows + gains of the first stages
+  L.u = o; { int a = as_std ? N * 16 * 8 : N * 32 * 8, b = OC_SCR * OC_SSTR * 8; o += a > b ? a : b; }    // D | Gd  /  dZ | gains  /  decode scratch
+  L.r = o; { int a = N * 32 * 8, b = as_std ? 0 : OC_GCAP * 16 + OC_KL0 * 64 * 8; o += a > b ? a : b; }   // box right-hand side keys (decode) / (sqrt(w), f) of the general rows + gains of the first stages
   L.gmeta = o; o += OC_GCAP * 16;
   L.gcoef = o; o += OC_GCOEF * 8;
   L.grhs = o; o += OC_GCAP * 8;
@@ -219,7 +222,9 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
   const int tid = threadIdx.x, lg = tid >> 4, lc = tid & 15;
   const int par = lg >> 1, side = lg & 1;                   // box rows of this lane: column lc, side, stages 2k + par
   const double bsgn = side ? -1.0 : 1.0;
-  const int nbatch = BIG && B.ovf_mode == 1 ? *B.ovf_count : (*B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap);
+  WAVE_DUMP(2);
+  const int* const clist = BIG && B.cls_take ? B.cls_list + (size_t)(B.cls_take - 1) * B.batch_cap : nullptr;   // (the list of this launch's class: nothing to scan)
+  const int nbatch = clist ? (B.cls_count[B.cls_take - 1] < B.batch_cap ? B.cls_count[B.cls_take - 1] : B.batch_cap) : BIG && B.ovf_mode == 1 ? *B.ovf_count : (*B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap);
   const int N = Y.N, NSLOT = Y.NSLOT;
   extern __shared__ double lds[];
   char* const L0 = (char*)lds;
@@ -257,7 +262,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
     if (tid == 0) sh_node = atomicAdd(B.work_counter, 1);
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(sh_node) >= nbatch) break;
-    const int node = __builtin_amdgcn_readfirstlane(BIG && B.ovf_mode == 1 ? B.ovf_list[sh_node] : sh_node);   // wave-uniform by construction: said so, everything derived from it
+    const int node = __builtin_amdgcn_readfirstlane(clist ? clist[sh_node] : BIG && B.ovf_mode == 1 ? B.ovf_list[sh_node] : sh_node);   // wave-uniform by construction: said so, everything derived from it
                                                                   // (instance tables, references) is then addressed from SGPRs
     // the concurrent launch of the larger variant takes the nodes known to be large before the round: the rounding probes (their
     // depth word says so) and the records marked by an earlier decode or inherited from a marked parent
@@ -267,6 +272,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) ipm_onchip_kernel(De
       if (BIG ? !marked : marked) continue;   // the other launch of the round solves it
       if (BIG && B.as_split && B.batch_large[node] != 2) continue;   // ... or the larger active-set launch (class 1), or the memory-backed launch on its own stream (class 3): large_class
     }
+    WAVE_DUMP_NODE();
     const int inst = __builtin_amdgcn_readfirstlane(B.batch_inst[node]);
     const double* D = B.inst_d + (size_t)inst * Y.dstride;
     const int* T = B.inst_i + (size_t)inst * Y.istride;

@@ -120,6 +120,7 @@ struct DevBuf {
   double* inc_obj;               // objective of the stored incumbent
   double* inc_ext;               // upper bound from outside (tree split over ranks: the best incumbent of the other ranks), 1e300 otherwise
   signed char* inc_fix; double* inc_Z;
+  unsigned short* inc_A; unsigned long long* inc_Mtag;   // [n_inst][64], [n_inst]: active set and ring tag of M of the solve that found the incumbent (active-set launches; tag 0: none) - the start of the local search's leaves
   double* lower_bound; int* inst_done; int* inst_flags; double* inst_gap; double* inst_const;
   long long* inst_nodes; long long* inst_iters; int* inst_ninc;
   // batch of the current round
@@ -200,6 +201,12 @@ struct DevBuf {
   int width_cap;                 // > 0: nodes a single solve takes per round at most (the host widens it when the solve is bound-limited)
   int as_probe_first;            // 1: a rounding probe that may be re-rounded goes to the active-set launch first and to the interior point only when it turns out infeasible (a round later)
   int as_chunk;                  // consecutive batch slots a wavefront of the active-set launches takes at a time
+  int* cls_list;                 // [3][batch_cap] batch slots of large_class 1 / 2 / 3, appended by select_kernel / lns_kernel as they write batch_large: the larger launches of a round
+                                 // take their nodes from these lists instead of scanning the whole batch through their hand-out counter (98 k same-address atomics = 1.1 ms each, tools/atomic_lab.hip)
+  int* cls_count;                // [3] their lengths (a set of the round's counters)
+  int cls_take;                  // per launch: 0 the whole batch (with the filters), c: the list of class c
+  int lns_warm;                  // 1: the leaves of the local search start from the incumbent's active set (inc_A, inc_Mtag)
+  int as_quota;                  // hand-outs after which a wavefront of the standard active-set launch leaves (0: it stays until the batch is handed out); the grid is sized to match
   int as_split;                  // 1: the larger interior point variant takes only the nodes of large_class 2 (class 1: the larger active-set launch on the third stream, class 3: the memory-backed launch on the fourth)
   unsigned long long* as_stats;  // [8] nodes, steps (rows added + dropped), handed to the interior point, rows dropped, infeasible, cut off, sum of the final active set sizes
 };
@@ -298,6 +305,15 @@ __device__ inline void pair_cars(int p, int C, int& c1, int& c2) {
 
 struct RowOut { double rhs; double aq; bool active; };
 // depth word of a rounding probe: tree depth >= 1, low bits 63 (eval_kernel: the children of a node carry 62 - their preference)
+// stage of a byte of the fix record (region codes, environment / obstacle / car-car disjunctions; -1: the masks behind them)
+__device__ inline int fix_stage(const Layout& Y, int k) {
+  const int N = Y.N;
+  if (k < Y.f_env) return (k - Y.f_reg) % N;
+  if (k < Y.f_obs) return ((k - Y.f_env) / 5) % N;
+  if (k < Y.f_c2c) return ((k - Y.f_obs) / 5) % N;
+  if (k < Y.f_c2n) return ((k - Y.f_c2c) / 4) % N;
+  return -1;
+}
 __device__ inline bool is_probe_word(int dw) { return (dw & 63) == 63 && (dw >> 6) >= 1; }
 // The nodes of a round go to one of four concurrent launches, and which one is decided ONCE, by select_kernel / lns_kernel when they write the batch
 // (batch_large: nothing a launch of the round writes - the marks on the records, the incumbents - can then change the split while the launches
@@ -309,6 +325,29 @@ __device__ inline bool is_probe_word(int dw) { return (dw & 63) == 63 && (dw >> 
 //     only the elastic interior point delivers;
 //   3 records known to exceed even the larger on-chip block (pool_big bit 1): the memory-backed kernel.
 // (Without the active-set launches - one, three, four cars, MIQP_AS=0 - only zero / non-zero matters.)
+#ifdef MIQP_PROFILE
+// one launch from the middle of a stream, wavefront by wavefront (MIQP_WAVE_DUMP, tools/wave_dump.py): start, end, where, nodes; kind 0 the standard
+// active-set launch (written there), 1 its larger block, 2 the larger interior point variant, 3 the memory-backed kernel
+struct WaveDump {
+  const DevBuf& B; int kind; unsigned long long r0; int nodes;
+  __device__ WaveDump(const DevBuf& b, int k) : B(b), kind(k), r0(__builtin_amdgcn_s_memrealtime()), nodes(0) {}
+  __device__ ~WaveDump() {
+    if (threadIdx.x == 0 && B.prof[125] == 300 && blockIdx.x < 4096) {
+      unsigned int hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned long long* const w = B.prof + 160 + 4 * (kind * 4096 + blockIdx.x);
+      w[0] = r0; w[1] = __builtin_amdgcn_s_memrealtime(); w[2] = ((unsigned long long)xcc << 32) | hw; w[3] = (unsigned long long)nodes;
+    }
+  }
+};
+#define WAVE_DUMP(kind) WaveDump wd_(B, kind)
+#define WAVE_DUMP_NODE() (++wd_.nodes)
+#else
+#define WAVE_DUMP(kind)
+#define WAVE_DUMP_NODE()
+#endif
+constexpr int CTR_SET = 16;   // counters of a round: [0] batch count, [1] .. [6] the launches' hand-out and hand-over counters, [8] .. [10] lengths of the class lists
 __device__ inline unsigned char large_class(const DevBuf& B, int rec, int dw, bool has_inc) {
   const unsigned int pb = B.pool_big ? (unsigned int)B.pool_big[rec] : 0u;
   const bool probe = is_probe_word(dw);
@@ -642,7 +681,9 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
   constexpr int RU = NX / 4, GU0 = NX % 4;  // register / first lane group holding the input rows NX..NZ-1  // rows are zero padded to the 16 columns of the MFMA tile
   const Layout& Y = B.Y;
   const int tid = threadIdx.x;
-  const int nbatch = B.ovf_mode == 1 ? *B.ovf_count : (*B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap);   // select may over-count when the batch is full
+  WAVE_DUMP(3);
+  const int* const clist = B.cls_take ? B.cls_list + (size_t)(B.cls_take - 1) * B.batch_cap : nullptr;   // (the list of this launch's class: nothing to scan)
+  const int nbatch = clist ? (B.cls_count[B.cls_take - 1] < B.batch_cap ? B.cls_count[B.cls_take - 1] : B.batch_cap) : B.ovf_mode == 1 ? *B.ovf_count : (*B.batch_count < B.batch_cap ? *B.batch_count : B.batch_cap);   // select may over-count when the batch is full
   const int N = Y.N, NSLOT = Y.NSLOT;
   extern __shared__ double lds[];
   double* Z = lds;                       // [N][NZ]
@@ -670,9 +711,10 @@ __global__ void __launch_bounds__(NT, (C <= 2 ? MIQP_IPM_WPE : (NT > 64 ? MIQP_W
   if (tid == 0) sh_node = atomicAdd(B.work_counter, 1);
   __syncthreads();
   if (sh_node >= nbatch) break;
-  const int node = __builtin_amdgcn_readfirstlane(B.ovf_mode == 1 ? B.ovf_list[sh_node] : sh_node);   // wave-uniform: addressed from SGPRs
+  const int node = __builtin_amdgcn_readfirstlane(clist ? clist[sh_node] : B.ovf_mode == 1 ? B.ovf_list[sh_node] : sh_node);   // wave-uniform: addressed from SGPRs
   if (B.ovf_mode == 2 && !is_probe_word(B.batch_depth[node])) continue;   // (this launch takes the rounding probes only)
   if (B.ovf_mode == 3 && B.batch_large[node] != 3) continue;   // (... the records known to exceed the larger on-chip block: large_class 3)
+  WAVE_DUMP_NODE();
   const int inst = __builtin_amdgcn_readfirstlane(B.batch_inst[node]);
   const double* D = B.inst_d + (size_t)inst * Y.dstride;
   const int* T = B.inst_i + (size_t)inst * Y.istride;
@@ -1961,6 +2003,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       unsigned long long key = (d2key(obj) & ~0xFFFFFull) | (unsigned long long)((unsigned int)hsh & 0xFFFFFu);
       B.batch_obj[node] = obj;
       B.batch_candkey[node] = key; B.batch_candinst[node] = inst;
+      if (B.ring_M && B.batch_Mtag && !(B.batch_large && B.batch_large[node] <= 1)) B.batch_Mtag[node] = 0ull;   // (an interior point node: the slot's active set is an earlier round's - select_kernel copies the candidate's to the incumbent)
       atomicMin(&B.inc_key[inst], key);
       atomicAdd(&B.inst_ninc[inst], 1);
     }
@@ -2392,6 +2435,13 @@ __device__ inline int wave_append(int* counter, bool pred) {
 __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round) {
   const Layout& Y = B.Y;
   const int slot = blockIdx.x, tid = threadIdx.x;
+#ifdef MIQP_PROFILE   // fold the last standard active-set launch's span and tail (as_onchip.hip) and reset its per-launch words
+  if (slot == 0 && tid == 0) {
+    const unsigned long long a = B.prof[120], b = B.prof[121], c = B.prof[122];
+    if (b != 0 && a != ~0ull && a != 0) { B.prof[123] += b - a; B.prof[124] += b - c; B.prof[125] += 1; }
+    B.prof[120] = ~0ull; B.prof[121] = 0; B.prof[122] = ~0ull;
+  }
+#endif
   const int inst = B.slot_inst[slot];
   if (inst < 0 || B.inst_done[inst] || B.inst_kill[inst]) { if (tid == 0) B.slot_demand[slot] = 0; }
   if (inst < 0) return;   // empty slot
@@ -2439,6 +2489,10 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
     for (int k = tid; k < Y.fixlen; k += SEL_THREADS) df[k] = cf[k];
     const double* zs = B.batch_Z + (size_t)bslot * Y.N * Y.nz; double* zd = B.inc_Z + (size_t)inst * Y.N * Y.nz;
     for (int k = tid; k < Y.N * Y.nz; k += SEL_THREADS) zd[k] = zs[k];
+    if (B.inc_A && B.batch_A && B.batch_Mtag) {   // the active set the incumbent was found with, for the leaves of the local search around it
+      if (tid < 64) B.inc_A[(size_t)inst * 64 + tid] = B.batch_A[(size_t)bslot * 64 + tid];
+      if (tid == 0) B.inc_Mtag[inst] = B.batch_Mtag[bslot];
+    }
     if (tid == 0) { B.inc_obj[inst] = B.batch_obj[bslot]; if (B.inst_lns) B.inst_lns[inst] |= 1; }   // (bit 1, "skeleton roots tried", stays)
   }
   __syncthreads();
@@ -2794,7 +2848,8 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(DevBuf B, int round
       if (pick) {
         int pos = atomicAdd(&sh_pick, 1);
         if (pos < take) { B.batch_node[base + pos] = nd; B.batch_inst[base + pos] = inst; B.batch_bound[base + pos] = b; B.batch_depth[base + pos] = dp;
-                          if (B.batch_large) B.batch_large[base + pos] = large_class(B, nd, dp, inc < 1e300); }   // (the launch of the round that solves the node)
+                          if (B.batch_large) { const int lc_ = large_class(B, nd, dp, inc < 1e300); B.batch_large[base + pos] = (unsigned char)lc_;   // (the launch of the round that solves the node)
+                            if (lc_ && B.cls_list) { const int q_ = atomicAdd(&B.cls_count[lc_ - 1], 1); if (q_ < B.batch_cap) B.cls_list[(size_t)(lc_ - 1) * B.batch_cap + q_] = base + pos; } } }
         else pick = false;
       }
     }
@@ -3135,12 +3190,29 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
       const double* zs = B.inc_Z + (size_t)inst * N * Y.nz; double* zd = B.pool_Z + (size_t)rec * N * Y.nz;
       for (int k = lane; k < N * Y.nz; k += 64) zd[k] = zs[k];
     }
-    if (B.pool_A && rec < B.z_cap) { B.pool_A[(size_t)rec * 64 + lane] = (unsigned short)0xFFFFu; if (B.ring_M && lane == 0) B.pool_Mtag[rec] = 0ull; }   // (a recycled record: no active set of a parent)
+    if (B.pool_A && rec < B.z_cap) {
+      // The leaf starts from the active set and the M of the solve that found the incumbent (the active-set launches; a recycled record has no parent):
+      // it differs from the incumbent in the stages of the moved stretch - the rows of those stages are handed on as rows the leaf no longer has (an
+      // identity no decode produces: the start removes them from M), the rest by identity; the start checks that M fits them.  Without it a leaf is a
+      // cold solve of |A| + 4 steps, and the leaves of a round - 5 % of its nodes - held a third of the device for two thirds of the round
+      unsigned short av = (unsigned short)0xFFFFu; unsigned long long tg = 0ull;
+      if (B.inc_A && B.ring_M && B.lns_warm) {
+        tg = B.inc_Mtag[inst];
+        if (tg != 0ull) {
+          unsigned int chg = 0u;
+          for (int k = k0; k < k1; k += st_) { const int sg = fix_stage(Y, k); if (sg >= 0 && sg < 32) chg |= 1u << sg; }
+          av = B.inc_A[(size_t)inst * 64 + lane];
+          if (av != 0xFFFFu) { const int sg = av < 1024u ? (int)(av >> 5) : ((int)av - 1024) / Y.NSLOT; if (sg < 32 && ((chg >> sg) & 1u)) av = (unsigned short)0xFFFEu; }
+        }
+      }
+      B.pool_A[(size_t)rec * 64 + lane] = av; if (B.ring_M && lane == 0) B.pool_Mtag[rec] = tg;
+    }
     if (lane == 0) {
       if (B.pool_big) B.pool_big[rec] = 1;
       if (B.pool_origin) B.pool_origin[rec] = 14;
       B.batch_node[bs] = rec; B.batch_inst[bs] = inst; B.batch_bound[bs] = lbq; B.batch_depth[bs] = (1 << 6) | 63;   // (the probe mark: a heuristic node - one that has not converged after probe_itcap iterations is abandoned)
-      if (B.batch_large) B.batch_large[bs] = large_class(B, rec, (1 << 6) | 63, true);
+      if (B.batch_large) { const int lc_ = large_class(B, rec, (1 << 6) | 63, true); B.batch_large[bs] = (unsigned char)lc_;
+        if (lc_ && B.cls_list) { const int q_ = atomicAdd(&B.cls_count[lc_ - 1], 1); if (q_ < B.batch_cap) B.cls_list[(size_t)(lc_ - 1) * B.batch_cap + q_] = bs; } }
     }
   }
 }
@@ -3148,7 +3220,7 @@ __global__ void __launch_bounds__(64) lns_kernel(DevBuf B) {
 // makes the records freed so far available to the next eval launch
 // ... and zeroes the counter set of the NEXT round (`zero8`: eight ints, null = the host uses memsets)
 __global__ void roll_kernel(DevBuf B, int* zero8) {
-  if (zero8 && threadIdx.x < 8) zero8[threadIdx.x] = 0;
+  if (zero8 && threadIdx.x < CTR_SET) zero8[threadIdx.x] = 0;
   if (threadIdx.x != 0) return;
   unsigned int t = *B.free_tail, h = *B.free_head, l = *B.free_limit;
   if ((int)(h - l) > 0) h = l;   // pops that overshot the limit took fresh records instead

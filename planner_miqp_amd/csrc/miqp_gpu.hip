@@ -262,6 +262,7 @@ struct DevCtx {
   bool concurrent_big = true;   // MIQP_CONCURRENT_BIG=0: the sequential chain standard -> larger -> memory-backed
   int ocb_grid = 0;  // resident wavefronts of its larger variant (OC_GCAP_BIG general rows, one wavefront per SIMD; 0: not in use)
   bool as_on = false, as_cap = false; unsigned long long* as_stats = nullptr;
+  int* cls_list = nullptr; int cls_n[3] = {-1, -1, -1};   // the round's class lists and (read back with the batch count) their lengths; -1: not known, the launches scan the batch
   unsigned short* as_batch_A = nullptr; unsigned short* as_pool_A = nullptr;   // (kept here: a call with MIQP_AS=0 runs with the DevBuf pointers nulled)   // dual active-set launch in front of the standard interior point launch (two cars; MIQP_AS=0: off)
   DevBuf B{};
   std::vector<void*> allocs;
@@ -431,6 +432,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&B.inc_ext, n_inst)) return false;
   if (!X.alloc(&B.inc_fix, (size_t)n_inst * Y.fixlen)) return false;
   if (!X.alloc(&B.inc_Z, (size_t)n_inst * Y.N * Y.nz)) return false;
+  if (Y.C == 2) { if (!X.alloc(&B.inc_A, (size_t)n_inst * 64) || !X.alloc(&B.inc_Mtag, (size_t)n_inst)) return false; } else { B.inc_A = nullptr; B.inc_Mtag = nullptr; }
   if (!X.alloc(&B.lower_bound, n_inst)) return false;
   if (!X.alloc(&B.inst_done, n_inst)) return false;
   if (!X.alloc(&B.inst_flags, n_inst)) return false;
@@ -462,13 +464,14 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
   if (!X.alloc(&B.rowcache, (size_t)std::min(batch_alloc, X.ipm_grid_max) * NCACHE * Y.ROWCAP)) return false;
   if (!X.alloc(&B.kgain, (size_t)std::min(batch_alloc, X.kg_blocks) * std::max(Y.N * Y.nu * (Y.nx + 2), oc_gain_doubles(Y.N)))) return false;
   if (!X.alloc(&B.work_counter, 1)) return false;
-  if (!X.alloc(&X.ctr, 16)) return false;
-  HIP_OK(hipMemset(X.ctr, 0, 64));
+  if (!X.alloc(&X.ctr, 2 * CTR_SET)) return false;
+  HIP_OK(hipMemset(X.ctr, 0, 2 * CTR_SET * 4));
   X.as_cap = Y.C == 2 && X.oc_grid > 0;   // the shape has the active-set launches (whether a call uses them: MIQP_AS, read per call)
   X.as_on = X.as_cap;
-  if (!X.alloc(&X.as_stats, 24)) return false;
-  HIP_OK(hipMemset(X.as_stats, 0, 192));
-  B.as_stats = X.as_stats; B.as_chunk = KNOB_T("MIQP_AS_CHUNK") ? std::atoi(KNOB_T("MIQP_AS_CHUNK")) : 1;   // (runs of 2 / 4 / 8 / 16: the standard launch 4.7 -> 5.2 / 6.6 / 7.9 / 10.3 ms - a wavefront solves ~14 nodes per launch, longer runs only lengthen its tail)
+  if (X.as_cap && !X.alloc(&X.cls_list, (size_t)3 * batch_cap)) return false;   // the class lists of a round (large_class 1 / 2 / 3)
+  if (!X.alloc(&X.as_stats, 32)) return false;
+  HIP_OK(hipMemset(X.as_stats, 0, 256));
+  B.as_stats = X.as_stats; B.as_chunk = KNOB_T("MIQP_AS_CHUNK") ? std::atoi(KNOB_T("MIQP_AS_CHUNK")) : 1; B.as_quota = KNOB_T("MIQP_AS_QUOTA") ? std::atoi(KNOB_T("MIQP_AS_QUOTA")) : 0;   // (runs of 2 / 4 / 8 / 16: the standard launch 4.7 -> 5.2 / 6.6 / 7.9 / 10.3 ms - a wavefront solves ~14 nodes per launch, longer runs only lengthen its tail)
   B.batch_A = nullptr; B.pool_A = nullptr; X.as_batch_A = nullptr; X.as_pool_A = nullptr; B.ring_M = nullptr; B.ring_head = nullptr; B.ring_doubles = 0; B.ring_margin = 0; B.batch_Mtag = nullptr; B.pool_Mtag = nullptr;
   if (X.as_on && B.z_cap > 0 && Y.N * Y.NSLOT + 1024 < 65535) {   // the parents' active sets for the children's starts (128 B per record)
     if (!X.alloc(&B.batch_A, (size_t)batch_alloc * 64)) return false;
@@ -513,8 +516,8 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
     if (!X.alloc(&B.pool_origin, (size_t)X.pool_cap)) return false; HIP_OK(hipMemset(B.pool_origin, 0, (size_t)X.pool_cap));
   }
   if (KNOB_T("MIQP_NOCUT")) B.use_cutoff = 0;   // diagnostic: every node relaxation runs to convergence (tells infeasible children from expensive ones)
-  if (!X.alloc(&B.prof, 128)) return false;
-  (void)hipMemset(B.prof, 0, 128 * 8);
+  if (!X.alloc(&B.prof, 160 + 5 * 4 * 4096)) return false;
+  (void)hipMemset(B.prof, 0, (160 + 5 * 4 * 4096) * 8);
   if (!X.alloc(&B.active_insts, 1)) return false;
   if (!X.alloc(&B.stat_rowiters, 1)) return false;
 #ifdef MIQP_PROFILE
@@ -567,12 +570,22 @@ void launch_ipm_c(int C, const DevBuf& B, int nblocks, size_t lds, hipStream_t s
 // by VALU issue, and the probes no longer cost a generation of their own behind it.  `overlap` false (the polish, solve_fixed): the
 // serial order of round 2.
 // `par` >= 0 (the rounds of a solve): the counters of this launch group are set `par` of X.ctr, zeroed one round ahead by roll_kernel
+// LDS of a larger launch's block beside the standard active-set launch: padded to TWO blocks of that launch (rounded to the allocation granule), as
+// long as four of them still fit a CU.  A larger block leaves a hole behind when it ends; the unpadded 34 KB took one standard block of 19.6 KB and
+// wasted the rest - no CU ever held more than seven of its eight standard blocks again (tools/wave_dump.py, tools/resident_lab.hip)
+inline size_t oc_big_lds_beside_as(const Layout& Y) {
+  const size_t lb = (size_t)oc_lds_layout(Y.N, Y.fixlen, OC_GCAP_BIG).total, la = (size_t)oc_lds_layout(Y.N, Y.fixlen, OC_GCAP, true).total;
+  const size_t st_ = 8 + 256;   // static LDS of the active-set kernels: the hand-out word and the wavefront's statistics
+  const size_t two = 2 * ((la + st_ + 1279) / 1280 * 1280) - st_;
+  return (two >= lb && 4 * (two + st_) <= 160 * 1024) ? two : lb;
+}
 void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool overlap = false, int par = -1, hipEvent_t ev_std_end = nullptr) {
   const Layout& Y = X.Y;
   const size_t l_ipm = ipm_lds_bytes(Y);
   if (X.oc_grid > 0) {
     const size_t l_oc = (size_t)oc_lds_layout(Y.N, Y.fixlen).total;
     const size_t l_ocb = (size_t)oc_lds_layout(Y.N, Y.fixlen, OC_GCAP_BIG).total;
+    const size_t l_ocb_as = Y.C == 2 && !(KNOB_T("MIQP_BIG_PAD") && std::atoi(KNOB_T("MIQP_BIG_PAD")) == 0) ? oc_big_lds_beside_as(Y) : l_ocb;
     const bool big = X.ocb_grid > 0;
     const bool ov = overlap && X.probe_grid > 0 && X.stream2 && bc <= 4096;   // (a full batch keeps the device busy on its own: measured no gain there, 5.4 against 5.1 s on a 2048-instance queue; single solves: median 6.0 instead of 7.0 ms)
     DevBuf Bc = B;
@@ -586,26 +599,44 @@ void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool o
       // being a launch of its own.  A node the standard kernel finds too large at its decode is marked and returned unsolved
       // (bounce): no second launch behind the standard one.
       (void)hipEventRecord(X.ev_fork, st); (void)hipStreamWaitEvent(X.stream2, X.ev_fork, 0);
-      int* const cs = pc ? X.ctr + 8 * par : nullptr;   // [0] batch count, [1] standard launch, [2] its hand-over list, [3] the larger variant's list, [4] the larger variant, [5] the memory-backed launch behind it
+      int* const cs = pc ? X.ctr + CTR_SET * par : nullptr;   // [0] batch count, [1] standard launch, [2] its hand-over list, [3] the larger variant's list, [4] the larger variant, [5] the memory-backed launch behind it
       if (pc) { Bc.work_counter = cs + 1; Bc.ovf_count = cs + 2; Bc.ovf2_count = cs + 3; }
       DevBuf Bp = Bc; Bp.ovf_mode = 2; Bp.work_counter = pc ? cs + 4 : X.work_counter2; Bp.rowstate = X.rowstate2; Bp.rowcache = X.rowcache2; Bp.kgain = X.kgain2;
       static const int big_grid_cap = KNOB_T("MIQP_BIG_GRID") ? std::atoi(KNOB_T("MIQP_BIG_GRID")) : 1 << 30;
       const int gb = std::min(std::min(bc, big_grid_cap), std::min(X.probe_grid, X.ocb_grid));
       const bool as2 = X.as_on && pc && Y.C == 2 && X.stream3;
+      const bool lists = as2 && X.stream4 && B.cls_list && X.cls_n[0] >= 0;
+      // With the class lists the larger launches get the SHARE of the device their work is of the round's, not all of it: their wavefronts take a SIMD
+      // each (450 / 424 registers) and are enqueued first - a full grid of them held every SIMD until the larger active-set launch was through
+      // (5 of 16 ms, tools/wave_dump.py), the standard launch started behind them and never got its holes back.  Weights: SIMD time of a node of the
+      // class in units of a standard node's (half a SIMD for ~0.19 ms)
+      static const double w1_ = KNOB_T("MIQP_BIG_W1") ? std::atof(KNOB_T("MIQP_BIG_W1")) : 4.0, w2_ = KNOB_T("MIQP_BIG_W2") ? std::atof(KNOB_T("MIQP_BIG_W2")) : 20.0;
+      int g1s = gb, g2s = gb;
+      if (lists && w1_ > 0) {
+        const double n1 = X.cls_n[0], n2 = X.cls_n[1], n0 = std::max(0, bc - X.cls_n[0] - X.cls_n[1] - X.cls_n[2]);
+        const double den = w1_ * n1 + w2_ * n2 + n0 + 1.0;
+        g1s = std::max(32, (int)(gb * w1_ * n1 / den + 0.5)); g2s = std::max(32, (int)(gb * w2_ * n2 / den + 0.5));
+      }
       if (as2) {
         // the large nodes of the round that the active-set method takes (large_class 1): its larger block, on a third stream beside the interior
         // point chain, which keeps the rest of them
         (void)hipStreamWaitEvent(X.stream3, X.ev_fork, 0);
         DevBuf Bq = Bp; Bq.work_counter = cs + 6;
-        hipLaunchKernelGGL((as_onchip_kernel<2, OC_NSL, OC_GCAP_BIG>), dim3(gb), dim3(64), l_ocb, X.stream3, Bq);
+        if (lists) Bq.cls_take = 1;
+        const int g1 = lists ? std::min(std::min(gb, g1s), X.cls_n[0]) : gb;   // (with the class lists: as many workgroups as the class has nodes, none when it is empty)
+        if (g1 > 0) hipLaunchKernelGGL((as_onchip_kernel<2, OC_NSL, OC_GCAP_BIG>), dim3(g1), dim3(64), l_ocb_as, X.stream3, Bq);
         (void)hipEventRecord(X.ev_join3, X.stream3);
         Bp.as_split = 1;
       }
+      if (lists) { Bp.cls_take = 2; const int g2 = std::min(std::min(gb, g2s), X.cls_n[1]); if (g2 > 0) launch_ipm_oc_big<2>(Bp, g2, l_ocb_as, X.stream2, false); Bp.cls_take = 0; }
+      else
       if (Y.C == 1) launch_ipm_oc_big<1>(Bp, gb, l_ocb, X.stream2, !pc); else launch_ipm_oc_big<2>(Bp, gb, l_ocb, X.stream2, !pc);
       DevBuf Bm = Bp; Bm.ovf_mode = 1; Bm.ovf_count = Bc.ovf2_count; Bm.ovf_list = B.ovf2_list; if (pc) Bm.work_counter = cs + 5;
       if (as2 && X.stream4) {   // the records known to exceed the larger block: the memory-backed kernel beside the three others, on a fourth stream (gain buffer of its own)
         (void)hipStreamWaitEvent(X.stream4, X.ev_fork, 0);
         Bm.ovf_mode = 3; Bm.kgain = X.kgain3;
+        if (lists) { Bm.cls_take = 3; const int g3 = std::min(X.probe_grid, X.cls_n[2]); if (g3 > 0) launch_ipm_c(Y.C, Bm, g3, l_ipm, X.stream4, false); }
+        else
         launch_ipm_c(Y.C, Bm, std::min(bc, X.probe_grid), l_ipm, X.stream4, !pc);
         (void)hipEventRecord(X.ev_join4, X.stream4);
       } else
@@ -616,7 +647,10 @@ void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool o
         // the ordinary nodes of the round: dual active-set solves (as_onchip.hip) in place of the standard interior point launch; a node that
         // launch cannot finish comes back marked, like a node that is too large, and the larger interior point variant takes it next round
         DevBuf Ba = Bc; Ba.work_counter = cs + 1;
-        hipLaunchKernelGGL((as_onchip_kernel<2, OC_NSL>), dim3(std::min(bc, X.oc_grid)), dim3(64), l_oc, st, Ba);
+        const size_t l_as = (size_t)oc_lds_layout(Y.N, Y.fixlen, OC_GCAP, true).total;
+        const int ch_ = std::max(1, Ba.as_chunk);
+        const int ga = Ba.as_quota > 0 ? std::max(1, (bc + Ba.as_quota * ch_ - 1) / (Ba.as_quota * ch_)) : std::min(bc, X.oc_grid);
+        hipLaunchKernelGGL((as_onchip_kernel<2, OC_NSL>), dim3(ga), dim3(64), l_as, st, Ba);
       } else if (Y.C == 1) launch_ipm_oc<1>(Bc, std::min(bc, X.oc_grid), l_oc, st, !pc); else launch_ipm_oc<2>(Bc, std::min(bc, X.oc_grid), l_oc, st, !pc);
       if (X.ev_mid) (void)hipEventRecord(X.ev_mid, st);
       if (ev_std_end) (void)hipEventRecord(ev_std_end, st);   // (where the standard launch of the round ends: the dominant kernel's own time)
@@ -669,7 +703,7 @@ template <int C> bool set_kernel_lds_c(size_t ipm_lds, size_t eval_lds) {
 }
 bool set_kernel_lds(const Layout& Y, size_t ipm_lds, size_t eval_lds) {
   if (Y.C <= 2 && Y.N <= 2 * OC_NSL) {
-    const size_t l = (size_t)oc_lds_layout(Y.N, Y.fixlen).total, lb = (size_t)oc_lds_layout(Y.N, Y.fixlen, OC_GCAP_BIG).total;
+    const size_t l = (size_t)oc_lds_layout(Y.N, Y.fixlen).total, lb = std::max((size_t)oc_lds_layout(Y.N, Y.fixlen, OC_GCAP_BIG).total, Y.C == 2 ? oc_big_lds_beside_as(Y) : (size_t)0);
     if (l <= 160 * 1024 && !(Y.C == 1 ? set_kernel_lds_oc<1>(l, lb) : set_kernel_lds_oc<2>(l, lb))) return false;
   }
   switch (Y.C) { case 1: return set_kernel_lds_c<1>(ipm_lds, eval_lds); case 2: return set_kernel_lds_c<2>(ipm_lds, eval_lds);
@@ -1047,6 +1081,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemsetAsync(B.inc_key, 0xFF, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inc_seen, 0xFF, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inc_fix, 0xFF, (size_t)n * Y.fixlen, st));   // no incumbent yet: every disjunction undecided
+  if (B.inc_Mtag) HIP_OK(hipMemsetAsync(B.inc_Mtag, 0, (size_t)n * 8, st));
+  B.lns_warm = !(KNOB_T("MIQP_LNS_WARM") && std::atoi(KNOB_T("MIQP_LNS_WARM")) == 0);
   { std::vector<double> big(n, 1e300); HIP_OK(hipMemcpyAsync(B.inc_obj, big.data(), n * 8, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(B.inc_ext, big.data(), n * 8, hipMemcpyHostToDevice, st)); HIP_OK(hipMemcpyAsync(B.near_thr, big.data(), n * 8, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(B.lower_bound, big.data(), n * 8, hipMemcpyHostToDevice, st)); HIP_OK(hipStreamSynchronize(st)); }
@@ -1057,7 +1093,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemsetAsync(B.inst_nodes, 0, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_iters, 0, (size_t)n * 8, st));
   HIP_OK(hipMemsetAsync(B.inst_ninc, 0, (size_t)n * 4, st));
-  HIP_OK(hipMemsetAsync(B.as_stats, 0, 192, st));
+  HIP_OK(hipMemsetAsync(B.as_stats, 0, 256, st));
   HIP_OK(hipMemsetAsync(B.inst_lns, 0, (size_t)n * 4, st));
   { std::vector<double> big_(n, 1e300); HIP_OK(hipMemcpyAsync(B.inst_lns_obj, big_.data(), (size_t)n * 8, hipMemcpyHostToDevice, st)); HIP_OK(hipStreamSynchronize(st)); }
   B.lns_step = KNOB_T("MIQP_LNS_STEP") ? std::atof(KNOB_T("MIQP_LNS_STEP")) : 0.0;
@@ -1121,24 +1157,27 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   // the counters of a round's launches (batch count, work counters, hand-over counts) come in two parity sets: a round uses one, its
   // roll_kernel zeroes the other for the round after - six 4-byte memsets per round less in the stream (0.65 ms of the 1.4 ms round of a single solve)
   const bool use_par = X.ctr && X.oc_grid > 0 && X.ocb_grid > 0 && X.concurrent_big && X.stream2 && X.probe_grid > 0 && !KNOB_T("MIQP_MEMSETS");
-  if (use_par) HIP_OK(hipMemsetAsync(X.ctr, 0, 64, st));
+  if (use_par) HIP_OK(hipMemsetAsync(X.ctr, 0, 2 * CTR_SET * 4, st));
+  const bool use_cls = use_par && X.as_on && X.cls_list && !(KNOB_T("MIQP_CLS_LISTS") && std::atoi(KNOB_T("MIQP_CLS_LISTS")) == 0);
+  B.cls_list = use_cls ? X.cls_list : nullptr; B.cls_take = 0; X.cls_n[0] = X.cls_n[1] = X.cls_n[2] = -1;
   int width_now = adaptive_width ? width0 : 0, width_since = 0, demand_now = 0; unsigned long long width_key = ~0ull, kinc_now = ~0ull; double lb_now = -1e300;
   for (;;) {
     const int par = rounds & 1;
     B.width_cap = width_now;
-    if (use_par) B.batch_count = X.ctr + 8 * par; else HIP_OK(hipMemsetAsync(B.batch_count, 0, 4, st));
+    if (use_par) { B.batch_count = X.ctr + CTR_SET * par; B.cls_count = B.batch_count + 8; } else HIP_OK(hipMemsetAsync(B.batch_count, 0, 4, st));
     B.open_sel = rounds & 1;
     B.prev_bc = prev_bc;
     hipLaunchKernelGGL(select_kernel, dim3(NS), dim3(SEL_THREADS), 0, st, B, rounds);
     if (B.lns_mode > 0) hipLaunchKernelGGL(lns_kernel, dim3(NS), dim3(64), 0, st, B);   // the neighbours of new incumbents join this round's batch
     if (KNOB_P("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d select: %s\n", rounds, hipGetErrorString(e_)); }
-    hipLaunchKernelGGL(roll_kernel, dim3(1), dim3(8), 0, st, B, use_par ? X.ctr + 8 * (par ^ 1) : (int*)nullptr);
+    hipLaunchKernelGGL(roll_kernel, dim3(1), dim3(CTR_SET), 0, st, B, use_par ? X.ctr + CTR_SET * (par ^ 1) : (int*)nullptr);
     hipLaunchKernelGGL(share_kernel, dim3(1), dim3(1024), 0, st, B);
-    int bc = 0;
-    HIP_OK(hipMemcpyAsync(&bc, B.batch_count, 4, hipMemcpyDeviceToHost, st));
+    int bc = 0; int hctr[CTR_SET] = {0};
+    HIP_OK(hipMemcpyAsync(use_cls ? hctr : &bc, B.batch_count, use_cls ? CTR_SET * 4 : 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(h_done_now.data(), B.inst_done, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     if (adaptive_width) { HIP_OK(hipMemcpyAsync(&kinc_now, B.inc_key, 8, hipMemcpyDeviceToHost, st)); HIP_OK(hipMemcpyAsync(&demand_now, B.slot_demand, 4, hipMemcpyDeviceToHost, st)); HIP_OK(hipMemcpyAsync(&lb_now, B.lower_bound, 8, hipMemcpyDeviceToHost, st)); }
     HIP_OK(hipStreamSynchronize(st));
+    if (use_cls) { bc = hctr[0]; for (int q = 0; q < 3; ++q) X.cls_n[q] = std::min(hctr[8 + q], X.batch_cap); }
     if (adaptive_width) {
       if (kinc_now != width_key) { width_key = kinc_now; width_since = rounds; }
       else if (kinc_now < 0xFFF0000000000000ull && rounds - width_since >= 32 && demand_now >= 8 * width_now && width_now < width_max) {
@@ -1355,7 +1394,19 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       if (pa[10]) { std::fprintf(stderr, "[miqp_gpu profile] active-set kernel nodes %llu steps %llu cycles/node %.0f :", pa[10], pa[11], ta / (double)pa[10]);
         for (int q = 0; q < 9; ++q) std::fprintf(stderr, " %s %.1f%% (%.0f)", na[q], 100.0 * pa[q] / ta, (double)pa[q] / (double)pa[10]);
         std::fprintf(stderr, "; inside the decode: bound classes %.0f, general-row pass %.0f", (double)pa[12] / (double)pa[10], (double)pa[13] / (double)pa[10]);
-        std::fprintf(stderr, "\n"); } }
+        std::fprintf(stderr, "\n");
+        unsigned long long pw[3], pl[6]; HIP_OK(hipMemcpy(pw, B.prof + 94, 3 * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(pl, B.prof + 120, 6 * 8, hipMemcpyDeviceToHost));
+        if (pw[2] && pw[1] && pl[5]) std::fprintf(stderr, "[miqp_gpu profile] standard active-set launches: %llu wavefronts resident %.0f shader cycles = %.1f us each (shader clock %.0f MHz); per launch (%llu folded): span %.3f ms, from the first wavefront out of work to the last end %.3f ms, wavefronts %.0f, resident wavefront time / (span x wavefronts) %.3f\n",
+          pw[2], (double)pw[0] / pw[2], (double)pw[1] / pw[2] / 100.0, 100.0 * (double)pw[0] / (double)pw[1], pl[5], (double)pl[3] / pl[5] / 1e5, (double)pl[4] / pl[5] / 1e5, (double)pw[2] / pl[5], ((double)pw[1]) / ((double)pl[3] * ((double)pw[2] / pl[5])));
+        unsigned long long ph[16]; HIP_OK(hipMemcpy(ph, B.prof + 128, 16 * 8, hipMemcpyDeviceToHost));
+        if (pw[2]) { std::fprintf(stderr, "[miqp_gpu profile] standard active-set wavefronts by their start after the launch's first (< 0.05 / 0.2 / 0.5 / 1 / 2 / 4 / 8 ms / later), %% :");
+          for (int q = 0; q < 8; ++q) std::fprintf(stderr, " %.1f", 100.0 * ph[q] / pw[2]);
+          std::fprintf(stderr, "; by the nodes they solved (0 / <= 4 / <= 16 / <= 32 / <= 64 / more), %% :");
+          for (int q = 8; q < 14; ++q) std::fprintf(stderr, " %.1f", 100.0 * ph[q] / pw[2]);
+          std::fprintf(stderr, "\n"); }
+        if (const char* wd = std::getenv("MIQP_WAVE_DUMP")) {
+          std::vector<unsigned long long> w(4 * 4 * 4096); HIP_OK(hipMemcpy(w.data(), B.prof + 160, w.size() * 8, hipMemcpyDeviceToHost));
+          if (FILE* f = std::fopen(wd, "w")) { for (int q = 0; q < 4 * 4096; ++q) if (w[4 * q]) std::fprintf(f, "%d %llu %llu %u %u %llu %d\n", q & 4095, w[4 * q], w[4 * q + 1], (unsigned)(w[4 * q + 2] >> 32), (unsigned)w[4 * q + 2], w[4 * q + 3], q >> 12); std::fclose(f); } } } }
     { unsigned long long pe[8]; HIP_OK(hipMemcpy(pe, B.prof + 100, 8 * 8, hipMemcpyDeviceToHost));
       const char* ne[6] = {"load", "regions", "leaf disjunctions", "branching", "lifting + reservation", "records"};
       double te = 0; for (int q = 0; q < 6; ++q) te += (double)pe[q];
@@ -1368,7 +1419,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
       if (ps[8]) { std::fprintf(stderr, "[miqp_gpu profile] select_kernel, %llu workgroups that reached the end (thread 0's clock), mean list %.0f entries, cycles each %.0f :", ps[8], (double)ps[9] / (double)ps[8], ts / (double)ps[8]);
         for (int q = 0; q < 8; ++q) std::fprintf(stderr, " %s %.1f%% (%.0f)", ns[q], 100.0 * ps[q] / ts, (double)ps[q] / (double)ps[8]);
         std::fprintf(stderr, "\n"); } }
-    HIP_OK(hipMemset(B.prof, 0, 128 * 8)); }
+    HIP_OK(hipMemset(B.prof, 0, 160 * 8)); }
 #endif
   if (B.stats) {
     unsigned long long hs[256]; HIP_OK(hipMemcpy(hs, B.stats, sizeof(hs), hipMemcpyDeviceToHost)); HIP_OK(hipMemset(B.stats, 0, sizeof(hs)));
@@ -1415,11 +1466,11 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   HIP_OK(hipMemcpy(h_nodes.data(), B.inst_nodes, n * 8, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(h_iters.data(), B.inst_iters, n * 8, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(&rowiters, B.stat_rowiters, 8, hipMemcpyDeviceToHost));
-  unsigned long long h_as[24] = {0};
-  HIP_OK(hipMemcpy(h_as, B.as_stats, 192, hipMemcpyDeviceToHost));
+  unsigned long long h_as[32] = {0};
+  HIP_OK(hipMemcpy(h_as, B.as_stats, 256, hipMemcpyDeviceToHost));
   if (B.stats && h_as[0] + h_as[2] > 0)
-    std::fprintf(stderr, "[miqp_gpu stats] active-set launch: %llu nodes (%.1f steps, %.1f drops, %.1f rows from the parent's active set, %.1f active rows at the end per node; %llu infeasible, %llu cut off; %llu started from the parent's M, %llu fell back to a cold start), %llu handed to the interior point (no free slot %llu, step cap %llu, curvature %llu, down-date pivot %llu, rows off their equalities %llu, other %llu); M rebuilt because: the parent left none %llu, the ring had come round %llu, another row count %llu\n",
-                 h_as[0], h_as[1] / (double)std::max(1ull, h_as[0]), h_as[3] / (double)std::max(1ull, h_as[0]), h_as[7] / (double)std::max(1ull, h_as[0]), h_as[6] / (double)std::max(1ull, h_as[0]), h_as[4], h_as[5], h_as[8], h_as[9], h_as[2], h_as[11], h_as[12], h_as[13], h_as[14], h_as[15], h_as[10], h_as[17], h_as[18], h_as[19]);
+    std::fprintf(stderr, "[miqp_gpu stats] active-set launch: %llu nodes (%.1f steps, %.1f drops, %.1f rows from the parent's active set, %.1f active rows at the end per node; %llu infeasible, %llu cut off; %llu started from the parent's M, %llu fell back to a cold start), %llu handed to the interior point (no free slot %llu, step cap %llu, curvature %llu, down-date pivot %llu, rows off their equalities %llu, other %llu); M rebuilt because: the parent left none %llu, the ring had come round %llu, another row count %llu; in the larger block %llu nodes (%.1f steps), of them leaves of the local search %llu (%.1f steps), rounding probes %llu; by their general rows (<= 64 / 96 / 128 / 192 / more) %llu / %llu / %llu / %llu / %llu\n",
+                 h_as[0], h_as[1] / (double)std::max(1ull, h_as[0]), h_as[3] / (double)std::max(1ull, h_as[0]), h_as[7] / (double)std::max(1ull, h_as[0]), h_as[6] / (double)std::max(1ull, h_as[0]), h_as[4], h_as[5], h_as[8], h_as[9], h_as[2], h_as[11], h_as[12], h_as[13], h_as[14], h_as[15], h_as[10], h_as[17], h_as[18], h_as[19], h_as[20], h_as[21] / (double)std::max(1ull, h_as[20]), h_as[22], h_as[23] / (double)std::max(1ull, h_as[22]), h_as[29], h_as[24], h_as[25], h_as[26], h_as[27], h_as[28]);
   std::vector<signed char> h_fix((size_t)n * Y.fixlen); std::vector<double> h_Z((size_t)n * Y.N * Y.nz);
   HIP_OK(hipMemcpy(h_fix.data(), B.inc_fix, h_fix.size(), hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(h_Z.data(), B.inc_Z, h_Z.size() * 8, hipMemcpyDeviceToHost));

@@ -34,3 +34,12 @@ for i in range(len(oc) - 1):
     if oc[i][0] >= lo and oc[i + 1][1] <= hi: nxt.append(oc[i + 1][0] - oc[i][1])
 if nxt:
     nxt.sort(); print("end of the standard launch -> start of the next: median %.3f ms, mean %.3f ms" % (nxt[len(nxt) // 2] / 1e6, sum(nxt) / len(nxt) / 1e6))
+# the timeline of three rounds from the middle of the steady state: start and end of every kernel, ms after the round's select_kernel started
+if len(sys.argv) > 2 and sys.argv[2] == "timeline":
+    mid = [r for r in sel if "select_kernel" in r[2]]
+    for s in mid[len(mid) // 2: len(mid) // 2 + 3]:
+        nx = [r for r in mid if r[0] > s[0]]
+        end = nx[0][0] if nx else hi
+        print("round at %.3f s:" % ((s[0] - t0) / 1e9))
+        for a, b, n in sel:
+            if s[0] <= a < end: print("    %-50s start %7.3f  end %7.3f  (%.3f ms)" % (n.split("(")[0][:50], (a - s[0]) / 1e6, (b - s[0]) / 1e6, (b - a) / 1e6))
