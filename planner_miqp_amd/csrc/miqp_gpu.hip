@@ -1404,7 +1404,7 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
           std::fprintf(stderr, "; by the nodes they solved (0 / <= 4 / <= 16 / <= 32 / <= 64 / more), %% :");
           for (int q = 8; q < 14; ++q) std::fprintf(stderr, " %.1f", 100.0 * ph[q] / pw[2]);
           std::fprintf(stderr, "\n"); }
-        if (const char* wd = std::getenv("MIQP_WAVE_DUMP")) {
+        if (const char* wd = KNOB_T("MIQP_WAVE_DUMP")) {
           std::vector<unsigned long long> w(4 * 4 * 4096); HIP_OK(hipMemcpy(w.data(), B.prof + 160, w.size() * 8, hipMemcpyDeviceToHost));
           if (FILE* f = std::fopen(wd, "w")) { for (int q = 0; q < 4 * 4096; ++q) if (w[4 * q]) std::fprintf(f, "%d %llu %llu %u %u %llu %d\n", q & 4095, w[4 * q], w[4 * q + 1], (unsigned)(w[4 * q + 2] >> 32), (unsigned)w[4 * q + 2], w[4 * q + 3], q >> 12); std::fclose(f); } } } }
     { unsigned long long pe[8]; HIP_OK(hipMemcpy(pe, B.prof + 100, 8 * 8, hipMemcpyDeviceToHost));
