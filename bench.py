@@ -17,6 +17,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before anything initialises HIP: a round's four launches and the null stream each get a hardware queue (miqp_gpu.hip)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -26,6 +26,13 @@
 #include "planner_core.hpp"
 #include "lp_export.hpp"
 
+// A round of two cars runs FOUR launches side by side on four streams (launch_ipm_batch), and the process has its null stream: with the HIP runtime's
+// default of four hardware queues two of those streams share one, and the launch behind on the shared queue - the memory-backed kernel - started only
+// when the larger active-set launch in front of it had ended, alone, for 1.7 ms of a 12 ms round (rocprofv3 trace of the driver's command,
+// profiles/r06_*round_gaps*).  The runtime reads GPU_MAX_HW_QUEUES once, at its first call: the library asks for eight when it is loaded, unless the
+// variable is set already; a process that initialised HIP before loading the library keeps its four queues (and that serial tail) - INTEGRATION.md 5.
+__attribute__((constructor)) static void miqp_gpu_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 using namespace miqp;
 
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "[miqp_gpu] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return false; } } while (0)
@@ -610,7 +617,7 @@ void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool o
       // each (450 / 424 registers) and are enqueued first - a full grid of them held every SIMD until the larger active-set launch was through
       // (5 of 16 ms, tools/wave_dump.py), the standard launch started behind them and never got its holes back.  Weights: SIMD time of a node of the
       // class in units of a standard node's (half a SIMD for ~0.19 ms)
-      static const double w1_ = KNOB_T("MIQP_BIG_W1") ? std::atof(KNOB_T("MIQP_BIG_W1")) : 4.0, w2_ = KNOB_T("MIQP_BIG_W2") ? std::atof(KNOB_T("MIQP_BIG_W2")) : 20.0;
+      static const double w1_ = KNOB_T("MIQP_BIG_W1") ? std::atof(KNOB_T("MIQP_BIG_W1")) : 5.0, w2_ = KNOB_T("MIQP_BIG_W2") ? std::atof(KNOB_T("MIQP_BIG_W2")) : 20.0;
       int g1s = gb, g2s = gb;
       if (lists && w1_ > 0) {
         const double n1 = X.cls_n[0], n2 = X.cls_n[1], n0 = std::max(0, bc - X.cls_n[0] - X.cls_n[1] - X.cls_n[2]);

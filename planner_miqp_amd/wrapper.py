@@ -9,6 +9,9 @@ import subprocess
 
 import numpy as np
 
+# (four concurrent launches per round + the null stream: see miqp_gpu.hip - effective when set before the process's first HIP call)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .ctypes_types import (ModelParameters, ModelParamsC, RawResults, RawResultsC, SolutionPropertiesC, SolverOptsC, c_double_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
