@@ -160,7 +160,7 @@ struct DevBuf {
   double cut_gate;               // the early cutoff is tested once the stationarity residual is below cut_gate x (1 + |objective|) (what is left of it enters the test with the instance's diameter: rigorous at any value)
   int seq_kinds;                 // bit k set: first-deviation (time family) branching for disjunction kind k, else single step
   int abl;                       // ablation mask of the diagnostic build (0 otherwise)
-  int opt2;                      // MIQP_OPT2: bit 0 rounding probe at every branched node; bits 4.. = K: probe at nodes where at most K lanes of the completion saw a violated disjunction (default 8; 0 = only until the first incumbent); bits 2..3 = s: only every 4^s-th such node (by a hash of its record number); bits 8.. = largest violation, in units of 0.05, a probed node may show; bit 1: dives prefer the sibling with the smallest lifted bound; bit 16: probes leave the front-point environment / obstacle disjunctions undecided (all measured: no gain)
+  int opt2;                      // MIQP_OPT2: bit 0 rounding probe at every branched node; bits 4.. = K: probe at nodes where at most K lanes of the completion saw a violated disjunction (default 8; 0 = only until the first incumbent); bits 2..3 = s: only every 4^s-th such node (by a hash of its record number); bits 8.. = largest violation, in units of 0.05, a probed node may show; bit 1: dives prefer the sibling with the smallest lifted bound; bit 16: probes leave the front-point environment / obstacle disjunctions undecided (all measured: no gain); bits 20 / 21: ties between disjunctions of equal branching priority go to the earliest / latest step whatever the car (default: the earliest step of the first car; latest: 2.4 x the work)
   int* work_counter;             // next node of the batch to be solved (reset before every ipm launch)
   unsigned long long* prof;      // [40] cycle counters of the phases of ipm_kernel (diagnostic build -DMIQP_PROFILE only)
   unsigned long long* stat_rowiters;
@@ -1826,8 +1826,11 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   // many region alternatives are only enumerated inside a class).
   const int prio_mode = inc_now < 1e300 ? ((B.seq_kinds >> 8) & 15) : 0;
   double myvmax = 0.0;   // largest violation this lane saw (the rounding probe is only worth its QP at nearly integral nodes)
+  unsigned long long vsites = 0ull; int cur_site = 0;
+  // ties between disjunctions of equal priority go, as when a lane was a site, to the lower lane of then, and there to the one considered first
+  unsigned int mine_tie = 0xFFFFFFFFu, cur_tie = 0u;   // the (car, step) / (pair, step) sites with a violated disjunction, one bit per site as when a lane was a site (bal_viol below counts them)
   auto consider = [&](int step, int kind, int c, int o, int pt, double vv, double sc = 0.0, int cause = 0) {
-    myvmax = fmax(myvmax, vv);
+    myvmax = fmax(myvmax, vv); vsites |= 1ull << (cur_site & 63);
     int major = step * 4 + kind;
     // score modes: sc = the smallest lift over the alternatives of the disjunction, i.e. what the bound gains at least on
     // every child (a surrogate of strong branching); 10: largest score first, 11: the same inside the kind order of mode 5
@@ -1845,22 +1848,27 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     else if (prio_mode == 9) major = (kind == 3 ? 0 : 1 + kind) * 32768 + (30000 - (int)(fmin(vv, 29.0) * 1000.0));  // car/car, region, env, obstacle; most violated
     else if (prio_mode == 7) major = (kind == 3 ? 0 : 1 + kind) * 32 + step;                          // car/car, then region, env, obstacle
     int prio = (major << 12) | ((c & 7) << 9) | ((o & 31) << 4) | (pt & 15);
-    if (prio < mine.prio) { mine.prio = prio; mine.kind = kind; mine.c = c; mine.o = o; mine.i = step; mine.pt = pt; mine.cause = cause; }
+    if (prio < mine.prio || (prio == mine.prio && cur_tie < mine_tie)) { mine_tie = cur_tie; mine.prio = prio; mine.kind = kind; mine.c = c; mine.o = o; mine.i = step; mine.pt = pt; mine.cause = cause; }
   };
-  for (int L0 = 0; L0 < NCI; L0 += 64) {
+  // one lane per (car, step, POINT) - a lane per (car, step) working through the five points kept 38 of the 64 lanes busy for five passes
+  for (int L0 = 0; L0 < NCI * 5; L0 += 64) {
     int L = L0 + lane;
-    if (L < NCI) {
-      int c = L / (N - 1), i = 1 + L % (N - 1);
+    if (L < NCI * 5) {
+      const int pt0 = L % 5, ci_ = L / 5; cur_site = ci_;
+      int c = ci_ / (N - 1), i = 1 + ci_ % (N - 1);
       const double* z = Z + i * NZ;
       CarState s = {z[6 * c], z[6 * c + 1], z[6 * c + 2], z[6 * c + 3], z[6 * c + 4], z[6 * c + 5], z[6 * C + 2 * c], z[6 * C + 2 * c + 1]};
-      if (vflag[c * N + i]) consider(i, 0, c, 0, 0, fastv[c * N + i], rlift[c * N + i]);
+      const unsigned int tie0_ = (B.opt2 & 0x300000) ? ((unsigned int)((B.opt2 & 0x200000) ? 63 - i : i) << 24) | ((unsigned int)c << 20) : ((unsigned int)(ci_ & 63) << 20) | ((unsigned int)(ci_ >> 6) << 12);   // (experiment, MIQP_OPT2 bits 20 / 21: ties to the earliest / latest step whatever the car)
+      cur_tie = tie0_;
+      if (pt0 == 0 && vflag[c * N + i]) consider(i, 0, c, 0, 0, fastv[c * N + i], rlift[c * N + i]);
       LiftDiag LX = {0.0, 0.0, 0.0, 0.0}, LYd = {0.0, 0.0, 0.0, 0.0}; if (prio_mode >= 10 || Y.O > 0) lift_diag(Y, D, c, i, LX, LYd);   // (scores: branching orders 10 / 11, and the obstacles' lifts)
       const double rsc = rlift[c * N + i];
       int code = (int)comp[Y.f_reg + c * N + i];
       const double* rt = D + Y.d_reg + (c * P + (code >> 2)) * REGSZ;
       bool runfixed = fix[Y.f_reg + c * N + i] < 0;
       if (Y.E >= 1)
-        for (int pt = 0; pt < 5; ++pt) {
+        for (int pt = pt0; pt < pt0 + 1; ++pt) {
+          cur_tie = tie0_ | (unsigned int)(1 + pt);
           double X, Yc; point_xy(s, rt, ENV_PT_D[pt][0], ENV_PT_D[pt][1], X, Yc);
           if (Y.E == 1) {
             if (pt > 0 && runfixed) { double v = env_alt_viol(Y, D, T, 0, X, Yc); if (v > tol) consider(i, 0, c, 0, 0, v, rsc, 1); }
@@ -1887,7 +1895,8 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
           if (!okk) { if (pt > 0 && runfixed) consider(i, 0, c, 0, 0, bv, rsc, 1); else consider(i, 1, c, 0, pt, bv, sc < 1e300 ? sc : 0.0); }
         }
       for (int o = 0; o < Y.O; ++o)
-        for (int pt = 0; pt < 5; ++pt) {
+        for (int pt = pt0; pt < pt0 + 1; ++pt) {
+          cur_tie = tie0_ | (unsigned int)(8 + o * 5 + pt);
           int fx = (int)fix[Y.f_obs + ((c * Y.O + o) * N + i) * 5 + pt];
           if (fx >= 0 && (fx >= Y.L || !(pt > 0 && runfixed))) continue;
           double X, Yc; point_xy(s, rt, OBS_PT_D[pt][0], OBS_PT_D[pt][1], X, Yc);
@@ -1908,10 +1917,12 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   }
   if (C >= 2) {
     const int NPI = Y.NP * (N - 1);
-    for (int L0 = 0; L0 < NPI; L0 += 64) {
+    // one lane per (pair, step, GROUP): 19 lanes with four groups each were the longest stretch of the kernel
+    for (int L0 = 0; L0 < NPI * 4; L0 += 64) {
       int L = L0 + lane;
-      if (L < NPI) {
-        int p = L / (N - 1), i = 1 + L % (N - 1); const double* z = Z + i * NZ;
+      if (L < NPI * 4) {
+        const int g0 = L & 3, pi_ = L >> 2; cur_site = pi_;
+        int p = pi_ / (N - 1), i = 1 + pi_ % (N - 1); const double* z = Z + i * NZ;
         int c1, c2; pair_cars(p, C, c1, c2);
         CarState s1 = {z[6 * c1], z[6 * c1 + 1], z[6 * c1 + 2], z[6 * c1 + 3], z[6 * c1 + 4], z[6 * c1 + 5], z[6 * C + 2 * c1], z[6 * C + 2 * c1 + 1]};
         CarState s2 = {z[6 * c2], z[6 * c2 + 1], z[6 * c2 + 2], z[6 * c2 + 3], z[6 * c2 + 4], z[6 * c2 + 5], z[6 * C + 2 * c2], z[6 * C + 2 * c2 + 1]};
@@ -1920,7 +1931,8 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
         double gx12 = 0.0, gy12 = 0.0;
         if (prio_mode >= 10) { LiftDiag A1, B1, A2, B2; lift_diag(Y, D, c1, i, A1, B1); lift_diag(Y, D, c2, i, A2, B2); gx12 = A1.p + A2.p; gy12 = B1.p + B2.p; }   // (the score of the branching orders 10 / 11 only)
         PosBlk PX1, PY1, PX2, PY2; bool have_pos = false;   // (the blocks of the set tightening: fetched when a group of this (pair, step) needs them)
-        for (int g = 0; g < 4; ++g) {
+        for (int g = g0; g < g0 + 1; ++g) {
+          cur_tie = (B.opt2 & 0x300000) ? ((unsigned int)((B.opt2 & 0x200000) ? 63 - i : i) << 24) | ((unsigned int)p << 20) | (1u << 19) | (unsigned int)g : ((unsigned int)(pi_ & 63) << 20) | (1u << 19) | ((unsigned int)(pi_ >> 6) << 12) | (unsigned int)g;
           bool need1 = g >= 2, need2 = (g == 1 || g == 3);
           int unf = -1;
           if (need1 && fix[Y.f_reg + c1 * N + i] < 0) unf = c1; else if (need2 && fix[Y.f_reg + c2 * N + i] < 0) unf = c2;
@@ -2010,9 +2022,12 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     FREE_NODE();
     return;
   }
-  const unsigned long long bal_viol = __ballot(mine.prio != 0x7FFFFFFF);   // lanes that saw a violated disjunction
+  unsigned long long bal_viol = vsites;   // sites that saw a violated disjunction (the lanes of the time when a lane was a site)
+  for (int o = 32; o > 0; o >>= 1) bal_viol |= ((unsigned long long)(unsigned int)__shfl_xor((int)(bal_viol >> 32), o) << 32) | (unsigned int)__shfl_xor((int)bal_viol, o);
   const double vmax_all = wave_max(myvmax);
-  unsigned long long bal = __ballot(mine.prio == best);
+  unsigned int best_tie = mine.prio == best ? mine_tie : 0xFFFFFFFFu;
+  for (int o = 32; o > 0; o >>= 1) best_tie = min(best_tie, (unsigned int)__shfl_xor((int)best_tie, o));
+  unsigned long long bal = __ballot(mine.prio == best && (best == 0x7FFFFFFF || mine_tie == best_tie));
   int winner = __ffsll((long long)bal) - 1;
   if (lane == winner) { chosen = mine; if (best == 0x7FFFFFFF) chosen.i = 1; }   // (no violated disjunction: a re-rounded probe - any valid step serves, it has no children but the probe)
   __syncthreads();
