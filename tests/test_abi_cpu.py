@@ -365,3 +365,21 @@ def test_environment_switches_of_the_shipped_library_are_the_documented_ones():
         inbin = set(m.decode() for m in re.findall(rb"MIQP_[A-Z0-9_]+", blob))
         assert prod <= inbin, sorted(prod - inbin)
         assert not (tune & inbin), sorted(tune & inbin)
+
+
+def test_loading_the_library_asks_for_eight_hardware_queues_unless_the_caller_chose():
+    """a round of two cars runs four launches on four streams beside the process's null stream: the library's constructor and
+    the Python wrapper set GPU_MAX_HW_QUEUES=8 when it is not set, and leave a value the caller exported alone (checked in fresh processes: the
+    HIP runtime reads the variable once)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, ctypes, sys; sys.path.insert(0, %r); os.environ.pop('GPU_MAX_HW_QUEUES', None) if sys.argv[1] == '-' else os.environ.__setitem__('GPU_MAX_HW_QUEUES', sys.argv[1]); "
+            "ctypes.CDLL(os.path.join(%r, 'planner_miqp_amd', 'libmiqp_gpu.so')); "
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; print((libc.getenv(b'GPU_MAX_HW_QUEUES') or b'').decode())") % (root, root)
+    for given, want in (("-", "8"), ("4", "4")):
+        out = subprocess.run([sys.executable, "-c", code, given], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-400:]
+        assert out.stdout.strip() == want, (given, out.stdout, out.stderr[-200:])
+    code2 = "import os, sys; sys.path.insert(0, %r); os.environ.pop('GPU_MAX_HW_QUEUES', None); import planner_miqp_amd.wrapper; print(os.environ.get('GPU_MAX_HW_QUEUES'))" % root
+    out = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "8", (out.stdout, out.stderr[-300:])

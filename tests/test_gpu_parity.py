@@ -1411,3 +1411,31 @@ def test_receding_horizon_through_the_bark_trajectory():
         pl.UpdateCar(idx, K.MiqpPlanner.CarStateToMiqpState(tr[1, 1], tr[1, 2], tr[1, 3], tr[1, 4], a).reshape(6), ref)
         t = float(np.float32(t) + np.float32(dt))                          # (the reference counts in float)
     assert x[0] < x[-1] and y[0] > y[-1] and v[0] < v[-1], (x, y, v)
+
+
+def test_the_launch_split_of_a_round_is_in_use_and_the_leaves_of_the_local_search_start_warm():
+    """round 6, second half: the larger launches of a round take their nodes from class lists, and the leaves of the local search start from the
+    active set of the solve that found the incumbent.  On a hard instance (seed 1913: ~150 k nodes) solved in a fresh process
+    with MIQP_STATS=1 the statistics of the larger active-set block must show local-search leaves, and their average number of Goldfarb-Idnani steps
+    must be that of a warm start (cold: |A| + 4 = 33; warm: ~10), the optimum the one the interior-point-only build proves"""
+    import re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import planner_miqp_amd as P; from planner_miqp_amd import synthetic; "
+            "w = P.CplexWrapper(); w.resetParameters(synthetic.generate('cfg3', 1913, gap=1e-2, max_time=30)); st = int(w.callCplex()); pr = w.getSolutionProperties(); "
+            "print('RESULT', st, pr.status, repr(pr.objective), pr.nodes)") % root
+    outs = {}
+    for mode in ("1", "0"):
+        env = dict(os.environ, MIQP_STATS="1", MIQP_AS=mode)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-600:]
+        m = re.search(r"RESULT (\d+) (\d+) (\S+) (\d+)", out.stdout)
+        assert m and int(m.group(1)) == 0 and int(m.group(2)) in (101, 102), out.stdout[-300:]
+        outs[mode] = (float(m.group(3)), out.stderr)
+    oa, err = outs["1"]; ob, _ = outs["0"]
+    assert abs(oa - ob) <= 1e-2 * max(abs(oa), abs(ob)) + 1e-9, (oa, ob)
+    m = re.search(r"in the larger block (\d+) nodes \(([0-9.]+) steps\), of them leaves of the local search (\d+) \(([0-9.]+) steps\)", err)
+    assert m, err[-800:]
+    big, leaves, lsteps = int(m.group(1)), int(m.group(3)), float(m.group(4))
+    print("larger block: %d nodes, %d local-search leaves at %.1f steps" % (big, leaves, lsteps))
+    assert big > 0 and leaves > 100, (big, leaves)
+    assert lsteps < 20.0, lsteps   # (a cold leaf takes the size of its active set + 4 steps: 33 on this workload)
