@@ -1415,13 +1415,14 @@ def test_receding_horizon_through_the_bark_trajectory():
 
 def test_the_launch_split_of_a_round_is_in_use_and_the_leaves_of_the_local_search_start_warm():
     """round 6, second half: the larger launches of a round take their nodes from class lists, and the leaves of the local search start from the
-    active set of the solve that found the incumbent.  On a hard instance (seed 1913: ~150 k nodes) solved in a fresh process
+    active set of the solve that found the incumbent - where an active-set launch found it; the incumbents of seeds 1913 and 662
+    come from interior point nodes and their leaves start cold, at 58 - 74 steps.  On a hard instance (seed 307: ~250 k nodes, 1270 leaves) solved in a fresh process
     with MIQP_STATS=1 the statistics of the larger active-set block must show local-search leaves, and their average number of Goldfarb-Idnani steps
-    must be that of a warm start (cold: |A| + 4 = 33; warm: ~10), the optimum the one the interior-point-only build proves"""
+    must be that of a warm start (cold: 57 on this instance; warm: 12.5), the optimum the one the interior-point-only build proves"""
     import re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys; sys.path.insert(0, %r); import planner_miqp_amd as P; from planner_miqp_amd import synthetic; "
-            "w = P.CplexWrapper(); w.resetParameters(synthetic.generate('cfg3', 1913, gap=1e-2, max_time=30)); st = int(w.callCplex()); pr = w.getSolutionProperties(); "
+            "w = P.CplexWrapper(); w.resetParameters(synthetic.generate('cfg3', 307, gap=1e-2, max_time=30)); st = int(w.callCplex()); pr = w.getSolutionProperties(); "
             "print('RESULT', st, pr.status, repr(pr.objective), pr.nodes)") % root
     outs = {}
     for mode in ("1", "0"):
@@ -1438,4 +1439,4 @@ def test_the_launch_split_of_a_round_is_in_use_and_the_leaves_of_the_local_searc
     big, leaves, lsteps = int(m.group(1)), int(m.group(3)), float(m.group(4))
     print("larger block: %d nodes, %d local-search leaves at %.1f steps" % (big, leaves, lsteps))
     assert big > 0 and leaves > 100, (big, leaves)
-    assert lsteps < 20.0, lsteps   # (a cold leaf takes the size of its active set + 4 steps: 33 on this workload)
+    assert lsteps < 30.0, lsteps   # (a cold leaf takes the size of its active set + 4 steps: 57 on average on this instance)
