@@ -267,7 +267,7 @@ def main():
             continue
         # the RawResults record of every solved instance (collectRawResults runs inside the reference's callCplex): built on the
         # host threads inside the library, inside the timed region
-        tr = time.time(); nrec += P.materialize_results(ws); results_s += time.time() - tr
+        tr = time.time(); nrec += P.materialize_results(ws, int(os.environ.get("MIQP_BENCH_MAT_THREADS", "0"))); results_s += time.time() - tr
         for w, st in zip(ws, sts):
             pr = w.getSolutionProperties()
             ok = st == P.OptimizationStatus.SUCCESS and pr.status in (101, 102)

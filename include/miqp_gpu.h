@@ -132,7 +132,7 @@ int miqp_solver_lift_tables(const miqp_solver_t* s, double* out, int cap);
 int miqp_solver_get_results(const miqp_solver_t* s, miqp_raw_results_c* out);
 
 /* collectRawResults for a whole batch                           src/cplex_wrapper.cpp:186 (collectRawResults() runs inside callCplex, before it returns)
- * Builds the RawResults record of every handle that holds a solution, on `threads` host threads (0: all hardware threads), and
+ * Builds the RawResults record of every handle that holds a solution, on `threads` host threads (0: up to 32 - more contend for the allocator), and
  * keeps it inside the handle; miqp_solver_get_results then only copies.  The reference produces the record inside callCplex;
  * the batch entry points leave it to this call so that a service can overlap it - bench.py calls it inside its timed region.
  * Returns the number of records built, < 0 on error. */

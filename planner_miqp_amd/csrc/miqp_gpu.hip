@@ -978,7 +978,11 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
   const double t_ctx = wall_s() - t_enter;
   DevBuf& B = X.B;
   // ---- host tables, step-1 presolve
-  std::vector<double> hD((size_t)n * Y.dstride); std::vector<int> hT((size_t)n * Y.istride);
+  // (not value-initialised: compile_instance writes every word of an instance's slice, and zeroing 1.4 GB for the 51 200 instances of the driver's stream
+  // on the calling thread came before the threads below could start)
+  const size_t nD_ = (size_t)n * Y.dstride, nT_ = (size_t)n * Y.istride;
+  std::unique_ptr<double[]> hD_own(new double[nD_]); std::unique_ptr<int[]> hT_own(new int[nT_]);
+  double* const hD = hD_own.get(); int* const hT = hT_own.get();
   std::vector<double> h_const(n, 0.0), h_gap(n), h_tlim(n);
   std::vector<int> h_done(n, 0);
   std::vector<signed char> roots; roots.reserve((size_t)MAXR * n * Y.fixlen);
@@ -1026,7 +1030,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     s->props = miqp_solution_properties_c{}; s->props.NrConstraints = rows; s->props.NrBinaryVariables = bin; s->props.NrFloatVariables = cont;
     s->props.NonZeroCoefficients = nnz;
   };
-  { const int nth = std::max(1, std::min<int>({n / 8, (int)std::thread::hardware_concurrency(), 32}));
+  { static const int prep_cap = KNOB_T("MIQP_PREP_THREADS") ? std::atoi(KNOB_T("MIQP_PREP_THREADS")) : 16;   // (the 51 200 instances of the driver's stream on a 2 x 64-core host: 0.38 / 0.44 / 0.57 / 0.76 s at 16 / 32 / 64 / 128 threads - allocator and first-touch contention, not arithmetic)
+    const int nth = std::max(1, std::min<int>({n / 8, (int)std::thread::hardware_concurrency(), prep_cap}));
     if (nth <= 1) for (int k = 0; k < n; ++k) prepare_one(k);
     else {
       std::atomic<int> next{0}; std::vector<std::thread> th;
@@ -1044,8 +1049,8 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     const double tolcap = KNOB_T("MIQP_QPTOL") ? std::atof(KNOB_T("MIQP_QPTOL")) : QP_TOL;
     B.qp_tol = std::min(tolcap, std::max(1e-12, ftol * gmin)); }  // node relaxations: accurate to a small fraction of the MIP gap
   hipStream_t st = X.stream;
-  HIP_OK(hipMemcpyAsync((void*)B.inst_d, hD.data(), hD.size() * 8, hipMemcpyHostToDevice, st));
-  HIP_OK(hipMemcpyAsync((void*)B.inst_i, hT.data(), hT.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync((void*)B.inst_d, hD, nD_ * 8, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync((void*)B.inst_i, hT, nT_ * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(B.pool_fix, roots.data(), roots.size(), hipMemcpyHostToDevice, st));
   int pool0 = nrec;
   if (B.pool_big && nrec > 0) HIP_OK(hipMemsetAsync(B.pool_big, 0, (size_t)nrec, st));   // the root records start unmarked (children are marked or cleared when they are written)
@@ -1827,7 +1832,7 @@ int miqp_solver_get_results(const miqp_solver_t* s, miqp_raw_results_c* out) {
 
 int miqp_solver_materialize_results(miqp_solver_t* const* solvers, int n, int threads) {
   if (!solvers || n < 0) return -1;
-  int nth = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+  int nth = threads > 0 ? threads : std::min((int)std::thread::hardware_concurrency(), 32);   // (20 480 records on a 2 x 64-core host: 0.29 / 0.16 / 0.13 / 0.15 / 0.25 s at 8 / 16 / 32 / 64 / 256 threads)
   nth = std::max(1, std::min(nth, std::max(1, n / 4)));
   std::atomic<int> next{0}, made{0};
   auto work = [&] {
