@@ -1836,11 +1836,12 @@ int miqp_solver_materialize_results(miqp_solver_t* const* solvers, int n, int th
   nth = std::max(1, std::min(nth, std::max(1, n / 4)));
   std::atomic<int> next{0}, made{0};
   auto work = [&] {
+    std::vector<double> D; std::vector<int> T;   // (one pair of table buffers per thread, not per record)
     for (int k = next.fetch_add(1); k < n; k = next.fetch_add(1)) {
       miqp_solver* s = solvers[k];
       if (!s || !s->has_sol || s->rescache) continue;
       std::unique_ptr<OwnedResults> R(new OwnedResults(s->inst));
-      std::vector<double> D(s->lay.dstride); std::vector<int> T(s->lay.istride);
+      D.resize(s->lay.dstride); T.resize(s->lay.istride);
       compile_instance(s->inst, s->lay, D.data(), T.data());
       fill_results(s->inst, s->lay, D.data(), T.data(), s->comp.data(), s->Z.data(), &R->r);
       s->rescache = std::move(R); made.fetch_add(1);
