@@ -259,7 +259,7 @@ struct DevCtx {
   int* d_pairs = nullptr;   // admissions of one round: (slot, instance) pairs
   // concurrent launch of the memory-backed kernel on the rounding probes of a batch (second stream, its own work counter and
   // per-block buffers): see launch_ipm_batch
-  hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sfork = nullptr, ev_sjoin = nullptr;
   hipStream_t stream3 = nullptr, stream4 = nullptr; hipEvent_t ev_join3 = nullptr, ev_join4 = nullptr; double* kgain3 = nullptr;   // the larger active-set launch beside the interior point chain of stream2
   hipEvent_t ev_mid = nullptr;   // MIQP_LAUNCH_TRACE
   int* work_counter2 = nullptr; double* rowstate2 = nullptr; double* rowcache2 = nullptr; double* kgain2 = nullptr; int probe_grid = 0;
@@ -507,7 +507,7 @@ bool ctx_prepare(DevCtx& X, const Layout& Y, int n_inst, int n_slots, int open_c
     if (!X.alloc(&X.rowstate2, (size_t)X.probe_grid * NFIELD * Y.ROWCAP)) return false;
     if (!X.alloc(&X.rowcache2, (size_t)X.probe_grid * NCACHE * Y.ROWCAP)) return false;
     if (!X.alloc(&X.kgain2, (size_t)X.probe_grid * std::max(Y.N * Y.nu * (Y.nx + 2), oc_gain_doubles(Y.N)))) return false;
-    if (!X.stream2) { HIP_OK(hipStreamCreate(&X.stream2)); HIP_OK(hipEventCreate(&X.ev_fork)); HIP_OK(hipEventCreate(&X.ev_join)); }
+    if (!X.stream2) { HIP_OK(hipStreamCreate(&X.stream2)); HIP_OK(hipEventCreate(&X.ev_fork)); HIP_OK(hipEventCreate(&X.ev_join)); HIP_OK(hipEventCreate(&X.ev_sfork)); HIP_OK(hipEventCreate(&X.ev_sjoin)); }
     if (!X.stream3) { HIP_OK(hipStreamCreate(&X.stream3)); HIP_OK(hipEventCreate(&X.ev_join3)); HIP_OK(hipStreamCreate(&X.stream4)); HIP_OK(hipEventCreate(&X.ev_join4)); }
     if (!X.alloc(&X.kgain3, (size_t)X.probe_grid * std::max(Y.N * Y.nu * (Y.nx + 2), oc_gain_doubles(Y.N)))) return false;
   }
@@ -1180,10 +1180,14 @@ bool solve_batch_impl(miqp_solver_t* const* S, int n, int* statuses, const Split
     B.open_sel = rounds & 1;
     B.prev_bc = prev_bc;
     hipLaunchKernelGGL(select_kernel, dim3(NS), dim3(SEL_THREADS), 0, st, B, rounds);
+    // (share_kernel - one workgroup, 0.23 ms: the shares of the NEXT round from this selection's demands - beside lns_kernel, 0.22 ms, on the second stream:
+    // neither reads what the other writes)
+    const bool share_aside = B.lns_mode > 0 && NS >= 64 && X.stream2 && X.ev_sfork && !KNOB_P("MIQP_DEBUG_SYNC");
+    if (share_aside) { (void)hipEventRecord(X.ev_sfork, st); (void)hipStreamWaitEvent(X.stream2, X.ev_sfork, 0); hipLaunchKernelGGL(share_kernel, dim3(1), dim3(1024), 0, X.stream2, B); (void)hipEventRecord(X.ev_sjoin, X.stream2); }
     if (B.lns_mode > 0) hipLaunchKernelGGL(lns_kernel, dim3(NS), dim3(64), 0, st, B);   // the neighbours of new incumbents join this round's batch
     if (KNOB_P("MIQP_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(st); std::fprintf(stderr, "[dbg] round %d select: %s\n", rounds, hipGetErrorString(e_)); }
     hipLaunchKernelGGL(roll_kernel, dim3(1), dim3(CTR_SET), 0, st, B, use_par ? X.ctr + CTR_SET * (par ^ 1) : (int*)nullptr);
-    hipLaunchKernelGGL(share_kernel, dim3(1), dim3(1024), 0, st, B);
+    if (share_aside) (void)hipStreamWaitEvent(st, X.ev_sjoin, 0); else hipLaunchKernelGGL(share_kernel, dim3(1), dim3(1024), 0, st, B);
     int bc = 0; int hctr[CTR_SET] = {0};
     HIP_OK(hipMemcpyAsync(use_cls ? hctr : &bc, B.batch_count, use_cls ? CTR_SET * 4 : 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(h_done_now.data(), B.inst_done, (size_t)n * 4, hipMemcpyDeviceToHost, st));
