@@ -76,8 +76,10 @@ __host__ __device__ inline int ipm_stage_doubles(int C) {
   return C <= 2 ? GROWS * (GSTR + 1) : NZ * (NZ + 1) + NX * (NX + 1) + NX * (NZ + 1) + NZ + NX + NU * (NX + 1);   // (rows padded by one: the column accesses of S, P, T stay off one LDS bank)
 }
 // eval_kernel: doubles of the LDS region shared by the slow-alternative table (floats) and the dense rows of the lifting
+// (the lifting decodes one dense row per lane, LIFT_LANES lanes at a time: with all 64 the rows were 8.7 KB of the 18 KB that keep eval_kernel at 8 wavefronts per CU)
+constexpr int LIFT_LANES = 32;
 __host__ __device__ inline int eval_shared_doubles(int C, int N, int P) {
-  const int a = (C * N * P + 1) / 2, b = 64 * (8 * C + 1);
+  const int a = (C * N * P + 1) / 2, b = LIFT_LANES * (8 * C + 1);
   return a > b ? a : b;
 }
 __host__ __device__ inline int ipm_scratch_doubles(int N, int C) {
@@ -1645,7 +1647,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
   // resolution right behind it - and the dense rows of the lifting.  Apart they were 10 + 9 KB of a two-car workgroup's 28 KB (5 workgroups per
   // CU of a kernel that waits on memory for 60 % of its cycles; 8 now) and 61 + 17 KB at four cars x 64 regions (ONE workgroup per CU; 3 now).)
   float* slowv = (float*)(Z + N * NZ);               // [C*N][P] slow-alternative violation per possible region (float: compared with tolerances and with each other only - a violation within one float ulp of the tolerance may be labelled differently from the double path; the label is a canonical choice among alternatives that hold, never a feasibility verdict)
-  double* gsc = Z + N * NZ;                          // [64][NZ + 1] one dense row per lane (lifting)
+  double* gsc = Z + N * NZ;                          // [LIFT_LANES][NZ + 1] one dense row per lane (lifting)
   double* fastv = Z + N * NZ + eval_shared_doubles(C, N, P);   // [C*N] best fast alternative violation
   double* rlift = fastv + C * N;                     // [C*N] smallest lift over the region alternatives (branching score)
   int* fastc = (int*)(rlift + C * N);                // [C*N] its code
@@ -2161,7 +2163,7 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
     for (int k = lane; k < Y.fixlen; k += 64) cfix[k] = fix[k];
     __syncthreads();
     const double* LT = D + Y.d_lift;
-    double* gl = gsc + lane * (NZ + 1);
+    double* gl = gsc + (lane & (LIFT_LANES - 1)) * (NZ + 1);   // (lanes >= LIFT_LANES sit the row passes out)
     for (int a = 0; a < nalt; ++a) {
       const int kk = ck[a];
       if (kk == -2) { if (lane == 0) clift[a] = (a > 0 && ck[0] != -2) ? clift[0] : 0.0; continue; }   // the probe lies inside the first child: it costs at least what that one costs
@@ -2190,10 +2192,10 @@ __global__ void __launch_bounds__(64) eval_kernel(DevBuf B) {
       // curvature against the acceleration box).
       const bool multi = (B.seq_kinds & 0x80000000u) != 0u;   // OFF by default (bit 31 of MIQP_SEQ_KINDS switches it on): measured without effect on the node counts (17.2 M against 17.4 M nodes on a 1024-instance queue; tools/lift_ab.sh) - what a child costs beyond its single-row lift comes from the rows of the OTHER stages
       int ncand = 0;
-      for (int e0 = 0; e0 < ntot; e0 += 64) {
+      for (int e0 = 0; e0 < ntot; e0 += LIFT_LANES) {
         const int e = e0 + lane;
         bool cand = false; double v = 0.0, gam = 0.0;
-        if (e < ntot) {
+        if (lane < LIFT_LANES && e < ntot) {
           const int sl = e < n01 ? s0 + e : s2 + (e - n01);
           const RowOut r = decode_row<C, true>(Y, D, T, cfix, i, sl, gl);
           if (r.active && r.aq == 0.0) {
