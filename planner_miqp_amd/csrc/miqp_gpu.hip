@@ -617,7 +617,7 @@ void launch_ipm_batch(DevCtx& X, const DevBuf& B, int bc, hipStream_t st, bool o
       // each (450 / 424 registers) and are enqueued first - a full grid of them held every SIMD until the larger active-set launch was through
       // (5 of 16 ms, tools/wave_dump.py), the standard launch started behind them and never got its holes back.  Weights: SIMD time of a node of the
       // class in units of a standard node's (half a SIMD for ~0.19 ms)
-      static const double w1_ = KNOB_T("MIQP_BIG_W1") ? std::atof(KNOB_T("MIQP_BIG_W1")) : 5.0, w2_ = KNOB_T("MIQP_BIG_W2") ? std::atof(KNOB_T("MIQP_BIG_W2")) : 20.0;
+      static const double w1_ = KNOB_T("MIQP_BIG_W1") ? std::atof(KNOB_T("MIQP_BIG_W1")) : 6.0, w2_ = KNOB_T("MIQP_BIG_W2") ? std::atof(KNOB_T("MIQP_BIG_W2")) : 28.0;   // (driver's stream, launch group / standard launch: 9.10 / 8.41 ms at 5 / 20, 8.76 / 8.50 at 6 / 28, 8.87 / 8.53 at 8 / 36)
       int g1s = gb, g2s = gb;
       if (lists && w1_ > 0) {
         const double n1 = X.cls_n[0], n2 = X.cls_n[1], n0 = std::max(0, bc - X.cls_n[0] - X.cls_n[1] - X.cls_n[2]);
