@@ -34,7 +34,7 @@ namespace miqp {
 constexpr int AS_MAXSTEP = 220;        // adds + drops after which a node goes to the interior point instead
 constexpr double AS_VTOL = 1.0e-8;     // a row is violated above this (rows are normalised: metres, m/s, ...)
 constexpr double AS_DEP = 1.0e-8;
-constexpr int AS_MT = 56;               // active sets of up to this many rows hand their M to the children
+constexpr int AS_MT = 64;               // active sets of up to this many rows hand their M to the children (56 until the last day of round 6: the children of the 57 - 64 row nodes rebuilt theirs with a substitution per row)
 constexpr int AS_MSTR = AS_MT * (AS_MT + 1) / 2;   // doubles per slot of the ring (packed triangle)      // curvature g P g' below this share of g H^-1 g': the row depends on the active ones
 
 // Column order inside this kernel: CHAIN-CONTIGUOUS - (position, velocity, acceleration, jerk) of chain ch = 2 car + axis at 4 ch .. 4 ch + 3 (the
@@ -775,7 +775,7 @@ __global__ void __launch_bounds__(64, (GCAP > 128 ? 1 : 2)) as_onchip_kernel(Dev
       const int n_ = __popcll(used);
       unsigned long long tg_ = 0ull;
       OC_WAVE_SYNC();
-      if (!fail && !infeas && ok == 1 && n_ >= 1 && n_ <= AS_MT) {
+      if (!fail && !infeas && ok == 1 && n_ >= 1 && n_ <= AS_MT && n_ * (n_ + 1) * 4 <= LL.total) {   // (... and the packed triangle fits the LDS block it is staged in)
         double* const stg = (double*)L0;
         const int ra = __popcll(used & lt);
 #pragma unroll
